@@ -1,0 +1,309 @@
+"""Shared parity-case catalogue  --  TEST INFRASTRUCTURE.
+
+One JSON-able description per case, from which the SAME operator / solver call can be
+built for three implementations:
+  * the reference (only inside `oracle/gen_golden.py`, in the build container),
+  * the CPU oracle `oracle/cpu_ref.py`,
+  * the product `ccqppy_amd` (HIP).
+Inputs are either seeded here or stored beside the expected outputs in tests/golden/.
+"""
+import numpy as np
+
+# ------------------------------------------------------------------ op specs
+# bound := None | {"scalar": v, "int": bool} | {"fill": v, "int": bool} | {"arr": "<npz key>"}
+
+
+def _bound(b, dim, arrays):
+    if b is None:
+        return None
+    if "arr" in b:
+        return arrays[b["arr"]]
+    v = int(b["scalar" if "scalar" in b else "fill"]) if b.get("int") else float(
+        b["scalar" if "scalar" in b else "fill"])
+    if "scalar" in b:
+        return v
+    return np.full(dim, v, dtype=np.int64 if b.get("int") else np.float64)
+
+
+def build_op(spec, factory, arrays=None):
+    """factory: dict kind -> class taking the reference's positional arguments."""
+    arrays = arrays or {}
+    k = spec["kind"]
+    if k == "Identity":
+        return factory[k](spec["dim"])
+    if k == "Lower":
+        return factory[k](spec["dim"], _bound(spec.get("lb"), spec["dim"], arrays))
+    if k == "Upper":
+        return factory[k](spec["dim"], _bound(spec.get("ub"), spec["dim"], arrays))
+    if k == "Box":
+        return factory[k](spec["dim"], _bound(spec.get("lb"), spec["dim"], arrays),
+                          _bound(spec.get("ub"), spec["dim"], arrays))
+    if k == "Sphere":
+        return factory[k](spec["dim"], spec.get("radius"))
+    if k == "Cone":
+        return factory[k](spec["dim"], spec.get("aspect_ratio"))
+    if k == "Disjoint":
+        subs = []
+        if "repeat" in spec:
+            subs += [spec["repeat"]["op"]] * spec["repeat"]["count"]
+        subs += spec.get("ops", [])
+        return factory[k](*[build_op(s, factory, arrays) for s in subs])
+    raise KeyError(k)
+
+
+def spec_dim(spec):
+    if spec["kind"] != "Disjoint":
+        return spec["dim"]
+    d = 0
+    if "repeat" in spec:
+        d += spec_dim(spec["repeat"]["op"]) * spec["repeat"]["count"]
+    return d + sum(spec_dim(s) for s in spec.get("ops", []))
+
+
+def spec_uses_norm(spec):
+    """True if the op's result depends on a floating-point REDUCTION (Sphere/Cone)."""
+    if spec["kind"] in ("Sphere", "Cone"):
+        return True
+    if spec["kind"] == "Disjoint":
+        subs = ([spec["repeat"]["op"]] if "repeat" in spec else []) + spec.get("ops", [])
+        return any(spec_uses_norm(s) for s in subs)
+    return False
+
+
+def spec_max_norm_dim(spec):
+    """Largest dimension over which a Sphere/Cone norm is taken (0 if none)."""
+    if spec["kind"] in ("Sphere", "Cone"):
+        return spec["dim"]
+    if spec["kind"] == "Disjoint":
+        subs = ([spec["repeat"]["op"]] if "repeat" in spec else []) + spec.get("ops", [])
+        return max([spec_max_norm_dim(s) for s in subs] + [0])
+    return 0
+
+
+def oracle_factory():
+    from oracle import cpu_ref as r
+    return {"Identity": r.Identity, "Lower": r.LowerBound, "Upper": r.UpperBound, "Box": r.Box,
+            "Sphere": r.Sphere, "Cone": r.Cone, "Disjoint": r.Disjoint}
+
+
+def product_factory():
+    from ccqppy_amd import solution_spaces as ss
+    return {"Identity": ss.IdentityProjOp, "Lower": ss.LowerBoundProjOp,
+            "Upper": ss.UpperBoundProjOp, "Box": ss.BoxProjOp, "Sphere": ss.SphereProjOp,
+            "Cone": ss.ConeProjOp, "Disjoint": ss.DisjointProjOp}
+
+
+# ------------------------------------------------------------------ op cases
+DIMS = [1, 2, 3, 8, 15, 16, 17, 64, 1000]
+
+
+def op_cases():
+    """Returns (cases, arrays): cases = list of dicts {id, spec, x (npz key), nv: bool}."""
+    rng = np.random.default_rng(20260101)
+    arrays = {}
+    cases = []
+
+    def add(cid, spec, x, nv=True):
+        arrays[cid + ".x"] = np.asarray(x, dtype=np.float64)
+        cases.append({"id": cid, "spec": spec, "x": cid + ".x", "nv": nv})
+
+    for d in DIMS:
+        lbv = np.sort(rng.normal(size=(2, d)), axis=0)
+        arrays["lb%d" % d] = lbv[0] - 0.05
+        arrays["ub%d" % d] = lbv[1] + 0.05
+        specs = {
+            "identity": {"kind": "Identity", "dim": d},
+            "lower_def": {"kind": "Lower", "dim": d},
+            "lower_arr": {"kind": "Lower", "dim": d, "lb": {"arr": "lb%d" % d}},
+            "upper_def": {"kind": "Upper", "dim": d},
+            "upper_arr": {"kind": "Upper", "dim": d, "ub": {"arr": "ub%d" % d}},
+            "box_def": {"kind": "Box", "dim": d},
+            "box_arr": {"kind": "Box", "dim": d, "lb": {"arr": "lb%d" % d}, "ub": {"arr": "ub%d" % d}},
+            "box_int": {"kind": "Box", "dim": d, "lb": {"fill": -2, "int": True}, "ub": {"fill": 1, "int": True}},
+            "box_scalar": {"kind": "Box", "dim": d, "lb": {"scalar": -0.5}, "ub": {"scalar": 0.5}},
+            "box_half": {"kind": "Box", "dim": d, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}},
+            "sphere_def": {"kind": "Sphere", "dim": d},
+            "sphere_r07": {"kind": "Sphere", "dim": d, "radius": 0.7},
+            "sphere_r25": {"kind": "Sphere", "dim": d, "radius": 2.5},
+            "cone_def": {"kind": "Cone", "dim": d},
+            "cone_mu05": {"kind": "Cone", "dim": d, "aspect_ratio": 0.5},
+            "cone_mu2": {"kind": "Cone", "dim": d, "aspect_ratio": 2},
+        }
+        for name, spec in specs.items():
+            for si, scale in enumerate((0.3, 3.0)):
+                x = rng.normal(size=d) * scale
+                # scalar bounds / Cone have no usable normal_vector -> error-type parity only
+                add("%s.d%d.s%d" % (name, d, si), spec, x)
+
+    # crafted elementwise edge values (-0.0 -> +0.0, +-inf -> NaN, NaN passes)
+    edge = np.array([-1.0, 1.0, -0.0, 0.0, np.inf, -np.inf, np.nan, 0.5, -1.0000000001,
+                     1.0000000001, 1e-300, -1e-300, 1e300, -1e300, 0.99999999, -0.99999999])
+    d = edge.size
+    add("edge.box_def", {"kind": "Box", "dim": d}, edge, nv=False)
+    add("edge.lower_def", {"kind": "Lower", "dim": d}, edge, nv=False)
+    add("edge.upper_def", {"kind": "Upper", "dim": d}, edge, nv=False)
+    add("edge.box_negint", {"kind": "Box", "dim": d, "lb": {"fill": -9, "int": True},
+                            "ub": {"fill": -3, "int": True}}, edge * 4 - 5, nv=False)
+    add("edge.box_negflt", {"kind": "Box", "dim": d, "lb": {"fill": -9.0}, "ub": {"fill": -3.0}},
+        np.where(np.isfinite(edge), edge * 4 - 5, edge), nv=False)
+    add("edge.box_scalar_int", {"kind": "Box", "dim": d, "lb": {"scalar": -1, "int": True},
+                                "ub": {"scalar": 1, "int": True}}, edge, nv=False)
+    add("edge.lower_posflt", {"kind": "Lower", "dim": d, "lb": {"fill": 2.0}}, edge, nv=False)
+    add("edge.upper_negint", {"kind": "Upper", "dim": d, "ub": {"fill": -2, "int": True}}, edge, nv=False)
+
+    # on-boundary / near-boundary points for normal_vector and np.isclose masks
+    for d in (3, 8, 40):
+        lb = arrays.setdefault("nlb%d" % d, -np.abs(rng.normal(size=d)) - 0.1)
+        ub = arrays.setdefault("nub%d" % d, np.abs(rng.normal(size=d)) + 0.1)
+        x = rng.uniform(lb, ub)
+        x[::3] = lb[::3]
+        x[1::3] = ub[1::3]
+        x_near = x.copy()
+        x_near[::3] += 3e-9           # inside isclose tolerance of the bound
+        x_near[1::3] -= 1.5e-5 * np.abs(ub[1::3])   # outside rtol band
+        for tag, xx in (("on", x), ("near", x_near), ("out", x + 1e-3), ("in", 0.5 * (lb + ub))):
+            add("nv.box.d%d.%s" % (d, tag), {"kind": "Box", "dim": d, "lb": {"arr": "nlb%d" % d},
+                                             "ub": {"arr": "nub%d" % d}}, xx)
+            add("nv.lower.d%d.%s" % (d, tag), {"kind": "Lower", "dim": d, "lb": {"arr": "nlb%d" % d}}, xx)
+            add("nv.upper.d%d.%s" % (d, tag), {"kind": "Upper", "dim": d, "ub": {"arr": "nub%d" % d}}, xx)
+        v = rng.normal(size=d)
+        v /= np.linalg.norm(v)
+        for tag, xx in (("on", v * 1.3), ("near", v * (1.3 + 2e-9)), ("out", v * 1.31), ("in", v * 0.4),
+                        ("zero", np.zeros(d))):
+            add("nv.sphere.d%d.%s" % (d, tag), {"kind": "Sphere", "dim": d, "radius": 1.3}, xx)
+
+    # cone branches: inside (mu*z >= r), polar (-z/mu >= r), generic
+    for d in (1, 2, 3, 8, 15):
+        for mu in (None, 0.5, 3.0):
+            base = rng.normal(size=d) * 0.05
+            ins = base.copy(); ins[-1] = 5.0
+            pol = base.copy(); pol[-1] = -5.0
+            gen = rng.normal(size=d)
+            spec = {"kind": "Cone", "dim": d, "aspect_ratio": mu}
+            tag = "mu%s" % ("def" if mu is None else str(mu))
+            add("cone.%s.d%d.inside" % (tag, d), spec, ins)
+            add("cone.%s.d%d.polar" % (tag, d), spec, pol)
+            add("cone.%s.d%d.generic" % (tag, d), spec, gen)
+
+    # Disjoint: mixed, nested, many small blocks
+    mixed = {"kind": "Disjoint", "ops": [
+        {"kind": "Box", "dim": 5}, {"kind": "Cone", "dim": 3}, {"kind": "Sphere", "dim": 3},
+        {"kind": "Identity", "dim": 2}, {"kind": "Lower", "dim": 4}, {"kind": "Upper", "dim": 4}]}
+    nested = {"kind": "Disjoint", "ops": [
+        {"kind": "Sphere", "dim": 2, "radius": 0.5}, mixed,
+        {"kind": "Disjoint", "ops": [{"kind": "Identity", "dim": 1}, {"kind": "Box", "dim": 3}]},
+        {"kind": "Cone", "dim": 7, "aspect_ratio": 0.25}]}
+    many = {"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 3}, "count": 341},
+            "ops": [{"kind": "Identity", "dim": 1}]}
+    big = {"kind": "Disjoint", "ops": [
+        {"kind": "Box", "dim": 500, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}},
+        {"kind": "Cone", "dim": 500}]}
+    nvmix = {"kind": "Disjoint", "ops": [
+        {"kind": "Box", "dim": 5}, {"kind": "Sphere", "dim": 3},
+        {"kind": "Identity", "dim": 2}, {"kind": "Lower", "dim": 4}, {"kind": "Upper", "dim": 4}]}
+    for name, spec in (("mixed", mixed), ("nested", nested), ("many", many), ("big", big), ("nvmix", nvmix)):
+        dd = spec_dim(spec)
+        for si, scale in enumerate((0.3, 1.0, 3.0)):
+            add("disjoint.%s.s%d" % (name, si), spec, rng.normal(size=dd) * scale)
+    xb = np.clip(rng.normal(size=spec_dim(nvmix)), -1, 1)
+    add("disjoint.nvmix.onbound", nvmix, xb)
+    return cases, arrays
+
+
+# ------------------------------------------------------------------ solver cases
+TRIDIAG = [[2, -1, 0], [-1, 2, -1], [0, -1, 2]]
+
+SUITE = {  # /root/reference/src/ccqppy/problem_suite.py:42-177 (data only)
+    "UnconstrainedSPD1": dict(xexact=[1, 0, 1], bfrom=[1, 0, 1], op={"kind": "Identity", "dim": 3}),
+    "UnconstrainedSPD2": dict(xexact=[1, 0, 1], bfrom=[1, 0, 1], op={"kind": "Disjoint", "ops": [
+        {"kind": "Identity", "dim": 1}, {"kind": "Identity", "dim": 1}, {"kind": "Identity", "dim": 1}]}),
+    "BoxConstrainedSPD": dict(xexact=[1, 0, 1], bfrom=[1, 0, 1], op={
+        "kind": "Box", "dim": 3, "lb": {"arr": "suite.box.lb"}, "ub": {"arr": "suite.box.ub"}}),
+    "ThinBoxConstrainedSPD": dict(xexact=[1, 0, 1], bfrom=[1, 0, 1], op={
+        "kind": "Box", "dim": 3, "lb": {"arr": "suite.thin.lb"}, "ub": {"arr": "suite.thin.ub"}}),
+    "ActiveBoxConstrainedSPD": dict(xexact=[9, 9, 9], bfrom=[1, 1, 1], op={
+        "kind": "Box", "dim": 3, "lb": {"arr": "suite.active.lb"}, "ub": {"arr": "suite.active.ub"}}),
+}
+
+SUITE_ARRAYS = {
+    "suite.box.lb": np.array([0, 0, 0]), "suite.box.ub": np.array([2, 2, 2]),
+    "suite.thin.lb": np.array([-10, -0.1, 0.9]), "suite.thin.ub": np.array([10, 0.1, 1.1]),
+    "suite.active.lb": np.array([9, 9, 9]), "suite.active.ub": np.array([10, 10, 10]),
+    "readme.lb": np.array([-2, -2, -4]), "readme.ub": np.array([2, 2, 5]),
+}
+
+SOLVER_NAMES = ["PGD", "APGD", "APGDAntiRelaxation", "BBPGD", "BBPGDf", "SPG", "MPRGP"]
+
+
+def suite_problem(name):
+    """(A int64, b int64) exactly as problem_suite.py builds them."""
+    A = np.array(TRIDIAG)
+    return A, -A.dot(np.array(SUITE[name]["bfrom"]))
+
+
+def _box_half(n):
+    return {"kind": "Box", "dim": n, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}}
+
+
+def solver_cases():
+    """List of dicts: id, problem ('suite:<name>' | 'readme' | 'gen:<n>:<seed>'), solver, tol,
+    max_mv (None = inf), kwargs, op spec, rng_seed."""
+    cases = []
+    for pname in SUITE:
+        for s in SOLVER_NAMES:
+            cases.append(dict(id="suite.%s.%s" % (pname, s), problem="suite:" + pname, solver=s,
+                              tol=1e-8, max_mv=10000, kwargs={"step_size": 0.1} if s == "PGD" else {},
+                              op=SUITE[pname]["op"], rng_seed=1234))
+    cases.append(dict(id="readme.SPG", problem="readme", solver="SPG", tol=1e-10, max_mv=5000, kwargs={},
+                      op={"kind": "Box", "dim": 3, "lb": {"arr": "readme.lb"}, "ub": {"arr": "readme.ub"}},
+                      rng_seed=0))
+    for n in (64, 256, 1024, 4096):
+        g = "gen:%d:1234" % n
+        half = n // 2
+        nsph = n // 3
+        rest = n - 3 * nsph
+        many = {"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 3}, "count": nsph}}
+        if rest:
+            many["ops"] = [{"kind": "Identity", "dim": rest}]
+        table = [
+            ("APGD.box", "APGD", 1e-8, 5000, _box_half(n)),
+            ("BBPGD.box", "BBPGD", 1e-8, 5000, _box_half(n)),
+            ("SPG.box", "SPG", 1e-8, 5000, _box_half(n)),
+            ("MPRGP.box", "MPRGP", 1e-6, 300, _box_half(n)),
+            ("BBPGD.cone", "BBPGD", 1e-8, 64, {"kind": "Cone", "dim": n}),
+            ("SPG.boxcone", "SPG", 1e-8, 64, {"kind": "Disjoint", "ops": [_box_half(half),
+                                                                         {"kind": "Cone", "dim": n - half}]}),
+            ("BBPGD.spheres", "BBPGD", 1e-8, 5000, many),
+        ]
+        if n <= 1024:
+            table += [
+                ("PGD.box", "PGD", 1e-8, 5000, _box_half(n)),
+                ("APGDAntiRelaxation.box", "APGDAntiRelaxation", 1e-8, 5000, _box_half(n)),
+                ("BBPGDf.box", "BBPGDf", 1e-8, 5000, _box_half(n)),
+                ("APGD.identity", "APGD", 1e-8, 5000, None),
+                ("BBPGD.sphere", "BBPGD", 1e-8, 5000, {"kind": "Sphere", "dim": n, "radius": 4.0}),
+                ("MPRGP.lower", "MPRGP", 1e-6, 300, {"kind": "Lower", "dim": n, "lb": {"fill": -0.25}}),
+            ]
+        for tag, s, tol, mx, op in table:
+            cases.append(dict(id="gen%d.%s" % (n, tag), problem=g, solver=s, tol=tol, max_mv=mx,
+                              kwargs={"step_size": 0.3} if s == "PGD" else {}, op=op, rng_seed=1234))
+    # exit paths: MV-cap behaviour, stale iterate, overshoot, UnboundLocalError
+    for s in SOLVER_NAMES:
+        for mx in (1, 2, 3, 4, 11, 12):
+            cases.append(dict(id="exit.%s.max%d" % (s, mx), problem="gen:64:1234", solver=s, tol=1e-12,
+                              max_mv=mx, kwargs={"step_size": 0.3} if s == "PGD" else {},
+                              op=_box_half(64), rng_seed=1234))
+    # warm start + default (infinite) MV budget
+    cases.append(dict(id="warm.BBPGD", problem="gen:256:7", solver="BBPGD", tol=1e-9, max_mv=None, kwargs={},
+                      op=_box_half(256), rng_seed=1234, x0="ramp"))
+    cases.append(dict(id="warm.APGD", problem="gen:256:7", solver="APGD", tol=1e-8, max_mv=None, kwargs={},
+                      op=_box_half(256), rng_seed=1234, x0="ramp"))
+    cases.append(dict(id="warm.MPRGP.identity", problem="gen:64:7", solver="MPRGP", tol=1e-8, max_mv=500,
+                      kwargs={}, op=None, rng_seed=1234, x0="ramp"))
+    return cases
+
+
+def case_x0(case, n):
+    if case.get("x0") == "ramp":
+        return np.linspace(-0.75, 0.75, n)
+    return None
