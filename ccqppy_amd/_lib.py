@@ -1,0 +1,110 @@
+"""ctypes binding of libccqp_hip.so (the C ABI declared in include/ccqp_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or fails to load, importing the
+compute path raises `CCQPHipUnavailable` with the build instruction.  `import torch` happens
+first so that the library binds to the HIP runtime torch already mapped (one runtime/process).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64.so.7 with torch)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libccqp_hip.so")
+
+NUM_SLOTS = 64
+MAX_DOTS = 8
+SMALL_SEG_MAX = 64
+
+OP_IDENTITY, OP_LOWER, OP_UPPER, OP_BOX, OP_SPHERE, OP_CONE = range(6)
+SEG_LB_INT, SEG_UB_INT, SEG_P0_INT = 1, 2, 4
+
+
+class CCQPHipUnavailable(ImportError):
+    pass
+
+
+class CCQPHipError(RuntimeError):
+    pass
+
+
+class Seg(ctypes.Structure):
+    """struct ccqp_seg (include/ccqp_hip.h)."""
+    _fields_ = [("kind", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("offset", ctypes.c_int64), ("dim", ctypes.c_int64),
+                ("lb", ctypes.c_void_p), ("ub", ctypes.c_void_p),
+                ("lb_s", ctypes.c_double), ("ub_s", ctypes.c_double)]
+
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_D = _c.c_double
+_I = _c.c_int
+
+# name -> argtypes (restype is int unless noted); must list EVERY symbol of include/ccqp_hip.h
+SIGNATURES = {
+    "ccqp_abi_version": [],
+    "ccqp_last_error": [],
+    "ccqp_ctx_create": [_I, _c.POINTER(_P)],
+    "ccqp_ctx_destroy": [_P],
+    "ccqp_ctx_info": [_P, _c.POINTER(_I), _c.POINTER(_I), _c.c_char_p, _I],
+    "ccqp_scalars_read": [_P, _I, _I, _c.POINTER(_D), _P],
+    "ccqp_scalars_devptr": [_P, _c.POINTER(_P)],
+    "ccqp_gemv_f64": [_P, _P, _I64, _P, _P, _I64, _I64, _I, _P],
+    "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
+    "ccqp_axpby_f64": [_P, _D, _P, _D, _P, _P, _I64, _P],
+    "ccqp_scale_f64": [_P, _D, _P, _P, _I64, _P],
+    "ccqp_copy_f64": [_P, _P, _P, _I64, _P],
+    "ccqp_fill_f64": [_P, _D, _P, _I64, _P],
+    "ccqp_mul_f64": [_P, _P, _P, _P, _I64, _P],
+    "ccqp_muldiv_f64": [_P, _P, _P, _D, _P, _I64, _P],
+    "ccqp_submul_f64": [_P, _P, _P, _P, _P, _I64, _P],
+    "ccqp_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _I64, _I, _P],
+    "ccqp_proj_elementwise_f64": [_P, _c.POINTER(Seg), _D, _P, _D, _P, _P, _P],
+    "ccqp_proj_normscale_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
+    "ccqp_proj_small_segments_f64": [_P, _P, _I64, _P, _P, _I, _P],
+    "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
+    "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
+    "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],
+    "ccqp_normal_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
+    "ccqp_normal_sphere_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _I, _P],
+    "ccqp_chopped_gradient_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
+    "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
+    "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises CCQPHipUnavailable if not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CCQPHipUnavailable(
+            "ccqppy_amd: %s is missing.  Build it with `make` at the repository root "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise CCQPHipUnavailable("ccqppy_amd: cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CCQPHipUnavailable("ccqppy_amd: %s does not export %s (stale build?)"
+                                     % (LIB_PATH, name)) from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "ccqp_last_error" else ctypes.c_int
+    if lib.ccqp_abi_version() != 1:
+        raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = _lib.ccqp_last_error()
+        raise CCQPHipError("libccqp_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

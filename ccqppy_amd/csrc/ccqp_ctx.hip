@@ -1,0 +1,93 @@
+// Context, error reporting and the scalar slab of libccqp_hip.so.
+#include <stdarg.h>
+
+#include "ccqp_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void ccqp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ccqp_abi_version(void) { return CCQP_ABI_VERSION; }
+
+extern "C" const char* ccqp_last_error(void) { return g_err; }
+
+extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
+  CCQP_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  CCQP_HIP(hipGetDeviceCount(&ndev));
+  CCQP_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+  int prev = 0;
+  CCQP_HIP(hipGetDevice(&prev));
+  CCQP_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  CCQP_HIP(hipGetDeviceProperties(&prop, device));
+  ccqp_ctx* c = new ccqp_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
+  c->arch[sizeof(c->arch) - 1] = 0;
+  c->slots = nullptr;
+  c->partials = nullptr;
+  c->host_slots = nullptr;
+  hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&c->partials, (size_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc(&c->host_slots, CCQP_NUM_SLOTS * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(c->slots, 0, CCQP_NUM_SLOTS * sizeof(double));
+  if (e != hipSuccess) {
+    ccqp_set_error("ccqp_ctx_create: allocation failed: %s", hipGetErrorString(e));
+    if (c->slots) (void)hipFree(c->slots);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->host_slots) (void)hipHostFree(c->host_slots);
+    delete c;
+    (void)hipSetDevice(prev);
+    return CCQP_ERR_HIP;
+  }
+  (void)hipSetDevice(prev);
+  *out = c;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
+  if (!c) return CCQP_OK;
+  (void)hipFree(c->slots);
+  (void)hipFree(c->partials);
+  (void)hipHostFree(c->host_slots);
+  delete c;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_ctx_info(ccqp_ctx* c, int* device, int* num_cu, char* arch_buf, int buflen) {
+  CCQP_REQUIRE(c != nullptr, "ctx is NULL");
+  if (device) *device = c->device;
+  if (num_cu) *num_cu = c->num_cu;
+  if (arch_buf && buflen > 0) {
+    strncpy(arch_buf, c->arch, (size_t)buflen - 1);
+    arch_buf[buflen - 1] = 0;
+  }
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_scalars_read(ccqp_ctx* c, int slot0, int count, double* host_out, void* stream) {
+  CCQP_REQUIRE(c != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(host_out != nullptr, "host_out is NULL");
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, count), "slot range outside the slab");
+  hipStream_t s = (hipStream_t)stream;
+  if (count > 0)
+    CCQP_HIP(hipMemcpyAsync(c->host_slots + slot0, c->slots + slot0, (size_t)count * sizeof(double),
+                            hipMemcpyDeviceToHost, s));
+  CCQP_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < count; ++i) host_out[i] = c->host_slots[slot0 + i];
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_scalars_devptr(ccqp_ctx* c, double** out) {
+  CCQP_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+  *out = c->slots;
+  return CCQP_OK;
+}

@@ -1,0 +1,143 @@
+// Internal declarations shared by the translation units of libccqp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ccqp_hip.h"
+
+#define CCQP_BLOCK 256          // 4 wave64 per workgroup
+#define CCQP_RED_CHUNK 8192     // elements per stage-1 reduction block (32 per thread)
+#define CCQP_RED_MAXBLK 1024    // stage-1 blocks per reduction (partials per dot)
+
+struct ccqp_ctx {
+  int device;
+  int num_cu;
+  char arch[64];
+  double* slots;      // device, CCQP_NUM_SLOTS doubles
+  double* partials;   // device, CCQP_MAX_DOTS * CCQP_RED_MAXBLK doubles
+  double* host_slots; // pinned host mirror
+};
+
+void ccqp_set_error(const char* fmt, ...);
+
+#define CCQP_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      ccqp_set_error("%s: %s", __func__, msg);                    \
+      return CCQP_ERR_INVALID;                                    \
+    }                                                             \
+  } while (0)
+
+#define CCQP_HIP(call)                                                            \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      ccqp_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+      return CCQP_ERR_HIP;                                                        \
+    }                                                                             \
+  } while (0)
+
+#define CCQP_LAUNCH_CHECK()                                                        \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      ccqp_set_error("%s: kernel launch failed: %s", __func__, hipGetErrorString(e_)); \
+      return CCQP_ERR_HIP;                                                         \
+    }                                                                              \
+  } while (0)
+
+static inline int ccqp_slot_ok(int slot, int count) {
+  return slot >= 0 && count >= 0 && slot + count <= CCQP_NUM_SLOTS;
+}
+
+// Stage-1 geometry of every reduction: a function of n ONLY (determinism contract).
+static inline void ccqp_red_geometry(int64_t n, int64_t* chunk, int* nblk) {
+  int64_t c = CCQP_RED_CHUNK;
+  if ((n + c - 1) / c > CCQP_RED_MAXBLK) {
+    c = (n + CCQP_RED_MAXBLK - 1) / CCQP_RED_MAXBLK;
+    c = (c + CCQP_BLOCK - 1) / CCQP_BLOCK * CCQP_BLOCK;
+  }
+  int64_t nb = n > 0 ? (n + c - 1) / c : 1;
+  *chunk = c;
+  *nblk = (int)nb;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device helpers
+// Sum over the 64 lanes of a wave; butterfly => every lane holds the same bits.
+__device__ __forceinline__ double ccqp_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum over a 256-thread workgroup in a fixed order (wave 0..3); result valid in thread 0.
+__device__ __forceinline__ double ccqp_block_sum(double v, double* lds4) {
+  v = ccqp_wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+  __syncthreads();
+  return s;
+}
+
+// np.isclose(a, b) with the default rtol=1e-5, atol=1e-8 (numpy/_core/numeric.py):
+//   (|a-b| <= atol + rtol*|b|) & isfinite(b) | (a == b)
+__device__ __forceinline__ bool ccqp_isclose(double a, double b) {
+  const double d = fabs(a - b);
+  const double t = 1e-5 * fabs(b);
+  const double tol = 1e-8 + t;
+  return ((d <= tol) && isfinite(b)) || (a == b);
+}
+
+struct ccqp_segk {  // by-value kernel copy of a descriptor, block-local pointers
+  int kind, flags;
+  int64_t dim;
+  const double* lb;
+  const double* ub;
+  double lb_s, ub_s;
+};
+
+// bound * mask exactly as numpy evaluates it: float bound -> float multiply (bound*0.0 keeps the
+// bound's sign / turns inf into NaN); integer-typed bound -> integer multiply -> +0.0 or bound.
+__device__ __forceinline__ double ccqp_bound_term(double bound, bool mask, bool is_int) {
+  if (is_int) return mask ? bound : 0.0;
+  return bound * (mask ? 1.0 : 0.0);
+}
+
+// Literal evaluation of the reference's elementwise projections (solution_spaces.py:200-201,
+// 276-277, 363-366), one rounding per operation (this file is built with -ffp-contract=off).
+__device__ __forceinline__ double ccqp_proj_elem(int kind, int flags, double x, double lb, double ub) {
+  switch (kind) {
+    case CCQP_OP_LOWER: {
+      const bool m = x < lb;
+      const double t1 = ccqp_bound_term(lb, m, flags & CCQP_SEG_LB_INT);
+      const double t2 = x * (m ? 0.0 : 1.0);
+      return t1 + t2;
+    }
+    case CCQP_OP_UPPER: {
+      const bool m = x > ub;
+      const double t1 = ccqp_bound_term(ub, m, flags & CCQP_SEG_UB_INT);
+      const double t2 = x * (m ? 0.0 : 1.0);
+      return t1 + t2;
+    }
+    case CCQP_OP_BOX: {
+      const bool hi = x > ub;
+      const bool lo = x < lb;
+      const bool li = flags & CCQP_SEG_LB_INT, ui = flags & CCQP_SEG_UB_INT;
+      const double t1 = ccqp_bound_term(lb, lo, li);
+      const double t2 = ccqp_bound_term(ub, hi, ui);
+      const double s = t1 + t2;
+      double t3 = x * (hi ? 0.0 : 1.0);
+      t3 = t3 * (lo ? 0.0 : 1.0);
+      return s + t3;
+    }
+    default:
+      return x;  // identity
+  }
+}
+#endif  // __HIPCC__

@@ -1,0 +1,134 @@
+"""The `A` of a solve as a device operator.
+
+The reference only ever calls `A.dot(v)` (solvers.py:25,133,...).  Here that call is one of
+  * DenseOperator        -- the whole matrix on one GPU, `ccqp_gemv_f64`;
+  * RowShardedOperator   -- one process per GPU (torch.distributed, backend "nccl" = RCCL over
+                            xGMI): rank r owns the contiguous row block [r*n/G, (r+1)*n/G), all
+                            n-vectors are replicated, every rank runs the same host loop.  One
+                            matvec = local GEMV on the block -> ONE exchange of the n-vector
+                            (all-gather by default; zero-padded all-reduce on request).
+Because every row sum is produced by exactly one wave in an order that depends on n only
+(include/ccqp_hip.h), A.x is bitwise identical for every GPU count, hence so are all scalars
+and therefore the control flow and MV counts on every rank.
+"""
+import torch
+
+from ._engine import get_engine
+
+
+def row_partition(n, world, rank):
+    """Contiguous row block of `rank`: (row0, rows, rows_per) with rows_per = ceil(n/world)."""
+    per = -(-n // world)
+    r0 = min(rank * per, n)
+    r1 = min(r0 + per, n)
+    return r0, r1 - r0, per
+
+
+def batch_partition(nproblems, world, rank):
+    """Problems of the batch-sharded mode handled by `rank`: p with p % world == rank."""
+    return list(range(rank, nproblems, world))
+
+
+class DenseOperator:
+    def __init__(self, A, engine=None):
+        if isinstance(A, torch.Tensor) and A.is_cuda:
+            self.engine = engine or get_engine(A.device)
+        else:
+            self.engine = engine or get_engine()
+        self.A = self.engine.to_device(A)
+        assert self.A.dim() == 2
+        self.n = self.A.shape[1]
+        self.rows = self.A.shape[0]
+
+    def matvec(self, x, y, b=None, g=None):
+        self.engine.gemv(self.A, x, y, b, g)
+
+
+class VectorExchange:
+    """Reassembles the replicated n-vector from per-rank row slabs.  Backend-agnostic on purpose:
+    the same code runs over RCCL (device tensors) and, in the CPU test-suite, over gloo."""
+
+    def __init__(self, n, group=None, mode="allgather"):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n = n
+        self.row0, self.rows, self.per = row_partition(n, self.world, self.rank)
+        assert mode in ("allgather", "allreduce")
+        self.mode = mode
+        self.even = (n % self.world) == 0
+        self._pad = None
+        backend = dist.get_backend(group)
+        self.stage_cpu = backend != "nccl"   # gloo: stage device tensors through the host (tests only)
+
+    def _run(self, fn, t):
+        """Run collective `fn` on tensor t, staging through the host when the backend cannot
+        take device tensors (gloo; test path only)."""
+        if self.stage_cpu and t.is_cuda:
+            host = t.cpu()
+            fn(host)
+            t.copy_(host)
+        else:
+            fn(t)
+
+    def _gather_into(self, full, mine):
+        # NCCL/RCCL accepts the in-place form (mine is a view of full at rank*chunk)
+        src = mine if (full.is_cuda and not self.stage_cpu) else mine.clone()
+        chunks = list(full.chunk(self.world))
+        try:
+            self.dist.all_gather_into_tensor(full, src, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            self.dist.all_gather(chunks, src, group=self.group)
+
+    def __call__(self, y):
+        """y holds this rank's slab at [row0, row0+rows); on return every rank holds all of y."""
+        if self.world == 1:
+            return
+        dist = self.dist
+        if self.mode == "allreduce":
+            # zero everything but the own slab, then sum: adding zeros is exact
+            if self.row0 > 0:
+                y[:self.row0].zero_()
+            if self.row0 + self.rows < self.n:
+                y[self.row0 + self.rows:].zero_()
+            self._run(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group), y)
+            return
+        if self.even:
+            self._run(lambda t: self._gather_into(t, t[self.row0:self.row0 + self.rows]), y)
+            return
+        # ragged: gather fixed-size (padded) slabs, then drop the padding
+        if self._pad is None or self._pad.device != y.device:
+            self._pad = torch.zeros(self.per * self.world, dtype=y.dtype, device=y.device)
+        full = self._pad
+        lo = self.rank * self.per
+        full[lo:lo + self.rows].copy_(y[self.row0:self.row0 + self.rows])
+        self._run(lambda t: self._gather_into(t, t[lo:lo + self.per]), full)
+        # rank r's rows sit at [r*per, r*per + rows_r); only the last non-empty rank is short
+        y.copy_(full[:self.n])
+
+
+class RowShardedOperator:
+    """A row block of A per rank + one vector exchange per matvec."""
+
+    def __init__(self, A_local, n, group=None, mode="allgather", engine=None):
+        self.engine = engine or get_engine(A_local.device)
+        self.A = A_local
+        self.n = n
+        self.exchange = VectorExchange(n, group, mode)
+        self.row0, self.rows = self.exchange.row0, self.exchange.rows
+        assert tuple(A_local.shape) == (self.rows, n), "local block must be rows [row0, row0+rows) x n"
+
+    def matvec(self, x, y, b=None, g=None):
+        sl = slice(self.row0, self.row0 + self.rows)
+        self.engine.gemv(self.A, x, y[sl])
+        self.exchange(y)
+        if g is not None:
+            self.engine.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
+
+
+def as_operator(A, engine=None):
+    if hasattr(A, "matvec") and hasattr(A, "engine"):
+        return A
+    return DenseOperator(A, engine)

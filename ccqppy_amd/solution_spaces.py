@@ -1,0 +1,453 @@
+"""Projection operators onto convex feasible sets -- MI355X (HIP) implementation.
+
+Drop-in for `ccqppy.solution_spaces` (reference: /root/reference/src/ccqppy/solution_spaces.py):
+same class names, constructor arguments, attributes (`dim`, `lower_bound`, `upper_bound`,
+`radius`, `aspect_ratio`, `proj_ops`), `name` strings, `embedded_dimension`, `__call__` and
+`normal_vector`.  `op(x)` accepts a numpy array (copied to the GPU and back) or a torch tensor
+on a ROCm device (zero copy) and returns the same kind; every FLOP runs in libccqp_hip.so.
+There is no CPU fallback.  `plot` / `projected_gradient` are out of scope.
+
+Device protocol used by `ccqppy_amd.solvers` (all arguments are fp64 device tensors):
+  _dev_project(eng, x, out)                  out = P(x)            (x is not out)
+  _dev_step_project(eng, a, x, b, y, out)    out = P(a*x + b*y)
+  _dev_residual_sq(eng, x, g, c, gd, slot)   slab[slot] = |c*(x - P(x - gd*g))|^2
+  _dev_normal_vector(eng, x, out)            out = normal_vector(x)
+"""
+from abc import ABC, abstractmethod
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._engine import get_engine
+
+__all__ = ["ProjOpBase", "IdentityProjOp", "LowerBoundProjOp", "UpperBoundProjOp", "BoxProjOp",
+           "SphereProjOp", "ConeProjOp", "DisjointProjOp"]
+
+# scalar-slab slots reserved for operator internals (solvers use 0..31)
+_SLOT_NORM2 = 40   # |x_block|^2 of a Sphere/Cone block
+_SLOT_DIST2 = 41   # |x - P(x)|^2 of a block (normal_vector)
+_SLOT_LEN2 = 42    # |P(x)|^2 of a Sphere block (normal_vector)
+
+
+def _is_scalar(b):
+    return np.ndim(b) == 0
+
+
+def _is_int(b):
+    if isinstance(b, (bool, np.bool_)):
+        return False
+    if isinstance(b, (int, np.integer)):
+        return True
+    return isinstance(b, np.ndarray) and np.issubdtype(b.dtype, np.integer)
+
+
+class ProjOpBase(ABC):
+    """Mirror of the reference ABC (solution_spaces.py:9-74)."""
+    _kind = None            # CCQP_OP_* for leaf operators
+    _fixed_dim = True       # False: the reference never uses `dim` inside __call__ (Identity/Sphere/Cone)
+
+    def __init__(self, embedded_dimension):
+        self.dim = embedded_dimension
+
+    @property
+    @abstractmethod
+    def name(self):
+        """Return the name of the projection operator."""
+
+    @property
+    def embedded_dimension(self):
+        """Return the embedded dimension of the projection operator."""
+        return self.dim
+
+    # -------------------------------------------------------------- public entry points
+    def __call__(self, x):
+        eng, xd, n = self._stage_in(x)
+        out = eng.empty(n)
+        same = self._dev_project(eng, xd, out, want_alias=True)
+        if same:
+            return x          # the reference returns the argument object itself
+        return self._stage_out(x, out)
+
+    def normal_vector(self, x):
+        eng, xd, n = self._stage_in(x)
+        out = eng.empty(n)
+        self._dev_normal_vector(eng, xd, out)
+        return self._stage_out(x, out)
+
+    def _stage_in(self, x):
+        if isinstance(x, torch.Tensor):
+            eng = get_engine(x.device if x.is_cuda else None)
+        else:
+            eng = get_engine()
+        xd = eng.to_device(x).reshape(-1)
+        n = xd.numel()
+        if self._fixed_dim and n != self.dim:
+            raise ValueError("operands could not be broadcast together with shapes (%d,) (%d,)" % (n, self.dim))
+        return eng, xd, n
+
+    @staticmethod
+    def _stage_out(x, out):
+        if isinstance(x, torch.Tensor):
+            return out
+        return out.cpu().numpy()
+
+    # -------------------------------------------------------------- device protocol (generic parts)
+    def _leaves(self, offset=0):
+        return [(self, offset)]
+
+    def _dev_project(self, eng, x, out, want_alias=False):
+        return self._block_project(eng, x, out, 0, x.numel(), want_alias)
+
+    def _dev_step_project(self, eng, a, x, b, y, out):
+        t = eng.scratch(x.numel(), "op.step")
+        eng.axpby(a, x, b, y, t)
+        self._dev_project(eng, t, out)
+
+    def _dev_residual_sq(self, eng, x, g, c, gd, slot):
+        n = x.numel()
+        t1 = eng.scratch(n, "op.res1")
+        t2 = eng.scratch(n, "op.res2")
+        eng.axpby(1.0, x, -gd, g, t1)      # x - gd*g
+        self._dev_project(eng, t1, t2)     # P(.)
+        eng.axpby(1.0, x, -1.0, t2, t1)    # x - P(.)
+        eng.scale(c, t1, t1)               # c * (...)
+        eng.dots([(t1, t1)], slot)
+
+    def _dev_normal_vector(self, eng, x, out):
+        self._block_normal(eng, x, out, 0, x.numel())
+
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        raise NotImplementedError
+
+    def _block_normal(self, eng, x, out, offset, n):
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------------ elementwise family
+class _ElementwiseOp(ProjOpBase):
+    """Identity / Lower / Upper / Box: one fused kernel per use, literal numpy expression order."""
+
+    def _bounds(self):
+        return None, None
+
+    def _seg(self, eng, offset, n):
+        lb, ub = self._bounds()
+        cache = self.__dict__.setdefault("_dev_bounds", {})
+        key = (eng.index, id(lb), id(ub))
+        ent = cache.get(key)
+        if ent is None:
+            def stage(b):
+                if b is None or _is_scalar(b):
+                    return None
+                return eng.to_device(np.asarray(b)).reshape(-1)
+            ent = (stage(lb), stage(ub))
+            cache.clear()
+            cache[key] = ent
+        dlb, dub = ent
+        seg = _lib.Seg()
+        seg.kind = self._kind
+        seg.flags = (_lib.SEG_LB_INT if _is_int(lb) else 0) | (_lib.SEG_UB_INT if _is_int(ub) else 0)
+        seg.offset = offset
+        seg.dim = n
+        seg.lb = dlb.data_ptr() if dlb is not None else None
+        seg.ub = dub.data_ptr() if dub is not None else None
+        seg.lb_s = float(lb) if (lb is not None and _is_scalar(lb)) else 0.0
+        seg.ub_s = float(ub) if (ub is not None and _is_scalar(ub)) else 0.0
+        seg._keep = ent
+        return seg
+
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        eng.proj_elementwise(self._seg(eng, offset, n), x, out)
+        return False
+
+    def _dev_step_project(self, eng, a, x, b, y, out):
+        eng.proj_elementwise(self._seg(eng, 0, x.numel()), x, out, a, b, y)
+
+    def _dev_residual_sq(self, eng, x, g, c, gd, slot):
+        eng.residual_sq_elementwise(self._seg(eng, 0, x.numel()), x, g, c, gd, slot)
+
+    def _scalar_bound_names(self):
+        lb, ub = self._bounds()
+        return [type(b).__name__ for b in (ub, lb) if b is not None and _is_scalar(b)]
+
+    def _block_normal(self, eng, x, out, offset, n):
+        # solution_spaces.py:146-160, 222-236, 306-322
+        xp = eng.scratch(x.numel(), "op.nv.xp")
+        d = eng.scratch(x.numel(), "op.nv.d")
+        sl = slice(offset, offset + n)
+        self._block_project(eng, x, xp, offset, n)
+        eng.axpby(1.0, x[sl], -1.0, xp[sl], d[sl])
+        eng.dots([(d[sl], d[sl])], _SLOT_DIST2)
+        scalars = self._scalar_bound_names()
+        if scalars and n > 0:
+            # the reference indexes `self.upper_bound[i]`: TypeError for a scalar bound, but only
+            # when x is not "outside" (it returns zeros before reaching the loop otherwise)
+            dist2 = eng.read(_SLOT_DIST2, 1)[0]
+            if np.isclose(np.sqrt(dist2), 0):
+                raise TypeError("'%s' object is not subscriptable" % scalars[0])
+        eng.normal_elementwise(self._seg(eng, offset, n), xp, out, _SLOT_DIST2)
+
+
+class IdentityProjOp(_ElementwiseOp):
+    """{x in R^n}.  solution_spaces.py:77-125."""
+    _kind = _lib.OP_IDENTITY
+    _fixed_dim = False
+
+    def __init__(self, embedded_dimension):
+        self.dim = embedded_dimension
+
+    @property
+    def name(self):
+        return "Identity"
+
+    def __call__(self, x):
+        return x                       # same object, :125
+
+    def normal_vector(self, x):
+        # :92-98 returns np.zeros(self.dim) whatever x is
+        if isinstance(x, torch.Tensor):
+            return torch.zeros(self.dim, dtype=torch.float64, device=x.device)
+        return np.zeros(self.dim)
+
+    def _block_normal(self, eng, x, out, offset, n):
+        eng.fill(0.0, out[offset:offset + n])
+
+
+class LowerBoundProjOp(_ElementwiseOp):
+    """{x : x >= lb}.  solution_spaces.py:128-201; default lb = -1 (:134)."""
+    _kind = _lib.OP_LOWER
+
+    def __init__(self, embedded_dimension, lower_bound=None):
+        self.dim = embedded_dimension
+        self.lower_bound = lower_bound if lower_bound is not None else -np.ones(embedded_dimension)
+
+    @property
+    def name(self):
+        return "Lower Bound"
+
+    def _bounds(self):
+        return self.lower_bound, None
+
+
+class UpperBoundProjOp(_ElementwiseOp):
+    """{x : x <= ub}.  solution_spaces.py:204-277; default ub = +1 (:210)."""
+    _kind = _lib.OP_UPPER
+
+    def __init__(self, embedded_dimension, upper_bound=None):
+        self.dim = embedded_dimension
+        self.upper_bound = upper_bound if upper_bound is not None else np.ones(embedded_dimension)
+
+    @property
+    def name(self):
+        return "Upper Bound"
+
+    def _bounds(self):
+        return None, self.upper_bound
+
+
+class BoxProjOp(_ElementwiseOp):
+    """{x : lb <= x <= ub}.  solution_spaces.py:280-366; defaults -1 / +1 (:286,291)."""
+    _kind = _lib.OP_BOX
+
+    def __init__(self, embedded_dimension, lower_bound=None, upper_bound=None):
+        self.dim = embedded_dimension
+        self.lower_bound = lower_bound if lower_bound is not None else -np.ones(embedded_dimension)
+        self.upper_bound = upper_bound if upper_bound is not None else np.ones(embedded_dimension)
+
+    @property
+    def name(self):
+        return "Box"
+
+    def _bounds(self):
+        return self.lower_bound, self.upper_bound
+
+
+# ------------------------------------------------------------------ norm-based family
+class _NormOp(ProjOpBase):
+    _fixed_dim = False
+
+    def _seg(self, eng, offset, n):
+        raise NotImplementedError
+
+    def _alias_test(self, r, x_last):
+        raise NotImplementedError
+
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        if n == 0:
+            return False
+        sl = x[offset:offset + n]
+        eng.dots([(sl, sl)], _SLOT_NORM2)
+        if want_alias:
+            # `return x` branches of the reference hand back the argument object (:435, :487)
+            r = np.sqrt(eng.read(_SLOT_NORM2, 1)[0])
+            if self._alias_test(r, x, offset, n):
+                return True
+        eng.proj_normscale(self._seg(eng, offset, n), x, out, _SLOT_NORM2)
+        return False
+
+
+class SphereProjOp(_NormOp):
+    """{x : |x| <= r}.  solution_spaces.py:369-435; default radius 1 (:375)."""
+    _kind = _lib.OP_SPHERE
+
+    def __init__(self, embedded_dimension, radius=None):
+        self.dim = embedded_dimension
+        self.radius = radius if radius is not None else 1
+
+    @property
+    def name(self):
+        return "Sphere"
+
+    def _seg(self, eng, offset, n):
+        seg = _lib.Seg()
+        seg.kind = self._kind
+        seg.flags = _lib.SEG_P0_INT if _is_int(self.radius) else 0
+        seg.offset = offset
+        seg.dim = n
+        seg.lb_s = float(self.radius)
+        seg.ub_s = 0.0
+        return seg
+
+    def _alias_test(self, r, x, offset, n):
+        return not (r > self.radius)
+
+    def _block_normal(self, eng, x, out, offset, n):
+        # solution_spaces.py:389-403
+        if n == 0:
+            return
+        xp = eng.scratch(x.numel(), "op.nv.xp")
+        d = eng.scratch(x.numel(), "op.nv.d")
+        sl = slice(offset, offset + n)
+        self._block_project(eng, x, xp, offset, n)
+        eng.axpby(1.0, x[sl], -1.0, xp[sl], d[sl])
+        eng.dots([(d[sl], d[sl]), (xp[sl], xp[sl])], _SLOT_DIST2)   # DIST2, LEN2 are adjacent slots
+        eng.normal_sphere(self._seg(eng, offset, n), xp, out, _SLOT_DIST2, _SLOT_LEN2)
+
+
+class ConeProjOp(_NormOp):
+    """{[x, z] : x.x <= mu^2 z^2} as coded in solution_spaces.py:438-492.  The reference flags this
+    operator "bugged" (:439: the norm at :484 includes the last entry); it is reproduced as is."""
+    _kind = _lib.OP_CONE
+
+    def __init__(self, embedded_dimension, aspect_ratio=None):
+        self.dim = embedded_dimension
+        self.aspect_ratio = aspect_ratio if aspect_ratio is not None else 1
+
+    @property
+    def name(self):
+        return "Cone"
+
+    def _seg(self, eng, offset, n):
+        mu = self.aspect_ratio
+        seg = _lib.Seg()
+        seg.kind = self._kind
+        seg.flags = _lib.SEG_P0_INT if _is_int(mu) else 0
+        seg.offset = offset
+        seg.dim = n
+        seg.lb_s = float(mu)
+        seg.ub_s = float(mu ** 2 + 1)     # evaluated here with Python/numpy semantics (:491)
+        return seg
+
+    def _alias_test(self, r, x, offset, n):
+        z = np.float64(x[offset + n - 1].item())
+        return bool(self.aspect_ratio * z >= r)
+
+    def normal_vector(self, x):
+        raise NotImplementedError("Cone normal not implemented, yet.")   # :465
+
+    def proximal_gradient(self, x, g):
+        raise NotImplementedError("Cone proximal gradient not implemented, yet.")   # :468
+
+    def _block_normal(self, eng, x, out, offset, n):
+        raise NotImplementedError("Cone normal not implemented, yet.")
+
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        if x.data_ptr() == out.data_ptr():
+            raise ValueError("ConeProjOp cannot project in place")
+        return super()._block_project(eng, x, out, offset, n, want_alias)
+
+
+# ------------------------------------------------------------------ disjoint union
+class DisjointProjOp(ProjOpBase):
+    """Cartesian product of sub-operators on consecutive slices.  solution_spaces.py:495-560.
+
+    Device plan: every leaf block of dimension <= CCQP_SMALL_SEG_MAX goes into ONE segment-table
+    launch (one thread per block; the reference spends ~85 % of a solve in the Python loop over
+    such blocks); larger blocks get their own kernels."""
+
+    def __init__(self, *convex_proj_ops):
+        self.proj_ops = convex_proj_ops
+        self.dim = 0
+        for proj_op in self.proj_ops:
+            self.dim += proj_op.embedded_dimension
+
+    @property
+    def name(self):
+        return "DisjointUnion"
+
+    def _leaves(self, offset=0):
+        out = []
+        for op in self.proj_ops:
+            out.extend(op._leaves(offset))
+            offset += op.embedded_dimension
+        return out
+
+    def _plan(self, eng, for_normal):
+        cache = self.__dict__.setdefault("_plans", {})
+        key = (eng.index, for_normal)
+        plan = cache.get(key)
+        if plan is not None:
+            return plan
+        small, large = [], []
+        for op, off in self._leaves():
+            d = op.embedded_dimension
+            if d == 0:
+                continue
+            tabled = d <= _lib.SMALL_SEG_MAX and op._kind is not None
+            if for_normal and tabled:
+                if isinstance(op, ConeProjOp):
+                    tabled = False         # raises when reached, like the reference
+                elif isinstance(op, _ElementwiseOp) and op._scalar_bound_names():
+                    tabled = False         # TypeError path needs the host
+            (small if tabled else large).append((op, off))
+        table = None
+        keep = []
+        if small:
+            segs = (_lib.Seg * len(small))()
+            for i, (op, off) in enumerate(small):
+                s = op._seg(eng, off, op.embedded_dimension)
+                keep.append(getattr(s, "_keep", None))
+                ctypes.memmove(ctypes.byref(segs[i]), ctypes.byref(s), ctypes.sizeof(_lib.Seg))
+            raw = np.frombuffer(bytes(segs), dtype=np.uint8).copy()
+            table = torch.from_numpy(raw).to(eng.device)
+        plan = (table, len(small), large, keep)
+        cache[key] = plan
+        return plan
+
+    def __call__(self, x):
+        eng, xd, n = self._stage_in(x)
+        out = torch.zeros(n, dtype=torch.float64, device=eng.device)   # `np.zeros(self.dim)` :553
+        self._dev_project(eng, xd, out)
+        return self._stage_out(x, out)
+
+    def _dev_project(self, eng, x, out, want_alias=False):
+        if x.data_ptr() == out.data_ptr():
+            raise ValueError("DisjointProjOp cannot project in place")
+        table, nsmall, large, _ = self._plan(eng, False)
+        if nsmall:
+            eng.proj_small(table, nsmall, x, out, 0)
+        for op, off in large:
+            op._block_project(eng, x, out, off, op.embedded_dimension)
+        return False
+
+    def _dev_normal_vector(self, eng, x, out):
+        table, nsmall, large, _ = self._plan(eng, True)
+        if nsmall:
+            eng.proj_small(table, nsmall, x, out, 1)
+        for op, off in large:
+            op._block_normal(eng, x, out, off, op.embedded_dimension)
+
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        raise AssertionError("DisjointProjOp is flattened by _leaves()")

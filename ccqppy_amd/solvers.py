@@ -1,0 +1,565 @@
+"""First-order solvers for  min 1/2 x'Ax + b'x  s.t. x in Omega  -- MI355X (HIP) implementation.
+
+Drop-in for `ccqppy.solvers` (reference: /root/reference/src/ccqppy/solvers.py): same seven class
+names, constructor signatures, `solve(A, b, x0=None, convex_proj_op=None) -> self`, the six result
+properties, the `name` strings and the stdout line printed per solve.
+
+Division of labour (BASELINE.json north_star): the host loop below is Python and only does what
+the reference's loop does with SCALARS (step sizes, Lipschitz test, momentum, MV counting, exit
+tests, SPG's draw from numpy's global RNG) -- in numpy float64 arithmetic so branch decisions
+match.  Every VECTOR operation (matvec, axpy, dot/norm, projection, residual) is a kernel of
+libccqp_hip.so acting on device-resident fp64 vectors; nothing vector-sized crosses PCIe during
+a solve.  Host<->device traffic per iteration = one read of a few scalars.
+
+`A` may be a numpy array (uploaded once), a torch tensor on the GPU (zero copy), or an operator
+from `ccqppy_amd.operators` (e.g. RowShardedOperator for one-process-per-GPU row sharding).
+The returned `solution` is a numpy array unless b was a torch tensor.
+"""
+from abc import ABC, abstractmethod
+from collections import deque
+import time
+
+import numpy as np
+import torch
+
+from . import solution_spaces as ss
+from .operators import as_operator
+
+__all__ = ["CCQPSolverBase", "CCQPSolverPGD", "CCQPSolverAPGD", "CCQPSolverAPGDAntiRelaxation",
+           "CCQPSolverBBPGD", "CCQPSolverBBPGDf", "CCQPSolverSPG", "CCQPSolverMPRGP"]
+
+_GD = 1e-6                            # solvers.py:137,321,496,629,768,1070
+_EPS10 = 10 * np.finfo(float).eps     # solvers.py:656,...
+
+
+class _Run:
+    """Per-solve device state: engine, operator, staged inputs, fresh-vector factory."""
+
+    def __init__(self, A, b, x0, convex_proj_op):
+        self.n = n = b.shape[0]
+        self.P = convex_proj_op if convex_proj_op is not None else ss.IdentityProjOp(n)   # :115-116
+        self.op = as_operator(A)
+        self.eng = eng = self.op.engine
+        self.torch_out = isinstance(b, torch.Tensor)
+        self.b = eng.to_device(b).reshape(-1)
+        if x0 is None:
+            self.x0 = torch.zeros(n, dtype=torch.float64, device=eng.device)             # :125-126
+        else:
+            self.x0 = eng.to_device(x0).reshape(-1)
+        self.c = 1.0 / (3 * n * _GD)                                                     # :138
+        self.mv0 = eng.mv_executed
+
+    def new(self):
+        return self.eng.empty(self.n)
+
+    def copy(self, x):
+        out = self.new()
+        self.eng.copy(x, out)
+        return out
+
+    def mv(self, v, with_g=False):
+        """A.v (and A.v + b) into fresh vectors."""
+        y = self.new()
+        if with_g:
+            g = self.new()
+            self.op.matvec(v, y, self.b, g)
+            return y, g
+        self.op.matvec(v, y)
+        return y
+
+    def lin(self, a, x, b, y):
+        out = self.new()
+        self.eng.axpby(a, x, b, y, out)
+        return out
+
+    def step_project(self, x, alpha, g):
+        """P(x - alpha*g)"""
+        out = self.new()
+        self.P._dev_step_project(self.eng, 1.0, x, -alpha, g, out)
+        return out
+
+    def project(self, x):
+        if isinstance(self.P, ss.IdentityProjOp):
+            return x                       # same object, as the reference
+        out = self.new()
+        self.P._dev_project(self.eng, x, out)
+        return out
+
+    def residual_sq(self, x, g, slot):
+        self.P._dev_residual_sq(self.eng, x, g, self.c, _GD, slot)
+
+    def residual_now(self, x, g, slot=0):
+        self.residual_sq(x, g, slot)
+        return np.sqrt(self.eng.read(slot, 1)[0])
+
+    def export(self, x):
+        if self.torch_out:
+            return x.clone()
+        return x.cpu().numpy()
+
+
+class CCQPSolverBase(ABC):
+    """Abstract base class for constrained quadratic programming problems (solvers.py:11-68)."""
+    _label = "?"
+
+    @abstractmethod
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf):
+        self.desired_residual_tol = desired_residual_tol
+        self.max_matrix_vector_multiplications = max_matrix_vector_multiplications
+        self._solution = None
+        self._solution_residual = None
+        self._solution_converged = None
+        self._solution_time = None
+        self._solution_num_matrix_vector_mults = None
+        self._executed_matrix_vector_mults = None
+
+    def solve(self, A, b, x0=None, convex_proj_op=None):
+        """Solve; returns self.  A: (n, n); b: (n,); x0: (n,) or None (zeros); convex_proj_op:
+        projection onto the feasible set (default IdentityProjOp)."""
+        time_start = time.time()
+        self._checkSolveInput(A, b, x0)
+        print("solving " + self._label)
+        run = _Run(A, b, x0, convex_proj_op)
+        with np.errstate(all="ignore"):
+            x, res, mv_count = self._iterate(run)
+        self._solution = run.export(x)
+        self._solution_converged = mv_count < self.max_matrix_vector_multiplications
+        self._solution_residual = res
+        self._solution_num_matrix_vector_mults = mv_count
+        self._executed_matrix_vector_mults = run.eng.mv_executed - run.mv0
+        self._solution_time = time.time() - time_start
+        return self
+
+    @abstractmethod
+    def _iterate(self, run):
+        """-> (solution device vector, residual, reported mv_count)"""
+
+    def _checkSolveInput(self, A, b, x0):
+        pass
+
+    @property
+    @abstractmethod
+    def name(self):
+        """Return the name of the solver."""
+
+    @property
+    def solution(self):
+        return self._solution
+
+    @property
+    def solution_residual(self):
+        return self._solution_residual
+
+    @property
+    def solution_converged(self):
+        return self._solution_converged
+
+    @property
+    def solution_time(self):
+        return self._solution_time
+
+    @property
+    def solution_num_matrix_vector_multiplications(self):
+        return self._solution_num_matrix_vector_mults
+
+    @property
+    def executed_matrix_vector_multiplications(self):
+        """Matvecs actually launched (the reference's counter skips solvers.py:635,775,1129,1163,1172)."""
+        return self._executed_matrix_vector_mults
+
+
+class CCQPSolverPGD(CCQPSolverBase):
+    """Projected gradient descent with a constant step (solvers.py:71-194)."""
+    _label = "PGD"
+
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, step_size=0.01):
+        super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        self.step_size = step_size
+
+    @property
+    def name(self):
+        return "PGD"
+
+    def _iterate(self, run):
+        tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        mv_count = 0
+        xk = run.copy(run.x0)
+        xkm1 = run.copy(run.x0)
+        _, gkm1 = run.mv(xkm1, True)
+        mv_count += 1
+        res = run.residual_now(xkm1, gkm1)
+        if res >= tol:
+            while True:
+                xk = run.step_project(xkm1, self.step_size, gkm1)
+                _, gk = run.mv(xk, True)
+                mv_count += 1
+                if mv_count >= max_mv:
+                    break
+                res = run.residual_now(xk, gk)
+                if res < tol:
+                    break
+                xk, xkm1 = xkm1, xk
+                gk, gkm1 = gkm1, gk
+        return xk, res, mv_count
+
+
+class _APGDCore(CCQPSolverBase):
+    """APGD (solvers.py:197-367) and its anti-relaxation variant (:370-557)."""
+    _anti_relaxation = False
+
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf):
+        super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+
+    def _iterate(self, run):
+        tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        eng, b, AR = run.eng, run.b, self._anti_relaxation
+        mv_count = 0
+        xk = run.copy(run.x0)
+        yk = run.copy(run.x0)
+        ones = run.new()
+        eng.fill(1.0, ones)
+        xhat = ones                                     # :432
+        thk = 1.0
+        thk1 = 1.0
+        d = run.lin(1.0, xk, -1.0, ones)                # xk - ones
+        Ad = run.mv(d)
+        s = eng.dots_now([(Ad, Ad), (d, d)])
+        mv_count += 1
+        L = np.sqrt(s[0]) / np.sqrt(s[1])               # :264-268
+        t = 1.0 / L
+        resmin = np.inf
+        xkp1 = None
+        res = None
+        while True:
+            Ayk, gk = run.mv(yk, True)
+            mv_count += 1
+            if mv_count >= max_mv:
+                break
+            xkp1 = run.step_project(yk, t, gk)
+            first = True
+            while True:
+                Ax1, g1 = run.mv(xkp1, True)
+                mv_count += 1
+                if mv_count >= max_mv:
+                    # the reference leaves the inner loop only; the tail below still runs
+                    run.residual_sq(xkp1, g1, 7)
+                    if AR:
+                        eng.dots([(gk, run.lin(1.0, xkp1, -1.0, xk))], 6)
+                    res2 = eng.read(6, 2)
+                    break
+                d = run.lin(1.0, xkp1, -1.0, yk)
+                pairs = [(xkp1, Ax1), (xkp1, b), (gk, d), (d, d)]
+                if AR:
+                    pairs.append((gk, run.lin(1.0, xkp1, -1.0, xk)))
+                if first:
+                    eng.dots([(yk, Ayk), (yk, b)] + pairs, 0)
+                else:
+                    eng.dots(pairs, 2)
+                # speculative: the residual needs xkp1 and A.xkp1 only -> same sync as the dots
+                run.residual_sq(xkp1, g1, 7)
+                if first:
+                    sc = eng.read(0, 8)
+                    r1 = sc[0] * 0.5
+                    r2 = sc[1]
+                    first = False
+                else:
+                    sc = [None, None] + eng.read(2, 6)
+                l1 = sc[2] * 0.5
+                l2 = sc[3]
+                r3 = sc[4]
+                r4 = 0.5 * L * sc[5]
+                res2 = sc[6:8]
+                if (l1 + l2) <= (r1 + r2 + r3 + r4):    # :302
+                    break
+                L *= 2
+                t = 1.0 / L
+                xkp1 = run.step_project(yk, t, gk)
+            thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
+            beta = thk * (1 - thk) / (thk * thk + thk1)
+            ykp1 = run.lin(1 + beta, xkp1, -beta, xk)   # (1+beta)*xkp1 - beta*xk
+            res = np.sqrt(res2[1])
+            if AR and res < resmin:                     # :501-503
+                resmin = res
+                xhat = run.copy(xkp1)
+            if res < tol:
+                break
+            if AR and res2[0] > 0:                      # gk.dot(xkp1 - xk) > 0, :510-512
+                ykp1 = run.copy(xkp1)
+                thk1 = 1
+            L *= 0.9
+            t = 1.0 / L
+            yk, ykp1 = ykp1, yk
+            xk, xkp1 = xkp1, xk                         # `xkp1` now names the OLDER iterate
+            thk = thk1
+        if res is None:
+            raise UnboundLocalError("local variable 'xkp1' referenced before assignment")
+        return (xhat if AR else xkp1), res, mv_count
+
+
+class CCQPSolverAPGD(_APGDCore):
+    _label = "APGD"
+
+    @property
+    def name(self):
+        return "APGD"
+
+
+class CCQPSolverAPGDAntiRelaxation(_APGDCore):
+    _label = "APGD"                                     # sic, solvers.py:422
+    _anti_relaxation = True
+
+    @property
+    def name(self):
+        return "Anti-relaxation APGD"
+
+
+class _BBPGDCore(CCQPSolverBase):
+    """BBPGD (solvers.py:560-693) and BBPGD with fallback (:696-843)."""
+    _label = "BBPGDf"                                   # both print this, solvers.py:613,748
+    _fallback = False
+
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf):
+        super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+
+    def _iterate(self, run):
+        tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        eng = run.eng
+        mv_count = 0
+        xk = run.copy(run.x0)
+        xkm1 = run.copy(run.x0)
+        xmin = gmin = None
+        if self._fallback:
+            xmin = run.copy(run.x0)
+            gmin = run.copy(run.x0)
+        _, gkm1 = run.mv(xkm1, True)
+        mv_count += 1
+        res = run.residual_now(xkm1, gkm1)
+        resmin = np.inf
+        if res >= tol:
+            Ag = run.mv(gkm1)                           # executed, not counted (:635,:775)
+            s = eng.dots_now([(gkm1, gkm1), (gkm1, Ag)])
+            alpha = s[0] / s[1]
+            while True:
+                xk = run.step_project(xkm1, alpha, gkm1)
+                _, gk = run.mv(xk, True)
+                mv_count += 1
+                if mv_count >= max_mv:
+                    break
+                run.residual_sq(xk, gk, 0)
+                if not self._fallback:
+                    # speculative BB dots share the residual's sync
+                    dx = run.lin(1.0, xk, -1.0, xkm1)
+                    dg = run.lin(1.0, gk, -1.0, gkm1)
+                    eng.dots([(dx, dx), (dx, dg)], 1)
+                    sc = eng.read(0, 3)
+                    res = np.sqrt(sc[0])
+                    if res < tol:
+                        break
+                else:
+                    res = np.sqrt(eng.read(0, 1)[0])
+                    if res < tol:
+                        break
+                    if res < resmin:                    # :793-796
+                        resmin = np.copy(res)
+                        xmin = run.copy(xk)
+                        gmin = run.copy(gk)
+                    if alpha < _EPS10:                  # :799-800
+                        xk = run.step_project(xmin, _GD, gmin)
+                    dx = run.lin(1.0, xk, -1.0, xkm1)
+                    dg = run.lin(1.0, gk, -1.0, gkm1)
+                    sc = [None] + eng.dots_now([(dx, dx), (dx, dg)], 1)
+                alpha = sc[1] / (sc[2] + _EPS10)
+                xk, xkm1 = xkm1, xk
+                gk, gkm1 = gkm1, gk
+        return xk, res, mv_count
+
+
+class CCQPSolverBBPGD(_BBPGDCore):
+    @property
+    def name(self):
+        return "BBGPD"                                  # sic, solvers.py:673
+
+
+class CCQPSolverBBPGDf(_BBPGDCore):
+    _fallback = True
+
+    @property
+    def name(self):
+        return "BBPDGf"                                 # sic, solvers.py:823
+
+
+class CCQPSolverSPG(CCQPSolverBase):
+    """SPG-QP (solvers.py:846-999).  One draw per iteration from numpy's GLOBAL legacy RNG
+    (`np.random.uniform`, :959): seed with np.random.seed exactly as for the reference."""
+    _label = "SPG"
+
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf,
+                 m=5, tau=0.5, sigma1=0.01, sigma2=0.5):
+        super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        self.m = m
+        self.t = tau
+        self.sigma1 = sigma1
+        self.sigma2 = sigma2
+
+    @property
+    def name(self):
+        return "SPG-QP"
+
+    def _iterate(self, run):
+        tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        eng = run.eng
+        mv_count = 0
+        xk = run.copy(run.x0)
+        _, gk = run.mv(xk, True)
+        Agk = run.mv(gk)
+        s = eng.dots_now([(gk, xk), (gk, gk), (gk, Agk)])
+        fk = s[0]                                       # sic: g.x, :923
+        alpha = s[1] / s[2]
+        mv_count += 2
+        tau, sig1, sig2 = self.t, self.sigma1, self.sigma2
+        fk_queue = deque(maxlen=self.m)
+        fk_queue.append(fk)
+        dkdotdk = None
+        while True:
+            tproj = run.step_project(xk, alpha, gk)
+            dk = run.lin(1.0, tproj, -1.0, xk)
+            Adk = run.mv(dk)
+            mv_count += 1
+            if mv_count >= max_mv:
+                break
+            dkdotdk, dkdotAdk, dkdotgk = eng.dots_now([(dk, dk), (dk, Adk), (dk, gk)])
+            if np.sqrt(dkdotdk) <= tol:
+                break
+            fmax = max(fk_queue)
+            xi = (fmax - fk) / dkdotAdk
+            beta = -dkdotgk / dkdotAdk
+            betahat = tau * beta + np.sqrt((tau ** 2) * (beta ** 2) + 2 * xi)
+            betak = np.random.uniform(low=sig1, high=min(betahat, sig2))
+            eng.axpby(1.0, xk, betak, dk, xk)           # xk += betak*dk
+            eng.axpby(1.0, gk, betak, Adk, gk)          # gk += betak*Adk
+            fk += betak * betak * dkdotgk + 0.5 * (betak ** 2) * dkdotAdk   # sic, :963
+            fk_queue.append(fk)
+            alpha = dkdotdk / dkdotAdk
+        if dkdotdk is None:
+            raise UnboundLocalError("local variable 'dkdotdk' referenced before assignment")
+        return xk, np.sqrt(dkdotdk), mv_count
+
+
+class CCQPSolverMPRGP(CCQPSolverBase):
+    """MPRGP with BB proportioning/expansion steps (solvers.py:1002-1224); README's "MPRGP-BB"."""
+    _label = "MPRGP"
+
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf):
+        super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+
+    @property
+    def name(self):
+        return "MPRGP"
+
+    @staticmethod
+    def _free_mask_mul(run, x, g, invert=False):
+        """isclose(x, P(x)) * g   (or (1 - isclose) * g)"""
+        out = run.new()
+        run.eng.isclose_mask_mul(x, run.project(x), g, out, invert)
+        return out
+
+    def _iterate(self, run):
+        tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        eng, P = run.eng, run.P
+        mv_count = 0
+        xk = run.project(run.x0)                        # :1063
+        xkp1 = run.copy(xk)
+        _, gk = run.mv(xk, True)
+        gkp1 = run.copy(gk)
+        mv_count += 1
+        res = run.residual_now(xk, gk)
+        if res >= tol:
+            Agk = run.mv(gk)
+            s = eng.dots_now([(gk, gk), (gk, Agk)])
+            alpha_bb = s[0] / s[1]
+            mv_count += 1
+            p = self._free_mask_mul(run, xk, gk)
+            while True:
+                _, gnew = run.mv(xk, True)
+                mv_count += 1
+                if mv_count >= max_mv:
+                    break
+                gk = gnew
+                txk = run.project(xk)
+                psi = run.new()
+                eng.isclose_mask_mul(xk, txk, gk, psi)
+                w = run.new()
+                eng.isclose_mask_mul(xk, txk, None, w, invert=True)      # 1 - delta
+                nv = run.new()
+                P._dev_normal_vector(eng, xk, nv)                        # :1095
+                eng.dots([(nv, gk)], 8)
+                beta_x = run.new()
+                eng.chopped_gradient(w, gk, nv, 8, beta_x)               # :1096-1097
+                bb, pp = eng.dots_now([(beta_x, beta_x), (psi, psi)])
+                if bb < pp:
+                    Ap = run.mv(p)
+                    mv_count += 1
+                    if mv_count >= max_mv:
+                        break
+                    psip, pAp = eng.dots_now([(psi, p), (p, Ap)])
+                    alpha_cg = psip / pAp
+                    y = run.lin(1.0, xk, -alpha_cg, p)
+                    alpha_f = alpha_cg + _EPS10
+                    nhalve = 0
+                    while True:                                          # :1113-1118
+                        yf = run.lin(1.0, xk, -alpha_f, p)
+                        eng.count_notclose(yf, run.project(yf), 9)
+                        if eng.read(9, 1)[0] == 0:
+                            break
+                        alpha_f *= 0.5
+                        nhalve += 1
+                        if nhalve > 1200:   # alpha_f has underflowed to 0: the reference never exits
+                            raise RuntimeError("MPRGP feasibility bisection cannot terminate "
+                                               "(solvers.py:1113-1118 loops forever on this input)")
+                    if alpha_cg <= alpha_f:
+                        xkp1 = run.copy(y)
+                        gkp1 = run.lin(1.0, gk, -alpha_cg, Ap)
+                        dx = run.lin(1.0, xkp1, -1.0, xk)
+                        Adx = run.mv(dx)                                 # executed, not counted (:1129)
+                        s = eng.dots_now([(dx, dx), (dx, Adx)])
+                        alpha_bb = s[0] / (s[1] + _EPS10)
+                        psi_y = self._free_mask_mul(run, y, gkp1)
+                        beta = run.new()
+                        eng.muldiv(psi_y, Ap, pAp, beta)                 # elementwise VECTOR, :1134
+                        pn = run.new()
+                        eng.submul(psi_y, beta, p, pn)
+                        p = pn
+                    else:
+                        xh = run.lin(1.0, xk, -alpha_f, p)
+                        gh = run.lin(1.0, gk, -alpha_f, Ap)
+                        dx = run.lin(1.0, xh, -1.0, xk)
+                        dg = run.lin(1.0, gh, -1.0, gk)
+                        s = eng.dots_now([(dx, dx), (dx, dg)])
+                        alpha = s[0] / (s[1] + _EPS10)
+                        xkp1 = run.step_project(xh, alpha, gh)
+                        _, gkp1 = run.mv(xkp1, True)
+                        mv_count += 1
+                        if mv_count >= max_mv:
+                            break
+                        p = self._free_mask_mul(run, xkp1, gkp1)
+                        dx = run.lin(1.0, xkp1, -1.0, xk)
+                        Adx = run.mv(dx)                                 # executed, not counted (:1163)
+                        s = eng.dots_now([(dx, dx), (dx, Adx)])
+                        alpha_bb = s[0] / (s[1] + _EPS10)
+                else:
+                    xkp1 = run.step_project(xk, alpha_bb, gk)
+                    dx = run.lin(1.0, xkp1, -1.0, xk)
+                    Adx = run.mv(dx)                                     # executed, not counted (:1172)
+                    s = eng.dots_now([(dx, dx), (dx, Adx)])
+                    alpha_bb = s[0] / (s[1] + _EPS10)
+                    _, gk = run.mv(xk, True)                             # redundant but counted (:1174)
+                    mv_count += 1
+                    if mv_count >= max_mv:
+                        break
+                    p = self._free_mask_mul(run, xkp1, gkp1)             # STALE gkp1 (:1180-1182)
+                res = run.residual_now(xkp1, gkp1)
+                if res < tol:
+                    break
+                xk, xkp1 = xkp1, xk
+                gk, gkp1 = gkp1, gk
+        return xkp1, res, mv_count

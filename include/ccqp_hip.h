@@ -1,0 +1,187 @@
+/*
+ * ccqp_hip.h -- C ABI of libccqp_hip.so, the MI355X (gfx950) engine behind the
+ * CCQPpy-compatible `ccqppy_amd.solvers.CCQPSolver*` / `ccqppy_amd.solution_spaces.*ProjOp`.
+ *
+ * The reference (palmerb4/CCQPpy) has no FFI: its hot path is numpy -> OpenBLAS calls made
+ * from Python.  Each entry point below replaces one family of those numpy calls; the
+ * reference call sites are cited as file:line relative to /root/reference/src/ccqppy/.
+ * INTEGRATION.md shows the ctypes stub a CCQPpy maintainer would add.
+ *
+ * Conventions
+ *  - plain C, no torch / C++ types; all vectors are fp64, contiguous, DEVICE pointers;
+ *    sizes are int64_t; `stream` is a hipStream_t passed as void*.
+ *  - every call returns 0 (CCQP_OK) or an error code; the message is available from
+ *    ccqp_last_error() (thread-local).  Nothing here allocates or frees caller memory.
+ *  - every call is asynchronous on `stream` except ccqp_scalars_read(), which copies the
+ *    requested scalar slots to the host and waits for the stream.
+ *  - reductions (dot products, norms, counts) land in the context's device "scalar slab":
+ *    `slot` arguments index doubles in that slab.  Their summation order is a function of
+ *    the vector length only (never of the grid, the GPU count or timing), so results are
+ *    bitwise reproducible run to run and rank to rank.
+ *  - elementwise kernels round after every arithmetic operation exactly like numpy
+ *    (no FMA contraction); only the matvec and the reductions use fused multiply-add.
+ */
+#ifndef CCQP_HIP_H
+#define CCQP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCQP_ABI_VERSION 1
+
+enum {
+  CCQP_OK = 0,
+  CCQP_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, slot out of range ...) */
+  CCQP_ERR_HIP = 2,         /* a HIP runtime call failed */
+  CCQP_ERR_UNSUPPORTED = 3  /* valid request this build does not implement */
+};
+
+#define CCQP_NUM_SLOTS 64   /* doubles in the scalar slab */
+#define CCQP_MAX_DOTS 8     /* dot products per ccqp_dots_f64 call */
+
+typedef struct ccqp_ctx ccqp_ctx;
+
+/* ---- context ------------------------------------------------------------------------ */
+int ccqp_abi_version(void);
+const char* ccqp_last_error(void);
+/* Binds to HIP device `device` (the caller keeps that device current when calling in). */
+int ccqp_ctx_create(int device, ccqp_ctx** out);
+int ccqp_ctx_destroy(ccqp_ctx* ctx);
+/* num_cu: compute units of the device; arch: e.g. "gfx950" copied into buf (<= buflen). */
+int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int buflen);
+/* Copy slots [slot0, slot0+count) to host_out and wait for `stream` (the only sync point). */
+int ccqp_scalars_read(ccqp_ctx* ctx, int slot0, int count, double* host_out, void* stream);
+/* Device address of the slab (for kernels of the caller's own / for tests). */
+int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
+
+/* ---- a1: dense matvec  y[0:rows] = A[rows x cols] . x --------------------------------
+ * replaces `A.dot(v)` at solvers.py:133,148,264,275,290,440,452,467,625,635,641,764,775,781,
+ * 922,924,938,1065,1077,1086,1100,1129,1152,1163,1172,1174.
+ * A is row-major with leading dimension lda (doubles).  Row sums are accumulated in an order
+ * that depends on `cols` only, so a row block [r0, r1) of A gives bitwise the same y[r0:r1]
+ * as the full matrix does -> row-sharded multi-GPU runs reproduce the 1-GPU iterates.
+ * variant: 0 = default streaming kernel; other values select tuning variants.
+ */
+int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, double* y,
+                  int64_t rows, int64_t cols, int variant, void* stream);
+/* Same with a fused epilogue: y = A.x ; if g != NULL: g = y + b, one extra rounding exactly like
+ * numpy's `A.dot(x) + b` (solvers.py:133,148,280,625,641,922,1065,1090).  b, y, g have `rows` entries. */
+int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x,
+                           const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                           int variant, void* stream);
+
+/* ---- a2: elementwise axpy family -------------------------------------------------------
+ * out = a*x + b*y with three roundings (mul, mul, add) -- covers `Ax+b`, `x - alpha*g`,
+ * `x - y`, `(1+beta)*x1 - beta*x0`, `xk += beta*dk` (solvers.py:139,145,280,283,299,316,
+ * 653-654,937,961-962 ...).  1.0*x and -1.0*x are exact, so the numpy forms are reproduced
+ * bit for bit.  out may alias x or y. */
+int ccqp_axpby_f64(ccqp_ctx* ctx, double a, const double* x, double b, const double* y,
+                   double* out, int64_t n, void* stream);
+/* out = a*x (one rounding) -- the `c * (...)` of the residual, solvers.py:138 */
+int ccqp_scale_f64(ccqp_ctx* ctx, double a, const double* x, double* out, int64_t n, void* stream);
+int ccqp_copy_f64(ccqp_ctx* ctx, const double* x, double* out, int64_t n, void* stream);
+int ccqp_fill_f64(ccqp_ctx* ctx, double value, double* out, int64_t n, void* stream);
+/* out = x * y (elementwise, one rounding). */
+int ccqp_mul_f64(ccqp_ctx* ctx, const double* x, const double* y, double* out, int64_t n, void* stream);
+/* out = (x * y) / s   -- `psi_y * Ap / p.dot(Ap)` solvers.py:1134 */
+int ccqp_muldiv_f64(ccqp_ctx* ctx, const double* x, const double* y, double s, double* out,
+                    int64_t n, void* stream);
+/* out = x - y * z      -- `psi_y - beta * p` with VECTOR beta, solvers.py:1135 */
+int ccqp_submul_f64(ccqp_ctx* ctx, const double* x, const double* y, const double* z, double* out,
+                    int64_t n, void* stream);
+
+/* ---- a3: dot / norm reductions ------------------------------------------------------------
+ * slab[slot0 + j] = xs[j] . ys[j]  for j < k <= CCQP_MAX_DOTS, one launch pair for all k.
+ * xs / ys are HOST arrays of device pointers.  Replaces `.dot` / `np.dot` / the squared
+ * `np.linalg.norm` at solvers.py:264-265,285-286,296-301,510,635,655-656,923-924,944-946,
+ * 1077,1098,1106,1129,1146-1147,1163,1171-1172. */
+int ccqp_dots_f64(ccqp_ctx* ctx, int k, const double* const* xs, const double* const* ys,
+                  int64_t n, int slot0, void* stream);
+
+/* ---- a5..a8: projection operators -------------------------------------------------------- */
+enum {
+  CCQP_OP_IDENTITY = 0, /* solution_spaces.py:111-125 */
+  CCQP_OP_LOWER = 1,    /* :186-201  lb*m + x*(1-m), m = x<lb */
+  CCQP_OP_UPPER = 2,    /* :262-277 */
+  CCQP_OP_BOX = 3,      /* :349-366  lb*lo + ub*hi + x*(1-hi)*(1-lo) */
+  CCQP_OP_SPHERE = 4,   /* :417-435  (radius*x)/|x| if |x| > radius */
+  CCQP_OP_CONE = 5      /* :470-492  reproduced as is, incl. the whole-vector norm (:484) */
+};
+#define CCQP_SEG_LB_INT 1 /* lower bound was integer-typed in Python: lb*mask is integer math */
+#define CCQP_SEG_UB_INT 2
+#define CCQP_SEG_P0_INT 4 /* Sphere radius / Cone aspect ratio was a Python int */
+
+/* One contiguous block x[offset : offset+dim) and the convex set it is projected on.
+ * DisjointProjOp (solution_spaces.py:495-560) = a list of these with running offsets. */
+typedef struct ccqp_seg {
+  int32_t kind;
+  int32_t flags;
+  int64_t offset;
+  int64_t dim;
+  const double* lb; /* device, dim doubles, or NULL -> lb_s broadcast */
+  const double* ub;
+  double lb_s;      /* scalar lower bound | sphere radius | cone aspect ratio */
+  double ub_s;
+} ccqp_seg;
+
+/* out[seg] = P(a*x + b*y)[seg] for an ELEMENTWISE kind (Identity/Lower/Upper/Box); y may be NULL
+ * (then out = P(x), a and b ignored).  Fuses the step `P(x - alpha*g)` (solvers.py:145,283,310,
+ * 638,778,937,1148,1167) with the projection; literal expression order => bit-exact. */
+int ccqp_proj_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, double a, const double* x,
+                              double b, const double* y, double* out, void* stream);
+/* Sphere / Cone, second phase: slab[norm2_slot] must already hold |x[seg]|^2 (ccqp_dots_f64 on the
+ * block).  Computes r = sqrt(slab[norm2_slot]) on the device and applies the op's branches. */
+int ccqp_proj_normscale_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, double* out,
+                            int norm2_slot, void* stream);
+/* Many small blocks in ONE launch, one thread per block (dim <= CCQP_SMALL_SEG_MAX), any kind.
+ * `table` is a DEVICE array of nseg descriptors.  Norms of blocks with dim <= 15 use the
+ * sequential chain s = fma(x_i, x_i, s) that OpenBLAS ddot performs for such lengths, so small
+ * Sphere/Cone blocks are bit-exact against numpy.  mode 0: out = P(x); mode 1: out = normal_vector(x)
+ * (solution_spaces.py:146-160,222-236,306-322,389-403,92-98). */
+#define CCQP_SMALL_SEG_MAX 64
+int ccqp_proj_small_segments_f64(ccqp_ctx* ctx, const ccqp_seg* table, int64_t nseg, const double* x,
+                                 double* out, int mode, void* stream);
+
+/* ---- a4: residual (Mazhar 2015 Eq. 25 as coded, solvers.py:138-139 etc.) --------------------
+ * slab[slot] = sum_i v_i^2, v = c*(x - P(x - gd*g)) for an ELEMENTWISE kind over the block;
+ * the caller takes the square root (np.linalg.norm = sqrt(v.v)). */
+int ccqp_residual_sq_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                     const double* g, double c, double gd, int slot, void* stream);
+
+/* ---- a12: MPRGP helpers (solvers.py:1081-1182; np.isclose rtol=1e-5, atol=1e-8) -----------
+ * mask_i = isclose(a_i, b_i) = (|a-b| <= 1e-8 + 1e-5*|b| and isfinite(b)) or a == b.
+ * out = (invert ? 1-mask : mask) * g   (g == NULL -> out = the 0.0/1.0 mask itself). */
+int ccqp_isclose_mask_mul_f64(ccqp_ctx* ctx, const double* a, const double* b, const double* g,
+                              int invert, double* out, int64_t n, void* stream);
+/* slab[slot] = number of i with NOT isclose(a_i, b_i)   (np.all(...) <=> 0), solvers.py:1115 */
+int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const double* b, int64_t n, int slot,
+                            void* stream);
+/* normal_vector of an ELEMENTWISE kind over its block: xp = P(x) (already computed),
+ * slab[dist2_slot] = |x - xp|^2 over the block.  If sqrt(dist2) > 1e-8 (x outside) -> zeros, else
+ * +1 where isclose(xp_i, ub_i) elif -1 where isclose(xp_i, lb_i) (solution_spaces.py:306-322). */
+int ccqp_normal_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp, double* out,
+                                int dist2_slot, void* stream);
+/* Sphere normal (solution_spaces.py:389-403): slab[dist2_slot] as above, slab[len2_slot] = |xp|^2. */
+int ccqp_normal_sphere_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp, double* out,
+                           int dist2_slot, int len2_slot, void* stream);
+/* out = w * (g - s*nv) with s = min(0, slab[ng_slot]) (NaN propagates like np.min),
+ * `(1 - delta) * (gk - np.min([0, n.dot(gk)]) * n)` solvers.py:1096-1097; w is a 0/1 vector. */
+int ccqp_chopped_gradient_f64(ccqp_ctx* ctx, const double* w, const double* g, const double* nv,
+                              int ng_slot, double* out, int64_t n, void* stream);
+
+/* ---- synthetic problems (replaces benchmarks/benchmark_random_ccqp.py:59-63,
+ * whose Wishart generator is O(n^3)) ---------------------------------------------------------
+ * Rows [row0, row0+rows) of the n x n counter-hashed symmetric matrix:
+ *   A[i][j] = (2u(min*n+max) - 1)/sqrt(n) (i != j), A[i][i] = 2 ; u = (splitmix64 >> 11) * 2^-53. */
+int ccqp_gen_spd_rows_f64(ccqp_ctx* ctx, double* A, int64_t lda, int64_t row0, int64_t rows,
+                          int64_t n, uint64_t seed, void* stream);
+/* out[i] = 1 - 2u_x(i), i < n  (the unconstrained solution x*, benchmark_random_ccqp.py:61) */
+int ccqp_gen_vec_f64(ccqp_ctx* ctx, double* out, int64_t n, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCQP_HIP_H */

@@ -1,0 +1,179 @@
+"""GPU parity of the seven solvers (host loop in Python, every vector op in libccqp_hip.so)
+against the reference's golden results and the CPU oracle.
+
+Bar (BASELINE.json north_star): identical reported MV count and converged flag, final x within
+1e-10 relative of the reference's x, same exception type on the reference's accidental error paths.
+Matrix input is generated on the device (ccqp_gen_spd_rows_f64), b comes from the fixture so both
+sides use the same right-hand side bits."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import cpu_ref, gen_ref
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SOLV, SOLV_ARR = H.load_solvers()
+RTOL = 1e-10
+
+
+def _solver_cls(name):
+    from ccqppy_amd import solvers
+    return getattr(solvers, "CCQPSolver" + name)
+
+
+_DEV_A = {}
+
+
+def _device_matrix(pid):
+    from ccqppy_amd import problems
+    from ccqppy_amd._engine import get_engine
+    if pid not in _DEV_A:
+        if pid.startswith("suite:") or pid == "readme":
+            _DEV_A[pid] = np.array(C.TRIDIAG)            # int64 numpy input, like the reference's tests
+        else:
+            _, n, seed = pid.split(":")
+            _DEV_A[pid] = problems.spd_rows(int(n), int(seed))
+    return _DEV_A[pid]
+
+
+def _solve(case, A, b, x0):
+    arrays = dict(C.SUITE_ARRAYS)
+    P = None if case["op"] is None else C.build_op(case["op"], C.product_factory(), arrays)
+    max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
+    np.random.seed(case["rng_seed"])
+    s = _solver_cls(case["solver"])(case["tol"], max_mv, **case["kwargs"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        s.solve(A, b, x0=x0, convex_proj_op=P)
+    return s, buf.getvalue()
+
+
+@pytest.mark.parametrize("case", SOLV, ids=[c["id"] for c in SOLV])
+def test_solver_golden(case):
+    A = _device_matrix(case["problem"])
+    b = SOLV_ARR[case["problem"] + ".b"]
+    n = b.shape[0]
+    x0 = C.case_x0(case, n)
+    try:
+        s, out = _solve(case, A, b, x0)
+        err = None
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    assert err == case["err"]
+    if err is not None:
+        return
+    assert out.startswith("solving ")
+    want = SOLV_ARR[case["id"] + ".x"]
+    assert s.solution_num_matrix_vector_multiplications == case["mv"]
+    assert bool(s.solution_converged) == case["converged"]
+    assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+    assert isinstance(s.solution, np.ndarray) and s.solution.shape == want.shape
+    scale = max(np.linalg.norm(want), 1e-300)
+    assert np.linalg.norm(s.solution - want) <= RTOL * scale + 1e-14
+    if case["res"] == 0.0:
+        assert float(s.solution_residual) == 0.0
+    elif case["converged"]:
+        assert float(s.solution_residual) < case["tol"] or case["solver"] == "SPG"
+    assert s.solution_time > 0
+
+
+def test_readme_example_stdout_and_types():
+    from ccqppy_amd import solvers, solution_spaces as ss
+    A = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]])
+    exact_x = np.array([1, 0, 1])
+    b = -A.dot(exact_x)
+    op = ss.BoxProjOp(3, np.array([-2, -2, -4]), np.array([2, 2, 5]))
+    np.random.seed(0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        result = solvers.CCQPSolverSPG(1e-10, 5000).solve(A, b, convex_proj_op=op)
+    assert buf.getvalue() == "solving SPG\n"
+    assert result.solution_converged is True
+    assert result.solution_num_matrix_vector_multiplications == 92     # SURVEY B.1 (seed 0)
+    assert np.linalg.norm(result.solution - exact_x) < 1e-9
+
+
+def test_reference_unit_test_assertions():
+    """The reference's own test (tests/test_module.py:18-67): 5 analytic problems x 7 solvers,
+    converged and |x - x*| < 1e-5."""
+    from ccqppy_amd import solvers
+    for pname, pd in C.SUITE.items():
+        A, b = C.suite_problem(pname)
+        for sname in C.SOLVER_NAMES:
+            P = C.build_op(pd["op"], C.product_factory(), dict(C.SUITE_ARRAYS))
+            args = (1e-8, 10000, 0.1) if sname == "PGD" else (1e-8, 10000)
+            np.random.seed(1234)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = getattr(solvers, "CCQPSolver" + sname)(*args).solve(A, b, convex_proj_op=P)
+            assert r.solution_converged
+            assert np.linalg.norm(r.solution - np.array(pd["xexact"])) < 1e-5
+
+
+def test_torch_tensor_inputs_are_zero_copy_and_return_tensors():
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    n = 512
+    op, b, xs = problems.random_problem(n, 3)
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = solvers.CCQPSolverBBPGD(1e-8, 500).solve(op.A, b, convex_proj_op=P)
+    assert isinstance(r.solution, torch.Tensor) and r.solution.is_cuda
+    A_host = gen_ref.spd_rows(n, 3)
+    bb = b.cpu().numpy()
+    o = cpu_ref.solve_bbpgd(A_host, bb, 1e-8, 500, P=C.build_op(
+        {"kind": "Box", "dim": n, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}}, C.oracle_factory()))
+    assert r.solution_num_matrix_vector_multiplications == o.solution_num_matrix_vector_multiplications
+    np.testing.assert_allclose(r.solution.cpu().numpy(), o.solution, rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("sname,tol,max_mv", [("APGD", 1e-8, 5000), ("BBPGD", 1e-8, 5000), ("SPG", 1e-8, 5000),
+                                              ("MPRGP", 1e-6, 300)])
+def test_larger_problem_against_oracle(sname, tol, max_mv):
+    """n = 8192 (BASELINE config 5's size): device generator + HIP solve vs host generator + oracle."""
+    from ccqppy_amd import problems, solution_spaces as ss
+    n, seed = 8192, 1234
+    op, b, xs = problems.random_problem(n, seed)
+    A_host = gen_ref.spd_rows(n, seed)
+    bb = b.cpu().numpy()
+    np.testing.assert_allclose(bb, -A_host.dot(xs.cpu().numpy()), rtol=0, atol=1e-12)
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    Po = C.build_op({"kind": "Box", "dim": n, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}}, C.oracle_factory())
+    np.random.seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = _solver_cls(sname)(tol, max_mv).solve(op, bb, convex_proj_op=P)
+    np.random.seed(1234)
+    o = cpu_ref.SOLVERS[sname](A_host, bb, tol, max_mv, P=Po)
+    assert r.solution_num_matrix_vector_multiplications == o.solution_num_matrix_vector_multiplications
+    assert r.executed_matrix_vector_multiplications == o.executed_mv
+    assert bool(r.solution_converged) == bool(o.solution_converged)
+    assert np.linalg.norm(r.solution - o.solution) <= RTOL * np.linalg.norm(o.solution)
+
+
+def test_full_size_properties_n32768():
+    """BASELINE config 2 (n = 32768, 8 GiB matrix, APGD + Box) through size-independent properties:
+    convergence, feasibility, KKT residual from an independent matvec, idempotence of P, and the MV
+    count the kappa ~ 3.7 spectrum predicts (44 at n = 1024/4096)."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    n = 32768
+    op, b, xs = problems.random_problem(n, 1234)
+    P = ss.BoxProjOp(n, -0.5, 0.5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = solvers.CCQPSolverAPGD(1e-8, 5000).solve(op, b, convex_proj_op=P)
+    assert r.solution_converged and r.solution_residual < 1e-8
+    assert 30 <= r.solution_num_matrix_vector_multiplications <= 60
+    x = r.solution
+    assert float(x.max()) <= 0.5 and float(x.min()) >= -0.5
+    assert torch.equal(P(x), x)                                    # idempotent on a feasible point
+    # KKT: projected gradient step leaves x unchanged to ~tol; gradient via torch's own fp64 matvec
+    g = op.A @ x + b
+    fixed = torch.clamp(x - 1e-6 * g, -0.5, 0.5)
+    assert float((x - fixed).norm()) / (3 * n * 1e-6) < 1e-8
+    # roughly half of the bounds are active at the solution
+    active = int(((x == 0.5) | (x == -0.5)).sum())
+    assert 0.35 * n < active < 0.65 * n

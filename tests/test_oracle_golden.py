@@ -1,0 +1,109 @@
+"""CPU: the oracle (oracle/cpu_ref.py, oracle/gen_ref.py) replays every golden vector.
+
+The expected values in tests/golden/ are the REFERENCE's outputs (palmerb4/CCQPpy imported in the
+build container by oracle/gen_golden.py).  Elementwise results must match bit for bit anywhere;
+results that pass through OpenBLAS reductions must match bit for bit on the host that generated
+them and to 1e-12 elsewhere, with identical MV counts.
+"""
+import numpy as np
+import pytest
+
+from oracle import cases as C
+from oracle import cpu_ref, gen_ref
+from tests import helpers as H
+
+OPS, OP_ARR = H.load_ops()
+SOLV, SOLV_ARR = H.load_solvers()
+SAME_HOST = H.same_host_as_golden()
+
+
+def _call(fn):
+    try:
+        with np.errstate(all="ignore"):
+            return fn(), None
+    except Exception as e:  # noqa: BLE001
+        return None, type(e).__name__
+
+
+def test_fixture_inventory():
+    assert len(OPS) >= 400 and len(SOLV) >= 120
+    kinds = {c["spec"]["kind"] for c in OPS}
+    assert kinds == {"Identity", "Lower", "Upper", "Box", "Sphere", "Cone", "Disjoint"}
+    assert {c["solver"] for c in SOLV} == set(C.SOLVER_NAMES)
+
+
+@pytest.mark.parametrize("case", OPS, ids=[c["id"] for c in OPS])
+def test_op_projection_and_normal(case):
+    op = C.build_op(case["spec"], C.oracle_factory(), OP_ARR)
+    x = OP_ARR[case["x"]]
+    y, err = _call(lambda: op(x.copy()))
+    assert err == case["err"]
+    exact = SAME_HOST or not C.spec_uses_norm(case["spec"]) or C.spec_max_norm_dim(case["spec"]) <= 15
+    if err is None:
+        want = OP_ARR[case["id"] + ".y"]
+        if exact:
+            assert H.same_bits(y, want)
+        else:
+            assert H.ulp_diff(y, want) <= 4
+    if case["nv"]:
+        nv, nerr = _call(lambda: op.normal_vector(x.copy()))
+        assert nerr == case["nv_err"]
+        if nerr is None:
+            want = OP_ARR[case["id"] + ".nv"]
+            assert H.same_bits(nv, want) if exact else H.ulp_diff(nv, want) <= 4
+
+
+_PROBLEMS = {}
+
+
+def _problem(pid):
+    if pid not in _PROBLEMS:
+        if pid.startswith("suite:"):
+            A, _ = C.suite_problem(pid[6:])
+        elif pid == "readme":
+            A = np.array(C.TRIDIAG)
+        else:
+            _, n, seed = pid.split(":")
+            A = gen_ref.spd_rows(int(n), int(seed))
+        _PROBLEMS[pid] = A
+    return _PROBLEMS[pid], SOLV_ARR[pid + ".b"]
+
+
+@pytest.mark.parametrize("case", SOLV, ids=[c["id"] for c in SOLV])
+def test_solver_case(case):
+    A, b = _problem(case["problem"])
+    n = b.shape[0]
+    arrays = dict(C.SUITE_ARRAYS)
+    P = None if case["op"] is None else C.build_op(case["op"], C.oracle_factory(), arrays)
+    max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
+    x0 = C.case_x0(case, n)
+
+    def run():
+        np.random.seed(case["rng_seed"])
+        return cpu_ref.SOLVERS[case["solver"]](A, b, case["tol"], max_mv, x0=x0, P=P, **case["kwargs"])
+
+    r, err = _call(run)
+    assert err == case["err"]
+    if err is not None:
+        return
+    assert r.solution_num_matrix_vector_multiplications == case["mv"]
+    assert bool(r.solution_converged) == case["converged"]
+    assert r.executed_mv == case["executed_mv"]
+    want = SOLV_ARR[case["id"] + ".x"]
+    if SAME_HOST:
+        assert H.same_bits(r.solution, want)
+        assert float(r.solution_residual) == case["res"]
+    else:
+        np.testing.assert_allclose(r.solution, want, rtol=1e-10, atol=1e-12)
+
+
+def test_generator_known_answers():
+    g = dict(np.load(H.GOLD + "/generator.npz"))
+    for n, seed in ((8, 1234), (33, 5), (256, 1234)):
+        assert H.same_bits(gen_ref.spd_rows(n, seed), g["A.%d.%d" % (n, seed)])
+        assert H.same_bits(gen_ref.xstar(n, seed), g["xstar.%d.%d" % (n, seed)])
+    assert H.same_bits(gen_ref.spd_rows(1024, 1234, 100, 4), g["rows.1024.1234.100_4"])
+    lo, hi = g["eig.1024.1234"]
+    assert 0.80 < lo < 0.90 and 3.10 < hi < 3.20        # SPD, kappa ~ 3.7
+    # splitmix64 published test vector (seed 0 -> first output of the reference implementation)
+    assert int(gen_ref.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
