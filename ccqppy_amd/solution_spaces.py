@@ -124,6 +124,21 @@ class ProjOpBase(ABC):
     def _block_normal(self, eng, x, out, offset, n):
         raise NotImplementedError
 
+    def _single_table(self, eng, offset, n):
+        """Device table holding this one block, for the thread-per-block kernel (blocks of
+        dimension <= CCQP_SMALL_SEG_MAX use its sequential-FMA norm: bit-exact vs numpy for <= 15)."""
+        cache = self.__dict__.setdefault("_single_tables", {})
+        key = (eng.index, offset, n)
+        ent = cache.get(key)
+        if ent is None:
+            seg = self._seg(eng, offset, n)
+            raw = np.frombuffer(bytes(seg), dtype=np.uint8).copy()
+            ent = (torch.from_numpy(raw).to(eng.device), getattr(seg, "_keep", None))
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = ent
+        return ent[0]
+
 
 # ------------------------------------------------------------------ elementwise family
 class _ElementwiseOp(ProjOpBase):
@@ -174,6 +189,9 @@ class _ElementwiseOp(ProjOpBase):
 
     def _block_normal(self, eng, x, out, offset, n):
         # solution_spaces.py:146-160, 222-236, 306-322
+        if 0 < n <= _lib.SMALL_SEG_MAX and not self._scalar_bound_names():
+            eng.proj_small(self._single_table(eng, offset, n), 1, x, out, 1)
+            return
         xp = eng.scratch(x.numel(), "op.nv.xp")
         d = eng.scratch(x.numel(), "op.nv.d")
         sl = slice(offset, offset + n)
@@ -277,6 +295,14 @@ class _NormOp(ProjOpBase):
     def _block_project(self, eng, x, out, offset, n, want_alias=False):
         if n == 0:
             return False
+        if n <= _lib.SMALL_SEG_MAX:
+            eng.proj_small(self._single_table(eng, offset, n), 1, x, out, 0)
+            if want_alias:
+                # the `return x` branches hand back the argument object (:435, :487); a block this
+                # small is cheapest to compare after the fact
+                a = x[offset:offset + n].view(torch.int64)
+                return bool(torch.equal(a, out[offset:offset + n].view(torch.int64)))
+            return False
         sl = x[offset:offset + n]
         eng.dots([(sl, sl)], _SLOT_NORM2)
         if want_alias:
@@ -316,6 +342,9 @@ class SphereProjOp(_NormOp):
     def _block_normal(self, eng, x, out, offset, n):
         # solution_spaces.py:389-403
         if n == 0:
+            return
+        if n <= _lib.SMALL_SEG_MAX:
+            eng.proj_small(self._single_table(eng, offset, n), 1, x, out, 1)
             return
         xp = eng.scratch(x.numel(), "op.nv.xp")
         d = eng.scratch(x.numel(), "op.nv.d")

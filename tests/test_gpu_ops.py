@@ -62,9 +62,12 @@ def test_projection_aliasing_and_tensor_io(eng):
     from ccqppy_amd import solution_spaces as ss
     x = np.array([0.1, -0.2, 0.3])
     assert ss.SphereProjOp(3)(x) is x                    # inside: same object (solution_spaces.py:435)
-    assert ss.ConeProjOp(3)(np.array([0.0, 0.0, 1.0])) is not None
-    xin = np.array([0.01, 0.02, 5.0])
-    assert ss.ConeProjOp(3)(xin) is xin                  # mu*z >= |x|: same object (:487)
+    xin = np.array([0.0, 0.0, 5.0])
+    assert ss.ConeProjOp(3)(xin) is xin                  # mu*z >= |x| (whole-vector norm!): same object (:487)
+    big = np.zeros(200)
+    big[-1] = 2.0
+    assert ss.ConeProjOp(200)(big) is big                # same for a block-reduced norm
+    assert ss.SphereProjOp(200)(big * 0.25) is not None and ss.SphereProjOp(200, 3.0)(big) is big
     xt = torch.tensor([2.0, -3.0, 0.5], dtype=torch.float64, device="cuda")
     yt = ss.BoxProjOp(3)(xt)
     assert isinstance(yt, torch.Tensor) and yt.is_cuda
