@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the CCQP hot path on MI355X (contract: see the task's bench.py section).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`): n = 131072 dense random-SPD fp64 box-constrained QP, APGD
+(tol 1e-8, max 5000 MVs), synthetic inputs generated on the GPU.  One STEP = one complete APGD solve
+from x0 = 0 (about 44 matvecs + all vector work + every host<->device scalar sync).
+`value` = matvecs executed per second over the whole job; `ms_per_step` = solve wall-clock.
+For N > 1 the matrix is row-block sharded (one process per GPU, RCCL all-gather of the n-vector per
+matvec) and the SAME problem is solved: strong scaling.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (fp64 streaming GEMV): algorithmic bytes per launch / average launch
+                  duration measured with HIP events on the launch stream inside the timed region,
+                  against the 8 TB/s HBM3E peak.
+  cpu_baseline -- the numpy oracle (oracle/cpu_ref.py, a port of the reference; OpenBLAS threads =
+                  host cores) solving a bounded sample (n = 32768, same generator / solver settings)
+                  on the GPU box's host, N = 1 only; reported in n=131072-equivalent matvecs/s.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def mv_bytes(rows, n):
+    """Algorithmic bytes of one (rows x n) fp64 matvec: A once + x read + y written."""
+    return 8.0 * (rows * n + n + rows)
+
+
+def pmc_traffic(bytes_per_launch):
+    """HBM bytes per GEMV launch from the committed rocprofv3 PMC summary of this same workload
+    (profiles/*_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes).
+    PMC counters cannot be read from inside the timed run, so this is the tracked measurement of
+    the identical launch (same kernel, same n, same rows); None if no matching profile exists."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        for k, e in d.items():
+            if "gemv" in k and e.get("algorithmic_bytes_per_launch") == bytes_per_launch \
+                    and "hbm_traffic_bytes_per_launch" in e:
+                return e["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
+def cpu_baseline(n_cpu, seed, tol, max_mv, n_metric):
+    """Time the oracle on the host cores on a bounded sample of the same workload."""
+    from ccqppy_amd import problems
+    from oracle import cpu_ref
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] + [1])
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count()
+    op, b, _ = problems.random_problem(n_cpu, seed)
+    A = op.A.cpu().numpy()
+    bb = b.cpu().numpy()
+    del op
+    torch.cuda.empty_cache()
+    lb, ub = -0.5 * np.ones(n_cpu), 0.5 * np.ones(n_cpu)
+    A.dot(bb)                                             # warm the BLAS thread pool / page in A
+    t0 = time.perf_counter()
+    r = cpu_ref.solve_apgd(A, bb, tol, max_mv, P=cpu_ref.Box(n_cpu, lb, ub))
+    dt = time.perf_counter() - t0
+    gbs = r.executed_mv * mv_bytes(n_cpu, n_cpu) / dt / 1e9
+    return {
+        "value": gbs * 1e9 / mv_bytes(n_metric, n_metric),
+        "unit": "matvecs/s (n=%d-equivalent: measured solve bytes/s / bytes per n=%d matvec)" % (n_metric, n_metric),
+        "cores": int(cores),
+        "kind": "port",
+        "sample": "oracle/cpu_ref.solve_apgd (numpy+OpenBLAS), n=%d box-QP, tol=%g: %d matvecs in %.2f s = "
+                  "%.1f matvecs/s at n=%d (%.1f GB/s)" % (n_cpu, tol, r.executed_mv, dt, r.executed_mv / dt,
+                                                         n_cpu, gbs),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=131072, help="problem size (default: the metric's n)")
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--max-mv", type=int, default=5000)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--mode", default="allgather", choices=["allgather", "allreduce"])
+    ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
+    ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+
+    eng = get_engine(local_rank)
+    eng.gemv_variant = args.variant
+    n = args.n
+    t_gen = time.perf_counter()
+    op, b, _ = problems.random_problem(n, args.seed, device=local_rank, group=group, mode=args.mode)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    P = ss.BoxProjOp(n, -0.5, 0.5)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        np.random.seed(args.seed)
+        s = solvers.CCQPSolverAPGD(args.tol, args.max_mv)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.solve(op, b, convex_proj_op=P)
+        return s
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.gemv_events = []
+    mv0 = eng.mv_executed
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mv_exec = eng.mv_executed - mv0
+    events = eng.gemv_events
+    eng.gemv_events = None
+    gemv_ms = [a.elapsed_time(b_) for a, b_ in events]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        rows_local = op.rows
+        avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
+        achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(mv_bytes(rows_local, n))
+        line = {
+            "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
+            "value": mv_exec / elapsed,
+            "unit": "matvecs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE metric: n=%d dense random-SPD fp64 + BoxProjOp(+-0.5), CCQPSolverAPGD(tol=%g, "
+                            "max_mv=%d); 1 step = 1 full solve from x0=0" % (n, args.tol, args.max_mv),
+                "n": n, "solver": "APGD", "projection": "Box", "tol": args.tol,
+                "sharding": "none" if world == 1 else "row-block x%d, RCCL %s of the n-vector per matvec" % (world, args.mode),
+                "matrix_bytes_per_gpu": 8 * rows_local * n,
+            },
+            "solve": {
+                "wall_s": elapsed / max(args.steps, 1),
+                "reported_mv": int(last.solution_num_matrix_vector_multiplications),
+                "executed_mv": int(last.executed_matrix_vector_multiplications),
+                "converged": bool(last.solution_converged),
+                "residual": float(last.solution_residual),
+                "generate_s": t_gen,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "gemv_stream_kernel (ccqp_gemv_f64)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "bytes_per_launch": mv_bytes(rows_local, n),
+                "avg_launch_ms": avg_ms,
+                "launches_timed": len(gemv_ms),
+                "solve_level_frac": mv_exec * mv_bytes(rows_local, n) / elapsed / 1e9 / HBM_PEAK_GBS,
+            },
+        }
+        if world == 1 and args.cpu_n > 0:
+            del op
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.seed, args.tol, args.max_mv, n)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

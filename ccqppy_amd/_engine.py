@@ -62,6 +62,7 @@ class Engine:
         self._scratch = {}
         self.gemv_variant = 0
         self.mv_executed = 0   # every matvec launched through this engine (counted or not)
+        self.gemv_events = None   # list of (start, end) HIP events per matvec when profiling is on
 
     # ------------------------------------------------------------------ memory plumbing
     @property
@@ -102,12 +103,20 @@ class Engine:
         assert A.stride(1) == 1 and x.numel() >= cols and y.numel() >= rows
         v = self.gemv_variant if variant is None else variant
         self.mv_executed += 1
+        ev = None
+        if self.gemv_events is not None:
+            # HIP events on the stream the kernel is launched on (torch's current stream)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self.device))
         if g is None:
             _lib.check(self.lib.ccqp_gemv_f64(self.ctx, ptr(A), A.stride(0), ptr(x), ptr(y), rows, cols, v,
                                               self.stream))
         else:
             _lib.check(self.lib.ccqp_gemv_epilogue_f64(self.ctx, ptr(A), A.stride(0), ptr(x), ptr(b), ptr(y),
                                                        ptr(g), rows, cols, v, self.stream))
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self.gemv_events.append(ev)
 
     # ------------------------------------------------------------------ a2 elementwise
     def axpby(self, a, x, b, y, out):

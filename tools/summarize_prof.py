@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/prof_*) into the small, tracked summaries
+under profiles/:  <tag>_kernel_stats.csv (verbatim --stats table) and <tag>_pmc.json (per-kernel
+means of each PMC counter + the derived HBM traffic per launch).
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB;
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read -> doubled here."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def main(tag, trace_dir, pmc_dirs, kernel_filter="gemv"):
+    os.makedirs("profiles", exist_ok=True)
+    for f in glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for d in pmc_dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"]
+                if kernel_filter not in k:
+                    continue
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[k]["_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+                meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                           "grid_threads": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]),
+                           "lds": int(r["LDS_Block_Size"])}
+    out = {}
+    for k, c in agg.items():
+        ncounters = max(len([n for n in c if n != "_ms"]), 1)
+        e = {"launches_profiled_per_counter": len(c["_ms"]) // ncounters,
+             "avg_ms_under_pmc": sum(c["_ms"]) / len(c["_ms"])}
+        e.update(json.loads(os.environ.get("PROF_META", "{}")))
+        e.update(meta[k])
+        for name, vals in c.items():
+            if name != "_ms":
+                e[name] = sum(vals) / len(vals)
+        if "FETCH_SIZE" in e:
+            e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2   # gfx950: x2 for wide streaming reads
+        if "WRITE_SIZE" in e:
+            e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
+        if "hbm_read_bytes_per_launch" in e:
+            e["hbm_traffic_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0.0)
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
+            e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+        out[k] = e
+    with open("profiles/%s_pmc.json" % tag, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])
