@@ -98,11 +98,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=131072, help="problem size (default: the metric's n)")
+    ap.add_argument("--size", dest="n", type=int, default=131072, help="problem size n (default: the metric's)")
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-mv", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--mode", default="allgather", choices=["allgather", "allreduce"])
+    ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
     ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -114,12 +114,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
+    # CCQP_DIST_BACKEND=gloo lets two ranks share one GPU for a rehearsal on a 1-GPU box
+    backend = os.environ.get("CCQP_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from ccqppy_amd import problems, solvers, solution_spaces as ss
