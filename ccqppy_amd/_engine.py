@@ -1,9 +1,14 @@
 """Per-device engine: thin, typed Python front of the C ABI (include/ccqp_hip.h).
 
-PyTorch is plumbing only: device memory (torch tensors), the current HIP stream and, for the
-row-sharded operator, torch.distributed (RCCL).  All arithmetic runs in libccqp_hip.so.
-Scalars that steer the solvers' control flow are read back into numpy float64 scalars so the
-host logic uses exactly the arithmetic types of the reference's Python loops.
+PyTorch is plumbing only: device memory (torch tensors), HIP streams and, for the row-sharded
+operator, torch.distributed (RCCL).  All arithmetic runs in libccqp_hip.so.  Scalars that steer
+the solvers' control flow are read back into numpy float64 scalars so the host logic uses exactly
+the arithmetic types of the reference's Python loops.
+
+An Engine owns one C-ABI context (scalar slab + reduction workspace) and launches on ONE stream:
+  * the default engine of a device follows torch's current stream (re-bound at every public entry);
+  * "lane" engines (batch-sharded mode, ccqppy_amd/batch.py) own a private stream each, so several
+    independent solves can be in flight on one GPU while the host round-robins between them.
 """
 import ctypes
 
@@ -22,52 +27,72 @@ def _require_gpu():
             "engine (gfx950); there is no CPU fallback.")
 
 
-def get_engine(device=None):
-    """Engine for a torch device / index (default: the current device)."""
-    _require_gpu()
+def _index_of(device):
     if device is None:
-        idx = torch.cuda.current_device()
-    elif isinstance(device, int):
-        idx = device
-    else:
-        dev = torch.device(device)
-        idx = torch.cuda.current_device() if dev.index is None else dev.index
+        return torch.cuda.current_device()
+    if isinstance(device, int):
+        return device
+    dev = torch.device(device)
+    return torch.cuda.current_device() if dev.index is None else dev.index
+
+
+def get_engine(device=None):
+    """Default engine of a torch device / index (default: the current device), bound to torch's
+    current stream on that device."""
+    _require_gpu()
+    idx = _index_of(device)
     eng = _engines.get(idx)
     if eng is None:
         eng = Engine(idx)
         _engines[idx] = eng
+    eng.bind()
     return eng
 
 
-def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+def make_lanes(device, count):
+    """`count` engines on `device`, each with its own context and its own HIP stream."""
+    _require_gpu()
+    idx = _index_of(device)
+    return [Engine(idx, torch.cuda.Stream(device=idx)) for _ in range(count)]
 
 
 class Engine:
-    def __init__(self, index):
-        self.lib = _lib.load()
+    def __init__(self, index, stream=None):
+        self.lib = lib = _lib.load()
         self.index = index
         self.device = torch.device("cuda", index)
         h = ctypes.c_void_p()
         with torch.cuda.device(index):
-            _lib.check(self.lib.ccqp_ctx_create(index, ctypes.byref(h)))
+            _lib.check(lib.ccqp_ctx_create(index, ctypes.byref(h)))
         self.ctx = h
         dev = ctypes.c_int()
         ncu = ctypes.c_int()
         buf = ctypes.create_string_buffer(64)
-        _lib.check(self.lib.ccqp_ctx_info(self.ctx, ctypes.byref(dev), ctypes.byref(ncu), buf, 64))
+        _lib.check(lib.ccqp_ctx_info(self.ctx, ctypes.byref(dev), ctypes.byref(ncu), buf, 64))
         self.num_cu = ncu.value
         self.arch = buf.value.decode()
         self._host = (ctypes.c_double * _lib.NUM_SLOTS)()
         self._scratch = {}
         self.gemv_variant = 0
-        self.mv_executed = 0   # every matvec launched through this engine (counted or not)
+        self.mv_executed = 0      # every matvec launched through this engine (counted or not)
         self.gemv_events = None   # list of (start, end) HIP events per matvec when profiling is on
+        self.own_stream = stream  # torch.cuda.Stream of a lane engine, None for the default engine
+        self.torch_stream = stream
+        self.stream = None        # raw hipStream_t (int) every launch goes to
+        self.bind()
 
-    # ------------------------------------------------------------------ memory plumbing
-    @property
-    def stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    def __del__(self):
+        try:
+            self.lib.ccqp_ctx_destroy(self.ctx)
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------ stream / memory plumbing
+    def bind(self):
+        """(Re)bind the launch stream: the lane's own stream, else torch's current stream."""
+        if self.own_stream is None:
+            self.torch_stream = torch.cuda.current_stream(self.device)
+        self.stream = self.torch_stream.cuda_stream
 
     def empty(self, n):
         return torch.empty(int(n), dtype=torch.float64, device=self.device)
@@ -92,9 +117,28 @@ class Engine:
 
     # ------------------------------------------------------------------ scalars
     def read(self, slot0, count):
-        """Blocking read of `count` slab slots -> list of np.float64 (the only sync point)."""
-        _lib.check(self.lib.ccqp_scalars_read(self.ctx, slot0, count, self._host, self.stream))
-        return [np.float64(self._host[i]) for i in range(count)]
+        """Blocking read of `count` slab slots -> list of np.float64 (a synchronisation point)."""
+        rc = self.lib.ccqp_scalars_read(self.ctx, slot0, count, self._host, self.stream)
+        if rc:
+            _lib.check(rc)
+        h = self._host
+        return [np.float64(h[i]) for i in range(count)]
+
+    def read_async(self, slot0, count):
+        """Enqueue the device->pinned copy of the slots; returns an event to wait on before fetch()."""
+        rc = self.lib.ccqp_scalars_read_async(self.ctx, slot0, count, self.stream)
+        if rc:
+            _lib.check(rc)
+        ev = torch.cuda.Event()
+        ev.record(self.torch_stream)
+        return ev
+
+    def fetch(self, slot0, count):
+        rc = self.lib.ccqp_scalars_host(self.ctx, slot0, count, self._host)
+        if rc:
+            _lib.check(rc)
+        h = self._host
+        return [np.float64(h[i]) for i in range(count)]
 
     # ------------------------------------------------------------------ a1 matvec
     def gemv(self, A, x, y, b=None, g=None, variant=None):
@@ -105,43 +149,59 @@ class Engine:
         self.mv_executed += 1
         ev = None
         if self.gemv_events is not None:
-            # HIP events on the stream the kernel is launched on (torch's current stream)
+            # HIP events on the stream the kernel is launched on
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record(torch.cuda.current_stream(self.device))
+            ev[0].record(self.torch_stream)
         if g is None:
-            _lib.check(self.lib.ccqp_gemv_f64(self.ctx, ptr(A), A.stride(0), ptr(x), ptr(y), rows, cols, v,
-                                              self.stream))
+            rc = self.lib.ccqp_gemv_f64(self.ctx, A.data_ptr(), A.stride(0), x.data_ptr(), y.data_ptr(), rows,
+                                        cols, v, self.stream)
         else:
-            _lib.check(self.lib.ccqp_gemv_epilogue_f64(self.ctx, ptr(A), A.stride(0), ptr(x), ptr(b), ptr(y),
-                                                       ptr(g), rows, cols, v, self.stream))
+            rc = self.lib.ccqp_gemv_epilogue_f64(self.ctx, A.data_ptr(), A.stride(0), x.data_ptr(), b.data_ptr(),
+                                                 y.data_ptr(), g.data_ptr(), rows, cols, v, self.stream)
+        if rc:
+            _lib.check(rc)
         if ev is not None:
-            ev[1].record(torch.cuda.current_stream(self.device))
+            ev[1].record(self.torch_stream)
             self.gemv_events.append(ev)
 
     # ------------------------------------------------------------------ a2 elementwise
     def axpby(self, a, x, b, y, out):
-        _lib.check(self.lib.ccqp_axpby_f64(self.ctx, float(a), ptr(x), float(b), ptr(y), ptr(out),
-                                           out.numel(), self.stream))
+        rc = self.lib.ccqp_axpby_f64(self.ctx, a, x.data_ptr(), b, y.data_ptr(), out.data_ptr(), out.numel(),
+                                     self.stream)
+        if rc:
+            _lib.check(rc)
 
     def scale(self, a, x, out):
-        _lib.check(self.lib.ccqp_scale_f64(self.ctx, float(a), ptr(x), ptr(out), out.numel(), self.stream))
+        rc = self.lib.ccqp_scale_f64(self.ctx, a, x.data_ptr(), out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def copy(self, x, out):
-        _lib.check(self.lib.ccqp_copy_f64(self.ctx, ptr(x), ptr(out), out.numel(), self.stream))
+        rc = self.lib.ccqp_copy_f64(self.ctx, x.data_ptr(), out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def fill(self, value, out):
-        _lib.check(self.lib.ccqp_fill_f64(self.ctx, float(value), ptr(out), out.numel(), self.stream))
+        rc = self.lib.ccqp_fill_f64(self.ctx, value, out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def mul(self, x, y, out):
-        _lib.check(self.lib.ccqp_mul_f64(self.ctx, ptr(x), ptr(y), ptr(out), out.numel(), self.stream))
+        rc = self.lib.ccqp_mul_f64(self.ctx, x.data_ptr(), y.data_ptr(), out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def muldiv(self, x, y, s, out):
-        _lib.check(self.lib.ccqp_muldiv_f64(self.ctx, ptr(x), ptr(y), float(s), ptr(out), out.numel(),
-                                            self.stream))
+        rc = self.lib.ccqp_muldiv_f64(self.ctx, x.data_ptr(), y.data_ptr(), s, out.data_ptr(), out.numel(),
+                                      self.stream)
+        if rc:
+            _lib.check(rc)
 
     def submul(self, x, y, z, out):
-        _lib.check(self.lib.ccqp_submul_f64(self.ctx, ptr(x), ptr(y), ptr(z), ptr(out), out.numel(),
-                                            self.stream))
+        rc = self.lib.ccqp_submul_f64(self.ctx, x.data_ptr(), y.data_ptr(), z.data_ptr(), out.data_ptr(),
+                                      out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     # ------------------------------------------------------------------ a3 reductions
     def dots(self, pairs, slot0=0):
@@ -150,7 +210,9 @@ class Engine:
         n = pairs[0][0].numel()
         xs = (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in pairs])
         ys = (ctypes.c_void_p * k)(*[p[1].data_ptr() for p in pairs])
-        _lib.check(self.lib.ccqp_dots_f64(self.ctx, k, xs, ys, n, slot0, self.stream))
+        rc = self.lib.ccqp_dots_f64(self.ctx, k, xs, ys, n, slot0, self.stream)
+        if rc:
+            _lib.check(rc)
 
     def dots_now(self, pairs, slot0=0):
         self.dots(pairs, slot0)
@@ -158,47 +220,71 @@ class Engine:
 
     # ------------------------------------------------------------------ projections
     def proj_elementwise(self, seg, x, out, a=1.0, b=0.0, y=None):
-        _lib.check(self.lib.ccqp_proj_elementwise_f64(self.ctx, ctypes.byref(seg), float(a), ptr(x), float(b),
-                                                      ptr(y), ptr(out), self.stream))
+        rc = self.lib.ccqp_proj_elementwise_f64(self.ctx, seg, a, x.data_ptr(), b,
+                                                None if y is None else y.data_ptr(), out.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def proj_normscale(self, seg, x, out, slot):
-        _lib.check(self.lib.ccqp_proj_normscale_f64(self.ctx, ctypes.byref(seg), ptr(x), ptr(out), slot,
-                                                    self.stream))
+        rc = self.lib.ccqp_proj_normscale_f64(self.ctx, seg, x.data_ptr(), out.data_ptr(), slot, self.stream)
+        if rc:
+            _lib.check(rc)
 
     def proj_small(self, table, nseg, x, out, mode):
-        _lib.check(self.lib.ccqp_proj_small_segments_f64(self.ctx, ptr(table), nseg, ptr(x), ptr(out), mode,
-                                                         self.stream))
+        rc = self.lib.ccqp_proj_small_segments_f64(self.ctx, table.data_ptr(), nseg, x.data_ptr(), out.data_ptr(),
+                                                   mode, self.stream)
+        if rc:
+            _lib.check(rc)
 
     def residual_sq_elementwise(self, seg, x, g, c, gd, slot):
-        _lib.check(self.lib.ccqp_residual_sq_elementwise_f64(self.ctx, ctypes.byref(seg), ptr(x), ptr(g),
-                                                             float(c), float(gd), slot, self.stream))
+        rc = self.lib.ccqp_residual_sq_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), c, gd, slot,
+                                                       self.stream)
+        if rc:
+            _lib.check(rc)
 
     # ------------------------------------------------------------------ MPRGP helpers
     def isclose_mask_mul(self, a, b, g, out, invert=False):
-        _lib.check(self.lib.ccqp_isclose_mask_mul_f64(self.ctx, ptr(a), ptr(b), ptr(g), 1 if invert else 0,
-                                                      ptr(out), out.numel(), self.stream))
+        rc = self.lib.ccqp_isclose_mask_mul_f64(self.ctx, a.data_ptr(), b.data_ptr(),
+                                                None if g is None else g.data_ptr(), 1 if invert else 0,
+                                                out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     def count_notclose(self, a, b, slot):
-        _lib.check(self.lib.ccqp_count_notclose_f64(self.ctx, ptr(a), ptr(b), a.numel(), slot, self.stream))
+        rc = self.lib.ccqp_count_notclose_f64(self.ctx, a.data_ptr(), b.data_ptr(), a.numel(), slot, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def feasible_steps_elementwise(self, seg, x, p, alpha0, K, slot0):
+        rc = self.lib.ccqp_feasible_steps_elementwise_f64(self.ctx, seg, x.data_ptr(), p.data_ptr(), alpha0, K,
+                                                          slot0, self.stream)
+        if rc:
+            _lib.check(rc)
 
     def normal_elementwise(self, seg, xp, out, dist2_slot):
-        _lib.check(self.lib.ccqp_normal_elementwise_f64(self.ctx, ctypes.byref(seg), ptr(xp), ptr(out),
-                                                        dist2_slot, self.stream))
+        rc = self.lib.ccqp_normal_elementwise_f64(self.ctx, seg, xp.data_ptr(), out.data_ptr(), dist2_slot,
+                                                  self.stream)
+        if rc:
+            _lib.check(rc)
 
     def normal_sphere(self, seg, xp, out, dist2_slot, len2_slot):
-        _lib.check(self.lib.ccqp_normal_sphere_f64(self.ctx, ctypes.byref(seg), ptr(xp), ptr(out), dist2_slot,
-                                                   len2_slot, self.stream))
+        rc = self.lib.ccqp_normal_sphere_f64(self.ctx, seg, xp.data_ptr(), out.data_ptr(), dist2_slot, len2_slot,
+                                             self.stream)
+        if rc:
+            _lib.check(rc)
 
     def chopped_gradient(self, w, g, nv, ng_slot, out):
-        _lib.check(self.lib.ccqp_chopped_gradient_f64(self.ctx, ptr(w), ptr(g), ptr(nv), ng_slot, ptr(out),
-                                                      out.numel(), self.stream))
+        rc = self.lib.ccqp_chopped_gradient_f64(self.ctx, w.data_ptr(), g.data_ptr(), nv.data_ptr(), ng_slot,
+                                                out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
 
     # ------------------------------------------------------------------ generator
     def gen_spd_rows(self, A, row0, n, seed):
         rows = A.shape[0]
-        _lib.check(self.lib.ccqp_gen_spd_rows_f64(self.ctx, ptr(A), A.stride(0), row0, rows, n,
-                                                  ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), self.stream))
+        _lib.check(self.lib.ccqp_gen_spd_rows_f64(self.ctx, A.data_ptr(), A.stride(0), row0, rows, n,
+                                                  seed & 0xFFFFFFFFFFFFFFFF, self.stream))
 
     def gen_vec(self, out, seed):
-        _lib.check(self.lib.ccqp_gen_vec_f64(self.ctx, ptr(out), out.numel(),
-                                             ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), self.stream))
+        _lib.check(self.lib.ccqp_gen_vec_f64(self.ctx, out.data_ptr(), out.numel(), seed & 0xFFFFFFFFFFFFFFFF,
+                                             self.stream))

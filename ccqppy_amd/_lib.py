@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libccqp_hip.so")
 NUM_SLOTS = 64
 MAX_DOTS = 8
 SMALL_SEG_MAX = 64
+MAX_STEPS = 16
 
 OP_IDENTITY, OP_LOWER, OP_UPPER, OP_BOX, OP_SPHERE, OP_CONE = range(6)
 SEG_LB_INT, SEG_UB_INT, SEG_P0_INT = 1, 2, 4
@@ -50,6 +51,8 @@ SIGNATURES = {
     "ccqp_ctx_destroy": [_P],
     "ccqp_ctx_info": [_P, _c.POINTER(_I), _c.POINTER(_I), _c.c_char_p, _I],
     "ccqp_scalars_read": [_P, _I, _I, _c.POINTER(_D), _P],
+    "ccqp_scalars_read_async": [_P, _I, _I, _P],
+    "ccqp_scalars_host": [_P, _I, _I, _c.POINTER(_D)],
     "ccqp_scalars_devptr": [_P, _c.POINTER(_P)],
     "ccqp_gemv_f64": [_P, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
@@ -67,6 +70,7 @@ SIGNATURES = {
     "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],
+    "ccqp_feasible_steps_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _I, _I, _P],
     "ccqp_normal_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
     "ccqp_normal_sphere_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _I, _P],
     "ccqp_chopped_gradient_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],

@@ -86,6 +86,23 @@ extern "C" int ccqp_scalars_read(ccqp_ctx* c, int slot0, int count, double* host
   return CCQP_OK;
 }
 
+extern "C" int ccqp_scalars_read_async(ccqp_ctx* c, int slot0, int count, void* stream) {
+  CCQP_REQUIRE(c != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, count), "slot range outside the slab");
+  if (count > 0)
+    CCQP_HIP(hipMemcpyAsync(c->host_slots + slot0, c->slots + slot0, (size_t)count * sizeof(double),
+                            hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_scalars_host(ccqp_ctx* c, int slot0, int count, double* host_out) {
+  CCQP_REQUIRE(c != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(host_out != nullptr, "host_out is NULL");
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, count), "slot range outside the slab");
+  for (int i = 0; i < count; ++i) host_out[i] = c->host_slots[slot0 + i];
+  return CCQP_OK;
+}
+
 extern "C" int ccqp_scalars_devptr(ccqp_ctx* c, double** out) {
   CCQP_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
   *out = c->slots;

@@ -144,9 +144,13 @@ static int gemv_dispatch(ccqp_ctx* ctx, const double* A, int64_t lda, const doub
   int R = variant & 0xF, U = (variant >> 4) & 0xF;
   const bool nt = !((variant >> 8) & 1);
   int bpc = (variant >> 12) & 0xFF;
-  if (R == 0) R = rows >= 16384 ? 4 : (rows >= 4096 ? 2 : 1);
-  if (U == 0) U = 2;
-  if (bpc == 0) bpc = 8;
+  // Defaults from the interleaved sweep on MI355X (tools/gemv_sweep.py, profiles/r01_gemv_sweep.md);
+  // every choice yields the same bits, so this is speed only.
+  const double elems = (double)rows * (double)cols;
+  const bool huge = elems >= 8589934592.0;  // >= 64 GiB of matrix
+  if (R == 0) R = (huge || cols >= 65536) ? 2 : 1;
+  if (U == 0) U = (rows < 8192 && cols < 65536) ? 2 : 1;
+  if (bpc == 0) bpc = huge ? 4 : 8;
   const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
                        (lda % 2) == 0;
   const int64_t ntasks = (rows + R - 1) / R;

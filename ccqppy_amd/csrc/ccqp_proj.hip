@@ -337,6 +337,60 @@ extern "C" int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const dou
   return CCQP_OK;
 }
 
+// grid (nblk, K): block (b, k) counts the not-close entries of yf = x - alpha_k*p over its chunk.
+__global__ __launch_bounds__(CCQP_BLOCK) void feasible_steps_stage1(ccqp_segk sg, const double* x,
+                                                                    const double* p, double alpha0,
+                                                                    int64_t chunk, double* dst, int nblk) {
+  __shared__ double lds4[4];
+  const int k = blockIdx.y;
+  double alpha = alpha0;
+  for (int j = 0; j < k; ++j) alpha *= 0.5;  // the reference's `alpha_f *= 0.5`, k times
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double t = alpha * p[i];
+    const double yf = x[i] - t;
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double pr = ccqp_proj_elem(sg.kind, sg.flags, yf, lb, ub);
+    acc += ccqp_isclose(yf, pr) ? 0.0 : 1.0;
+  }
+  const double s = ccqp_block_sum(acc, lds4);
+  if (threadIdx.x == 0) dst[(int64_t)k * nblk + blockIdx.x] = s;
+}
+
+extern "C" int ccqp_feasible_steps_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                                   const double* p, double alpha0, int K, int slot0,
+                                                   void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = seg_check(seg, true);
+  if (rc) return rc;
+  CCQP_REQUIRE(K >= 1 && K <= CCQP_MAX_STEPS, "K outside [1, CCQP_MAX_STEPS]");
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, K), "slot range outside the slab");
+  CCQP_REQUIRE(seg->dim == 0 || (x && p), "NULL vector");
+  hipStream_t s = (hipStream_t)stream;
+  const ccqp_segk k = seg_by_value(seg);
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(k.dim, &chunk, &nblk);
+  // partials area holds CCQP_MAX_DOTS * CCQP_RED_MAXBLK doubles: K * nblk must fit
+  CCQP_REQUIRE((int64_t)K * nblk <= (int64_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK, "K * blocks exceeds the workspace");
+  const double* xs = x ? x + seg->offset : x;
+  const double* ps = p ? p + seg->offset : p;
+  if (nblk == 1) {
+    hipLaunchKernelGGL(feasible_steps_stage1, dim3(1, K), dim3(CCQP_BLOCK), 0, s, k, xs, ps, alpha0, chunk,
+                       ctx->slots + slot0, 1);
+  } else {
+    hipLaunchKernelGGL(feasible_steps_stage1, dim3(nblk, K), dim3(CCQP_BLOCK), 0, s, k, xs, ps, alpha0, chunk,
+                       ctx->partials, nblk);
+    ccqp_launch_stage2(ctx, K, nblk, slot0, s);
+  }
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 __global__ __launch_bounds__(CCQP_BLOCK) void normal_elem_kernel(ccqp_segk sg, const double* xp, double* out,
                                                                  const double* dist2) {
   // `not np.isclose(np.linalg.norm(x - x_proj), 0)` -> zeros (solution_spaces.py:313-314)

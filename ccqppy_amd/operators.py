@@ -40,8 +40,9 @@ class DenseOperator:
         self.n = self.A.shape[1]
         self.rows = self.A.shape[0]
 
-    def matvec(self, x, y, b=None, g=None):
-        self.engine.gemv(self.A, x, y, b, g)
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        """y = A.x (and g = y + b); `engine` = the lane to launch on (default: the operator's)."""
+        (engine or self.engine).gemv(self.A, x, y, b, g)
 
 
 class VectorExchange:
@@ -120,12 +121,13 @@ class RowShardedOperator:
         self.row0, self.rows = self.exchange.row0, self.exchange.rows
         assert tuple(A_local.shape) == (self.rows, n), "local block must be rows [row0, row0+rows) x n"
 
-    def matvec(self, x, y, b=None, g=None):
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        eng = engine or self.engine
         sl = slice(self.row0, self.row0 + self.rows)
-        self.engine.gemv(self.A, x, y[sl])
+        eng.gemv(self.A, x, y[sl])
         self.exchange(y)
         if g is not None:
-            self.engine.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
+            eng.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
 
 
 def as_operator(A, engine=None):

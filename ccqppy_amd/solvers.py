@@ -35,11 +35,14 @@ _EPS10 = 10 * np.finfo(float).eps     # solvers.py:656,...
 class _Run:
     """Per-solve device state: engine, operator, staged inputs, fresh-vector factory."""
 
-    def __init__(self, A, b, x0, convex_proj_op):
+    def __init__(self, A, b, x0, convex_proj_op, engine=None):
         self.n = n = b.shape[0]
         self.P = convex_proj_op if convex_proj_op is not None else ss.IdentityProjOp(n)   # :115-116
         self.op = as_operator(A)
-        self.eng = eng = self.op.engine
+        # `engine` = a lane engine of the batch scheduler (own stream + scalar slab); default: the
+        # operator's engine, bound to torch's current stream
+        self.eng = eng = engine if engine is not None else self.op.engine
+        eng.bind()
         self.torch_out = isinstance(b, torch.Tensor)
         self.b = eng.to_device(b).reshape(-1)
         if x0 is None:
@@ -62,9 +65,9 @@ class _Run:
         y = self.new()
         if with_g:
             g = self.new()
-            self.op.matvec(v, y, self.b, g)
+            self.op.matvec(v, y, self.b, g, self.eng)
             return y, g
-        self.op.matvec(v, y)
+        self.op.matvec(v, y, None, None, self.eng)
         return y
 
     def lin(self, a, x, b, y):
@@ -88,9 +91,20 @@ class _Run:
     def residual_sq(self, x, g, slot):
         self.P._dev_residual_sq(self.eng, x, g, self.c, _GD, slot)
 
+    # -- synchronisation points.  The solver loops are GENERATORS: wherever the reference needs a
+    # scalar on the host they `yield (slot0, count)` and are resumed with the values.  solve() answers
+    # with a blocking read; the batch scheduler (batch.py) parks the solve and runs another lane.
+    def read(self, slot0, count):
+        return (yield (slot0, count))
+
+    def dots_now(self, pairs, slot0=0):
+        self.eng.dots(pairs, slot0)
+        return (yield (slot0, len(pairs)))
+
     def residual_now(self, x, g, slot=0):
         self.residual_sq(x, g, slot)
-        return np.sqrt(self.eng.read(slot, 1)[0])
+        v = yield (slot, 1)
+        return np.sqrt(v[0])
 
     def export(self, x):
         if self.torch_out:
@@ -120,19 +134,35 @@ class CCQPSolverBase(ABC):
         self._checkSolveInput(A, b, x0)
         print("solving " + self._label)
         run = _Run(A, b, x0, convex_proj_op)
+        gen = self._iterate(run)
         with np.errstate(all="ignore"):
-            x, res, mv_count = self._iterate(run)
+            try:
+                req = next(gen)
+                while True:
+                    req = gen.send(run.eng.read(*req))      # blocking scalar read
+            except StopIteration as stop:
+                x, res, mv_count = stop.value
+        self._finish(run, x, res, mv_count, time_start)
+        return self
+
+    def _start(self, A, b, x0=None, convex_proj_op=None, engine=None):
+        """Batch-scheduler entry: stage one solve on `engine` and return (run, generator)."""
+        self._checkSolveInput(A, b, x0)
+        run = _Run(A, b, x0, convex_proj_op, engine)
+        return run, self._iterate(run)
+
+    def _finish(self, run, x, res, mv_count, time_start):
         self._solution = run.export(x)
         self._solution_converged = mv_count < self.max_matrix_vector_multiplications
         self._solution_residual = res
         self._solution_num_matrix_vector_mults = mv_count
         self._executed_matrix_vector_mults = run.eng.mv_executed - run.mv0
         self._solution_time = time.time() - time_start
-        return self
 
     @abstractmethod
     def _iterate(self, run):
-        """-> (solution device vector, residual, reported mv_count)"""
+        """Generator; yields (slot0, count) read requests, returns (solution device vector,
+        residual, reported mv_count)."""
 
     def _checkSolveInput(self, A, b, x0):
         pass
@@ -187,7 +217,7 @@ class CCQPSolverPGD(CCQPSolverBase):
         xkm1 = run.copy(run.x0)
         _, gkm1 = run.mv(xkm1, True)
         mv_count += 1
-        res = run.residual_now(xkm1, gkm1)
+        res = yield from run.residual_now(xkm1, gkm1)
         if res >= tol:
             while True:
                 xk = run.step_project(xkm1, self.step_size, gkm1)
@@ -195,7 +225,7 @@ class CCQPSolverPGD(CCQPSolverBase):
                 mv_count += 1
                 if mv_count >= max_mv:
                     break
-                res = run.residual_now(xk, gk)
+                res = yield from run.residual_now(xk, gk)
                 if res < tol:
                     break
                 xk, xkm1 = xkm1, xk
@@ -223,7 +253,7 @@ class _APGDCore(CCQPSolverBase):
         thk1 = 1.0
         d = run.lin(1.0, xk, -1.0, ones)                # xk - ones
         Ad = run.mv(d)
-        s = eng.dots_now([(Ad, Ad), (d, d)])
+        s = yield from run.dots_now([(Ad, Ad), (d, d)])
         mv_count += 1
         L = np.sqrt(s[0]) / np.sqrt(s[1])               # :264-268
         t = 1.0 / L
@@ -245,7 +275,7 @@ class _APGDCore(CCQPSolverBase):
                     run.residual_sq(xkp1, g1, 7)
                     if AR:
                         eng.dots([(gk, run.lin(1.0, xkp1, -1.0, xk))], 6)
-                    res2 = eng.read(6, 2)
+                    res2 = yield from run.read(6, 2)
                     break
                 d = run.lin(1.0, xkp1, -1.0, yk)
                 pairs = [(xkp1, Ax1), (xkp1, b), (gk, d), (d, d)]
@@ -258,12 +288,12 @@ class _APGDCore(CCQPSolverBase):
                 # speculative: the residual needs xkp1 and A.xkp1 only -> same sync as the dots
                 run.residual_sq(xkp1, g1, 7)
                 if first:
-                    sc = eng.read(0, 8)
+                    sc = yield from run.read(0, 8)
                     r1 = sc[0] * 0.5
                     r2 = sc[1]
                     first = False
                 else:
-                    sc = [None, None] + eng.read(2, 6)
+                    sc = [None, None] + (yield from run.read(2, 6))
                 l1 = sc[2] * 0.5
                 l2 = sc[3]
                 r3 = sc[4]
@@ -333,11 +363,11 @@ class _BBPGDCore(CCQPSolverBase):
             gmin = run.copy(run.x0)
         _, gkm1 = run.mv(xkm1, True)
         mv_count += 1
-        res = run.residual_now(xkm1, gkm1)
+        res = yield from run.residual_now(xkm1, gkm1)
         resmin = np.inf
         if res >= tol:
             Ag = run.mv(gkm1)                           # executed, not counted (:635,:775)
-            s = eng.dots_now([(gkm1, gkm1), (gkm1, Ag)])
+            s = yield from run.dots_now([(gkm1, gkm1), (gkm1, Ag)])
             alpha = s[0] / s[1]
             while True:
                 xk = run.step_project(xkm1, alpha, gkm1)
@@ -351,12 +381,12 @@ class _BBPGDCore(CCQPSolverBase):
                     dx = run.lin(1.0, xk, -1.0, xkm1)
                     dg = run.lin(1.0, gk, -1.0, gkm1)
                     eng.dots([(dx, dx), (dx, dg)], 1)
-                    sc = eng.read(0, 3)
+                    sc = yield from run.read(0, 3)
                     res = np.sqrt(sc[0])
                     if res < tol:
                         break
                 else:
-                    res = np.sqrt(eng.read(0, 1)[0])
+                    res = np.sqrt((yield from run.read(0, 1))[0])
                     if res < tol:
                         break
                     if res < resmin:                    # :793-796
@@ -367,7 +397,7 @@ class _BBPGDCore(CCQPSolverBase):
                         xk = run.step_project(xmin, _GD, gmin)
                     dx = run.lin(1.0, xk, -1.0, xkm1)
                     dg = run.lin(1.0, gk, -1.0, gkm1)
-                    sc = [None] + eng.dots_now([(dx, dx), (dx, dg)], 1)
+                    sc = [None] + (yield from run.dots_now([(dx, dx), (dx, dg)], 1))
                 alpha = sc[1] / (sc[2] + _EPS10)
                 xk, xkm1 = xkm1, xk
                 gk, gkm1 = gkm1, gk
@@ -412,7 +442,7 @@ class CCQPSolverSPG(CCQPSolverBase):
         xk = run.copy(run.x0)
         _, gk = run.mv(xk, True)
         Agk = run.mv(gk)
-        s = eng.dots_now([(gk, xk), (gk, gk), (gk, Agk)])
+        s = yield from run.dots_now([(gk, xk), (gk, gk), (gk, Agk)])
         fk = s[0]                                       # sic: g.x, :923
         alpha = s[1] / s[2]
         mv_count += 2
@@ -427,7 +457,7 @@ class CCQPSolverSPG(CCQPSolverBase):
             mv_count += 1
             if mv_count >= max_mv:
                 break
-            dkdotdk, dkdotAdk, dkdotgk = eng.dots_now([(dk, dk), (dk, Adk), (dk, gk)])
+            dkdotdk, dkdotAdk, dkdotgk = yield from run.dots_now([(dk, dk), (dk, Adk), (dk, gk)])
             if np.sqrt(dkdotdk) <= tol:
                 break
             fmax = max(fk_queue)
@@ -472,10 +502,10 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         _, gk = run.mv(xk, True)
         gkp1 = run.copy(gk)
         mv_count += 1
-        res = run.residual_now(xk, gk)
+        res = yield from run.residual_now(xk, gk)
         if res >= tol:
             Agk = run.mv(gk)
-            s = eng.dots_now([(gk, gk), (gk, Agk)])
+            s = yield from run.dots_now([(gk, gk), (gk, Agk)])
             alpha_bb = s[0] / s[1]
             mv_count += 1
             p = self._free_mask_mul(run, xk, gk)
@@ -495,34 +525,22 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 eng.dots([(nv, gk)], 8)
                 beta_x = run.new()
                 eng.chopped_gradient(w, gk, nv, 8, beta_x)               # :1096-1097
-                bb, pp = eng.dots_now([(beta_x, beta_x), (psi, psi)])
+                bb, pp = yield from run.dots_now([(beta_x, beta_x), (psi, psi)])
                 if bb < pp:
                     Ap = run.mv(p)
                     mv_count += 1
                     if mv_count >= max_mv:
                         break
-                    psip, pAp = eng.dots_now([(psi, p), (p, Ap)])
+                    psip, pAp = yield from run.dots_now([(psi, p), (p, Ap)])
                     alpha_cg = psip / pAp
                     y = run.lin(1.0, xk, -alpha_cg, p)
-                    alpha_f = alpha_cg + _EPS10
-                    nhalve = 0
-                    while True:                                          # :1113-1118
-                        yf = run.lin(1.0, xk, -alpha_f, p)
-                        eng.count_notclose(yf, run.project(yf), 9)
-                        if eng.read(9, 1)[0] == 0:
-                            break
-                        alpha_f *= 0.5
-                        nhalve += 1
-                        if nhalve > 1200:   # alpha_f has underflowed to 0: the reference never exits
-                            raise RuntimeError("MPRGP feasibility bisection cannot terminate "
-                                               "(solvers.py:1113-1118 loops forever on this input)")
+                    alpha_f = yield from self._feasible_step(run, xk, p, alpha_cg + _EPS10)
                     if alpha_cg <= alpha_f:
                         xkp1 = run.copy(y)
                         gkp1 = run.lin(1.0, gk, -alpha_cg, Ap)
                         dx = run.lin(1.0, xkp1, -1.0, xk)
                         Adx = run.mv(dx)                                 # executed, not counted (:1129)
-                        s = eng.dots_now([(dx, dx), (dx, Adx)])
-                        alpha_bb = s[0] / (s[1] + _EPS10)
+                        eng.dots([(dx, dx), (dx, Adx)], 0)               # alpha_bb: read in the tail
                         psi_y = self._free_mask_mul(run, y, gkp1)
                         beta = run.new()
                         eng.muldiv(psi_y, Ap, pAp, beta)                 # elementwise VECTOR, :1134
@@ -534,7 +552,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                         gh = run.lin(1.0, gk, -alpha_f, Ap)
                         dx = run.lin(1.0, xh, -1.0, xk)
                         dg = run.lin(1.0, gh, -1.0, gk)
-                        s = eng.dots_now([(dx, dx), (dx, dg)])
+                        s = yield from run.dots_now([(dx, dx), (dx, dg)])
                         alpha = s[0] / (s[1] + _EPS10)
                         xkp1 = run.step_project(xh, alpha, gh)
                         _, gkp1 = run.mv(xkp1, True)
@@ -544,22 +562,56 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                         p = self._free_mask_mul(run, xkp1, gkp1)
                         dx = run.lin(1.0, xkp1, -1.0, xk)
                         Adx = run.mv(dx)                                 # executed, not counted (:1163)
-                        s = eng.dots_now([(dx, dx), (dx, Adx)])
-                        alpha_bb = s[0] / (s[1] + _EPS10)
+                        eng.dots([(dx, dx), (dx, Adx)], 0)
                 else:
                     xkp1 = run.step_project(xk, alpha_bb, gk)
                     dx = run.lin(1.0, xkp1, -1.0, xk)
                     Adx = run.mv(dx)                                     # executed, not counted (:1172)
-                    s = eng.dots_now([(dx, dx), (dx, Adx)])
-                    alpha_bb = s[0] / (s[1] + _EPS10)
+                    eng.dots([(dx, dx), (dx, Adx)], 0)
                     _, gk = run.mv(xk, True)                             # redundant but counted (:1174)
                     mv_count += 1
                     if mv_count >= max_mv:
                         break
                     p = self._free_mask_mul(run, xkp1, gkp1)             # STALE gkp1 (:1180-1182)
-                res = run.residual_now(xkp1, gkp1)
+                # one sync for the BB step length of every branch (slots 0,1) and the residual (slot 2)
+                run.residual_sq(xkp1, gkp1, 2)
+                sc = yield from run.read(0, 3)
+                alpha_bb = sc[0] / (sc[1] + _EPS10)
+                res = np.sqrt(sc[2])
                 if res < tol:
                     break
                 xk, xkp1 = xkp1, xk
                 gk, gkp1 = gkp1, gk
         return xkp1, res, mv_count
+
+    _STEPS = 8      # candidate steps per feasibility launch
+
+    def _feasible_step(self, run, xk, p, alpha_f):
+        """Largest alpha in {alpha_f * 0.5^k} with  all(isclose(y, P(y))), y = xk - alpha*p  -- the
+        reference's halving loop (solvers.py:1112-1118).  For elementwise P, `_STEPS` candidates are
+        evaluated per launch (the values visited are exactly the reference's: *0.5 is exact)."""
+        eng, P = run.eng, run.P
+        tried = 0
+        if isinstance(P, ss._ElementwiseOp):
+            seg = P._seg(eng, 0, run.n)
+            while True:
+                eng.feasible_steps_elementwise(seg, xk, p, alpha_f, self._STEPS, 16)
+                counts = yield from run.read(16, self._STEPS)
+                for c in counts:
+                    if c == 0:
+                        return alpha_f
+                    alpha_f *= 0.5
+                tried += self._STEPS
+                if tried > 1200:   # alpha_f has underflowed to 0: the reference never exits either
+                    raise RuntimeError("MPRGP feasibility bisection cannot terminate "
+                                       "(solvers.py:1113-1118 loops forever on this input)")
+        while True:
+            yf = run.lin(1.0, xk, -alpha_f, p)
+            eng.count_notclose(yf, run.project(yf), 9)
+            if (yield from run.read(9, 1))[0] == 0:
+                return alpha_f
+            alpha_f *= 0.5
+            tried += 1
+            if tried > 1200:
+                raise RuntimeError("MPRGP feasibility bisection cannot terminate "
+                                   "(solvers.py:1113-1118 loops forever on this input)")

@@ -54,6 +54,12 @@ int ccqp_ctx_destroy(ccqp_ctx* ctx);
 int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int buflen);
 /* Copy slots [slot0, slot0+count) to host_out and wait for `stream` (the only sync point). */
 int ccqp_scalars_read(ccqp_ctx* ctx, int slot0, int count, double* host_out, void* stream);
+/* Split form for callers that interleave several solves on several streams (batch-sharded mode):
+ * ccqp_scalars_read_async enqueues the device->pinned-host copy on `stream` and returns at once;
+ * after the caller has waited for that point of the stream (event / stream sync),
+ * ccqp_scalars_host copies the values out of the pinned mirror.  One context per stream. */
+int ccqp_scalars_read_async(ccqp_ctx* ctx, int slot0, int count, void* stream);
+int ccqp_scalars_host(ccqp_ctx* ctx, int slot0, int count, double* host_out);
 /* Device address of the slab (for kernels of the caller's own / for tests). */
 int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
 
@@ -159,6 +165,13 @@ int ccqp_isclose_mask_mul_f64(ccqp_ctx* ctx, const double* a, const double* b, c
 /* slab[slot] = number of i with NOT isclose(a_i, b_i)   (np.all(...) <=> 0), solvers.py:1115 */
 int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const double* b, int64_t n, int slot,
                             void* stream);
+/* MPRGP's feasible-step bisection (solvers.py:1112-1118) evaluated for K candidate steps in ONE
+ * launch: for k < K (<= 16), alpha_k = alpha0 * 0.5^k (exact, the same values the reference's
+ * `alpha_f *= 0.5` loop visits), yf = x - alpha_k*p, slab[slot0+k] = #{i : not isclose(yf_i, P(yf)_i)}.
+ * ELEMENTWISE kinds only.  The host takes the first k whose count is 0. */
+#define CCQP_MAX_STEPS 16
+int ccqp_feasible_steps_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                        const double* p, double alpha0, int K, int slot0, void* stream);
 /* normal_vector of an ELEMENTWISE kind over its block: xp = P(x) (already computed),
  * slab[dist2_slot] = |x - xp|^2 over the block.  If sqrt(dist2) > 1e-8 (x outside) -> zeros, else
  * +1 where isclose(xp_i, ub_i) elif -1 where isclose(xp_i, lb_i) (solution_spaces.py:306-322). */

@@ -1,0 +1,74 @@
+"""GPU: batch-sharded mode (BASELINE config 5: many independent box-QPs, MPRGP, no collective).
+The interleaving scheduler must not change any result: every problem's x, residual and MV counts
+are bitwise those of a plain sequential solve(), for several lane counts; and the MPRGP solves agree
+with the CPU oracle on the per-problem MV counts."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, gen_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(n, count):
+    from ccqppy_amd import problems, solution_spaces as ss
+    out = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, 1234 + p)
+        out.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+    return out
+
+
+@pytest.mark.parametrize("sname,args", [("MPRGP", (1e-6, 300)), ("BBPGD", (1e-8, 5000)), ("APGD", (1e-8, 5000)),
+                                        ("BBPGDf", (1e-8, 5000)), ("PGD", (1e-8, 5000, 0.3))])
+def test_batch_equals_sequential(sname, args):
+    from ccqppy_amd import solvers
+    from ccqppy_amd.batch import solve_batch
+    cls = getattr(solvers, "CCQPSolver" + sname)
+    probs = _problems(1024, 7)
+    seq = []
+    for A, b, x0, P in probs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            seq.append(cls(*args).solve(A, b, x0, P))
+    for lanes in (1, 3, 8):
+        got = solve_batch(lambda: cls(*args), probs, lanes=lanes)
+        assert len(got) == len(seq)
+        for g, s in zip(got, seq):
+            assert g.solution_num_matrix_vector_multiplications == s.solution_num_matrix_vector_multiplications
+            assert g.executed_matrix_vector_multiplications == s.executed_matrix_vector_multiplications
+            assert g.solution_converged == s.solution_converged
+            assert float(g.solution_residual) == float(s.solution_residual)
+            a = g.solution.cpu().numpy()
+            bb = s.solution.cpu().numpy()
+            assert np.array_equal(a.view(np.uint64), bb.view(np.uint64))
+
+
+def test_batch_mprgp_matches_oracle_counts():
+    from ccqppy_amd import solvers
+    from ccqppy_amd.batch import solve_batch
+    n, count = 2048, 5
+    probs = _problems(n, count)
+    got = solve_batch(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), probs, lanes=4)
+    for p, g in enumerate(got):
+        A = gen_ref.spd_rows(n, 1234 + p)
+        b = probs[p][1].cpu().numpy()
+        o = cpu_ref.solve_mprgp(A, b, 1e-6, 300, P=cpu_ref.Box(n, -0.5 * np.ones(n), 0.5 * np.ones(n)))
+        assert g.solution_num_matrix_vector_multiplications == o.solution_num_matrix_vector_multiplications
+        assert g.executed_matrix_vector_multiplications == o.executed_mv
+        assert np.linalg.norm(g.solution.cpu().numpy() - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+
+
+def test_batch_partition_driver_single_rank():
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd.batch import solve_batch_sharded
+    n = 512
+
+    def make(p):
+        op, b, _ = problems.random_problem(n, 100 + p)
+        return op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    res = solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), make, 6, lanes=3)
+    assert sorted(res) == list(range(6))
+    assert all(r.solution_converged for r in res.values())
