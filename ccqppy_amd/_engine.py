@@ -125,15 +125,13 @@ class Engine:
         return [np.float64(h[i]) for i in range(count)]
 
     def read_async(self, slot0, count):
-        """Enqueue the device->pinned copy of the slots; returns an event to wait on before fetch()."""
+        """Enqueue the device->pinned copy of the slots (+ the context's event); fetch() completes it."""
         rc = self.lib.ccqp_scalars_read_async(self.ctx, slot0, count, self.stream)
         if rc:
             _lib.check(rc)
-        ev = torch.cuda.Event()
-        ev.record(self.torch_stream)
-        return ev
 
     def fetch(self, slot0, count):
+        """Wait for the pending read_async (no-op if it has landed) and return the values."""
         rc = self.lib.ccqp_scalars_host(self.ctx, slot0, count, self._host)
         if rc:
             _lib.check(rc)
@@ -276,6 +274,37 @@ class Engine:
     def chopped_gradient(self, w, g, nv, ng_slot, out):
         rc = self.lib.ccqp_chopped_gradient_f64(self.ctx, w.data_ptr(), g.data_ptr(), nv.data_ptr(), ng_slot,
                                                 out.data_ptr(), out.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
+
+    # fused MPRGP steps (elementwise feasible sets)
+    def mprgp_split(self, seg, x, g, xp, psi, w, dist2_slot):
+        rc = self.lib.ccqp_mprgp_split_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), xp.data_ptr(),
+                                           psi.data_ptr(), w.data_ptr(), dist2_slot, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def mprgp_normal_dot(self, seg, xp, g, nv, dist2_slot, ng_slot):
+        rc = self.lib.ccqp_mprgp_normal_dot_f64(self.ctx, seg, xp.data_ptr(), g.data_ptr(), nv.data_ptr(),
+                                                dist2_slot, ng_slot, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def mprgp_proportion(self, w, g, nv, psi, ng_slot, slot0):
+        rc = self.lib.ccqp_mprgp_proportion_f64(self.ctx, w.data_ptr(), g.data_ptr(), nv.data_ptr(),
+                                                psi.data_ptr(), ng_slot, w.numel(), slot0, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def free_gradient_elementwise(self, seg, x, g, out):
+        rc = self.lib.ccqp_free_gradient_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(),
+                                                         out.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def cg_direction(self, psi, Ap, pAp, p, out):
+        rc = self.lib.ccqp_cg_direction_f64(self.ctx, psi.data_ptr(), Ap.data_ptr(), pAp, p.data_ptr(),
+                                            out.data_ptr(), out.numel(), self.stream)
         if rc:
             _lib.check(rc)
 

@@ -74,6 +74,11 @@ SIGNATURES = {
     "ccqp_normal_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
     "ccqp_normal_sphere_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _I, _P],
     "ccqp_chopped_gradient_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
+    "ccqp_mprgp_split_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _P, _I, _P],
+    "ccqp_mprgp_normal_dot_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _I, _I, _P],
+    "ccqp_mprgp_proportion_f64": [_P, _P, _P, _P, _P, _I, _I64, _I, _P],
+    "ccqp_free_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
+    "ccqp_cg_direction_f64": [_P, _P, _P, _D, _P, _P, _I64, _P],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
     "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
 }

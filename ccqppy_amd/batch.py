@@ -42,11 +42,11 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
         A, b, x0, op = problems[pidx]
         eng = lane_engines[lane]
         t0 = time.time()
-        with torch.cuda.stream(eng.own_stream):
-            print("solving " + solvers[pidx]._label, file=out)
-            run, gen = solvers[pidx]._start(A, b, x0, op, eng)
-            state = [pidx, run, gen, None, None, t0]
-            advance(state, None)
+        set_stream(eng.own_stream)
+        print("solving " + solvers[pidx]._label, file=out)
+        run, gen = solvers[pidx]._start(A, b, x0, op, eng)
+        state = [pidx, run, gen, None, None, t0]
+        advance(state, None)
         return state
 
     def advance(state, values):
@@ -55,13 +55,16 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
         try:
             req = next(gen) if values is None and state[3] is None else gen.send(values)
             state[3] = req
-            state[4] = run.eng.read_async(*req)
+            run.eng.read_async(*req)
         except StopIteration as stop:
             x, res, mv = stop.value
             solvers[pidx]._finish(run, x, res, mv, state[5])
             state[2] = None
 
-    with np.errstate(all="ignore"):
+    set_stream = torch.cuda.set_stream
+    caller_stream = torch.cuda.current_stream(base.device)
+    try:
+      with np.errstate(all="ignore"):
         for lane in range(nl):
             if pending:
                 active[lane] = start(lane)
@@ -74,10 +77,11 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
                         active[lane] = start(lane)
                     continue
                 eng = state[1].eng
-                state[4].synchronize()          # usually already complete: other lanes ran meanwhile
-                vals = eng.fetch(*state[3])
-                with torch.cuda.stream(eng.own_stream):
-                    advance(state, vals)
+                vals = eng.fetch(*state[3])     # usually already there: other lanes ran meanwhile
+                set_stream(eng.own_stream)      # allocations below belong to this lane's stream
+                advance(state, vals)
+    finally:
+        set_stream(caller_stream)
     torch.cuda.synchronize(base.device)
     if not quiet:
         print(out.getvalue(), end="")

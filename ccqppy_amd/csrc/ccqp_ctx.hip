@@ -35,15 +35,18 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->slots = nullptr;
   c->partials = nullptr;
   c->host_slots = nullptr;
+  c->read_event = nullptr;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&c->partials, (size_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->host_slots, CCQP_NUM_SLOTS * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->read_event, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(c->slots, 0, CCQP_NUM_SLOTS * sizeof(double));
   if (e != hipSuccess) {
     ccqp_set_error("ccqp_ctx_create: allocation failed: %s", hipGetErrorString(e));
     if (c->slots) (void)hipFree(c->slots);
     if (c->partials) (void)hipFree(c->partials);
     if (c->host_slots) (void)hipHostFree(c->host_slots);
+    if (c->read_event) (void)hipEventDestroy(c->read_event);
     delete c;
     (void)hipSetDevice(prev);
     return CCQP_ERR_HIP;
@@ -58,6 +61,7 @@ extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
   (void)hipFree(c->slots);
   (void)hipFree(c->partials);
   (void)hipHostFree(c->host_slots);
+  (void)hipEventDestroy(c->read_event);
   delete c;
   return CCQP_OK;
 }
@@ -92,6 +96,7 @@ extern "C" int ccqp_scalars_read_async(ccqp_ctx* c, int slot0, int count, void* 
   if (count > 0)
     CCQP_HIP(hipMemcpyAsync(c->host_slots + slot0, c->slots + slot0, (size_t)count * sizeof(double),
                             hipMemcpyDeviceToHost, (hipStream_t)stream));
+  CCQP_HIP(hipEventRecord(c->read_event, (hipStream_t)stream));
   return CCQP_OK;
 }
 
@@ -99,6 +104,7 @@ extern "C" int ccqp_scalars_host(ccqp_ctx* c, int slot0, int count, double* host
   CCQP_REQUIRE(c != nullptr, "ctx is NULL");
   CCQP_REQUIRE(host_out != nullptr, "host_out is NULL");
   CCQP_REQUIRE(ccqp_slot_ok(slot0, count), "slot range outside the slab");
+  CCQP_HIP(hipEventSynchronize(c->read_event));   // returns at once if the copy has completed
   for (int i = 0; i < count; ++i) host_out[i] = c->host_slots[slot0 + i];
   return CCQP_OK;
 }

@@ -8,7 +8,7 @@
 #include "ccqp_hip.h"
 
 #define CCQP_BLOCK 256          // 4 wave64 per workgroup
-#define CCQP_RED_CHUNK 8192     // elements per stage-1 reduction block (32 per thread)
+#define CCQP_RED_CHUNK 2048     // elements per stage-1 reduction block (8 per thread)
 #define CCQP_RED_MAXBLK 1024    // stage-1 blocks per reduction (partials per dot)
 
 struct ccqp_ctx {
@@ -18,6 +18,7 @@ struct ccqp_ctx {
   double* slots;      // device, CCQP_NUM_SLOTS doubles
   double* partials;   // device, CCQP_MAX_DOTS * CCQP_RED_MAXBLK doubles
   double* host_slots; // pinned host mirror
+  hipEvent_t read_event;  // marks the end of the last ccqp_scalars_read_async copy
 };
 
 void ccqp_set_error(const char* fmt, ...);

@@ -1,0 +1,228 @@
+// Fused MPRGP steps for ELEMENTWISE feasible sets (Identity / Lower / Upper / Box).
+// Reference: solvers.py:1081-1098 (proportioning test), :1132-1135 (CG direction update).
+// At n = 8192 (BASELINE config 5) one matvec is 83 us, so the ~25 tiny launches the literal
+// operation sequence needs per iteration dominate; these kernels perform the same arithmetic, in
+// the same order, with the same reduction geometry (bitwise identical results, asserted in
+// tests/test_gpu_batch.py) in 5 launches instead of 14.
+#include "ccqp_internal.h"
+
+int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s);
+
+static inline int vec_grid(int64_t n) {
+  int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static inline ccqp_segk segk(const ccqp_seg* seg) {
+  ccqp_segk k;
+  k.kind = seg->kind;
+  k.flags = seg->flags;
+  k.dim = seg->dim;
+  k.lb = seg->lb;
+  k.ub = seg->ub;
+  k.lb_s = seg->lb_s;
+  k.ub_s = seg->ub_s;
+  return k;
+}
+
+static int elementwise_seg_ok(const ccqp_seg* seg) {
+  CCQP_REQUIRE(seg != nullptr, "seg is NULL");
+  CCQP_REQUIRE(seg->dim >= 0 && seg->offset >= 0, "negative offset/dim");
+  CCQP_REQUIRE(seg->kind >= CCQP_OP_IDENTITY && seg->kind <= CCQP_OP_BOX, "kind is not elementwise");
+  return CCQP_OK;
+}
+
+// ---- K1: xp = P(x); delta = isclose(x, xp); psi = delta*g; w = 1-delta; sum (x-xp)^2 -> dst
+__global__ __launch_bounds__(CCQP_BLOCK) void split_stage1(ccqp_segk sg, const double* x, const double* g,
+                                                           double* xp, double* psi, double* w, int64_t chunk,
+                                                           double* dst) {
+  __shared__ double lds4[4];
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double xi = x[i];
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
+    const bool close = ccqp_isclose(xi, p);
+    xp[i] = p;
+    psi[i] = (close ? 1.0 : 0.0) * g[i];
+    w[i] = close ? 0.0 : 1.0;
+    const double d = xi - p;
+    acc = fma(d, d, acc);
+  }
+  const double s = ccqp_block_sum(acc, lds4);
+  if (threadIdx.x == 0) dst[blockIdx.x] = s;
+}
+
+extern "C" int ccqp_mprgp_split_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, const double* g,
+                                    double* xp, double* psi, double* w, int dist2_slot, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = elementwise_seg_ok(seg);
+  if (rc) return rc;
+  CCQP_REQUIRE(ccqp_slot_ok(dist2_slot, 1), "slot outside the slab");
+  CCQP_REQUIRE(seg->dim == 0 || (x && g && xp && psi && w), "NULL vector");
+  hipStream_t s = (hipStream_t)stream;
+  const ccqp_segk k = segk(seg);
+  const int64_t o = seg->offset;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(k.dim, &chunk, &nblk);
+  double* dst = nblk == 1 ? ctx->slots + dist2_slot : ctx->partials;
+  hipLaunchKernelGGL(split_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, x + o, g + o, xp + o, psi + o, w + o,
+                     chunk, dst);
+  if (nblk > 1) ccqp_launch_stage2(ctx, 1, nblk, dist2_slot, s);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// ---- K2: nv = normal_vector from xp (+ the "outside => zeros" rule); sum nv*g -> dst
+__global__ __launch_bounds__(CCQP_BLOCK) void normal_dot_stage1(ccqp_segk sg, const double* xp, const double* g,
+                                                                double* nvout, const double* dist2,
+                                                                int64_t chunk, double* dst) {
+  __shared__ double lds4[4];
+  const bool outside = !ccqp_isclose(sqrt(*dist2), 0.0);
+  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    double nv = 0.0;
+    if (!outside) {
+      const double v = xp[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
+      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
+    }
+    nvout[i] = nv;
+    acc = fma(nv, g[i], acc);
+  }
+  const double s = ccqp_block_sum(acc, lds4);
+  if (threadIdx.x == 0) dst[blockIdx.x] = s;
+}
+
+extern "C" int ccqp_mprgp_normal_dot_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp, const double* g,
+                                         double* nv, int dist2_slot, int ng_slot, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = elementwise_seg_ok(seg);
+  if (rc) return rc;
+  CCQP_REQUIRE(ccqp_slot_ok(dist2_slot, 1) && ccqp_slot_ok(ng_slot, 1), "slot outside the slab");
+  CCQP_REQUIRE(seg->dim == 0 || (xp && g && nv), "NULL vector");
+  hipStream_t s = (hipStream_t)stream;
+  const ccqp_segk k = segk(seg);
+  const int64_t o = seg->offset;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(k.dim, &chunk, &nblk);
+  double* dst = nblk == 1 ? ctx->slots + ng_slot : ctx->partials;
+  hipLaunchKernelGGL(normal_dot_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, xp + o, g + o, nv + o,
+                     ctx->slots + dist2_slot, chunk, dst);
+  if (nblk > 1) ccqp_launch_stage2(ctx, 1, nblk, ng_slot, s);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// ---- K3: beta = w*(g - min(0, ng)*nv);  (sum beta^2, sum psi^2) -> dst[0..1]
+__global__ __launch_bounds__(CCQP_BLOCK) void proportion_stage1(const double* w, const double* g,
+                                                                const double* nv, const double* psi,
+                                                                const double* ng, int64_t n, int64_t chunk,
+                                                                double* dst, int nblk) {
+  __shared__ double lds4[4];
+  const double v = *ng;
+  const double sc = (v != v) ? v : (v < 0.0 ? v : 0.0);  // np.min([0, v])
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > n) hi = n;
+  double ab = 0.0, ap = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double t = sc * nv[i];
+    const double u = g[i] - t;
+    const double be = w[i] * u;
+    ab = fma(be, be, ab);
+    const double ps = psi[i];
+    ap = fma(ps, ps, ap);
+  }
+  const double sb = ccqp_block_sum(ab, lds4);
+  const double sp = ccqp_block_sum(ap, lds4);
+  if (threadIdx.x == 0) {
+    dst[blockIdx.x] = sb;
+    dst[nblk + blockIdx.x] = sp;
+  }
+}
+
+extern "C" int ccqp_mprgp_proportion_f64(ccqp_ctx* ctx, const double* w, const double* g, const double* nv,
+                                         const double* psi, int ng_slot, int64_t n, int slot0, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(n >= 0, "negative size");
+  CCQP_REQUIRE(ccqp_slot_ok(ng_slot, 1) && ccqp_slot_ok(slot0, 2), "slot outside the slab");
+  CCQP_REQUIRE(n == 0 || (w && g && nv && psi), "NULL vector");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  double* dst = nblk == 1 ? ctx->slots + slot0 : ctx->partials;
+  hipLaunchKernelGGL(proportion_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, w, g, nv, psi, ctx->slots + ng_slot, n,
+                     chunk, dst, nblk);
+  if (nblk > 1) ccqp_launch_stage2(ctx, 2, nblk, slot0, s);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// ---- out = isclose(x, P(x)) * g   (free gradient)
+__global__ __launch_bounds__(CCQP_BLOCK) void free_gradient_kernel(ccqp_segk sg, const double* x, const double* g,
+                                                                   double* out) {
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < sg.dim;
+       i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    const double xi = x[i];
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
+    out[i] = (ccqp_isclose(xi, p) ? 1.0 : 0.0) * g[i];
+  }
+}
+
+extern "C" int ccqp_free_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                                  const double* g, double* out, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = elementwise_seg_ok(seg);
+  if (rc) return rc;
+  if (seg->dim == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && g && out, "NULL vector");
+  const ccqp_segk k = segk(seg);
+  const int64_t o = seg->offset;
+  hipLaunchKernelGGL(free_gradient_kernel, dim3(vec_grid(k.dim)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, k,
+                     x + o, g + o, out + o);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// ---- out = psi - ((psi*Ap)/pAp)*p   (solvers.py:1134-1135, four roundings)
+__global__ __launch_bounds__(CCQP_BLOCK) void cg_direction_kernel(const double* psi, const double* Ap, double pAp,
+                                                                  const double* p, double* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    const double ps = psi[i];
+    const double t1 = ps * Ap[i];
+    const double beta = t1 / pAp;
+    const double t2 = beta * p[i];
+    out[i] = ps - t2;
+  }
+}
+
+extern "C" int ccqp_cg_direction_f64(ccqp_ctx* ctx, const double* psi, const double* Ap, double pAp,
+                                     const double* p, double* out, int64_t n, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return CCQP_OK;
+  CCQP_REQUIRE(psi && Ap && p && out, "NULL vector");
+  hipLaunchKernelGGL(cg_direction_kernel, dim3(vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, psi, Ap, pAp,
+                     p, out, n);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

@@ -486,16 +486,27 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     def name(self):
         return "MPRGP"
 
-    @staticmethod
-    def _free_mask_mul(run, x, g, invert=False):
-        """isclose(x, P(x)) * g   (or (1 - isclose) * g)"""
+    FUSED = True    # use the fused elementwise-set kernels (bitwise identical to the literal sequence)
+
+    def _free_mask_mul(self, run, x, g):
+        """isclose(x, P(x)) * g"""
         out = run.new()
-        run.eng.isclose_mask_mul(x, run.project(x), g, out, invert)
+        if self._seg is not None:
+            run.eng.free_gradient_elementwise(self._seg, x, g, out)
+        else:
+            run.eng.isclose_mask_mul(x, run.project(x), g, out)
         return out
 
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, P = run.eng, run.P
+        # elementwise feasible set with array bounds: the proportioning test, the free gradient and
+        # the CG direction run as fused kernels (ccqp_mprgp.hip); anything else takes the literal path
+        self._seg = None
+        if self.FUSED and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names() \
+                and run.n > ss._lib.SMALL_SEG_MAX:
+            self._seg = P._seg(eng, 0, run.n)
+        seg = self._seg
         mv_count = 0
         xk = run.project(run.x0)                        # :1063
         xkp1 = run.copy(xk)
@@ -515,17 +526,24 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 if mv_count >= max_mv:
                     break
                 gk = gnew
-                txk = run.project(xk)
                 psi = run.new()
-                eng.isclose_mask_mul(xk, txk, gk, psi)
                 w = run.new()
-                eng.isclose_mask_mul(xk, txk, None, w, invert=True)      # 1 - delta
                 nv = run.new()
-                P._dev_normal_vector(eng, xk, nv)                        # :1095
-                eng.dots([(nv, gk)], 8)
-                beta_x = run.new()
-                eng.chopped_gradient(w, gk, nv, 8, beta_x)               # :1096-1097
-                bb, pp = yield from run.dots_now([(beta_x, beta_x), (psi, psi)])
+                if seg is not None:
+                    txk = run.new()
+                    eng.mprgp_split(seg, xk, gk, txk, psi, w, 10)        # P(xk), psi, 1-delta, |xk-P(xk)|^2
+                    eng.mprgp_normal_dot(seg, txk, gk, nv, 10, 8)        # n(xk), n.gk          (:1095)
+                    eng.mprgp_proportion(w, gk, nv, psi, 8, 0)           # beta.beta, psi.psi   (:1096-1098)
+                    bb, pp = yield from run.read(0, 2)
+                else:
+                    txk = run.project(xk)
+                    eng.isclose_mask_mul(xk, txk, gk, psi)
+                    eng.isclose_mask_mul(xk, txk, None, w, invert=True)  # 1 - delta
+                    P._dev_normal_vector(eng, xk, nv)                    # :1095
+                    eng.dots([(nv, gk)], 8)
+                    beta_x = run.new()
+                    eng.chopped_gradient(w, gk, nv, 8, beta_x)           # :1096-1097
+                    bb, pp = yield from run.dots_now([(beta_x, beta_x), (psi, psi)])
                 if bb < pp:
                     Ap = run.mv(p)
                     mv_count += 1
@@ -536,16 +554,14 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                     y = run.lin(1.0, xk, -alpha_cg, p)
                     alpha_f = yield from self._feasible_step(run, xk, p, alpha_cg + _EPS10)
                     if alpha_cg <= alpha_f:
-                        xkp1 = run.copy(y)
+                        xkp1 = y                                         # np.copy(y): nothing writes in place
                         gkp1 = run.lin(1.0, gk, -alpha_cg, Ap)
                         dx = run.lin(1.0, xkp1, -1.0, xk)
                         Adx = run.mv(dx)                                 # executed, not counted (:1129)
                         eng.dots([(dx, dx), (dx, Adx)], 0)               # alpha_bb: read in the tail
                         psi_y = self._free_mask_mul(run, y, gkp1)
-                        beta = run.new()
-                        eng.muldiv(psi_y, Ap, pAp, beta)                 # elementwise VECTOR, :1134
                         pn = run.new()
-                        eng.submul(psi_y, beta, p, pn)
+                        eng.cg_direction(psi_y, Ap, pAp, p, pn)          # psi_y - (psi_y*Ap/pAp)*p, :1134-1135
                         p = pn
                     else:
                         xh = run.lin(1.0, xk, -alpha_f, p)

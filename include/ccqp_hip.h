@@ -55,9 +55,9 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
 /* Copy slots [slot0, slot0+count) to host_out and wait for `stream` (the only sync point). */
 int ccqp_scalars_read(ccqp_ctx* ctx, int slot0, int count, double* host_out, void* stream);
 /* Split form for callers that interleave several solves on several streams (batch-sharded mode):
- * ccqp_scalars_read_async enqueues the device->pinned-host copy on `stream` and returns at once;
- * after the caller has waited for that point of the stream (event / stream sync),
- * ccqp_scalars_host copies the values out of the pinned mirror.  One context per stream. */
+ * ccqp_scalars_read_async enqueues the device->pinned-host copy on `stream`, records the context's
+ * event behind it and returns at once; ccqp_scalars_host waits for that event (a no-op once the copy
+ * has landed) and copies the values out of the pinned mirror.  One context per stream. */
 int ccqp_scalars_read_async(ccqp_ctx* ctx, int slot0, int count, void* stream);
 int ccqp_scalars_host(ccqp_ctx* ctx, int slot0, int count, double* host_out);
 /* Device address of the slab (for kernels of the caller's own / for tests). */
@@ -184,6 +184,24 @@ int ccqp_normal_sphere_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp,
  * `(1 - delta) * (gk - np.min([0, n.dot(gk)]) * n)` solvers.py:1096-1097; w is a 0/1 vector. */
 int ccqp_chopped_gradient_f64(ccqp_ctx* ctx, const double* w, const double* g, const double* nv,
                               int ng_slot, double* out, int64_t n, void* stream);
+
+/* Fused forms of the MPRGP proportioning test for ELEMENTWISE kinds (solvers.py:1093-1098); same
+ * arithmetic, order and reduction geometry as the unfused calls above (bitwise identical results):
+ *  split      : xp = P(x); psi = isclose(x,xp)*g; w = 1 - isclose(x,xp); slab[dist2_slot] = |x-xp|^2
+ *  normal_dot : nv = normal_vector (from xp, slab[dist2_slot]); slab[ng_slot] = nv . g
+ *  proportion : beta = w*(g - min(0, slab[ng_slot])*nv); slab[slot0] = beta.beta, slab[slot0+1] = psi.psi */
+int ccqp_mprgp_split_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, const double* g,
+                         double* xp, double* psi, double* w, int dist2_slot, void* stream);
+int ccqp_mprgp_normal_dot_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp, const double* g,
+                              double* nv, int dist2_slot, int ng_slot, void* stream);
+int ccqp_mprgp_proportion_f64(ccqp_ctx* ctx, const double* w, const double* g, const double* nv,
+                              const double* psi, int ng_slot, int64_t n, int slot0, void* stream);
+/* out = isclose(x, P(x)) * g for an ELEMENTWISE kind (`delta * g`, solvers.py:1081-1082,1132-1133,1157-1158) */
+int ccqp_free_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                       const double* g, double* out, void* stream);
+/* out = psi - ((psi*Ap)/pAp)*p   -- solvers.py:1134-1135 in one pass (four roundings, as numpy) */
+int ccqp_cg_direction_f64(ccqp_ctx* ctx, const double* psi, const double* Ap, double pAp,
+                          const double* p, double* out, int64_t n, void* stream);
 
 /* ---- synthetic problems (replaces benchmarks/benchmark_random_ccqp.py:59-63,
  * whose Wishart generator is O(n^3)) ---------------------------------------------------------

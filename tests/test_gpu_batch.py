@@ -72,3 +72,28 @@ def test_batch_partition_driver_single_rank():
     res = solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), make, 6, lanes=3)
     assert sorted(res) == list(range(6))
     assert all(r.solution_converged for r in res.values())
+
+
+@pytest.mark.parametrize("kind", ["Box", "Lower", "Upper", "Identity"])
+def test_mprgp_fused_kernels_equal_literal_sequence(kind):
+    """ccqp_mprgp_* / ccqp_free_gradient / ccqp_cg_direction are pure launch-count optimisations:
+    solves with and without them must agree bit for bit (x, residual, MV counts)."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    for n in (1000, 4096, 20000):          # 20000 > 8192: exercises the two-stage reductions
+        op, b, _ = problems.random_problem(n, 77)
+        lo, hi = -0.3 * np.ones(n), 0.4 * np.ones(n)
+        P = {"Box": ss.BoxProjOp(n, lo, hi), "Lower": ss.LowerBoundProjOp(n, lo),
+             "Upper": ss.UpperBoundProjOp(n, hi), "Identity": ss.IdentityProjOp(n)}[kind]
+        out = []
+        for fused in (True, False):
+            solvers.CCQPSolverMPRGP.FUSED = fused
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    out.append(solvers.CCQPSolverMPRGP(1e-7, 400).solve(op, b, convex_proj_op=P))
+            finally:
+                solvers.CCQPSolverMPRGP.FUSED = True
+        a, c = out
+        assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+        assert float(a.solution_residual) == float(c.solution_residual)
+        assert np.array_equal(a.solution.cpu().numpy().view(np.uint64), c.solution.cpu().numpy().view(np.uint64))
