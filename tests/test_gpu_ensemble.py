@@ -1,0 +1,70 @@
+"""GPU: the "next" rows of SURVEY.md 8(f) -- the ensemble harness (counterpart of
+benchmarks/benchmark_random_ccqp.py) and the analytic problem suite module -- to the same parity
+bar as the hot path: per-cell MV counts equal to the CPU oracle run on the same problems."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, gen_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_problem_suite_module_matches_reference_data():
+    from ccqppy_amd import problem_suite, solvers
+    from oracle import cases as C
+    for name, pd in C.SUITE.items():
+        p = getattr(problem_suite, name)()
+        A, b = C.suite_problem(name)
+        assert p.number_of_unknowns == 3
+        assert np.array_equal(p.A, A) and np.array_equal(p.b, b) and p.b.dtype == b.dtype
+        assert np.array_equal(p.exact_solution, np.array(pd["xexact"]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = solvers.CCQPSolverBBPGD(1e-8, 10000).solve(p.A, p.b, convex_proj_op=p.convex_proj_op)
+        assert r.solution_converged and np.linalg.norm(r.solution - p.exact_solution) < 1e-5
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_ensemble_grid_matches_oracle(lanes):
+    from ccqppy_amd import solvers, solution_spaces as ss
+    from ccqppy_amd.ensemble import BenchmarkRandomCCQP
+    sizes = [6, 9, 12, 48]
+    tol, max_mv, trials = 1e-5, 5000, 3
+    slv = [solvers.CCQPSolverPGD(tol, max_mv, 0.2), solvers.CCQPSolverAPGD(tol, max_mv),
+           solvers.CCQPSolverBBPGD(tol, max_mv), solvers.CCQPSolverBBPGDf(tol, max_mv),
+           solvers.CCQPSolverMPRGP(tol, max_mv)]
+    fams = [[ss.IdentityProjOp(d) for d in sizes], [ss.BoxProjOp(d) for d in sizes],
+            [ss.SphereProjOp(d) for d in sizes],
+            [ss.DisjointProjOp(*[ss.SphereProjOp(3)] * (d // 3)) for d in sizes]]
+    bench = BenchmarkRandomCCQP(trials, slv, fams, lanes=lanes).run()
+    shape = (len(slv), len(fams), len(sizes), trials)
+    assert bench._problem_num_matrix_vector_mults.shape == shape
+    assert bench._problem_time.dtype == np.float32 and bench._problem_converged.dtype == int
+    ofam = [[cpu_ref.Identity(d) for d in sizes], [cpu_ref.Box(d) for d in sizes],
+            [cpu_ref.Sphere(d) for d in sizes],
+            [cpu_ref.Disjoint(*[cpu_ref.Sphere(3)] * (d // 3)) for d in sizes]]
+    osolve = [lambda A, b, P: cpu_ref.solve_pgd(A, b, tol, max_mv, 0.2, P=P),
+              lambda A, b, P: cpu_ref.solve_apgd(A, b, tol, max_mv, P=P),
+              lambda A, b, P: cpu_ref.solve_bbpgd(A, b, tol, max_mv, P=P),
+              lambda A, b, P: cpu_ref.solve_bbpgdf(A, b, tol, max_mv, P=P),
+              lambda A, b, P: cpu_ref.solve_mprgp(A, b, tol, max_mv, P=P)]
+    mism = 0
+    for pi, n in enumerate(sizes):
+        for t in range(trials):
+            A, b, _ = gen_ref.problem(n, t)
+            for f in range(len(fams)):
+                for s in range(len(slv)):
+                    with np.errstate(all="ignore"):
+                        o = osolve[s](A, b, ofam[f][pi])
+                    got = bench._problem_num_matrix_vector_mults[s, f, pi, t]
+                    mism += int(got != o.solution_num_matrix_vector_multiplications)
+                    assert bool(bench._problem_converged[s, f, pi, t]) == bool(o.solution_converged)
+    # tol 1e-5 on well-conditioned problems: counts agree cell by cell (b differs in the last bit
+    # between the device and host matvec, so allow a handful of off-by-one-iteration cells)
+    assert mism <= 0.02 * np.prod(shape)
+    out = bench.process_results(stream=io.StringIO())
+    assert set(out) == {"wall-clock time [s]", "number of matrix-vector multiplications", "solution residual"}
+    m = out["number of matrix-vector multiplications"]
+    assert np.all(m["lower_95"] <= m["mean"]) and np.all(m["mean"] <= m["upper_95"])
