@@ -277,6 +277,13 @@ class Engine:
         if rc:
             _lib.check(rc)
 
+    def projected_gradient_elementwise(self, seg, x, g, nv, free_g, chopped_g):
+        rc = self.lib.ccqp_projected_gradient_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(),
+                                                              nv.data_ptr(), free_g.data_ptr(),
+                                                              chopped_g.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
+
     # fused MPRGP steps (elementwise feasible sets)
     def mprgp_split(self, seg, x, g, xp, psi, w, dist2_slot):
         rc = self.lib.ccqp_mprgp_split_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), xp.data_ptr(),

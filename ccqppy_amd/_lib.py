@@ -79,6 +79,7 @@ SIGNATURES = {
     "ccqp_mprgp_proportion_f64": [_P, _P, _P, _P, _P, _I, _I64, _I, _P],
     "ccqp_free_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
     "ccqp_cg_direction_f64": [_P, _P, _P, _D, _P, _P, _I64, _P],
+    "ccqp_projected_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _P, _P],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
     "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
 }

@@ -474,3 +474,56 @@ extern "C" int ccqp_chopped_gradient_f64(ccqp_ctx* ctx, const double* w, const d
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
+
+// ------------------------------------------------------------------ projected_gradient (8(f)2)
+// Free / chopped gradient split of the ELEMENTWISE kinds, solution_spaces.py:162-184, 238-260,
+// 324-347 -- including the Box condition's misplaced parenthesis (:340-341):
+//   isclose(x, ub) or x > ub or isclose(x, (lb or x < ub))
+// where Python's `or` yields lb unless lb == 0, else the boolean (x < ub) as 1.0 / 0.0.
+__global__ __launch_bounds__(CCQP_BLOCK) void projected_gradient_kernel(ccqp_segk sg, const double* x,
+                                                                        const double* g, const double* nv,
+                                                                        double* free_g, double* chopped_g) {
+  VEC_LOOP(i, sg.dim) {
+    const double xi = x[i];
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    bool active;
+    if (sg.kind == CCQP_OP_LOWER) {
+      active = ccqp_isclose(xi, lb);
+    } else if (sg.kind == CCQP_OP_UPPER) {
+      active = ccqp_isclose(xi, ub);
+    } else {
+      const double second = (lb != 0.0) ? lb : ((xi < ub) ? 1.0 : 0.0);  // NaN != 0 -> truthy, like Python
+      active = ccqp_isclose(xi, ub) || (xi > ub) || ccqp_isclose(xi, second);
+    }
+    double fr = 0.0, ch = 0.0;
+    if (active) {
+      const double n = nv[i];
+      const double m = n * g[i];
+      const double mn = (m < 0.0 || m != m) ? m : 0.0;  // np.min((m, 0))
+      const double t = mn * n;
+      ch = g[i] - t;
+    } else {
+      fr = g[i];
+    }
+    free_g[i] = fr;
+    chopped_g[i] = ch;
+  }
+}
+
+extern "C" int ccqp_projected_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                                       const double* g, const double* nv, double* free_g,
+                                                       double* chopped_g, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = seg_check(seg, true);
+  if (rc) return rc;
+  CCQP_REQUIRE(seg->kind != CCQP_OP_IDENTITY, "Identity has no projected gradient");
+  if (seg->dim == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && g && nv && free_g && chopped_g, "NULL vector");
+  const ccqp_segk k = seg_by_value(seg);
+  const int64_t o = seg->offset;
+  hipLaunchKernelGGL(projected_gradient_kernel, dim3(vec_grid(k.dim)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, k,
+                     x + o, g + o, nv + o, free_g + o, chopped_g + o);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

@@ -187,6 +187,24 @@ class _ElementwiseOp(ProjOpBase):
         lb, ub = self._bounds()
         return [type(b).__name__ for b in (ub, lb) if b is not None and _is_scalar(b)]
 
+    def projected_gradient(self, x, g):
+        """(free gradient, chopped gradient) at x; their sum is the projected gradient.
+        solution_spaces.py:162-184, 238-260, 324-347 (unused by any live solver of the reference)."""
+        eng, xd, n = self._stage_in(x)
+        gd = eng.to_device(g).reshape(-1)
+        free_g, chopped_g = eng.empty(n), eng.empty(n)
+        self._block_projected_gradient(eng, xd, gd, free_g, chopped_g, 0, n)
+        return (self._stage_out(x, free_g), self._stage_out(x, chopped_g))
+
+    def _block_projected_gradient(self, eng, x, g, free_g, chopped_g, offset, n):
+        scalars = self._scalar_bound_names()
+        if scalars and n > 0:
+            # `self.lower_bound[i]` inside the loop (or inside normal_vector) on a scalar bound
+            raise TypeError("'%s' object is not subscriptable" % scalars[0])
+        nv = eng.scratch(x.numel(), "op.pg.nv")
+        self._block_normal(eng, x, nv, offset, n)
+        eng.projected_gradient_elementwise(self._seg(eng, offset, n), x, g, nv, free_g, chopped_g)
+
     def _block_normal(self, eng, x, out, offset, n):
         # solution_spaces.py:146-160, 222-236, 306-322
         if 0 < n <= _lib.SMALL_SEG_MAX and not self._scalar_bound_names():
@@ -231,6 +249,13 @@ class IdentityProjOp(_ElementwiseOp):
 
     def _block_normal(self, eng, x, out, offset, n):
         eng.fill(0.0, out[offset:offset + n])
+
+    def projected_gradient(self, x, g):
+        return None                    # the reference's method body is a docstring only (:100-109)
+
+    def _block_projected_gradient(self, eng, x, g, free_g, chopped_g, offset, n):
+        # inside a DisjointProjOp the reference unpacks this None (:533)
+        raise TypeError("cannot unpack non-iterable NoneType object")
 
 
 class LowerBoundProjOp(_ElementwiseOp):
@@ -338,6 +363,12 @@ class SphereProjOp(_NormOp):
 
     def _alias_test(self, r, x, offset, n):
         return not (r > self.radius)
+
+    def projected_gradient(self, x, g):
+        raise NotImplementedError("Cone proximal gradient not implemented, yet.")   # sic, :415
+
+    def _block_projected_gradient(self, eng, x, g, free_g, chopped_g, offset, n):
+        raise NotImplementedError("Cone proximal gradient not implemented, yet.")
 
     def _block_normal(self, eng, x, out, offset, n):
         # solution_spaces.py:389-403
@@ -477,6 +508,18 @@ class DisjointProjOp(ProjOpBase):
             eng.proj_small(table, nsmall, x, out, 1)
         for op, off in large:
             op._block_normal(eng, x, out, off, op.embedded_dimension)
+
+    def projected_gradient(self, x, g):
+        """Concatenation of the sub-operators' (free, chopped) gradients, solution_spaces.py:527-538."""
+        eng, xd, n = self._stage_in(x)
+        gd = eng.to_device(g).reshape(-1)
+        free_g = torch.zeros(n, dtype=torch.float64, device=eng.device)
+        chopped_g = torch.zeros(n, dtype=torch.float64, device=eng.device)
+        for op, off in self._leaves():
+            if not hasattr(op, "_block_projected_gradient"):
+                raise AttributeError("'%s' object has no attribute 'projected_gradient'" % type(op).__name__)
+            op._block_projected_gradient(eng, xd, gd, free_g, chopped_g, off, op.embedded_dimension)
+        return (self._stage_out(x, free_g), self._stage_out(x, chopped_g))
 
     def _block_project(self, eng, x, out, offset, n, want_alias=False):
         raise AssertionError("DisjointProjOp is flattened by _leaves()")

@@ -203,6 +203,13 @@ int ccqp_free_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const
 int ccqp_cg_direction_f64(ccqp_ctx* ctx, const double* psi, const double* Ap, double pAp,
                           const double* p, double* out, int64_t n, void* stream);
 
+/* projected_gradient of an ELEMENTWISE kind (solution_spaces.py:162-184,238-260,324-347; the Box
+ * condition keeps the reference's misplaced parenthesis :340-341): nv = normal_vector(x) of the block;
+ * active entries get chopped = g - min(nv*g, 0)*nv, free = 0; the others free = g, chopped = 0. */
+int ccqp_projected_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
+                                            const double* g, const double* nv, double* free_g,
+                                            double* chopped_g, void* stream);
+
 /* ---- synthetic problems (replaces benchmarks/benchmark_random_ccqp.py:59-63,
  * whose Wishart generator is O(n^3)) ---------------------------------------------------------
  * Rows [row0, row0+rows) of the n x n counter-hashed symmetric matrix:

@@ -210,6 +210,52 @@ def op_cases():
     return cases, arrays
 
 
+def pg_cases():
+    """projected_gradient cases: (cases, arrays); each case has x and g."""
+    rng = np.random.default_rng(424242)
+    arrays, cases = {}, []
+
+    def add(cid, spec, x, g):
+        arrays[cid + ".x"] = np.asarray(x, dtype=np.float64)
+        arrays[cid + ".g"] = np.asarray(g, dtype=np.float64)
+        cases.append({"id": cid, "spec": spec, "x": cid + ".x", "g": cid + ".g"})
+
+    for d in (1, 3, 8, 40, 200):
+        lb = arrays.setdefault("pglb%d" % d, np.where(rng.random(d) < 0.3, 0.0, -np.abs(rng.normal(size=d)) - 0.1))
+        ub = arrays.setdefault("pgub%d" % d, np.abs(rng.normal(size=d)) + 1.1)
+        x = rng.uniform(lb, ub)
+        x[::3] = lb[::3]
+        x[1::3] = ub[1::3]
+        x[2::7] = 1.0          # hits the `isclose(x, True)` arm of the Box condition where lb == 0
+        x[4::9] = 0.0
+        for tag, xx in (("on", x), ("near", x + 2e-9), ("out", x + 1e-3 * (rng.random(d) < 0.2)),
+                        ("in", 0.5 * (lb + ub))):
+            g = rng.normal(size=d)
+            add("pg.box.d%d.%s" % (d, tag), {"kind": "Box", "dim": d, "lb": {"arr": "pglb%d" % d},
+                                             "ub": {"arr": "pgub%d" % d}}, xx, g)
+            add("pg.lower.d%d.%s" % (d, tag), {"kind": "Lower", "dim": d, "lb": {"arr": "pglb%d" % d}}, xx, g)
+            add("pg.upper.d%d.%s" % (d, tag), {"kind": "Upper", "dim": d, "ub": {"arr": "pgub%d" % d}}, xx, g)
+    d = 6
+    x, g = rng.normal(size=d), rng.normal(size=d)
+    add("pg.identity", {"kind": "Identity", "dim": d}, x, g)
+    add("pg.sphere", {"kind": "Sphere", "dim": d}, x, g)
+    add("pg.cone", {"kind": "Cone", "dim": d}, x, g)
+    add("pg.box_scalar", {"kind": "Box", "dim": d, "lb": {"scalar": -0.5}, "ub": {"scalar": 0.5}}, x, g)
+    add("pg.box_default", {"kind": "Box", "dim": d}, np.clip(x, -1, 1), g)
+    add("pg.box_int", {"kind": "Box", "dim": d, "lb": {"fill": 0, "int": True}, "ub": {"fill": 1, "int": True}},
+        np.array([0.0, 1.0, 0.5, 1.0 + 3e-9, -1e-9, 2.0]), g)
+    dj = {"kind": "Disjoint", "ops": [{"kind": "Box", "dim": 5}, {"kind": "Lower", "dim": 4},
+                                      {"kind": "Disjoint", "ops": [{"kind": "Upper", "dim": 3}, {"kind": "Box", "dim": 70}]}]}
+    dd = spec_dim(dj)
+    for si, scale in enumerate((0.5, 1.0)):
+        add("pg.disjoint.s%d" % si, dj, np.clip(rng.normal(size=dd) * scale, -1, 1), rng.normal(size=dd))
+    dj_id = {"kind": "Disjoint", "ops": [{"kind": "Box", "dim": 2}, {"kind": "Identity", "dim": 2}]}
+    add("pg.disjoint_identity", dj_id, rng.normal(size=4), rng.normal(size=4))
+    dj_sp = {"kind": "Disjoint", "ops": [{"kind": "Sphere", "dim": 2}, {"kind": "Box", "dim": 2}]}
+    add("pg.disjoint_sphere", dj_sp, rng.normal(size=4), rng.normal(size=4))
+    return cases, arrays
+
+
 # ------------------------------------------------------------------ solver cases
 TRIDIAG = [[2, -1, 0], [-1, 2, -1], [0, -1, 2]]
 

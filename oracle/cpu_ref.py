@@ -47,9 +47,17 @@ class _Op:
         return not np.isclose(np.linalg.norm(x - xp), 0)
 
 
+def _chop(g_i, n_i):
+    # `g[i] - np.min((normal[i]*g[i], 0))*(normal[i])`  solution_spaces.py:180,256,343
+    return g_i - np.min((n_i * g_i, 0)) * (n_i)
+
+
 class Identity(_Op):
     """solution_spaces.py:77-125: returns the argument object itself."""
     kind = "Identity"
+
+    def projected_gradient(self, x, g):  # :100-109: the body is a docstring only
+        return None
 
     def __call__(self, x):
         return x
@@ -86,6 +94,17 @@ class LowerBound(_Op):
         nv[np.isclose(xp, self.lower_bound)] = -1
         return nv
 
+    def projected_gradient(self, x, g):  # :162-184
+        free_g = np.zeros(self.dim)
+        chopped_g = np.zeros(self.dim)
+        normal = self.normal_vector(x)
+        for i in range(self.dim):
+            if np.isclose(x[i], self.lower_bound[i]):
+                chopped_g[i] = _chop(g[i], normal[i])
+            else:
+                free_g[i] = g[i]
+        return (free_g, chopped_g)
+
 
 class UpperBound(_Op):
     """solution_spaces.py:204-277 (default bound +1, :210)."""
@@ -107,6 +126,17 @@ class UpperBound(_Op):
         nv = np.zeros(self.dim)
         nv[np.isclose(xp, self.upper_bound)] = 1
         return nv
+
+    def projected_gradient(self, x, g):  # :238-260
+        free_g = np.zeros(self.dim)
+        chopped_g = np.zeros(self.dim)
+        normal = self.normal_vector(x)
+        for i in range(self.dim):
+            if np.isclose(x[i], self.upper_bound[i]):
+                chopped_g[i] = _chop(g[i], normal[i])
+            else:
+                free_g[i] = g[i]
+        return (free_g, chopped_g)
 
 
 class Box(_Op):
@@ -136,6 +166,20 @@ class Box(_Op):
         nv[at_ub] = 1  # `if ub ... elif lb`: ub wins
         return nv
 
+    def projected_gradient(self, x, g):  # :324-347, incl. the misplaced parenthesis of :340-341
+        free_g = np.zeros(self.dim)
+        chopped_g = np.zeros(self.dim)
+        normal = self.normal_vector(x)
+        for i in range(self.dim):
+            ub_i, lb_i = self.upper_bound[i], self.lower_bound[i]
+            # the reference writes  isclose(x, lb or x < ub):  Python `or` picks lb unless lb == 0
+            second = lb_i or x[i] < ub_i
+            if np.isclose(x[i], ub_i) or x[i] > ub_i or np.isclose(x[i], second):
+                chopped_g[i] = _chop(g[i], normal[i])
+            else:
+                free_g[i] = g[i]
+        return (free_g, chopped_g)
+
 
 class Sphere(_Op):
     """solution_spaces.py:369-435 (default radius 1, :375)."""
@@ -160,6 +204,9 @@ class Sphere(_Op):
         if np.isclose(length, self.radius):
             nv = xp / length
         return nv
+
+    def projected_gradient(self, x, g):  # :405-415 (sic: the message says "Cone")
+        raise NotImplementedError("Cone proximal gradient not implemented, yet.")
 
 
 class Cone(_Op):
@@ -210,6 +257,15 @@ class Disjoint(_Op):
         for op, s, e in self._walk():
             out[s:e] = op.normal_vector(x[s:e])
         return out
+
+    def projected_gradient(self, x, g):  # :527-538
+        free_g = np.zeros(self.dim)
+        chopped_g = np.zeros(self.dim)
+        for op, s, e in self._walk():
+            f_g, c_g = op.projected_gradient(x[s:e], g[s:e])
+            free_g[s:e] = f_g
+            chopped_g[s:e] = c_g
+        return (free_g, chopped_g)
 
 
 # --------------------------------------------------------------------------

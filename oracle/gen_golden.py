@@ -103,6 +103,35 @@ def gen_ops():
     print("ops: %d cases pinned" % len(meta))
 
 
+def gen_pg():
+    cases, arrays = C.pg_cases()
+    ofac = C.oracle_factory()
+    out = dict(arrays)
+    meta = []
+    for c in cases:
+        x, g = arrays[c["x"]], arrays[c["g"]]
+        rop = C.build_op(c["spec"], REF_FACTORY, arrays)
+        oop = C.build_op(c["spec"], ofac, arrays)
+        r, rerr = call_or_error(lambda: rop.projected_gradient(x.copy(), g.copy()))
+        o, oerr = call_or_error(lambda: oop.projected_gradient(x.copy(), g.copy()))
+        assert rerr == oerr, (c["id"], rerr, oerr)
+        entry = dict(c)
+        entry["err"] = rerr
+        entry["none"] = rerr is None and r is None
+        if rerr is None and r is not None:
+            assert o is not None and same_bits(r[0], o[0]) and same_bits(r[1], o[1]), c["id"]
+            out[c["id"] + ".free"] = np.asarray(r[0], dtype=np.float64)
+            out[c["id"] + ".chop"] = np.asarray(r[1], dtype=np.float64)
+        else:
+            assert (r is None) == (o is None)
+        meta.append(entry)
+    np.savez_compressed(os.path.join(GOLD, "pg.npz"), **out)
+    with open(os.path.join(GOLD, "pg_cases.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    from collections import Counter
+    print("projected_gradient: %d cases pinned" % len(meta), Counter(e["err"] for e in meta))
+
+
 _PROBLEMS = {}
 
 
@@ -225,6 +254,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     gen_generator()
     gen_ops()
+    gen_pg()
     gen_solvers()
     import platform
     meta = {"numpy": np.__version__, "python": platform.python_version(), "machine": platform.machine(),

@@ -251,3 +251,25 @@ def test_abi_error_reporting(eng):
     assert rc != 0
     with pytest.raises(_lib.CCQPHipError):
         _lib.check(rc)
+
+
+import json as _json
+
+with open(H.GOLD + "/pg_cases.json") as _f:
+    PG = _json.load(_f)
+PG_ARR = dict(np.load(H.GOLD + "/pg.npz"))
+
+
+@pytest.mark.parametrize("case", PG, ids=[c["id"] for c in PG])
+def test_projected_gradient_golden(case, eng):
+    """8(f)2: free/chopped gradient split, bit-exact against the reference (incl. the Box condition's
+    misplaced parenthesis and the None / NotImplementedError / TypeError / AttributeError paths)."""
+    op = C.build_op(case["spec"], C.product_factory(), PG_ARR)
+    r, err = _call(lambda: op.projected_gradient(PG_ARR[case["x"]].copy(), PG_ARR[case["g"]].copy()))
+    assert err == case["err"]
+    if err is None:
+        assert (r is None) == case["none"]
+        if r is not None:
+            assert isinstance(r, tuple) and len(r) == 2
+            assert H.same_bits(r[0], PG_ARR[case["id"] + ".free"])
+            assert H.same_bits(r[1], PG_ARR[case["id"] + ".chop"])

@@ -189,3 +189,47 @@ def test_full_size_properties_n32768():
     # roughly half of the bounds are active at the solution
     active = int(((x == 0.5) | (x == -0.5)).sum())
     assert 0.35 * n < active < 0.65 * n
+
+
+def test_full_size_properties_n131072_metric_workload():
+    """The bench workload itself (BASELINE metric: n = 131072, 128 GiB matrix, APGD + Box +-0.5),
+    checked through size-independent properties: convergence, feasibility, idempotence of P, KKT
+    residual recomputed from row blocks of an independent matvec, bitwise row-block invariance of the
+    GEMV, and the MV count the kappa ~ 3.7 spectrum gives at every smaller n of the fixtures."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    n = 131072
+    torch.cuda.empty_cache()
+    op, b, xs = problems.random_problem(n, 1234)
+    eng = get_engine(0)
+    P = ss.BoxProjOp(n, -0.5, 0.5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = solvers.CCQPSolverAPGD(1e-8, 5000).solve(op, b, convex_proj_op=P)
+    assert r.solution_converged and r.solution_residual < 1e-8
+    assert 30 <= r.solution_num_matrix_vector_multiplications <= 60
+    assert r.executed_matrix_vector_multiplications == r.solution_num_matrix_vector_multiplications
+    x = r.solution
+    assert float(x.max()) <= 0.5 and float(x.min()) >= -0.5
+    assert torch.equal(P(x), x)
+    # gradient from an independent implementation (torch fp64 matvec), 16 row blocks of 8192 rows
+    y = eng.empty(n)
+    eng.gemv(op.A, x, y)
+    worst = 0.0
+    for r0 in range(0, n, 8192):
+        ref = op.A[r0:r0 + 8192] @ x
+        worst = max(worst, float((ref - y[r0:r0 + 8192]).abs().max()))
+        yb = eng.empty(8192)
+        eng.gemv(op.A[r0:r0 + 8192], x, yb)              # what a rank of a 16-way row-sharded run computes
+        assert torch.equal(yb, y[r0:r0 + 8192])          # bitwise
+    assert worst < 1e-11
+    g = y + b
+    fixed = torch.clamp(x - 1e-6 * g, -0.5, 0.5)
+    assert float((x - fixed).norm()) / (3 * n * 1e-6) < 1e-8
+    active = int(((x == 0.5) | (x == -0.5)).sum())
+    assert 0.35 * n < active < 0.65 * n
+    # symmetry + unit generator checks at full size: A[i, j] == A[j, i] on a random sample, diag == 2
+    idx = torch.randint(0, n, (4096, 2), device=x.device)
+    assert torch.equal(op.A[idx[:, 0], idx[:, 1]], op.A[idx[:, 1], idx[:, 0]])
+    assert bool((op.A.diagonal() == 2.0).all())
+    del op
+    torch.cuda.empty_cache()
