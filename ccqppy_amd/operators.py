@@ -75,8 +75,9 @@ class VectorExchange:
             fn(t)
 
     def _gather_into(self, full, mine):
-        # NCCL/RCCL accepts the in-place form (mine is a view of full at rank*chunk)
-        src = mine if (full.is_cuda and not self.stage_cpu) else mine.clone()
+        # the slab is staged in its own small buffer (n/G doubles) so that send and receive buffers
+        # never alias, whatever the backend's rules about in-place all-gather are
+        src = mine.clone()
         chunks = list(full.chunk(self.world))
         try:
             self.dist.all_gather_into_tensor(full, src, group=self.group)

@@ -5,7 +5,8 @@ same class names, constructor arguments, attributes (`dim`, `lower_bound`, `uppe
 `radius`, `aspect_ratio`, `proj_ops`), `name` strings, `embedded_dimension`, `__call__` and
 `normal_vector`.  `op(x)` accepts a numpy array (copied to the GPU and back) or a torch tensor
 on a ROCm device (zero copy) and returns the same kind; every FLOP runs in libccqp_hip.so.
-There is no CPU fallback.  `plot` / `projected_gradient` are out of scope.
+There is no CPU fallback.  `plot` (matplotlib) is out of scope; `projected_gradient` (dead code in the
+reference) is provided for API completeness.
 
 Device protocol used by `ccqppy_amd.solvers` (all arguments are fp64 device tensors):
   _dev_project(eng, x, out)                  out = P(x)            (x is not out)

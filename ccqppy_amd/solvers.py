@@ -38,6 +38,10 @@ class _Run:
     def __init__(self, A, b, x0, convex_proj_op, engine=None):
         self.n = n = b.shape[0]
         self.P = convex_proj_op if convex_proj_op is not None else ss.IdentityProjOp(n)   # :115-116
+        if not isinstance(self.P, ss.ProjOpBase):
+            raise TypeError("convex_proj_op must be one of ccqppy_amd.solution_spaces.*ProjOp (the projection "
+                            "runs on the GPU; arbitrary host callables are not supported), got %r"
+                            % type(self.P).__name__)
         self.op = as_operator(A)
         # `engine` = a lane engine of the batch scheduler (own stream + scalar slab); default: the
         # operator's engine, bound to torch's current stream
