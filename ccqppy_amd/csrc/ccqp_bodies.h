@@ -1,0 +1,294 @@
+// Kernel BODIES shared by the single-problem kernels (ccqp_vec/proj/mprgp/gemv.hip) and their
+// batched twins (ccqp_batch.hip, one problem per blockIdx.y).  A body takes the block coordinates
+// (bx of nbx) explicitly, so both launch shapes execute literally the same arithmetic in the same
+// order: batched results are bitwise those of one launch per problem.
+#pragma once
+#include "ccqp_internal.h"
+
+#ifdef __HIPCC__
+#define BODY_LOOP(i, n) \
+  for (int64_t i = (int64_t)bx * CCQP_BLOCK + threadIdx.x; i < (n); i += (int64_t)nbx * CCQP_BLOCK)
+
+// ------------------------------------------------------------------ elementwise
+__device__ __forceinline__ void axpby_body(double a, const double* x, double b, const double* y, double* out,
+                                           int64_t n, int bx, int nbx) {
+  BODY_LOOP(i, n) {
+    const double t1 = a * x[i];
+    const double t2 = b * y[i];
+    out[i] = t1 + t2;
+  }
+}
+
+__device__ __forceinline__ void scale_body(double a, const double* x, double* out, int64_t n, int bx, int nbx) {
+  BODY_LOOP(i, n) out[i] = a * x[i];
+}
+
+__device__ __forceinline__ void copy_body(const double* x, double* out, int64_t n, int bx, int nbx) {
+  BODY_LOOP(i, n) out[i] = x[i];
+}
+
+__device__ __forceinline__ void fill_body(double v, double* out, int64_t n, int bx, int nbx) {
+  BODY_LOOP(i, n) out[i] = v;
+}
+
+// out = P(a*x + b*y) (y == NULL: out = P(x)), elementwise kinds
+__device__ __forceinline__ void proj_elem_body(const ccqp_segk& sg, double a, const double* x, double b,
+                                               const double* y, double* out, int bx, int nbx) {
+  BODY_LOOP(i, sg.dim) {
+    double u = x[i];
+    if (y) {
+      const double t1 = a * u;
+      const double t2 = b * y[i];
+      u = t1 + t2;
+    }
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    out[i] = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+  }
+}
+
+// out = isclose(x, P(x)) * g
+__device__ __forceinline__ void free_gradient_body(const ccqp_segk& sg, const double* x, const double* g,
+                                                   double* out, int bx, int nbx) {
+  BODY_LOOP(i, sg.dim) {
+    const double xi = x[i];
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
+    out[i] = (ccqp_isclose(xi, p) ? 1.0 : 0.0) * g[i];
+  }
+}
+
+// out = psi - ((psi*Ap)/pAp)*p
+__device__ __forceinline__ void cg_direction_body(const double* psi, const double* Ap, double pAp, const double* p,
+                                                  double* out, int64_t n, int bx, int nbx) {
+  BODY_LOOP(i, n) {
+    const double ps = psi[i];
+    const double t1 = ps * Ap[i];
+    const double beta = t1 / pAp;
+    const double t2 = beta * p[i];
+    out[i] = ps - t2;
+  }
+}
+
+// ------------------------------------------------------------------ stage-1 reductions
+// Every stage-1 body reduces elements [bx*chunk, (bx+1)*chunk) with the same thread->element map
+// (t, t+256, ...) and returns the block sum in thread 0.
+#define CHUNK_RANGE(n)                       \
+  const int64_t lo = (int64_t)bx * chunk;    \
+  int64_t hi = lo + chunk;                   \
+  if (hi > (n)) hi = (n);
+
+__device__ __forceinline__ double dot_body(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                                           int64_t chunk, int bx, double* lds4) {
+  CHUNK_RANGE(n)
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) acc = fma(x[i], y[i], acc);
+  return ccqp_block_sum(acc, lds4);
+}
+
+__device__ __forceinline__ double partial_sum_body(const double* partials, int nblk, double* lds4) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += partials[i];
+  return ccqp_block_sum(acc, lds4);
+}
+
+__device__ __forceinline__ double residual_body(const ccqp_segk& sg, const double* x, const double* g, double c,
+                                                double gd, int64_t chunk, int bx, double* lds4) {
+  CHUNK_RANGE(sg.dim)
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double xi = x[i];
+    const double t = gd * g[i];
+    const double u = xi - t;
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+    const double d = xi - p;
+    const double v = c * d;
+    acc = fma(v, v, acc);
+  }
+  return ccqp_block_sum(acc, lds4);
+}
+
+// count of i with not isclose(yf_i, P(yf)_i), yf = x - (alpha0 * 0.5^k)*p
+__device__ __forceinline__ double feasible_body(const ccqp_segk& sg, const double* x, const double* p,
+                                                double alpha0, int k, int64_t chunk, int bx, double* lds4) {
+  double alpha = alpha0;
+  for (int j = 0; j < k; ++j) alpha *= 0.5;  // the reference's `alpha_f *= 0.5`, k times
+  CHUNK_RANGE(sg.dim)
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double t = alpha * p[i];
+    const double yf = x[i] - t;
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double pr = ccqp_proj_elem(sg.kind, sg.flags, yf, lb, ub);
+    acc += ccqp_isclose(yf, pr) ? 0.0 : 1.0;
+  }
+  return ccqp_block_sum(acc, lds4);
+}
+
+// xp = P(x); psi = isclose(x,xp)*g; w = 1 - isclose; returns sum (x-xp)^2
+__device__ __forceinline__ double split_body(const ccqp_segk& sg, const double* x, const double* g, double* xp,
+                                             double* psi, double* w, int64_t chunk, int bx, double* lds4) {
+  CHUNK_RANGE(sg.dim)
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double xi = x[i];
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
+    const bool close = ccqp_isclose(xi, p);
+    xp[i] = p;
+    psi[i] = (close ? 1.0 : 0.0) * g[i];
+    w[i] = close ? 0.0 : 1.0;
+    const double d = xi - p;
+    acc = fma(d, d, acc);
+  }
+  return ccqp_block_sum(acc, lds4);
+}
+
+// nv = normal vector from xp (zeros if sqrt(dist2) > 1e-8); returns sum nv*g
+__device__ __forceinline__ double normal_dot_body(const ccqp_segk& sg, const double* xp, const double* g,
+                                                  double* nvout, double dist2, int64_t chunk, int bx,
+                                                  double* lds4) {
+  const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
+  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+  CHUNK_RANGE(sg.dim)
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    double nv = 0.0;
+    if (!outside) {
+      const double v = xp[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
+      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
+    }
+    nvout[i] = nv;
+    acc = fma(nv, g[i], acc);
+  }
+  return ccqp_block_sum(acc, lds4);
+}
+
+// beta = w*(g - min(0, ng)*nv); *sb = sum beta^2, *sp = sum psi^2 (valid in thread 0)
+__device__ __forceinline__ void proportion_body(const double* w, const double* g, const double* nv,
+                                                const double* psi, double ng, int64_t n, int64_t chunk, int bx,
+                                                double* lds4, double* sb, double* sp) {
+  const double sc = (ng != ng) ? ng : (ng < 0.0 ? ng : 0.0);  // np.min([0, ng])
+  CHUNK_RANGE(n)
+  double ab = 0.0, ap = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double t = sc * nv[i];
+    const double u = g[i] - t;
+    const double be = w[i] * u;
+    ab = fma(be, be, ab);
+    const double ps = psi[i];
+    ap = fma(ps, ps, ap);
+  }
+  *sb = ccqp_block_sum(ab, lds4);
+  *sp = ccqp_block_sum(ap, lds4);
+}
+
+// ------------------------------------------------------------------ matvec
+typedef double ccqp_d2 __attribute__((ext_vector_type(2)));
+
+template <bool ALIGNED, bool NT>
+__device__ __forceinline__ ccqp_d2 ccqp_ld2(const double* p) {
+  if constexpr (ALIGNED) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const ccqp_d2*>(p));
+    else return *reinterpret_cast<const ccqp_d2*>(p);
+  } else {
+    ccqp_d2 v;
+    if constexpr (NT) {
+      v.x = __builtin_nontemporal_load(p);
+      v.y = __builtin_nontemporal_load(p + 1);
+    } else {
+      v.x = p[0];
+      v.y = p[1];
+    }
+    return v;
+  }
+}
+
+// One wave64 per task of R consecutive rows; wave `wave` of `nwaves` grid-strides over the tasks.
+// Lane l accumulates columns {128k+2l, 128k+2l+1} in increasing k into one accumulator per row.
+template <int R, int U, bool ALIGNED, bool NT>
+__device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
+                                          const double* __restrict__ b, double* __restrict__ y,
+                                          double* __restrict__ g, int64_t rows, int64_t cols, int64_t ntasks,
+                                          int64_t wave, int64_t nwaves) {
+  const int lane = threadIdx.x & 63;
+  constexpr int64_t SPAN = 128 * U;
+  const int64_t nfull = cols / SPAN;
+  for (int64_t task = wave; task < ntasks; task += nwaves) {
+    const int64_t r0 = task * R;
+    const double* rp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t row = r0 + r;
+      if (row > rows - 1) row = rows - 1;  // clamp: tail rows re-read a valid row, never stored
+      rp[r] = A + row * lda;
+    }
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+
+    for (int64_t s = 0; s < nfull; ++s) {
+      const int64_t c0 = s * SPAN + 2 * lane;
+      ccqp_d2 xv[U];
+      ccqp_d2 av[R][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[u] = ccqp_ld2<ALIGNED, false>(x + c0 + 128 * u);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) av[r][u] = ccqp_ld2<ALIGNED, NT>(rp[r] + c0 + 128 * u);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          acc[r] = fma(av[r][u].x, xv[u].x, acc[r]);
+          acc[r] = fma(av[r][u].y, xv[u].y, acc[r]);
+        }
+    }
+    // column tail (< SPAN columns), same lane -> column map and order
+    for (int64_t c = nfull * SPAN + 2 * lane; c < cols; c += 128) {
+      if (c + 1 < cols) {
+        const ccqp_d2 xv = ccqp_ld2<ALIGNED, false>(x + c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const ccqp_d2 a = ccqp_ld2<ALIGNED, NT>(rp[r] + c);
+          acc[r] = fma(a.x, xv.x, acc[r]);
+          acc[r] = fma(a.y, xv.y, acc[r]);
+        }
+      } else {
+        const double xs = x[c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fma(rp[r][c], xs, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = r0 + r;
+      if (lane == r && row < rows) {
+        y[row] = acc[r];
+        if (g) g[row] = acc[r] + b[row];  // `A.dot(x) + b`: one more rounding, as numpy
+      }
+    }
+  }
+}
+#endif  // __HIPCC__
+
+// Default (R, U, workgroups per CU) of the matvec for a shape: host-side, shared by both launch forms.
+static inline void ccqp_gemv_defaults(int64_t rows, int64_t cols, int* R, int* U, int* bpc) {
+  const double elems = (double)rows * (double)cols;
+  const bool huge = elems >= 8589934592.0;  // >= 64 GiB of matrix
+  if (*R == 0) *R = (huge || cols >= 65536) ? 2 : 1;
+  if (*U == 0) *U = (rows < 8192 && cols < 65536) ? 2 : 1;
+  if (*bpc == 0) *bpc = huge ? 4 : 8;
+}

@@ -13,97 +13,17 @@
 // Determinism: lane l accumulates columns {128k+2l, 128k+2l+1 : k = 0,1,..} in increasing k with
 // one fma per element into ONE accumulator per row, so the bits of y[i] depend on (row i, cols)
 // only -- not on R, the unroll U, the grid, the load width or how rows are sharded over GPUs.
-#include "ccqp_internal.h"
-
-typedef double ccqp_d2 __attribute__((ext_vector_type(2)));
-
-template <bool ALIGNED, bool NT>
-__device__ __forceinline__ ccqp_d2 ld2(const double* p) {
-  if constexpr (ALIGNED) {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const ccqp_d2*>(p));
-    else return *reinterpret_cast<const ccqp_d2*>(p);
-  } else {
-    ccqp_d2 v;
-    if constexpr (NT) {
-      v.x = __builtin_nontemporal_load(p);
-      v.y = __builtin_nontemporal_load(p + 1);
-    } else {
-      v.x = p[0];
-      v.y = p[1];
-    }
-    return v;
-  }
-}
+// The body lives in ccqp_bodies.h (shared with the batched launch form of ccqp_batch.hip).
+#include "ccqp_bodies.h"
 
 template <int R, int U, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(CCQP_BLOCK) void gemv_stream_kernel(
     const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
     const double* __restrict__ b, double* __restrict__ y, double* __restrict__ g,
     int64_t rows, int64_t cols, int64_t ntasks) {
-  const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
-  constexpr int64_t SPAN = 128 * U;
-  const int64_t nfull = cols / SPAN;
-
-  for (int64_t task = wave; task < ntasks; task += nwaves) {
-    const int64_t r0 = task * R;
-    const double* rp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int64_t row = r0 + r;
-      if (row > rows - 1) row = rows - 1;  // clamp: tail rows re-read a valid row, never stored
-      rp[r] = A + row * lda;
-    }
-    double acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
-
-    for (int64_t s = 0; s < nfull; ++s) {
-      const int64_t c0 = s * SPAN + 2 * lane;
-      ccqp_d2 xv[U];
-      ccqp_d2 av[R][U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) xv[u] = ld2<ALIGNED, false>(x + c0 + 128 * u);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) av[r][u] = ld2<ALIGNED, NT>(rp[r] + c0 + 128 * u);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          acc[r] = fma(av[r][u].x, xv[u].x, acc[r]);
-          acc[r] = fma(av[r][u].y, xv[u].y, acc[r]);
-        }
-    }
-    // column tail (< SPAN columns), same lane -> column map and order
-    for (int64_t c = nfull * SPAN + 2 * lane; c < cols; c += 128) {
-      if (c + 1 < cols) {
-        const ccqp_d2 xv = ld2<ALIGNED, false>(x + c);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const ccqp_d2 a = ld2<ALIGNED, NT>(rp[r] + c);
-          acc[r] = fma(a.x, xv.x, acc[r]);
-          acc[r] = fma(a.y, xv.y, acc[r]);
-        }
-      } else {
-        const double xs = x[c];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fma(rp[r][c], xs, acc[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = r0 + r;
-      if (lane == r && row < rows) {
-        y[row] = acc[r];
-        if (g) g[row] = acc[r] + b[row];  // `A.dot(x) + b`: one more rounding, as numpy
-      }
-    }
-  }
+  gemv_body<R, U, ALIGNED, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves);
 }
 
 template <int R, int U, bool ALIGNED, bool NT>
@@ -138,19 +58,15 @@ static int launch_r(int U, bool aligned, bool nt, hipStream_t s, int grid, const
 }
 
 // variant word: bits 0-3 R (rows per wave: 1,2,4,8), bits 4-7 U (unroll: 1,2,4), bit 8 = 1 disables
-// the non-temporal A loads, bits 12-19 workgroups per CU (0 = default).  0 = tuned default.
+// the non-temporal A loads, bits 12-19 workgroups per CU (0 = default).  0 = tuned default
+// (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
+// yields the same bits, so this is speed only.
 static int gemv_dispatch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
                          double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s) {
   int R = variant & 0xF, U = (variant >> 4) & 0xF;
   const bool nt = !((variant >> 8) & 1);
   int bpc = (variant >> 12) & 0xFF;
-  // Defaults from the interleaved sweep on MI355X (tools/gemv_sweep.py, profiles/r01_gemv_sweep.md);
-  // every choice yields the same bits, so this is speed only.
-  const double elems = (double)rows * (double)cols;
-  const bool huge = elems >= 8589934592.0;  // >= 64 GiB of matrix
-  if (R == 0) R = (huge || cols >= 65536) ? 2 : 1;
-  if (U == 0) U = (rows < 8192 && cols < 65536) ? 2 : 1;
-  if (bpc == 0) bpc = huge ? 4 : 8;
+  ccqp_gemv_defaults(rows, cols, &R, &U, &bpc);
   const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
                        (lda % 2) == 0;
   const int64_t ntasks = (rows + R - 1) / R;

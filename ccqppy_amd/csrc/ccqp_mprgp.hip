@@ -4,7 +4,7 @@
 // operation sequence needs per iteration dominate; these kernels perform the same arithmetic, in
 // the same order, with the same reduction geometry (bitwise identical results, asserted in
 // tests/test_gpu_batch.py) in 5 launches instead of 14.
-#include "ccqp_internal.h"
+#include "ccqp_bodies.h"
 
 int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s);
 
@@ -39,23 +39,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void split_stage1(ccqp_segk sg, const d
                                                            double* xp, double* psi, double* w, int64_t chunk,
                                                            double* dst) {
   __shared__ double lds4[4];
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    const double xi = x[i];
-    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
-    const bool close = ccqp_isclose(xi, p);
-    xp[i] = p;
-    psi[i] = (close ? 1.0 : 0.0) * g[i];
-    w[i] = close ? 0.0 : 1.0;
-    const double d = xi - p;
-    acc = fma(d, d, acc);
-  }
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = split_body(sg, x, g, xp, psi, w, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
 }
 
@@ -85,26 +69,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void normal_dot_stage1(ccqp_segk sg, co
                                                                 double* nvout, const double* dist2,
                                                                 int64_t chunk, double* dst) {
   __shared__ double lds4[4];
-  const bool outside = !ccqp_isclose(sqrt(*dist2), 0.0);
-  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
-  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    double nv = 0.0;
-    if (!outside) {
-      const double v = xp[i];
-      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
-      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
-    }
-    nvout[i] = nv;
-    acc = fma(nv, g[i], acc);
-  }
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = normal_dot_body(sg, xp, g, nvout, *dist2, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
 }
 
@@ -135,22 +100,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void proportion_stage1(const double* w,
                                                                 const double* ng, int64_t n, int64_t chunk,
                                                                 double* dst, int nblk) {
   __shared__ double lds4[4];
-  const double v = *ng;
-  const double sc = (v != v) ? v : (v < 0.0 ? v : 0.0);  // np.min([0, v])
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > n) hi = n;
-  double ab = 0.0, ap = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    const double t = sc * nv[i];
-    const double u = g[i] - t;
-    const double be = w[i] * u;
-    ab = fma(be, be, ab);
-    const double ps = psi[i];
-    ap = fma(ps, ps, ap);
-  }
-  const double sb = ccqp_block_sum(ab, lds4);
-  const double sp = ccqp_block_sum(ap, lds4);
+  double sb, sp;
+  proportion_body(w, g, nv, psi, *ng, n, chunk, blockIdx.x, lds4, &sb, &sp);
   if (threadIdx.x == 0) {
     dst[blockIdx.x] = sb;
     dst[nblk + blockIdx.x] = sp;
@@ -178,14 +129,7 @@ extern "C" int ccqp_mprgp_proportion_f64(ccqp_ctx* ctx, const double* w, const d
 // ---- out = isclose(x, P(x)) * g   (free gradient)
 __global__ __launch_bounds__(CCQP_BLOCK) void free_gradient_kernel(ccqp_segk sg, const double* x, const double* g,
                                                                    double* out) {
-  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < sg.dim;
-       i += (int64_t)gridDim.x * CCQP_BLOCK) {
-    const double xi = x[i];
-    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-    const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
-    out[i] = (ccqp_isclose(xi, p) ? 1.0 : 0.0) * g[i];
-  }
+  free_gradient_body(sg, x, g, out, blockIdx.x, gridDim.x);
 }
 
 extern "C" int ccqp_free_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
@@ -206,13 +150,7 @@ extern "C" int ccqp_free_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg*
 // ---- out = psi - ((psi*Ap)/pAp)*p   (solvers.py:1134-1135, four roundings)
 __global__ __launch_bounds__(CCQP_BLOCK) void cg_direction_kernel(const double* psi, const double* Ap, double pAp,
                                                                   const double* p, double* out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
-    const double ps = psi[i];
-    const double t1 = ps * Ap[i];
-    const double beta = t1 / pAp;
-    const double t2 = beta * p[i];
-    out[i] = ps - t2;
-  }
+  cg_direction_body(psi, Ap, pAp, p, out, n, blockIdx.x, gridDim.x);
 }
 
 extern "C" int ccqp_cg_direction_f64(ccqp_ctx* ctx, const double* psi, const double* Ap, double pAp,

@@ -3,7 +3,7 @@
 // Sphere :417-435, Cone :470-492, Disjoint :540-560, normal_vector :92-98,146-160,222-236,306-322,
 // 389-403) and the residual / isclose call sites of solvers.py.
 // Built with -ffp-contract=off: every elementwise expression rounds once per operation like numpy.
-#include "ccqp_internal.h"
+#include "ccqp_bodies.h"
 
 int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s);
 
@@ -43,17 +43,7 @@ static inline ccqp_segk seg_by_value(const ccqp_seg* seg) {
 // ------------------------------------------------------------------ elementwise P(a*x + b*y)
 __global__ __launch_bounds__(CCQP_BLOCK) void proj_elem_kernel(ccqp_segk sg, double a, const double* x,
                                                                double b, const double* y, double* out) {
-  VEC_LOOP(i, sg.dim) {
-    double u = x[i];
-    if (y) {
-      const double t1 = a * u;
-      const double t2 = b * y[i];
-      u = t1 + t2;
-    }
-    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-    out[i] = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
-  }
+  proj_elem_body(sg, a, x, b, y, out, blockIdx.x, gridDim.x);
 }
 
 extern "C" int ccqp_proj_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, double a, const double* x,
@@ -234,22 +224,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void residual_stage1(ccqp_segk sg, cons
                                                               double c, double gd, int64_t chunk,
                                                               double* dst) {
   __shared__ double lds4[4];
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    const double xi = x[i];
-    const double t = gd * g[i];
-    const double u = xi - t;
-    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-    const double p = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
-    const double d = xi - p;
-    const double v = c * d;
-    acc = fma(v, v, acc);
-  }
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = residual_body(sg, x, g, c, gd, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
 }
 
@@ -343,21 +318,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void feasible_steps_stage1(ccqp_segk sg
                                                                     int64_t chunk, double* dst, int nblk) {
   __shared__ double lds4[4];
   const int k = blockIdx.y;
-  double alpha = alpha0;
-  for (int j = 0; j < k; ++j) alpha *= 0.5;  // the reference's `alpha_f *= 0.5`, k times
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    const double t = alpha * p[i];
-    const double yf = x[i] - t;
-    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-    const double pr = ccqp_proj_elem(sg.kind, sg.flags, yf, lb, ub);
-    acc += ccqp_isclose(yf, pr) ? 0.0 : 1.0;
-  }
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = feasible_body(sg, x, p, alpha0, k, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[(int64_t)k * nblk + blockIdx.x] = s;
 }
 

@@ -2,7 +2,7 @@
 // -ffp-contract=off) and the deterministic two-stage dot-product reduction.
 // These carry < 2 % of the HBM traffic of a solve; they are written for
 // exact numpy parity and few launches, not for bandwidth.
-#include "ccqp_internal.h"
+#include "ccqp_bodies.h"
 
 static inline int vec_grid(int64_t n) {
   int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
@@ -17,23 +17,19 @@ static inline int vec_grid(int64_t n) {
 
 __global__ __launch_bounds__(CCQP_BLOCK) void axpby_kernel(double a, const double* x, double b,
                                                            const double* y, double* out, int64_t n) {
-  VEC_LOOP(i, n) {
-    const double t1 = a * x[i];
-    const double t2 = b * y[i];
-    out[i] = t1 + t2;
-  }
+  axpby_body(a, x, b, y, out, n, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void scale_kernel(double a, const double* x, double* out, int64_t n) {
-  VEC_LOOP(i, n) out[i] = a * x[i];
+  scale_body(a, x, out, n, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void copy_kernel(const double* x, double* out, int64_t n) {
-  VEC_LOOP(i, n) out[i] = x[i];
+  copy_body(x, out, n, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void fill_kernel(double v, double* out, int64_t n) {
-  VEC_LOOP(i, n) out[i] = v;
+  fill_body(v, out, n, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void mul_kernel(const double* x, const double* y, double* out,
@@ -129,14 +125,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void dots_stage1(dot_args a, int64_t n,
                                                           double* dst, int nblk) {
   __shared__ double lds4[4];
   const int j = blockIdx.y;
-  const double* __restrict__ x = a.x[j];
-  const double* __restrict__ y = a.y[j];
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > n) hi = n;
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) acc = fma(x[i], y[i], acc);
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = dot_body(a.x[j], a.y[j], n, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[(int64_t)j * nblk + blockIdx.x] = s;
 }
 
@@ -145,9 +134,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void reduce_stage2(const double* partia
                                                             double* slots, int slot0) {
   __shared__ double lds4[4];
   const int j = blockIdx.x;
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += partials[(int64_t)j * nblk + i];
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = partial_sum_body(partials + (int64_t)j * nblk, nblk, lds4);
   if (threadIdx.x == 0) slots[slot0 + j] = s;
 }
 
