@@ -37,6 +37,19 @@ class Seg(ctypes.Structure):
                 ("lb_s", ctypes.c_double), ("ub_s", ctypes.c_double)]
 
 
+class Bop(ctypes.Structure):
+    """struct ccqp_bop (include/ccqp_hip.h): one (problem, operation) descriptor of a batched launch."""
+    _fields_ = [("p", ctypes.c_void_p * 16), ("s", ctypes.c_double * 4),
+                ("n", ctypes.c_int64), ("n2", ctypes.c_int64), ("lda", ctypes.c_int64),
+                ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("slot", ctypes.c_int32 * 4), ("k", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("seg", Seg)]
+
+
+(BOP_GEMV, BOP_AXPBY, BOP_SCALE, BOP_COPY, BOP_FILL, BOP_DOTS, BOP_PROJ_ELEM, BOP_RESIDUAL_ELEM,
+ BOP_FEASIBLE_ELEM, BOP_MPRGP_SPLIT, BOP_MPRGP_NORMAL_DOT, BOP_MPRGP_PROPORTION, BOP_FREE_GRADIENT_ELEM,
+ BOP_CG_DIRECTION) = range(1, 15)
+
 _c = ctypes
 _P = _c.c_void_p
 _I64 = _c.c_int64
@@ -80,6 +93,10 @@ SIGNATURES = {
     "ccqp_free_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
     "ccqp_cg_direction_f64": [_P, _P, _P, _D, _P, _P, _I64, _P],
     "ccqp_projected_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _P, _P],
+    "ccqp_ctx_workspace": [_P, _c.POINTER(_P), _c.POINTER(_P)],
+    "ccqp_batch_run_f64": [_P, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(Bop), _P],
+    "ccqp_scalars_gather_async": [_P, _I, _c.POINTER(_P), _c.POINTER(_I), _c.POINTER(_I), _P],
+    "ccqp_scalars_gather_host": [_P, _I, _c.POINTER(_D)],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
     "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
 }

@@ -88,14 +88,184 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
     return solvers
 
 
-def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=4, device=None):
+def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=None, device=None, fused=True):
     """One process per GPU: this rank generates and solves problems p = rank, rank+world, ...
     (`make_problem(p)` -> (A, b, x0, op) on this rank's GPU).  Returns {p: solver} for the local
-    problems; no collective is issued."""
+    problems; no collective is issued.  fused=True uses the lock-step scheduler with batched launches
+    (solve_batch_fused, 32 lanes in 4 groups by default), fused=False the one-stream-per-solve scheduler."""
     world, rank = 1, 0
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size(group)
         rank = torch.distributed.get_rank(group)
     mine = batch_partition(nproblems, world, rank)
-    solved = solve_batch(make_solver, [make_problem(p) for p in mine], lanes=lanes, device=device)
+    probs = [make_problem(p) for p in mine]
+    if fused:
+        solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=4, device=device)
+    else:
+        solved = solve_batch(make_solver, probs, lanes=lanes or 4, device=device)
     return dict(zip(mine, solved))
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused scheduler: the same operation of many in-flight solves becomes ONE batched launch.
+# ---------------------------------------------------------------------------------------------
+class _Lane:
+    __slots__ = ("eng", "pidx", "run", "gen", "req", "t0")
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.pidx = None
+        self.gen = None
+        self.req = None
+
+
+def _flush_group(lanes, grp_eng, ops_buf, codes_buf, counts_buf):
+    """Merge the queues of `lanes` position by position: all operations at queue position p that have
+    the same signature (opcode + shape) form one group = one launch; groups are issued in position
+    order, which preserves every lane's own program order.  One descriptor upload for everything."""
+    queues = [(ln.eng, ln.eng.take()) for ln in lanes]
+    depth = max((len(q) for _, q in queues), default=0)
+    nops = ngroups = 0
+    for pos in range(depth):
+        buckets = {}
+        for eng, q in queues:
+            if pos < len(q):
+                op = q[pos]
+                buckets.setdefault(op[1], []).append((eng, op))
+        for sig, members in buckets.items():
+            codes_buf[ngroups] = sig[0]
+            counts_buf[ngroups] = len(members)
+            ngroups += 1
+            for eng, op in members:
+                eng.write_bop(ops_buf[nops], op)
+                nops += 1
+    if ngroups:
+        rc = grp_eng.lib.ccqp_batch_run_f64(grp_eng.ctx, ngroups, codes_buf, counts_buf, ops_buf, grp_eng.stream)
+        if rc:
+            from . import _lib
+            _lib.check(rc)
+    for ln in lanes:
+        ln.eng.release()
+    return nops, ngroups
+
+
+def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, quiet=True, stats=None):
+    """Like solve_batch, but the in-flight solves are executed in lock-step ROUNDS: each solve is advanced
+    (on the host only) to its next scalar read while its operations are recorded; the recorded
+    operations of all solves of a lane group are merged into batched launches (ccqp_batch_run_f64), the
+    scalar reads are enqueued, and the host moves on to the other lane group while the GPU works.
+    Per problem the operation sequence and every operand are exactly those of a plain solve(), so the
+    results are bitwise identical; only the number of launches changes (x `lanes/groups` fewer).
+    """
+    import ctypes
+    from . import _lib
+    from ._engine import Engine
+    from ._record import RecordingEngine
+    problems = list(problems)
+    base = get_engine(device)
+    nl = max(1, min(lanes, len(problems)))
+    groups = max(1, min(groups, nl))
+    torch.cuda.synchronize(base.device)
+    streams = [torch.cuda.Stream(device=base.index) for _ in range(groups)]
+    grp_engs = [Engine(base.index, s) for s in streams]
+    lane_objs = [_Lane(RecordingEngine(base.index, streams[i % groups])) for i in range(nl)]
+    grp_lanes = [[ln for i, ln in enumerate(lane_objs) if i % groups == g] for g in range(groups)]
+    cap = 4096
+    ops_buf = (_lib.Bop * cap)()
+    codes_buf = (ctypes.c_int * cap)()
+    counts_buf = (ctypes.c_int * cap)()
+    solvers = [make_solver() for _ in problems]
+    out = io.StringIO()
+    pending = list(range(len(problems)))[::-1]
+    set_stream = torch.cuda.set_stream
+    caller_stream = torch.cuda.current_stream(base.device)
+    tot_ops = tot_groups = rounds = 0
+
+    def begin(ln):
+        ln.pidx = pending.pop()
+        A, b, x0, op = problems[ln.pidx]
+        ln.t0 = time.time()
+        print("solving " + solvers[ln.pidx]._label, file=out)
+        ln.run, ln.gen = solvers[ln.pidx]._start(A, b, x0, op, ln.eng)
+        ln.req = None
+
+    def step(ln, values):
+        """Resume until the next read request; returns False when the solve has finished."""
+        try:
+            ln.req = next(ln.gen) if values is None else ln.gen.send(values)
+            return True
+        except StopIteration as stop:
+            x, res, mv = stop.value
+            ln.eng.flush_self()                     # trailing operations recorded after the last read
+            solvers[ln.pidx]._finish(ln.run, x, res, mv, ln.t0)
+            ln.gen = None
+            return False
+
+    try:
+        with np.errstate(all="ignore"):
+            live = [True] * groups
+            waiting = [None] * groups
+            gbuf = (ctypes.c_double * (64 * 16))()
+            gslabs = (ctypes.c_void_p * 64)()
+            gslot0 = (ctypes.c_int * 64)()
+            gcount = (ctypes.c_int * 64)()
+            while any(live):
+                for g in range(groups):
+                    if not live[g]:
+                        continue
+                    set_stream(streams[g])
+                    gathered = {}
+                    if waiting[g]:
+                        # one wait + one host copy for all lanes of the group (previous round's read)
+                        wl = waiting[g]
+                        rc = grp_engs[g].lib.ccqp_scalars_gather_host(grp_engs[g].ctx, len(wl), gbuf)
+                        if rc:
+                            _lib.check(rc)
+                        for i, ln in enumerate(wl):
+                            base_i = i * 16
+                            gathered[id(ln)] = [np.float64(gbuf[base_i + j]) for j in range(ln.req[1])]
+                        waiting[g] = None
+                    busy = []
+                    for ln in grp_lanes[g]:
+                        while True:
+                            if ln.gen is None:
+                                if not pending:
+                                    break
+                                begin(ln)
+                                vals = None
+                            else:
+                                vals = gathered.pop(id(ln))     # delivered by this group's previous round
+                            if step(ln, vals):
+                                busy.append(ln)
+                                break
+                            # finished: try to start the next problem on this lane right away
+                    if not busy:
+                        live[g] = False
+                        continue
+                    if len(ops_buf) < sum(len(ln.eng.queue) for ln in busy):
+                        raise RuntimeError("solve_batch_fused: descriptor buffer too small")
+                    a, b_ = _flush_group(busy, grp_engs[g], ops_buf, codes_buf, counts_buf)
+                    tot_ops += a
+                    tot_groups += b_
+                    rounds += 1
+                    for chunk0 in range(0, len(busy), 64):
+                        part = busy[chunk0:chunk0 + 64]
+                        if chunk0:
+                            raise RuntimeError("solve_batch_fused: at most 64 lanes per group")
+                        for i, ln in enumerate(part):
+                            gslabs[i] = ln.eng.slab_ptr
+                            gslot0[i] = ln.req[0]
+                            gcount[i] = ln.req[1]
+                        rc = grp_engs[g].lib.ccqp_scalars_gather_async(grp_engs[g].ctx, len(part), gslabs, gslot0,
+                                                                       gcount, grp_engs[g].stream)
+                        if rc:
+                            _lib.check(rc)
+                    waiting[g] = busy
+    finally:
+        set_stream(caller_stream)
+    torch.cuda.synchronize(base.device)
+    if stats is not None:
+        stats.update(ops=tot_ops, launches=tot_groups, rounds=rounds)
+    if not quiet:
+        print(out.getvalue(), end="")
+    return solvers

@@ -1,0 +1,343 @@
+// Batched launch form: ONE launch executes the same operation for many independent problems
+// (blockIdx.y / .z = problem).  Used by the batch-sharded mode (BASELINE config 5: 1024 independent
+// n = 8192 QPs, 128 per GPU): at that size a matvec is 83 us and a solve needs ~170 O(n) kernels, so
+// per-problem launches leave the GPU half idle.  The host scheduler (ccqppy_amd/batch.py) records
+// the operations of many in-flight solves and hands groups of identical operations to
+// ccqp_batch_run_f64; every group becomes one launch (plus one stage-2 launch for reductions).
+// The bodies are the ones of the single-problem kernels (ccqp_bodies.h): results are bitwise equal.
+#include "ccqp_bodies.h"
+
+#define BATCH_RING 16384  // descriptors in the device ring (one flush uses a few hundred)
+
+struct ccqp_batch {
+  ccqp_bop* dev;     // device ring
+  ccqp_bop* host;    // pinned staging ring
+  int64_t cursor;
+};
+
+static ccqp_batch* batch_of(ccqp_ctx* ctx) {
+  if (ctx->batch) return ctx->batch;
+  ccqp_batch* b = new ccqp_batch();
+  b->dev = nullptr;
+  b->host = nullptr;
+  b->cursor = 0;
+  if (hipMalloc(&b->dev, sizeof(ccqp_bop) * BATCH_RING) != hipSuccess ||
+      hipHostMalloc(&b->host, sizeof(ccqp_bop) * BATCH_RING, hipHostMallocDefault) != hipSuccess) {
+    if (b->dev) (void)hipFree(b->dev);
+    delete b;
+    return nullptr;
+  }
+  ctx->batch = b;
+  return b;
+}
+
+void ccqp_batch_free(ccqp_ctx* ctx) {
+  if (!ctx->batch) return;
+  (void)hipFree(ctx->batch->dev);
+  (void)hipHostFree(ctx->batch->host);
+  delete ctx->batch;
+  ctx->batch = nullptr;
+}
+
+__device__ __forceinline__ ccqp_segk segk_of(const ccqp_bop& o) {
+  ccqp_segk k;
+  k.kind = o.seg.kind;
+  k.flags = o.seg.flags;
+  k.dim = o.seg.dim;
+  k.lb = o.seg.lb;
+  k.ub = o.seg.ub;
+  k.lb_s = o.seg.lb_s;
+  k.ub_s = o.seg.ub_s;
+  return k;
+}
+
+// ------------------------------------------------------------------ elementwise groups
+__global__ __launch_bounds__(CCQP_BLOCK) void b_elementwise(const ccqp_bop* t, int opcode) {
+  const ccqp_bop& o = t[blockIdx.y];
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  switch (opcode) {
+    case CCQP_BOP_AXPBY:
+      axpby_body(o.s[0], o.p[0], o.s[1], o.p[1], const_cast<double*>(o.p[2]), o.n, bx, nbx);
+      break;
+    case CCQP_BOP_SCALE:
+      scale_body(o.s[0], o.p[0], const_cast<double*>(o.p[1]), o.n, bx, nbx);
+      break;
+    case CCQP_BOP_COPY:
+      copy_body(o.p[0], const_cast<double*>(o.p[1]), o.n, bx, nbx);
+      break;
+    case CCQP_BOP_FILL:
+      fill_body(o.s[0], const_cast<double*>(o.p[0]), o.n, bx, nbx);
+      break;
+    case CCQP_BOP_PROJ_ELEM: {
+      const int64_t off = o.seg.offset;
+      proj_elem_body(segk_of(o), o.s[0], o.p[0] + off, o.s[1], o.p[1] ? o.p[1] + off : nullptr,
+                     const_cast<double*>(o.p[2]) + off, bx, nbx);
+      break;
+    }
+    case CCQP_BOP_FREE_GRADIENT_ELEM: {
+      const int64_t off = o.seg.offset;
+      free_gradient_body(segk_of(o), o.p[0] + off, o.p[1] + off, const_cast<double*>(o.p[2]) + off, bx, nbx);
+      break;
+    }
+    case CCQP_BOP_CG_DIRECTION:
+      cg_direction_body(o.p[0], o.p[1], o.s[0], o.p[2], const_cast<double*>(o.p[3]), o.n, bx, nbx);
+      break;
+    default:
+      break;
+  }
+}
+
+// ------------------------------------------------------------------ reduction groups
+// grid (nblk, k, count).  dst of block (b, j) of problem z: the problem's partials (nblk > 1) or slab.
+__global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage1(const ccqp_bop* t, int opcode, int64_t chunk, int nblk) {
+  __shared__ double lds4[4];
+  const ccqp_bop& o = t[blockIdx.z];
+  const int bx = blockIdx.x, j = blockIdx.y;
+  double* dst = nblk == 1 ? o.slab + o.slot[0] : o.partials;
+  double s = 0.0;
+  switch (opcode) {
+    case CCQP_BOP_DOTS:
+      s = dot_body(o.p[2 * j], o.p[2 * j + 1], o.n, chunk, bx, lds4);
+      break;
+    case CCQP_BOP_RESIDUAL_ELEM: {
+      const int64_t off = o.seg.offset;
+      s = residual_body(segk_of(o), o.p[0] + off, o.p[1] + off, o.s[0], o.s[1], chunk, bx, lds4);
+      break;
+    }
+    case CCQP_BOP_FEASIBLE_ELEM: {
+      const int64_t off = o.seg.offset;
+      s = feasible_body(segk_of(o), o.p[0] + off, o.p[1] + off, o.s[0], j, chunk, bx, lds4);
+      break;
+    }
+    case CCQP_BOP_MPRGP_SPLIT: {
+      const int64_t off = o.seg.offset;
+      s = split_body(segk_of(o), o.p[0] + off, o.p[1] + off, const_cast<double*>(o.p[2]) + off,
+                     const_cast<double*>(o.p[3]) + off, const_cast<double*>(o.p[4]) + off, chunk, bx, lds4);
+      break;
+    }
+    case CCQP_BOP_MPRGP_NORMAL_DOT: {
+      const int64_t off = o.seg.offset;
+      s = normal_dot_body(segk_of(o), o.p[0] + off, o.p[1] + off, const_cast<double*>(o.p[2]) + off,
+                          o.slab[o.slot[1]], chunk, bx, lds4);
+      break;
+    }
+    case CCQP_BOP_MPRGP_PROPORTION: {
+      double sb, sp;
+      proportion_body(o.p[0], o.p[1], o.p[2], o.p[3], o.slab[o.slot[1]], o.n, chunk, bx, lds4, &sb, &sp);
+      if (threadIdx.x == 0) {
+        dst[bx] = sb;
+        dst[nblk + bx] = sp;
+      }
+      return;
+    }
+    default:
+      break;
+  }
+  if (threadIdx.x == 0) dst[(int64_t)j * nblk + bx] = s;
+}
+
+// grid (k, count): slab[slot0 + j] = sum of the problem's partials of reduction j
+__global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage2(const ccqp_bop* t, int nblk) {
+  __shared__ double lds4[4];
+  const ccqp_bop& o = t[blockIdx.y];
+  const int j = blockIdx.x;
+  const double s = partial_sum_body(o.partials + (int64_t)j * nblk, nblk, lds4);
+  if (threadIdx.x == 0) o.slab[o.slot[0] + j] = s;
+}
+
+// ------------------------------------------------------------------ matvec group
+template <int R, int U, bool ALIGNED>
+__global__ __launch_bounds__(CCQP_BLOCK) void b_gemv(const ccqp_bop* t, int64_t ntasks) {
+  const ccqp_bop& o = t[blockIdx.y];
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  gemv_body<R, U, ALIGNED, true>(o.p[0], o.lda, o.p[1], o.p[2], const_cast<double*>(o.p[3]),
+                                 const_cast<double*>(o.p[4]), o.n, o.n2, ntasks, wave, nwaves);
+}
+
+template <int R, int U>
+static void launch_b_gemv(bool aligned, dim3 grid, hipStream_t s, const ccqp_bop* t, int64_t ntasks) {
+  if (aligned) hipLaunchKernelGGL((b_gemv<R, U, true>), grid, dim3(CCQP_BLOCK), 0, s, t, ntasks);
+  else hipLaunchKernelGGL((b_gemv<R, U, false>), grid, dim3(CCQP_BLOCK), 0, s, t, ntasks);
+}
+
+static inline int vec_grid(int64_t n) {
+  int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* host, const ccqp_bop* dev,
+                        hipStream_t s) {
+  const ccqp_bop& h = host[0];
+  switch (opcode) {
+    case CCQP_BOP_AXPBY:
+    case CCQP_BOP_SCALE:
+    case CCQP_BOP_COPY:
+    case CCQP_BOP_FILL:
+    case CCQP_BOP_CG_DIRECTION: {
+      int64_t nmax = 0;
+      for (int i = 0; i < count; ++i) nmax = host[i].n > nmax ? host[i].n : nmax;
+      if (nmax == 0) return CCQP_OK;
+      hipLaunchKernelGGL(b_elementwise, dim3(vec_grid(nmax), count), dim3(CCQP_BLOCK), 0, s, dev, opcode);
+      return CCQP_OK;
+    }
+    case CCQP_BOP_PROJ_ELEM:
+    case CCQP_BOP_FREE_GRADIENT_ELEM: {
+      int64_t nmax = 0;
+      for (int i = 0; i < count; ++i) nmax = host[i].seg.dim > nmax ? host[i].seg.dim : nmax;
+      if (nmax == 0) return CCQP_OK;
+      hipLaunchKernelGGL(b_elementwise, dim3(vec_grid(nmax), count), dim3(CCQP_BLOCK), 0, s, dev, opcode);
+      return CCQP_OK;
+    }
+    case CCQP_BOP_DOTS:
+    case CCQP_BOP_RESIDUAL_ELEM:
+    case CCQP_BOP_FEASIBLE_ELEM:
+    case CCQP_BOP_MPRGP_SPLIT:
+    case CCQP_BOP_MPRGP_NORMAL_DOT:
+    case CCQP_BOP_MPRGP_PROPORTION: {
+      const bool seg_sized = opcode != CCQP_BOP_DOTS && opcode != CCQP_BOP_MPRGP_PROPORTION;
+      const int64_t n = seg_sized ? h.seg.dim : h.n;
+      int k = 1;                       // reductions per problem
+      if (opcode == CCQP_BOP_DOTS || opcode == CCQP_BOP_FEASIBLE_ELEM) k = h.k;
+      if (opcode == CCQP_BOP_MPRGP_PROPORTION) k = 2;
+      const bool kvar = opcode == CCQP_BOP_DOTS || opcode == CCQP_BOP_FEASIBLE_ELEM;
+      for (int i = 0; i < count; ++i) {
+        const int64_t ni = seg_sized ? host[i].seg.dim : host[i].n;
+        CCQP_REQUIRE(ni == n && (!kvar || host[i].k == h.k), "batched reduction: problems differ in size");
+        CCQP_REQUIRE(ccqp_slot_ok(host[i].slot[0], k), "slot range outside the slab");
+      }
+      CCQP_REQUIRE(k >= 1 && k <= CCQP_MAX_STEPS, "batched reduction: bad k");
+      int64_t chunk;
+      int nblk;
+      ccqp_red_geometry(n, &chunk, &nblk);
+      CCQP_REQUIRE((int64_t)k * nblk <= (int64_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK, "k * blocks exceeds the workspace");
+      const int gy = opcode == CCQP_BOP_MPRGP_PROPORTION ? 1 : k;
+      hipLaunchKernelGGL(b_reduce_stage1, dim3(nblk, gy, count), dim3(CCQP_BLOCK), 0, s, dev, opcode, chunk, nblk);
+      if (nblk > 1) hipLaunchKernelGGL(b_reduce_stage2, dim3(k, count), dim3(CCQP_BLOCK), 0, s, dev, nblk);
+      return CCQP_OK;
+    }
+    case CCQP_BOP_GEMV: {
+      const int64_t rows = h.n, cols = h.n2;
+      bool aligned = true;
+      for (int i = 0; i < count; ++i) {
+        CCQP_REQUIRE(host[i].n == rows && host[i].n2 == cols, "batched matvec: problems differ in shape");
+        CCQP_REQUIRE(host[i].lda >= cols, "lda < cols");
+        aligned = aligned && ((reinterpret_cast<uintptr_t>(host[i].p[0]) | reinterpret_cast<uintptr_t>(host[i].p[1])) & 15) == 0 &&
+                  (host[i].lda % 2) == 0;
+      }
+      if (rows == 0) return CCQP_OK;
+      int R = 0, U = 0, bpc = 0;
+      ccqp_gemv_defaults(rows, cols, &R, &U, &bpc);
+      const int64_t ntasks = (rows + R - 1) / R;
+      int64_t blocks = (ntasks + (CCQP_BLOCK / 64) - 1) / (CCQP_BLOCK / 64);
+      // the whole group shares the GPU: size the per-problem grid so the group fills it ~8 workgroups/CU
+      int64_t cap = ((int64_t)ctx->num_cu * bpc + count - 1) / count;
+      if (cap < 32) cap = 32;
+      if (blocks > cap) blocks = cap;
+      const dim3 grid((unsigned)blocks, (unsigned)count);
+      if (R == 1 && U == 1) launch_b_gemv<1, 1>(aligned, grid, s, dev, ntasks);
+      else if (R == 1 && U == 2) launch_b_gemv<1, 2>(aligned, grid, s, dev, ntasks);
+      else if (R == 2 && U == 1) launch_b_gemv<2, 1>(aligned, grid, s, dev, ntasks);
+      else launch_b_gemv<2, 2>(aligned, grid, s, dev, ntasks);
+      return CCQP_OK;
+    }
+    default:
+      ccqp_set_error("ccqp_batch_run_f64: unknown opcode %d", opcode);
+      return CCQP_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes, const int* counts,
+                                  const ccqp_bop* ops, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(ngroups >= 0, "negative group count");
+  if (ngroups == 0) return CCQP_OK;
+  CCQP_REQUIRE(opcodes && counts && ops, "NULL argument");
+  int64_t total = 0;
+  for (int gidx = 0; gidx < ngroups; ++gidx) {
+    CCQP_REQUIRE(counts[gidx] >= 1 && counts[gidx] <= 65535, "group size outside [1, 65535]");
+    total += counts[gidx];
+  }
+  CCQP_REQUIRE(total <= BATCH_RING / 4, "too many descriptors in one flush");
+  ccqp_batch* b = batch_of(ctx);
+  if (!b) {
+    ccqp_set_error("ccqp_batch_run_f64: cannot allocate the descriptor ring");
+    return CCQP_ERR_HIP;
+  }
+  if (b->cursor + total > BATCH_RING) b->cursor = 0;
+  ccqp_bop* hst = b->host + b->cursor;
+  ccqp_bop* dev = b->dev + b->cursor;
+  b->cursor += total;
+  memcpy(hst, ops, sizeof(ccqp_bop) * (size_t)total);
+  hipStream_t s = (hipStream_t)stream;
+  CCQP_HIP(hipMemcpyAsync(dev, hst, sizeof(ccqp_bop) * (size_t)total, hipMemcpyHostToDevice, s));
+  int64_t at = 0;
+  for (int gidx = 0; gidx < ngroups; ++gidx) {
+    int rc = launch_group(ctx, opcodes[gidx], counts[gidx], hst + at, dev + at, s);
+    if (rc) return rc;
+    at += counts[gidx];
+  }
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_ctx_workspace(ccqp_ctx* ctx, double** slab, double** partials) {
+  CCQP_REQUIRE(ctx != nullptr && slab != nullptr && partials != nullptr, "NULL argument");
+  *slab = ctx->slots;
+  *partials = ctx->partials;
+  return CCQP_OK;
+}
+
+// ------------------------------------------------------------------ gathered scalar read
+// The lanes of a group each own a scalar slab; one tiny kernel collects the slots every lane asked
+// for into one staging area, ONE device->host copy brings them over (instead of one copy per lane).
+#define GATHER_MAX 64       // lanes per gather
+#define GATHER_WIDTH 16     // slots per lane
+
+struct gather_args {
+  const double* slab[GATHER_MAX];
+  int slot0[GATHER_MAX];
+  int count[GATHER_MAX];
+};
+
+__global__ void gather_kernel(gather_args a, int n, double* out) {
+  const int lane = blockIdx.x;
+  const int j = threadIdx.x;
+  if (lane < n && j < a.count[lane]) out[lane * GATHER_WIDTH + j] = a.slab[lane][a.slot0[lane] + j];
+}
+
+extern "C" int ccqp_scalars_gather_async(ccqp_ctx* ctx, int n, double* const* slabs, const int* slot0,
+                                         const int* count, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(n >= 1 && n <= GATHER_MAX, "n outside [1, 64]");
+  CCQP_REQUIRE(slabs && slot0 && count, "NULL argument");
+  if (!ctx->gather_dev) {
+    CCQP_HIP(hipMalloc(&ctx->gather_dev, sizeof(double) * GATHER_MAX * GATHER_WIDTH));
+    CCQP_HIP(hipHostMalloc(&ctx->gather_host, sizeof(double) * GATHER_MAX * GATHER_WIDTH, hipHostMallocDefault));
+  }
+  gather_args a;
+  for (int i = 0; i < n; ++i) {
+    CCQP_REQUIRE(slabs[i] != nullptr, "NULL slab");
+    CCQP_REQUIRE(count[i] >= 0 && count[i] <= GATHER_WIDTH && ccqp_slot_ok(slot0[i], count[i]), "bad slot range");
+    a.slab[i] = slabs[i];
+    a.slot0[i] = slot0[i];
+    a.count[i] = count[i];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gather_kernel, dim3(n), dim3(GATHER_WIDTH), 0, s, a, n, ctx->gather_dev);
+  CCQP_LAUNCH_CHECK();
+  CCQP_HIP(hipMemcpyAsync(ctx->gather_host, ctx->gather_dev, sizeof(double) * (size_t)n * GATHER_WIDTH,
+                          hipMemcpyDeviceToHost, s));
+  CCQP_HIP(hipEventRecord(ctx->read_event, s));
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_scalars_gather_host(ccqp_ctx* ctx, int n, double* host_out) {
+  CCQP_REQUIRE(ctx != nullptr && host_out != nullptr, "NULL argument");
+  CCQP_REQUIRE(n >= 1 && n <= GATHER_MAX && ctx->gather_host != nullptr, "no gather pending");
+  CCQP_HIP(hipEventSynchronize(ctx->read_event));
+  memcpy(host_out, ctx->gather_host, sizeof(double) * (size_t)n * GATHER_WIDTH);
+  return CCQP_OK;
+}

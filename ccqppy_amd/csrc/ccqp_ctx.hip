@@ -36,6 +36,9 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->partials = nullptr;
   c->host_slots = nullptr;
   c->read_event = nullptr;
+  c->batch = nullptr;
+  c->gather_dev = nullptr;
+  c->gather_host = nullptr;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&c->partials, (size_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->host_slots, CCQP_NUM_SLOTS * sizeof(double), hipHostMallocDefault);
@@ -62,6 +65,9 @@ extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
   (void)hipFree(c->partials);
   (void)hipHostFree(c->host_slots);
   (void)hipEventDestroy(c->read_event);
+  ccqp_batch_free(c);
+  if (c->gather_dev) (void)hipFree(c->gather_dev);
+  if (c->gather_host) (void)hipHostFree(c->gather_host);
   delete c;
   return CCQP_OK;
 }

@@ -11,7 +11,13 @@
 #define CCQP_RED_CHUNK 2048     // elements per stage-1 reduction block (8 per thread)
 #define CCQP_RED_MAXBLK 1024    // stage-1 blocks per reduction (partials per dot)
 
+struct ccqp_batch;                 // descriptor ring of the batched launch form (ccqp_batch.hip)
+void ccqp_batch_free(struct ccqp_ctx* ctx);
+
 struct ccqp_ctx {
+  ccqp_batch* batch;
+  double* gather_dev;   // staging of ccqp_scalars_gather_async (device / pinned host)
+  double* gather_host;
   int device;
   int num_cu;
   char arch[64];

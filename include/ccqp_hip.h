@@ -210,6 +210,51 @@ int ccqp_projected_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, 
                                             const double* g, const double* nv, double* free_g,
                                             double* chopped_g, void* stream);
 
+/* ---- batched launch form (batch-sharded mode, BASELINE config 5) --------------------------------
+ * One descriptor per (problem, operation); a GROUP = `count` descriptors of the same opcode and shape,
+ * executed by ONE launch (blockIdx.y/z = problem) with the bodies of the single-problem kernels, so the
+ * results are bitwise those of one call per problem.  Reductions write into the scalar slab of the
+ * problem's OWN context (`slab`/`partials` from ccqp_ctx_workspace).  Operand meaning per opcode:
+ *   GEMV        p0=A p1=x p2=b|NULL p3=y p4=g|NULL; n=rows n2=cols lda       (ccqp_gemv_epilogue_f64)
+ *   AXPBY       p0=x p1=y p2=out; s0=a s1=b; n          SCALE p0=x p1=out; s0=a      COPY p0=x p1=out
+ *   FILL        p0=out; s0=value                        CG_DIRECTION p0=psi p1=Ap p2=p p3=out; s0=pAp
+ *   DOTS        p[2j], p[2j+1] for j < k; n; slot0      PROJ_ELEM seg; p0=x p1=y|NULL p2=out; s0=a s1=b
+ *   RESIDUAL_ELEM seg; p0=x p1=g; s0=c s1=gd; slot0     FEASIBLE_ELEM seg; p0=x p1=p; s0=alpha0; k; slot0
+ *   MPRGP_SPLIT seg; p0=x p1=g p2=xp p3=psi p4=w; slot0=dist2
+ *   MPRGP_NORMAL_DOT seg; p0=xp p1=g p2=nv; slot0=ng, slot1=dist2
+ *   MPRGP_PROPORTION p0=w p1=g p2=nv p3=psi; n; slot0 (2 results), slot1=ng
+ *   FREE_GRADIENT_ELEM seg; p0=x p1=g p2=out */
+enum {
+  CCQP_BOP_GEMV = 1, CCQP_BOP_AXPBY, CCQP_BOP_SCALE, CCQP_BOP_COPY, CCQP_BOP_FILL, CCQP_BOP_DOTS,
+  CCQP_BOP_PROJ_ELEM, CCQP_BOP_RESIDUAL_ELEM, CCQP_BOP_FEASIBLE_ELEM, CCQP_BOP_MPRGP_SPLIT,
+  CCQP_BOP_MPRGP_NORMAL_DOT, CCQP_BOP_MPRGP_PROPORTION, CCQP_BOP_FREE_GRADIENT_ELEM, CCQP_BOP_CG_DIRECTION
+};
+typedef struct ccqp_bop {
+  const double* p[16];
+  double s[4];
+  int64_t n, n2, lda;
+  double* slab;      /* scalar slab of the problem's context */
+  double* partials;  /* reduction workspace of the problem's context */
+  int32_t slot[4];
+  int32_t k;
+  int32_t reserved;
+  ccqp_seg seg;
+} ccqp_bop;
+/* Device addresses of a context's scalar slab and reduction workspace (to fill ccqp_bop). */
+int ccqp_ctx_workspace(ccqp_ctx* ctx, double** slab, double** partials);
+/* Upload all descriptors once, then launch group after group on `stream`:
+ * group i = opcodes[i] applied to the next counts[i] descriptors of `ops` (host array). */
+int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes, const int* counts,
+                       const ccqp_bop* ops, void* stream);
+
+/* Scalar read of many contexts at once (the lanes of a batched group): slots
+ * [slot0[i], slot0[i]+count[i]) (count <= 16) of slab i are collected by one kernel and copied to the
+ * host with ONE transfer; ccqp_scalars_gather_host waits for it and returns n x 16 doubles (row i =
+ * lane i).  `ctx` owns the staging buffers and the event; n <= 64. */
+int ccqp_scalars_gather_async(ccqp_ctx* ctx, int n, double* const* slabs, const int* slot0,
+                              const int* count, void* stream);
+int ccqp_scalars_gather_host(ccqp_ctx* ctx, int n, double* host_out);
+
 /* ---- synthetic problems (replaces benchmarks/benchmark_random_ccqp.py:59-63,
  * whose Wishart generator is O(n^3)) ---------------------------------------------------------
  * Rows [row0, row0+rows) of the n x n counter-hashed symmetric matrix:

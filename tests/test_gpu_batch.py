@@ -69,9 +69,10 @@ def test_batch_partition_driver_single_rank():
     def make(p):
         op, b, _ = problems.random_problem(n, 100 + p)
         return op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
-    res = solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), make, 6, lanes=3)
-    assert sorted(res) == list(range(6))
-    assert all(r.solution_converged for r in res.values())
+    for fused in (True, False):
+        res = solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), make, 6, lanes=3, fused=fused)
+        assert sorted(res) == list(range(6))
+        assert all(r.solution_converged for r in res.values())
 
 
 @pytest.mark.parametrize("kind", ["Box", "Lower", "Upper", "Identity"])
@@ -97,3 +98,52 @@ def test_mprgp_fused_kernels_equal_literal_sequence(kind):
         assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
         assert float(a.solution_residual) == float(c.solution_residual)
         assert np.array_equal(a.solution.cpu().numpy().view(np.uint64), c.solution.cpu().numpy().view(np.uint64))
+
+
+@pytest.mark.parametrize("sname,args", [("MPRGP", (1e-6, 300)), ("BBPGD", (1e-8, 5000)), ("APGD", (1e-8, 5000)),
+                                        ("APGDAntiRelaxation", (1e-8, 5000)), ("BBPGDf", (1e-8, 5000)),
+                                        ("PGD", (1e-8, 5000, 0.3))])
+def test_fused_batch_equals_sequential(sname, args):
+    """solve_batch_fused merges the same operation of many solves into one batched launch
+    (ccqp_batch_run_f64); results must be bitwise those of plain sequential solves."""
+    from ccqppy_amd import solvers
+    from ccqppy_amd.batch import solve_batch_fused
+    cls = getattr(solvers, "CCQPSolver" + sname)
+    probs = _problems(1024, 9) + _problems(3000, 3)          # two sizes in one batch (nblk 1 and 2)
+    seq = []
+    for A, b, x0, P in probs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            seq.append(cls(*args).solve(A, b, x0, P))
+    for lanes, groups in ((1, 1), (5, 2), (12, 2), (12, 3)):
+        stats = {}
+        got = solve_batch_fused(lambda: cls(*args), probs, lanes=lanes, groups=groups, stats=stats)
+        assert stats["ops"] >= stats["launches"] > 0
+        for g, s in zip(got, seq):
+            assert g.solution_num_matrix_vector_multiplications == s.solution_num_matrix_vector_multiplications
+            assert g.executed_matrix_vector_multiplications == s.executed_matrix_vector_multiplications
+            assert g.solution_converged == s.solution_converged
+            assert float(g.solution_residual) == float(s.solution_residual)
+            assert np.array_equal(g.solution.cpu().numpy().view(np.uint64), s.solution.cpu().numpy().view(np.uint64))
+
+
+def test_fused_batch_with_non_elementwise_sets_falls_back_in_order():
+    """Sphere / Disjoint projections have no batched form: their kernels are launched immediately after
+    the lane's recorded operations have been flushed, so program order (and the result) is unchanged."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd.batch import solve_batch_fused
+    n = 900
+    probs = []
+    for p in range(5):
+        op, b, _ = problems.random_problem(n, 50 + p)
+        P = ss.SphereProjOp(n, 4.0) if p % 2 else ss.DisjointProjOp(
+            ss.BoxProjOp(n // 2, -0.5 * np.ones(n // 2), 0.5 * np.ones(n // 2)), ss.SphereProjOp(n - n // 2, 2.0))
+        probs.append((op, b, None, P))
+    for cls, args in ((solvers.CCQPSolverBBPGD, (1e-8, 500)), (solvers.CCQPSolverMPRGP, (1e-6, 200))):
+        seq = []
+        for A, b, x0, P in probs:
+            with contextlib.redirect_stdout(io.StringIO()):
+                seq.append(cls(*args).solve(A, b, x0, P))
+        got = solve_batch_fused(lambda: cls(*args), probs, lanes=4, groups=2)
+        for g, s in zip(got, seq):
+            assert g.solution_num_matrix_vector_multiplications == s.solution_num_matrix_vector_multiplications
+            assert np.array_equal(g.solution.cpu().numpy().view(np.uint64), s.solution.cpu().numpy().view(np.uint64))

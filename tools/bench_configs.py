@@ -96,6 +96,34 @@ def main():
                                   solve_level_hbm_frac=mv * mv_bytes(n) / best / 8e12,
                                   reported_mv=[int(r.solution_num_matrix_vector_multiplications) for r in res][:8])),
                   flush=True)
+    if "5f" in which:
+        from ccqppy_amd import problems
+        from ccqppy_amd.batch import solve_batch_fused
+        n = 8192
+        probs = []
+        for p in range(args.batch):
+            op, b, _ = problems.random_problem(n, 1234 + p)
+            probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+        for lanes, groups in ((8, 1), (8, 2), (16, 2), (32, 2), (32, 4)):
+            if lanes > args.batch:
+                continue
+            best = None
+            stats = {}
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = solve_batch_fused(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), probs, lanes=lanes,
+                                        groups=groups, stats=stats)
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best):
+                    best = dt
+            mv = sum(r.executed_matrix_vector_multiplications for r in res)
+            print(json.dumps(dict(config="config5 slice via solve_batch_fused: %d x n=8192 MPRGP" % args.batch,
+                                  lanes=lanes, groups=groups, wall_s=best, problems_per_s=args.batch / best,
+                                  executed_mv=mv, mv_per_s=mv / best,
+                                  solve_level_hbm_frac=mv * mv_bytes(n) / best / 8e12, stats=stats,
+                                  reported_mv=[int(r.solution_num_matrix_vector_multiplications) for r in res][:8])),
+                  flush=True)
     if "5b" in which:
         for name, mk in (("BBPGD", lambda: solvers.CCQPSolverBBPGD(1e-8, 5000)),
                          ("APGD", lambda: solvers.CCQPSolverAPGD(1e-8, 5000)),
