@@ -9,7 +9,6 @@ scalars the GPU runs the kernels of the others and the host keeps launching.  Ev
 executes exactly the reference's sequence of operations, so per-problem results and MV counts are
 identical to a sequential run (asserted in tests/test_gpu_batch.py).
 """
-import contextlib
 import io
 import time
 

@@ -233,3 +233,33 @@ def test_full_size_properties_n131072_metric_workload():
     assert bool((op.A.diagonal() == 2.0).all())
     del op
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("sname,tol,max_mv,opname", [("APGD", 1e-8, 5000, "box"), ("BBPGD", 1e-8, 64, "cone")])
+def test_config2_full_size_against_oracle(sname, tol, max_mv, opname):
+    """BASELINE config 2 (n = 32768, APGD + Box) and config 3's solver/set pair (BBPGD + Cone, fixed
+    64-MV budget) at n = 32768 against the CPU oracle on the SAME matrix (copied from the device; the
+    device generator is bit-identical to the host statement, test_generator_bits).  Bar: identical
+    reported and executed MV counts, x within 1e-10 relative."""
+    from ccqppy_amd import problems, solution_spaces as ss
+    n, seed = 32768, 1234
+    torch.cuda.empty_cache()
+    op, b, xs = problems.random_problem(n, seed)
+    A_host = op.A.cpu().numpy()
+    bb = b.cpu().numpy()
+    assert H.same_bits(A_host[12345], gen_ref.spd_rows(n, seed, 12345, 1)[0])
+    if opname == "box":
+        P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+        Po = cpu_ref.Box(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    else:
+        P, Po = ss.ConeProjOp(n), cpu_ref.Cone(n)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = _solver_cls(sname)(tol, max_mv).solve(op, bb, convex_proj_op=P)
+    with np.errstate(all="ignore"):
+        o = cpu_ref.SOLVERS[sname](A_host, bb, tol, max_mv, P=Po)
+    assert r.solution_num_matrix_vector_multiplications == o.solution_num_matrix_vector_multiplications
+    assert r.executed_matrix_vector_multiplications == o.executed_mv
+    assert bool(r.solution_converged) == bool(o.solution_converged)
+    assert np.linalg.norm(r.solution - o.solution) <= RTOL * np.linalg.norm(o.solution)
+    del op, A_host
+    torch.cuda.empty_cache()
