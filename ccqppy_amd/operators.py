@@ -135,3 +135,28 @@ def as_operator(A, engine=None):
     if hasattr(A, "matvec") and hasattr(A, "engine"):
         return A
     return DenseOperator(A, engine)
+
+
+class RegeneratedRowBlocksOperator:
+    """Matrix-free form of the synthetic generator matrix (operator generality): A is
+    never stored; each matvec visits `blocks` row blocks one after the other, regenerating each block
+    in one reusable buffer (`ccqp_gen_spd_rows_f64`, 64 GiB in ~20 ms) and multiplying it with the
+    production GEMV.  The row sums are those of any row-sharded run (GEMV bits depend on (row, n) only),
+    so this reproduces an 8-rank n = 262144 solve on ONE GPU, where 512 GiB could not be resident."""
+
+    def __init__(self, n, seed, blocks, engine=None):
+        assert n % blocks == 0
+        self.engine = engine or get_engine()
+        self.n, self.seed, self.blocks = n, seed, blocks
+        self.rows = n // blocks
+        self.buf = torch.empty((self.rows, n), dtype=torch.float64, device=self.engine.device)
+        self.A = self.buf
+
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        eng = engine or self.engine
+        for r in range(self.blocks):
+            eng.gen_spd_rows(self.buf, r * self.rows, self.n, self.seed)
+            eng.gemv(self.buf, x, y[r * self.rows:(r + 1) * self.rows])
+        eng.mv_executed -= self.blocks - 1          # one matvec per call, however many blocks
+        if g is not None:
+            eng.axpby(1.0, y, 1.0, b, g)

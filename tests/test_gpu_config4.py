@@ -22,25 +22,6 @@ N = 262144
 G = 8
 
 
-class _RegeneratedRowBlocks:
-    """A = the n x n generator matrix; matvec visits the G row blocks sequentially through one buffer."""
-
-    def __init__(self, n, seed, blocks, engine):
-        self.n, self.seed, self.blocks, self.engine = n, seed, blocks, engine
-        self.rows = n // blocks
-        self.buf = torch.empty((self.rows, n), dtype=torch.float64, device=engine.device)
-        self.A = self.buf
-
-    def matvec(self, x, y, b=None, g=None, engine=None):
-        eng = engine or self.engine
-        for r in range(self.blocks):
-            eng.gen_spd_rows(self.buf, r * self.rows, self.n, self.seed)
-            eng.gemv(self.buf, x, y[r * self.rows:(r + 1) * self.rows])
-        eng.mv_executed -= self.blocks - 1          # count one matvec per call
-        if g is not None:
-            eng.axpby(1.0, y, 1.0, b, g)
-
-
 def test_last_rank_slab_generator_and_gemv():
     from ccqppy_amd import problems
     from ccqppy_amd._engine import get_engine
@@ -70,7 +51,8 @@ def test_config4_solve_by_regenerated_row_blocks():
     from ccqppy_amd._engine import get_engine
     eng = get_engine(0)
     torch.cuda.empty_cache()
-    op = _RegeneratedRowBlocks(N, 1234, G, eng)
+    from ccqppy_amd.operators import RegeneratedRowBlocksOperator
+    op = RegeneratedRowBlocksOperator(N, 1234, G, eng)
     xs = problems.xstar(N, 1234)
     Ax = eng.empty(N)
     op.matvec(xs, Ax)
