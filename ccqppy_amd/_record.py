@@ -87,7 +87,7 @@ class RecordingEngine(Engine):
         self.mv_executed += 1
         lda = A.stride(0)
         aligned = ((A.data_ptr() | x.data_ptr()) & 15) == 0 and lda % 2 == 0
-        self._rec(_lib.BOP_GEMV, (_lib.BOP_GEMV, rows, cols, aligned), (A, x, b if g is not None else None, y, g),
+        self._rec(_lib.BOP_GEMV, (_lib.BOP_GEMV, rows, cols, lda, aligned), (A, x, b if g is not None else None, y, g),
                   n=rows, n2=cols, lda=lda)
 
     def axpby(self, a, x, b, y, out):

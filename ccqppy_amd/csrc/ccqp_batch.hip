@@ -146,20 +146,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage2(const ccqp_bop* t,
 }
 
 // ------------------------------------------------------------------ matvec group
-template <int R, int U, bool ALIGNED>
-__global__ __launch_bounds__(CCQP_BLOCK) void b_gemv(const ccqp_bop* t, int64_t ntasks) {
-  const ccqp_bop& o = t[blockIdx.y];
-  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
-  gemv_body<R, U, ALIGNED, true>(o.p[0], o.lda, o.p[1], o.p[2], const_cast<double*>(o.p[3]),
-                                 const_cast<double*>(o.p[4]), o.n, o.n2, ntasks, wave, nwaves);
-}
-
-template <int R, int U>
-static void launch_b_gemv(bool aligned, dim3 grid, hipStream_t s, const ccqp_bop* t, int64_t ntasks) {
-  if (aligned) hipLaunchKernelGGL((b_gemv<R, U, true>), grid, dim3(CCQP_BLOCK), 0, s, t, ntasks);
-  else hipLaunchKernelGGL((b_gemv<R, U, false>), grid, dim3(CCQP_BLOCK), 0, s, t, ntasks);
-}
+// Measured at n = 8192 (scratch microbenchmark, MI355X): ONE launch streaming 8-32 matrices -- whether
+// with blockIdx.y = problem or with a 1-D grid walking the problems in order -- reaches 5.4-6.1 TB/s,
+// because the waves drift apart and several matrices are streamed at once (DRAM page locality), while
+// the same matvecs as back-to-back single-matrix launches reach 6.5 TB/s (a launch costs the host
+// ~2 us, the kernel runs 83 us).  So a matvec group is issued as `count` launches of the
+// single-problem kernel from this C loop: no Python between them, identical bits by construction.
+int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b, double* y,
+                     double* g, int64_t rows, int64_t cols, int variant, hipStream_t s);
 
 static inline int vec_grid(int64_t n) {
   int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
@@ -219,28 +213,16 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
       return CCQP_OK;
     }
     case CCQP_BOP_GEMV: {
-      const int64_t rows = h.n, cols = h.n2;
-      bool aligned = true;
       for (int i = 0; i < count; ++i) {
-        CCQP_REQUIRE(host[i].n == rows && host[i].n2 == cols, "batched matvec: problems differ in shape");
-        CCQP_REQUIRE(host[i].lda >= cols, "lda < cols");
-        aligned = aligned && ((reinterpret_cast<uintptr_t>(host[i].p[0]) | reinterpret_cast<uintptr_t>(host[i].p[1])) & 15) == 0 &&
-                  (host[i].lda % 2) == 0;
+        const ccqp_bop& o = host[i];
+        CCQP_REQUIRE(o.n >= 0 && o.n2 >= 0 && o.lda >= o.n2, "batched matvec: bad shape");
+        if (o.n == 0) continue;
+        CCQP_REQUIRE(o.p[0] && o.p[3] && (o.n2 == 0 || o.p[1]), "batched matvec: NULL operand");
+        CCQP_REQUIRE(o.p[4] == nullptr || o.p[2] != nullptr, "batched matvec: g requested but b is NULL");
+        int rc = ccqp_gemv_launch(ctx, o.p[0], o.lda, o.p[1], o.p[2], const_cast<double*>(o.p[3]),
+                                  const_cast<double*>(o.p[4]), o.n, o.n2, 0, s);
+        if (rc) return rc;
       }
-      if (rows == 0) return CCQP_OK;
-      int R = 0, U = 0, bpc = 0;
-      ccqp_gemv_defaults(rows, cols, &R, &U, &bpc);
-      const int64_t ntasks = (rows + R - 1) / R;
-      int64_t blocks = (ntasks + (CCQP_BLOCK / 64) - 1) / (CCQP_BLOCK / 64);
-      // the whole group shares the GPU: size the per-problem grid so the group fills it ~8 workgroups/CU
-      int64_t cap = ((int64_t)ctx->num_cu * bpc + count - 1) / count;
-      if (cap < 32) cap = 32;
-      if (blocks > cap) blocks = cap;
-      const dim3 grid((unsigned)blocks, (unsigned)count);
-      if (R == 1 && U == 1) launch_b_gemv<1, 1>(aligned, grid, s, dev, ntasks);
-      else if (R == 1 && U == 2) launch_b_gemv<1, 2>(aligned, grid, s, dev, ntasks);
-      else if (R == 2 && U == 1) launch_b_gemv<2, 1>(aligned, grid, s, dev, ntasks);
-      else launch_b_gemv<2, 2>(aligned, grid, s, dev, ntasks);
       return CCQP_OK;
     }
     default:

@@ -213,17 +213,16 @@ __device__ __forceinline__ ccqp_d2 ccqp_ld2(const double* p) {
   }
 }
 
-// One wave64 per task of R consecutive rows; wave `wave` of `nwaves` grid-strides over the tasks.
+// One wave64 computes one TASK = R consecutive rows.
 // Lane l accumulates columns {128k+2l, 128k+2l+1} in increasing k into one accumulator per row.
 template <int R, int U, bool ALIGNED, bool NT>
-__device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
+__device__ __forceinline__ void gemv_task(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
                                           const double* __restrict__ b, double* __restrict__ y,
-                                          double* __restrict__ g, int64_t rows, int64_t cols, int64_t ntasks,
-                                          int64_t wave, int64_t nwaves) {
+                                          double* __restrict__ g, int64_t rows, int64_t cols, int64_t task) {
   const int lane = threadIdx.x & 63;
   constexpr int64_t SPAN = 128 * U;
   const int64_t nfull = cols / SPAN;
-  for (int64_t task = wave; task < ntasks; task += nwaves) {
+  {
     const int64_t r0 = task * R;
     const double* rp[R];
 #pragma unroll
@@ -281,6 +280,16 @@ __device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t 
       }
     }
   }
+}
+
+// wave `wave` of `nwaves` grid-strides over the tasks of ONE matrix
+template <int R, int U, bool ALIGNED, bool NT>
+__device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
+                                          const double* __restrict__ b, double* __restrict__ y,
+                                          double* __restrict__ g, int64_t rows, int64_t cols, int64_t ntasks,
+                                          int64_t wave, int64_t nwaves) {
+  for (int64_t task = wave; task < ntasks; task += nwaves)
+    gemv_task<R, U, ALIGNED, NT>(A, lda, x, b, y, g, rows, cols, task);
 }
 #endif  // __HIPCC__
 

@@ -61,8 +61,8 @@ static int launch_r(int U, bool aligned, bool nt, hipStream_t s, int grid, const
 // the non-temporal A loads, bits 12-19 workgroups per CU (0 = default).  0 = tuned default
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
 // yields the same bits, so this is speed only.
-static int gemv_dispatch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
-                         double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s) {
+int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
+                     double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s) {
   int R = variant & 0xF, U = (variant >> 4) & 0xF;
   const bool nt = !((variant >> 8) & 1);
   int bpc = (variant >> 12) & 0xFF;
@@ -105,7 +105,7 @@ extern "C" int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const 
   int rc = gemv_check(ctx, A, lda, x, y, rows, cols);
   if (rc) return rc;
   if (rows == 0) return CCQP_OK;
-  rc = gemv_dispatch(ctx, A, lda, x, nullptr, y, nullptr, rows, cols, variant, (hipStream_t)stream);
+  rc = ccqp_gemv_launch(ctx, A, lda, x, nullptr, y, nullptr, rows, cols, variant, (hipStream_t)stream);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -119,7 +119,7 @@ extern "C" int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t ld
   CCQP_REQUIRE(g == nullptr || b != nullptr, "g requested but b is NULL");
   CCQP_REQUIRE(g == nullptr || g != x, "g must not alias x");
   if (rows == 0) return CCQP_OK;
-  rc = gemv_dispatch(ctx, A, lda, x, b, y, g, rows, cols, variant, (hipStream_t)stream);
+  rc = ccqp_gemv_launch(ctx, A, lda, x, b, y, g, rows, cols, variant, (hipStream_t)stream);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
