@@ -339,6 +339,35 @@ def solver_cases():
             cases.append(dict(id="exit.%s.max%d" % (s, mx), problem="gen:64:1234", solver=s, tol=1e-12,
                               max_mv=mx, kwargs={"step_size": 0.3} if s == "PGD" else {},
                               op=_box_half(64), rng_seed=1234))
+    # solver x operator matrix at n = 256 (every pair the fixtures above do not already hold)
+    n = 256
+    mixed = {"kind": "Disjoint", "ops": [
+        {"kind": "Box", "dim": 100, "lb": {"fill": -0.5}, "ub": {"fill": 0.5}},
+        {"kind": "Sphere", "dim": 56, "radius": 1.5},
+        {"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 3}, "count": 20}},
+        {"kind": "Lower", "dim": 20, "lb": {"fill": -0.25}}, {"kind": "Identity", "dim": 20}]}
+    opsx = {"lower": {"kind": "Lower", "dim": n, "lb": {"fill": -0.25}},
+            "upper": {"kind": "Upper", "dim": n, "ub": {"fill": 0.25}},
+            "sphere": {"kind": "Sphere", "dim": n, "radius": 4.0},
+            "cone": {"kind": "Cone", "dim": n},
+            "mixed": mixed}
+    for s in SOLVER_NAMES:
+        for oname, op in opsx.items():
+            mx = 40 if oname == "cone" else 3000
+            cases.append(dict(id="matrix256.%s.%s" % (s, oname), problem="gen:256:1234", solver=s,
+                              tol=1e-6 if s == "MPRGP" else 1e-8, max_mv=mx,
+                              kwargs={"step_size": 0.3} if s == "PGD" else {}, op=op, rng_seed=1234))
+    # non-default SPG parameters (m, tau, sigma1, sigma2), PGD's default step, NaN path of APGD (x0 == ones
+    # makes the Lipschitz estimate 0/0, solvers.py:263-268)
+    cases.append(dict(id="params.SPG.a", problem="gen:256:1234", solver="SPG", tol=1e-8, max_mv=5000,
+                      kwargs={"m": 3, "tau": 0.3, "sigma1": 0.05, "sigma2": 0.8}, op=_box_half(256), rng_seed=7))
+    cases.append(dict(id="params.SPG.b", problem="gen:256:1234", solver="SPG", tol=1e-8, max_mv=5000,
+                      kwargs={"m": 1, "tau": 0.9, "sigma1": 0.2, "sigma2": 0.25}, op=_box_half(256), rng_seed=8))
+    cases.append(dict(id="params.PGD.default_step", problem="gen:64:1234", solver="PGD", tol=1e-6, max_mv=5000,
+                      kwargs={}, op=_box_half(64), rng_seed=1234))
+    for s in ("APGD", "APGDAntiRelaxation"):
+        cases.append(dict(id="nan.%s.x0_ones" % s, problem="gen:64:1234", solver=s, tol=1e-8, max_mv=14, kwargs={},
+                          op=_box_half(64), rng_seed=1234, x0="ones"))
     # warm start + default (infinite) MV budget
     cases.append(dict(id="warm.BBPGD", problem="gen:256:7", solver="BBPGD", tol=1e-9, max_mv=None, kwargs={},
                       op=_box_half(256), rng_seed=1234, x0="ramp"))
@@ -352,4 +381,6 @@ def solver_cases():
 def case_x0(case, n):
     if case.get("x0") == "ramp":
         return np.linspace(-0.75, 0.75, n)
+    if case.get("x0") == "ones":
+        return np.ones(n)
     return None

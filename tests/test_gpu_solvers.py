@@ -86,8 +86,11 @@ def test_solver_golden(case):
         rtol = max(RTOL, 8 * case["x_spread"])
     assert bool(s.solution_converged) == case["converged"]
     assert isinstance(s.solution, np.ndarray) and s.solution.shape == want.shape
-    scale = max(np.linalg.norm(want), 1e-300)
-    assert np.linalg.norm(s.solution - want) <= rtol * scale + 1e-14
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(s.solution), nan)            # NaN paths (x0 == ones in APGD) reproduced
+    assert np.isnan(case["res"]) == bool(np.isnan(s.solution_residual))
+    scale = max(np.linalg.norm(want[~nan]), 1e-300)
+    assert np.linalg.norm((s.solution - want)[~nan]) <= rtol * scale + 1e-14
     if case["res"] == 0.0:
         assert float(s.solution_residual) == 0.0
     elif case["converged"]:
