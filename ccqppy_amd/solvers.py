@@ -434,6 +434,10 @@ class CCQPSolverSPG(CCQPSolverBase):
         self.t = tau
         self.sigma1 = sigma1
         self.sigma2 = sigma2
+        # extension (default = reference behaviour): set `solver.rng = np.random.RandomState(seed)` to
+        # draw from a private stream instead of numpy's global one -- needed for reproducible results
+        # when several SPG solves are interleaved by ccqppy_amd.batch
+        self.rng = None
 
     @property
     def name(self):
@@ -468,7 +472,7 @@ class CCQPSolverSPG(CCQPSolverBase):
             xi = (fmax - fk) / dkdotAdk
             beta = -dkdotgk / dkdotAdk
             betahat = tau * beta + np.sqrt((tau ** 2) * (beta ** 2) + 2 * xi)
-            betak = np.random.uniform(low=sig1, high=min(betahat, sig2))
+            betak = (self.rng or np.random).uniform(low=sig1, high=min(betahat, sig2))
             eng.axpby(1.0, xk, betak, dk, xk)           # xk += betak*dk
             eng.axpby(1.0, gk, betak, Adk, gk)          # gk += betak*Adk
             fk += betak * betak * dkdotgk + 0.5 * (betak ** 2) * dkdotAdk   # sic, :963

@@ -147,3 +147,51 @@ def test_fused_batch_with_non_elementwise_sets_falls_back_in_order():
         for g, s in zip(got, seq):
             assert g.solution_num_matrix_vector_multiplications == s.solution_num_matrix_vector_multiplications
             assert np.array_equal(g.solution.cpu().numpy().view(np.uint64), s.solution.cpu().numpy().view(np.uint64))
+
+
+def test_spg_with_private_rng_is_reproducible_under_interleaving():
+    """SPG draws one uniform per iteration from numpy's GLOBAL stream (solvers.py:959), so interleaved
+    solves would consume it in scheduling order.  With the `rng` extension every solve owns its stream
+    and the batch result equals the sequential one bit for bit."""
+    from ccqppy_amd import solvers
+    from ccqppy_amd.batch import solve_batch, solve_batch_fused
+    probs = _problems(1024, 6)
+
+    def make(i=[0]):
+        s = solvers.CCQPSolverSPG(1e-8, 5000)
+        s.rng = np.random.RandomState(100 + i[0] % 6)
+        i[0] += 1
+        return s
+    seq = []
+    for A, b, x0, P in probs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            seq.append(make().solve(A, b, x0, P))
+    for runner in (lambda: solve_batch(make, probs, lanes=3), lambda: solve_batch_fused(make, probs, lanes=6, groups=2)):
+        got = runner()
+        for g, s in zip(got, seq):
+            assert g.solution_num_matrix_vector_multiplications == s.solution_num_matrix_vector_multiplications
+            assert np.array_equal(g.solution.cpu().numpy().view(np.uint64), s.solution.cpu().numpy().view(np.uint64))
+
+
+def test_gemv_bandwidth_floor():
+    """Regression guard for the dominant kernel: n = 32768 (8 GiB) must stream at >= 5.0 TB/s
+    (measured 6.7-7.0 TB/s on MI355X; 8 TB/s peak)."""
+    import torch
+    from ccqppy_amd import problems
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    n = 32768
+    A = problems.spd_rows(n, 1)
+    x = problems.xstar(n, 1)
+    y = eng.empty(n)
+    for _ in range(3):
+        eng.gemv(A, x, y)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        eng.gemv(A, x, y)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 20
+    tbs = 8.0 * (n * n + 2 * n) / ms / 1e9
+    assert tbs >= 5.0, "GEMV at %.2f TB/s" % tbs
