@@ -241,12 +241,20 @@ class _APGDCore(CCQPSolverBase):
     """APGD (solvers.py:197-367) and its anti-relaxation variant (:370-557)."""
     _anti_relaxation = False
 
-    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf):
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, reuse_matvec=False):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        # Extension, OFF by default (SURVEY.md 8(f)3): y_{k+1} = (1+beta) x_{k+1} - beta x_k is linear, so
+        # A.y_{k+1} = (1+beta) A.x_{k+1} - beta A.x_k needs no matvec.  Saves one of the two matvecs per
+        # iteration (half the HBM traffic of a solve) but changes the reported MV count and rounds A.y
+        # differently from a direct product: an opt-in, NON-parity mode.
+        self.reuse_matvec = reuse_matvec
 
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, b, AR = run.eng, run.b, self._anti_relaxation
+        reuse = self.reuse_matvec
+        Ay_next = None                                  # A.yk obtained without a matvec (reuse mode)
+        Axk = None                                      # A.xk
         mv_count = 0
         xk = run.copy(run.x0)
         yk = run.copy(run.x0)
@@ -265,10 +273,16 @@ class _APGDCore(CCQPSolverBase):
         xkp1 = None
         res = None
         while True:
-            Ayk, gk = run.mv(yk, True)
-            mv_count += 1
-            if mv_count >= max_mv:
-                break
+            if reuse and Ay_next is not None:
+                Ayk = Ay_next
+                gk = run.lin(1.0, Ayk, 1.0, b)
+            else:
+                Ayk, gk = run.mv(yk, True)
+                mv_count += 1
+                if mv_count >= max_mv:
+                    break
+                if reuse:
+                    Axk = Ayk                           # first iteration: xk == yk == x0
             xkp1 = run.step_project(yk, t, gk)
             first = True
             while True:
@@ -311,6 +325,8 @@ class _APGDCore(CCQPSolverBase):
             thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
             beta = thk * (1 - thk) / (thk * thk + thk1)
             ykp1 = run.lin(1 + beta, xkp1, -beta, xk)   # (1+beta)*xkp1 - beta*xk
+            if reuse:
+                Ay_next = run.lin(1 + beta, Ax1, -beta, Axk)
             res = np.sqrt(res2[1])
             if AR and res < resmin:                     # :501-503
                 resmin = res
@@ -320,10 +336,13 @@ class _APGDCore(CCQPSolverBase):
             if AR and res2[0] > 0:                      # gk.dot(xkp1 - xk) > 0, :510-512
                 ykp1 = run.copy(xkp1)
                 thk1 = 1
+                if reuse:
+                    Ay_next = Ax1
             L *= 0.9
             t = 1.0 / L
             yk, ykp1 = ykp1, yk
             xk, xkp1 = xkp1, xk                         # `xkp1` now names the OLDER iterate
+            Axk = Ax1
             thk = thk1
         if res is None:
             raise UnboundLocalError("local variable 'xkp1' referenced before assignment")

@@ -266,3 +266,23 @@ def test_config2_full_size_against_oracle(sname, tol, max_mv, opname):
     assert np.linalg.norm(r.solution - o.solution) <= RTOL * np.linalg.norm(o.solution)
     del op, A_host
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("cls_name", ["APGD", "APGDAntiRelaxation"])
+def test_apgd_reuse_matvec_opt_in(cls_name):
+    """8(f)3 extension, OFF by default: A.y_{k+1} = (1+beta) A.x_{k+1} - beta A.x_k.  Non-parity mode:
+    about half the matvecs, the same minimiser to ~1e-9 (the residual tolerance), default untouched."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    n = 4096
+    op, b, _ = problems.random_problem(n, 1234)
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    cls = _solver_cls(cls_name)
+    assert cls(1e-8).reuse_matvec is False
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = cls(1e-8, 5000).solve(op, b, convex_proj_op=P)
+        fast = cls(1e-8, 5000, reuse_matvec=True).solve(op, b, convex_proj_op=P)
+    assert base.solution_converged and fast.solution_converged
+    assert fast.executed_matrix_vector_multiplications <= 0.62 * base.executed_matrix_vector_multiplications
+    xb, xf = base.solution.cpu().numpy(), fast.solution.cpu().numpy()
+    assert np.linalg.norm(xb - xf) <= 1e-7 * np.linalg.norm(xb)
+    assert float(fast.solution_residual) < 1e-8
