@@ -210,6 +210,15 @@ int ccqp_projected_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, 
                                             const double* g, const double* nv, double* free_g,
                                             double* chopped_g, void* stream);
 
+/* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
+ * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
+ * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from
+ * ccqp_gemv_f64 (the reference's `A.dot(v)` never assumes symmetry).  n % 128 == 0; `workspace` =
+ * ccqp_symv_workspace_doubles(n) doubles of device memory owned by the caller (n^2/32 + n*ceil(n/8192)). */
+int64_t ccqp_symv_workspace_doubles(int64_t n);
+int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
+                        double* y, double* g, int64_t n, double* workspace, void* stream);
+
 /* ---- batched launch form (batch-sharded mode, BASELINE config 5) --------------------------------
  * One descriptor per (problem, operation); a GROUP = `count` descriptors of the same opcode and shape,
  * executed by ONE launch (blockIdx.y/z = problem) with the bodies of the single-problem kernels, so the
