@@ -25,6 +25,7 @@ typedef double symv_d2 __attribute__((ext_vector_type(2)));
 
 // grid (ceil(nb/4), nseg): wave (I, s) handles block-row I over the absolute columns of segment s that lie
 // right of the block-row's first chunk; (I, s) pairs left of the diagonal exit at once.
+// (forcing 3 waves/SIMD with __launch_bounds__(256, 3) spills 230 VGPRs and runs 3x slower: measured)
 __global__ __launch_bounds__(CCQP_BLOCK) void symv_upper_kernel(const double* __restrict__ A, int64_t lda,
                                                                 const double* __restrict__ x,
                                                                 double* __restrict__ yrow,   // [nseg][n]
