@@ -5,8 +5,8 @@ same class names, constructor arguments, attributes (`dim`, `lower_bound`, `uppe
 `radius`, `aspect_ratio`, `proj_ops`), `name` strings, `embedded_dimension`, `__call__` and
 `normal_vector`.  `op(x)` accepts a numpy array (copied to the GPU and back) or a torch tensor
 on a ROCm device (zero copy) and returns the same kind; every FLOP runs in libccqp_hip.so.
-There is no CPU fallback.  `plot` (matplotlib) is out of scope; `projected_gradient` (dead code in the
-reference) is provided for API completeness.
+There is no CPU fallback.  `projected_gradient` (dead code in the reference) and the
+host-side `plot` helper are provided for API completeness.
 
 Device protocol used by `ccqppy_amd.solvers` (all arguments are fp64 device tensors):
   _dev_project(eng, x, out)                  out = P(x)            (x is not out)
@@ -76,6 +76,19 @@ class ProjOpBase(ABC):
         out = eng.empty(n)
         self._dev_normal_vector(eng, xd, out)
         return self._stage_out(x, out)
+
+    def plot(self, num_random_samples, lower_bound, upper_bound):
+        """Scatter-plot the projections of random samples of the box [lower_bound, upper_bound] (1-3 D).
+        Host-side visualisation only (solution_spaces.py:48-74); matplotlib is imported on demand."""
+        import matplotlib.pyplot as plt
+        dim = self.embedded_dimension
+        fig = plt.figure()
+        ax = fig.add_subplot(projection='3d')
+        for _ in range(num_random_samples):
+            sample = np.random.rand(dim) * (upper_bound - lower_bound) + lower_bound
+            p = np.asarray(self.__call__(sample))
+            ax.scatter(p[0], p[1] if dim > 1 else 0.0, p[2] if dim > 2 else 0.0)
+        plt.show()
 
     def _stage_in(self, x):
         if isinstance(x, torch.Tensor):
