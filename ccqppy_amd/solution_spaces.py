@@ -163,6 +163,18 @@ class _ElementwiseOp(ProjOpBase):
 
     def _seg(self, eng, offset, n):
         lb, ub = self._bounds()
+        segs = self.__dict__.setdefault("_seg_cache", {})
+        skey = (eng.index, offset, n, id(lb), id(ub))
+        hit = segs.get(skey)
+        if hit is not None:
+            return hit                      # descriptors are read-only: built once per (device, block)
+        seg = self._build_seg(eng, offset, n, lb, ub)
+        if len(segs) > 256:
+            segs.clear()
+        segs[skey] = seg
+        return seg
+
+    def _build_seg(self, eng, offset, n, lb, ub):
         cache = self.__dict__.setdefault("_dev_bounds", {})
         key = (eng.index, id(lb), id(ub))
         ent = cache.get(key)
