@@ -93,6 +93,7 @@ SIGNATURES = {
     "ccqp_free_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
     "ccqp_cg_direction_f64": [_P, _P, _P, _D, _P, _P, _I64, _P],
     "ccqp_projected_gradient_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _P, _P],
+    "ccqp_batch_serialize_matvecs": [_P, _I],
     "ccqp_ctx_workspace": [_P, _c.POINTER(_P), _c.POINTER(_P)],
     "ccqp_batch_run_f64": [_P, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(Bop), _P],
     "ccqp_scalars_gather_async": [_P, _I, _c.POINTER(_P), _c.POINTER(_I), _c.POINTER(_I), _P],

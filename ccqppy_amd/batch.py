@@ -148,7 +148,8 @@ def _flush_group(lanes, grp_eng, ops_buf, codes_buf, counts_buf):
     return nops, ngroups
 
 
-def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, quiet=True, stats=None):
+def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, quiet=True, stats=None,
+                      serialize_matvecs=True):
     """Like solve_batch, but the in-flight solves are executed in lock-step ROUNDS: each solve is advanced
     (on the host only) to its next scalar read while its operations are recorded; the recorded
     operations of all solves of a lane group are merged into batched launches (ccqp_batch_run_f64), the
@@ -167,6 +168,9 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
     torch.cuda.synchronize(base.device)
     streams = [torch.cuda.Stream(device=base.index) for _ in range(groups)]
     grp_engs = [Engine(base.index, s) for s in streams]
+    if groups > 1 and serialize_matvecs:
+        for ge in grp_engs:
+            _lib.check(ge.lib.ccqp_batch_serialize_matvecs(ge.ctx, 1))
     lane_objs = [_Lane(RecordingEngine(base.index, streams[i % groups])) for i in range(nl)]
     grp_lanes = [[ln for i, ln in enumerate(lane_objs) if i % groups == g] for g in range(groups)]
     cap = 4096

@@ -213,6 +213,21 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
       return CCQP_OK;
     }
     case CCQP_BOP_GEMV: {
+      // All matvec groups of the process go through ONE dedicated stream (event-chained to the
+      // caller's stream): matvecs of different lane groups then run one after the other at full
+      // bandwidth instead of overlapping and splitting it, while the small kernels of the other
+      // groups still overlap with them.
+      static hipStream_t mv_stream = nullptr;
+      if (ctx->mv_serialize) {
+        if (!mv_stream) CCQP_HIP(hipStreamCreateWithFlags(&mv_stream, hipStreamNonBlocking));
+        if (!ctx->mv_ev_in) {
+          CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_in, hipEventDisableTiming));
+          CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_out, hipEventDisableTiming));
+        }
+        CCQP_HIP(hipEventRecord(ctx->mv_ev_in, s));
+        CCQP_HIP(hipStreamWaitEvent(mv_stream, ctx->mv_ev_in, 0));
+      }
+      hipStream_t ms = ctx->mv_serialize ? mv_stream : s;
       for (int i = 0; i < count; ++i) {
         const ccqp_bop& o = host[i];
         CCQP_REQUIRE(o.n >= 0 && o.n2 >= 0 && o.lda >= o.n2, "batched matvec: bad shape");
@@ -220,8 +235,12 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
         CCQP_REQUIRE(o.p[0] && o.p[3] && (o.n2 == 0 || o.p[1]), "batched matvec: NULL operand");
         CCQP_REQUIRE(o.p[4] == nullptr || o.p[2] != nullptr, "batched matvec: g requested but b is NULL");
         int rc = ccqp_gemv_launch(ctx, o.p[0], o.lda, o.p[1], o.p[2], const_cast<double*>(o.p[3]),
-                                  const_cast<double*>(o.p[4]), o.n, o.n2, 0, s);
+                                  const_cast<double*>(o.p[4]), o.n, o.n2, 0, ms);
         if (rc) return rc;
+      }
+      if (ctx->mv_serialize) {
+        CCQP_HIP(hipEventRecord(ctx->mv_ev_out, mv_stream));
+        CCQP_HIP(hipStreamWaitEvent(s, ctx->mv_ev_out, 0));
       }
       return CCQP_OK;
     }
@@ -262,6 +281,12 @@ extern "C" int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes
     at += counts[gidx];
   }
   CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_batch_serialize_matvecs(ccqp_ctx* ctx, int on) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  ctx->mv_serialize = on ? 1 : 0;
   return CCQP_OK;
 }
 

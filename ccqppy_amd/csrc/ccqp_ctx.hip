@@ -37,6 +37,9 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->host_slots = nullptr;
   c->read_event = nullptr;
   c->batch = nullptr;
+  c->mv_serialize = 0;
+  c->mv_ev_in = nullptr;
+  c->mv_ev_out = nullptr;
   c->gather_dev = nullptr;
   c->gather_host = nullptr;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
@@ -66,6 +69,8 @@ extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
   (void)hipHostFree(c->host_slots);
   (void)hipEventDestroy(c->read_event);
   ccqp_batch_free(c);
+  if (c->mv_ev_in) (void)hipEventDestroy(c->mv_ev_in);
+  if (c->mv_ev_out) (void)hipEventDestroy(c->mv_ev_out);
   if (c->gather_dev) (void)hipFree(c->gather_dev);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   delete c;

@@ -16,6 +16,8 @@ void ccqp_batch_free(struct ccqp_ctx* ctx);
 
 struct ccqp_ctx {
   ccqp_batch* batch;
+  int mv_serialize;     // batched matvec groups go through the process-wide matvec stream
+  hipEvent_t mv_ev_in, mv_ev_out;
   double* gather_dev;   // staging of ccqp_scalars_gather_async (device / pinned host)
   double* gather_host;
   int device;

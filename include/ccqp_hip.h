@@ -249,6 +249,10 @@ typedef struct ccqp_bop {
   int32_t reserved;
   ccqp_seg seg;
 } ccqp_bop;
+/* on != 0: the matvec groups of ccqp_batch_run_f64 calls made with this context are issued on one
+ * process-wide stream, event-chained to the caller's stream, so that matvecs of different lane groups
+ * never overlap each other (they would only split the HBM bandwidth). */
+int ccqp_batch_serialize_matvecs(ccqp_ctx* ctx, int on);
 /* Device addresses of a context's scalar slab and reduction workspace (to fill ccqp_bop). */
 int ccqp_ctx_workspace(ccqp_ctx* ctx, double** slab, double** partials);
 /* Upload all descriptors once, then launch group after group on `stream`:
