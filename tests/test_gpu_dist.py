@@ -80,3 +80,48 @@ def test_row_sharded_equals_single_gpu_bitwise(n, mode):
                 assert resid == res1
             else:   # all-reduce adds +0.0 to every entry: only the sign of an exact zero may differ
                 assert np.array_equal(x, x1), (name, rank)
+
+
+def _rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from ccqppy_amd import problems, solvers, solution_spaces as ss
+        from ccqppy_amd.operators import VectorExchange
+        n = 4096
+        op, b, _ = problems.random_problem(n, 1234, device=0, group=dist.group.WORLD, mode="allgather")
+        ex = VectorExchange(n, dist.group.WORLD, "allgather")
+        assert not ex.stage_cpu
+        y = torch.arange(n, dtype=torch.float64, device="cuda") * 0.37
+        want = y.clone()
+        # the RCCL calls of the N>1 path, issued on torch's current stream right behind a HIP kernel of ours
+        op.engine.bind()
+        op.engine.scale(1.0, want, y)
+        ex._gather_into(y, y[ex.row0:ex.row0 + ex.rows])
+        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(y, want))
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = solvers.CCQPSolverAPGD(1e-8, 5000).solve(op, b, convex_proj_op=ss.BoxProjOp(n, -0.5, 0.5))
+        q.put((same, bool(r.solution_converged), int(r.solution_num_matrix_vector_multiplications)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_collectives():
+    """RCCL itself (backend "nccl") on the box's one GPU: process-group creation on the device, the
+    all_gather_into_tensor / all_reduce calls of the vector exchange ordered behind our own kernels on
+    the same stream, and a solve through a group-bound operator."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    same, conv, mv = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert same and conv and mv > 0
