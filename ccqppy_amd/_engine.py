@@ -162,6 +162,33 @@ class Engine:
             ev[1].record(self.torch_stream)
             self.gemv_events.append(ev)
 
+    def spmv_csr(self, rowptr, col, val, cols, x, y, b=None, g=None, width=0):
+        """y = A.x for a CSR matrix (rowptr int64[rows+1], col int32[nnz], val float64[nnz]); g = y + b."""
+        rows = rowptr.numel() - 1
+        assert x.numel() >= cols and y.numel() >= rows
+        self.mv_executed += 1
+        ev = None
+        if self.gemv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.torch_stream)
+        rc = self.lib.ccqp_spmv_csr_f64(self.ctx, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), x.data_ptr(),
+                                        None if g is None else b.data_ptr(), y.data_ptr(),
+                                        None if g is None else g.data_ptr(), rows, cols, val.numel(), width,
+                                        self.stream)
+        if rc:
+            _lib.check(rc)
+        if ev is not None:
+            ev[1].record(self.torch_stream)
+            self.gemv_events.append(ev)
+
+    def csr_violations(self, rowptr, col, cols):
+        """Number of violated CSR invariants (blocking read of one scalar)."""
+        rc = self.lib.ccqp_csr_validate(self.ctx, rowptr.data_ptr(), col.data_ptr(), rowptr.numel() - 1, cols,
+                                        col.numel(), 0, self.stream)
+        if rc:
+            _lib.check(rc)
+        return int(self.read(0, 1)[0])
+
     # ------------------------------------------------------------------ a2 elementwise
     def axpby(self, a, x, b, y, out):
         rc = self.lib.ccqp_axpby_f64(self.ctx, a, x.data_ptr(), b, y.data_ptr(), out.data_ptr(), out.numel(),

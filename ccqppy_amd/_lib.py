@@ -100,6 +100,8 @@ SIGNATURES = {
     "ccqp_scalars_gather_host": [_P, _I, _c.POINTER(_D)],
     "ccqp_symv_workspace_doubles": [_I64],
     "ccqp_symv_upper_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
+    "ccqp_spmv_csr_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P],
+    "ccqp_csr_validate": [_P, _P, _P, _I64, _I64, _I64, _I, _P],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
     "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
 }

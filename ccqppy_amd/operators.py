@@ -2,6 +2,7 @@
 
 The reference only ever calls `A.dot(v)` (solvers.py:25,133,...).  Here that call is one of
   * DenseOperator        -- the whole matrix on one GPU, `ccqp_gemv_f64`;
+  * SparseOperator       -- a CSR matrix on one GPU (scipy.sparse / torch sparse input), `ccqp_spmv_csr_f64`;
   * RowShardedOperator   -- one process per GPU (torch.distributed, backend "nccl" = RCCL over
                             xGMI): rank r owns the contiguous row block [r*n/G, (r+1)*n/G), all
                             n-vectors are replicated, every rank runs the same host loop.  One
@@ -111,11 +112,105 @@ class VectorExchange:
         y.copy_(full[:self.n])
 
 
+def _is_sparse_input(A):
+    """scipy.sparse matrix/array or torch sparse tensor (the reference accepts anything with `.dot`)."""
+    if isinstance(A, torch.Tensor):
+        return A.layout != torch.strided
+    return hasattr(A, "tocsr") and hasattr(A, "nnz")
+
+
+class SparseOperator:
+    """`A.dot(v)` for a SPARSE matrix held in HBM as CSR (int64 row pointers, int32 columns, fp64
+    values): one `ccqp_spmv_csr_f64` launch per matvec, 12 B per stored entry.  Accepts a
+    scipy.sparse matrix (any format), a torch sparse tensor (CSR or COO), or the CSR triple
+    `(rowptr, col, val)` with `shape=`.  Stored entries are kept exactly as given (explicit zeros and
+    the storage order within a row included); the bits of A.x depend on them and on x only
+    (include/ccqp_hip.h), so row-sharded and single-GPU runs agree bitwise.
+    `check=True` validates the index arrays on the device once (the matvec does not bounds-check)."""
+
+    def __init__(self, A, shape=None, engine=None, check=True, width=0):
+        if isinstance(A, torch.Tensor) and A.is_cuda:
+            self.engine = engine or get_engine(A.device)
+        elif isinstance(A, (tuple, list)) and isinstance(A[2], torch.Tensor) and A[2].is_cuda:
+            self.engine = engine or get_engine(A[2].device)
+        else:
+            self.engine = engine or get_engine()
+        dev = self.engine.device
+        if isinstance(A, (tuple, list)):
+            if shape is None:
+                raise ValueError("SparseOperator: shape=(rows, cols) is required with a (rowptr, col, val) triple")
+            rowptr, col, val = A
+        elif isinstance(A, torch.Tensor):
+            if A.layout == torch.sparse_coo:
+                A = A.coalesce().to_sparse_csr()
+            if A.layout != torch.sparse_csr:
+                A = A.to_sparse_csr()
+            shape = tuple(A.shape)
+            rowptr, col, val = A.crow_indices(), A.col_indices(), A.values()
+        else:
+            A = A.tocsr()
+            shape = tuple(A.shape)
+            rowptr, col, val = A.indptr, A.indices, A.data
+        self.rows, self.n = int(shape[0]), int(shape[1])
+        if self.n > 2 ** 31 - 1:
+            raise ValueError("SparseOperator: more than 2^31-1 columns")
+
+        def dev_tensor(a, dtype):
+            if not isinstance(a, torch.Tensor):
+                import numpy as np
+                a = torch.from_numpy(np.ascontiguousarray(a))
+            return a.to(device=dev, dtype=dtype).contiguous()
+
+        self.rowptr = dev_tensor(rowptr, torch.int64)
+        self.col = dev_tensor(col, torch.int32)
+        self.val = dev_tensor(val, torch.float64)
+        if self.rowptr.numel() != self.rows + 1 or self.col.numel() != self.val.numel():
+            raise ValueError("SparseOperator: inconsistent CSR array lengths")
+        self.nnz = self.val.numel()
+        self.width = width
+        self.A = self                      # what `op.A` means for a dense operator: the stored matrix
+        if check:
+            self.engine.bind()
+            bad = self.engine.csr_violations(self.rowptr, self.col, self.n)
+            if bad:
+                raise ValueError("SparseOperator: %d violated CSR invariants (row pointers not monotone / "
+                                 "not ending at nnz, or column index outside [0, %d))" % (bad, self.n))
+
+    @property
+    def shape(self):
+        return (self.rows, self.n)
+
+    def row_block(self, row0, rows):
+        """Rows [row0, row0+rows) as a SparseOperator of their own (device-side slicing, no copy of the
+        entries: `col` / `val` are views, only the row pointers are rebased)."""
+        lo = int(self.rowptr[row0].item())
+        hi = int(self.rowptr[row0 + rows].item())
+        rp = (self.rowptr[row0:row0 + rows + 1] - lo).contiguous()
+        return SparseOperator((rp, self.col[lo:hi], self.val[lo:hi]), shape=(rows, self.n), engine=self.engine,
+                              check=False, width=self.width)
+
+    def apply(self, eng, x, y, b=None, g=None):
+        eng.spmv_csr(self.rowptr, self.col, self.val, self.n, x, y, b, g, self.width)
+
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        self.apply(engine or self.engine, x, y, b, g)
+
+    def dot(self, x):
+        """numpy-style convenience: A.x as a new device vector."""
+        eng = self.engine
+        eng.bind()
+        y = torch.empty(self.rows, dtype=torch.float64, device=eng.device)
+        self.apply(eng, eng.to_device(x), y)
+        return y
+
+
 class RowShardedOperator:
-    """A row block of A per rank + one vector exchange per matvec."""
+    """A row block of A per rank + one vector exchange per matvec.  The local block is a dense
+    (rows, n) device matrix or a SparseOperator holding the same rows in CSR."""
 
     def __init__(self, A_local, n, group=None, mode="allgather", engine=None):
-        self.engine = engine or get_engine(A_local.device)
+        self.sparse = isinstance(A_local, SparseOperator)
+        self.engine = engine or (A_local.engine if self.sparse else get_engine(A_local.device))
         self.A = A_local
         self.n = n
         self.exchange = VectorExchange(n, group, mode)
@@ -125,7 +220,10 @@ class RowShardedOperator:
     def matvec(self, x, y, b=None, g=None, engine=None):
         eng = engine or self.engine
         sl = slice(self.row0, self.row0 + self.rows)
-        eng.gemv(self.A, x, y[sl])
+        if self.sparse:
+            self.A.apply(eng, x, y[sl])
+        else:
+            eng.gemv(self.A, x, y[sl])
         self.exchange(y)
         if g is not None:
             eng.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
@@ -134,6 +232,8 @@ class RowShardedOperator:
 def as_operator(A, engine=None):
     if hasattr(A, "matvec") and hasattr(A, "engine"):
         return A
+    if _is_sparse_input(A):
+        return SparseOperator(A, engine=engine)
     return DenseOperator(A, engine)
 
 

@@ -50,3 +50,90 @@ def random_problem(n, seed, device=None, group=None, mode="allgather"):
     b = eng.empty(n)
     eng.scale(-1.0, Ax, b)
     return op, b, xs
+
+
+# ------------------------------------------------------------------ sparse problems
+_M64 = (1 << 64) - 1
+_GOLDEN, _M1, _M2 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+_OFF_STREAM = 0xA0761D6478BD642F
+
+
+def _mix_int(z):
+    """SplitMix64 output step on a Python int (host side: keys and the few pattern offsets)."""
+    z = (z + _GOLDEN) & _M64
+    z = ((z ^ (z >> 30)) * _M1) & _M64
+    z = ((z ^ (z >> 27)) * _M2) & _M64
+    return z ^ (z >> 31)
+
+
+def _signed(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _mix_tensor(z):
+    """The same step on an int64 tensor (wrapping arithmetic; logical shifts by masking)."""
+    z = z + _signed(_GOLDEN)
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * _signed(_M1)
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * _signed(_M2)
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def sparse_offsets(n, k, seed):
+    """The k/2 distinct positive offsets d_t in [1, n/2 - 1] of the circulant sparsity pattern."""
+    m, span = k // 2, n // 2 - 1
+    if k % 2 or m < 1 or m > span:
+        raise ValueError("sparse pattern needs an even k with 2 <= k <= 2*(n/2 - 1)")
+    key = _mix_int((seed & _M64) ^ _OFF_STREAM)
+    used, out = set(), []
+    for t in range(m):
+        d = 1 + _mix_int((key + t) & _M64) % span
+        while d in used:
+            d = d % span + 1
+        used.add(d)
+        out.append(d)
+    return out
+
+
+def sparse_spd_csr(n, k, seed, row0=0, rows=None, device=None):
+    """Rows [row0, row0+rows) of the sparse SPD test matrix as device CSR arrays (rowptr int64, col int32,
+    val float64): the entries of the dense generator matrix on k hashed symmetric off-diagonals
+    (columns (i +- d_t) mod n), rescaled to (2u - 1)/k, diagonal 2 => spectrum inside [1, 3] (Gershgorin).
+    Columns are sorted within a row; every row holds k + 1 entries."""
+    rows = n - row0 if rows is None else rows
+    dev = torch.device("cpu") if device == "cpu" else get_engine(device).device
+    offs = sparse_offsets(n, k, seed)
+    delta = torch.tensor(sorted([-d for d in offs] + [0] + offs), dtype=torch.int64, device=dev)
+    i = torch.arange(row0, row0 + rows, dtype=torch.int64, device=dev)[:, None]
+    cols = torch.sort(torch.remainder(i + delta[None, :], n), dim=1).values
+    kk = torch.minimum(i, cols) * n + torch.maximum(i, cols)
+    h = _mix_tensor(kk + _signed(_mix_int(seed & _M64)))
+    u = ((h >> 11) & ((1 << 53) - 1)).to(torch.float64) * (2.0 ** -53)
+    # divide by a TENSOR: torch's GPU division by a Python scalar multiplies by the rounded reciprocal
+    vals = (2.0 * u - 1.0) / torch.full((1, 1), float(k), dtype=torch.float64, device=dev)
+    vals[cols == i] = 2.0
+    rowptr = torch.arange(rows + 1, dtype=torch.int64, device=dev) * delta.numel()
+    return rowptr, cols.reshape(-1).to(torch.int32), vals.reshape(-1)
+
+
+def random_sparse_problem(n, k, seed, device=None, group=None, mode="allgather"):
+    """(operator, b, xstar) for the sparse SPD test matrix with k off-diagonal entries per row;
+    b = -A.xstar by the engine's own sparse matvec.  With a process group of > 1 rank the matrix is
+    row-sharded (each rank builds only its own rows)."""
+    from .operators import SparseOperator
+    eng = get_engine(device)
+    xs = xstar(n, seed, eng.device)
+    world = 1
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        world = torch.distributed.get_world_size(group)
+    if world > 1:
+        rank = torch.distributed.get_rank(group)
+        row0, rows, _ = row_partition(n, world, rank)
+        local = SparseOperator(sparse_spd_csr(n, k, seed, row0, rows, eng.device), shape=(rows, n), engine=eng)
+        op = RowShardedOperator(local, n, group, mode, eng)
+    else:
+        op = SparseOperator(sparse_spd_csr(n, k, seed, 0, n, eng.device), shape=(n, n), engine=eng)
+    Ax = eng.empty(n)
+    op.matvec(xs, Ax)
+    b = eng.empty(n)
+    eng.scale(-1.0, Ax, b)
+    return op, b, xs

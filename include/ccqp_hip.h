@@ -219,6 +219,24 @@ int64_t ccqp_symv_workspace_doubles(int64_t n);
 int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
                         double* y, double* g, int64_t n, double* workspace, void* stream);
 
+/* ---- sparse operator: CSR fp64 matvec (operator generality) ------------------------
+ * The reference only calls `A.dot(v)` (solvers.py:25,133,...), so a scipy.sparse matrix is a legal A
+ * there; this is that call for a CSR matrix resident in HBM: y = A.x for rows [0, rows) of a
+ * rows x cols matrix (rowptr: rows+1 int64, rowptr[0] == 0; col: nnz int32; val: nnz doubles), with
+ * the optional epilogue g = y + b.  The bits of y[i] depend on row i's stored entries (in storage
+ * order) and x only -- not on `width`, the subgroup size working on one row (0 = pick from the mean
+ * row length; 4, 8, 16, 32, 64 to force), and not on how the rows are sharded over GPUs: entry e goes
+ * to canonical lane e mod 64 (fma chain from +0.0), lanes are combined by the xor butterfly 32..1.
+ * Traffic per call: 12 B per stored entry + 16 B per row (+ x once). */
+int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
+                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                      int64_t nnz, int width, void* stream);
+/* Counts violated CSR invariants into scalar slot `slot` (0.0 = valid): rowptr[0] == 0, rowptr
+ * non-decreasing, rowptr[rows] == nnz, 0 <= col[e] < cols.  Call once before the first matvec on
+ * untrusted index arrays: the matvec itself does not bounds-check its gathers. */
+int ccqp_csr_validate(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, int64_t rows, int64_t cols,
+                      int64_t nnz, int slot, void* stream);
+
 /* ---- batched launch form (batch-sharded mode, BASELINE config 5) --------------------------------
  * One descriptor per (problem, operation); a GROUP = `count` descriptors of the same opcode and shape,
  * executed by ONE launch (blockIdx.y/z = problem) with the bodies of the single-problem kernels, so the

@@ -384,3 +384,37 @@ def case_x0(case, n):
     if case.get("x0") == "ones":
         return np.ones(n)
     return None
+
+
+# ------------------------------------------------------------------ sparse-operator solver cases
+def sparse_solver_cases():
+    """Same record layout as solver_cases(); problems are 'sgen:<n>:<k>:<seed>' (circulant-pattern sparse
+    SPD matrix, oracle/gen_ref.py:sparse_spd) or 'sirr:<n>:<seed>' (irregular, gen_ref.irregular_spd).
+    The reference solves them with A = scipy.sparse.csr_matrix (it only calls `A.dot`)."""
+    cases = []
+
+    def add(cid, problem, solver, tol, mx, op, **extra):
+        cases.append(dict(id=cid, problem=problem, solver=solver, tol=tol, max_mv=mx,
+                          kwargs={"step_size": 0.3} if solver == "PGD" else {}, op=op, rng_seed=1234, **extra))
+
+    for s in SOLVER_NAMES:
+        add("sgen256k8.%s.box" % s, "sgen:256:8:1234", s, 1e-6 if s == "MPRGP" else 1e-8, 5000, _box_half(256))
+    for n, k in ((1024, 8), (4096, 32), (4096, 100)):
+        p = "sgen:%d:%d:1234" % (n, k)
+        half = n // 2
+        tag = "sgen%dk%d" % (n, k)
+        add(tag + ".APGD.box", p, "APGD", 1e-8, 5000, _box_half(n))
+        add(tag + ".BBPGD.box", p, "BBPGD", 1e-8, 5000, _box_half(n))
+        add(tag + ".SPG.box", p, "SPG", 1e-8, 5000, _box_half(n))
+        add(tag + ".MPRGP.box", p, "MPRGP", 1e-6, 300, _box_half(n))
+        add(tag + ".BBPGD.cone", p, "BBPGD", 1e-8, 64, {"kind": "Cone", "dim": n})
+        add(tag + ".SPG.boxcone", p, "SPG", 1e-8, 64,
+            {"kind": "Disjoint", "ops": [_box_half(half), {"kind": "Cone", "dim": n - half}]})
+    for n in (300, 2000):
+        p = "sirr:%d:5" % n
+        for s in ("APGD", "BBPGD", "SPG", "MPRGP"):
+            add("sirr%d.%s.box" % (n, s), p, s, 1e-6 if s == "MPRGP" else 1e-8, 3000, _box_half(n))
+        add("sirr%d.BBPGD.identity" % n, p, "BBPGD", 1e-8, 3000, None)
+        add("sirr%d.BBPGDf.lower" % n, p, "BBPGDf", 1e-8, 3000, {"kind": "Lower", "dim": n, "lb": {"fill": -0.25}})
+    add("sgen256k8.warm.BBPGD", "sgen:256:8:7", "BBPGD", 1e-9, None, _box_half(256), x0="ramp")
+    return cases

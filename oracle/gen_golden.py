@@ -143,6 +143,12 @@ def get_problem(pid):
     elif pid == "readme":
         A = np.array(C.TRIDIAG)
         b = -A.dot(np.array([1, 0, 1]))
+    elif pid.startswith("sgen:"):
+        _, n, k, seed = pid.split(":")
+        A, b, _ = gen_ref.sparse_problem(int(n), int(k), int(seed))
+    elif pid.startswith("sirr:"):
+        _, n, seed = pid.split(":")
+        A, b, _ = gen_ref.irregular_problem(int(n), int(seed))
     else:
         _, n, seed = pid.split(":")
         A, b, _ = gen_ref.problem(int(n), int(seed))
@@ -150,17 +156,30 @@ def get_problem(pid):
     return A, b
 
 
-def gen_solvers():
-    cases = C.solver_cases()
+def gen_solvers(sparse=False):
+    """sparse=False: the dense cases -> solvers.npz; sparse=True: the reference run with A =
+    scipy.sparse.csr_matrix (it only calls `A.dot`) -> sparse.npz, which also holds the CSR arrays of the
+    irregular matrices and of one small generated matrix (known-answer vectors for the product generator)."""
+    cases = C.sparse_solver_cases() if sparse else C.solver_cases()
+    stem = "sparse" if sparse else "solvers"
     ofac = C.oracle_factory()
     arrays = dict(C.SUITE_ARRAYS)
     out = {}
     meta = []
     t0 = time.time()
+    if sparse:
+        K = gen_ref.sparse_spd(64, 4, 5)
+        out["kat.sgen:64:4:5.indptr"], out["kat.sgen:64:4:5.indices"], out["kat.sgen:64:4:5.data"] = \
+            K.indptr, K.indices, K.data
+        K = gen_ref.sparse_spd(1000, 32, 7, 100, 333)
+        out["kat.sgen:1000:32:7.rows100_333.indices"], out["kat.sgen:1000:32:7.rows100_333.data"] = K.indices, K.data
     for c in cases:
         A, b = get_problem(c["problem"])
         n = b.shape[0]
         out[c["problem"] + ".b"] = b
+        if c["problem"].startswith("sirr:"):
+            out[c["problem"] + ".indptr"], out[c["problem"] + ".indices"], out[c["problem"] + ".data"] = \
+                A.indptr, A.indices, A.data
         rop = None if c["op"] is None else C.build_op(c["op"], REF_FACTORY, arrays)
         oop = None if c["op"] is None else C.build_op(c["op"], ofac, arrays)
         max_mv = np.inf if c["max_mv"] is None else c["max_mv"]
@@ -207,7 +226,7 @@ def gen_solvers():
             for _ in range(8):
                 bp = np.asarray(b, dtype=np.float64) * (1 + rng.integers(-1, 2, size=n) * 2.0 ** -52)
                 Ap = A
-                if n <= 64:
+                if n <= 64 and not sparse:
                     Ap = np.asarray(A, dtype=np.float64) * (1 + rng.integers(-1, 2, size=A.shape) * 2.0 ** -52)
                 np.random.seed(c["rng_seed"])
                 with warnings.catch_warnings():
@@ -226,10 +245,10 @@ def gen_solvers():
             time.time() - t0), flush=True)
     for k, v in arrays.items():
         out[k] = v
-    np.savez_compressed(os.path.join(GOLD, "solvers.npz"), **out)
-    with open(os.path.join(GOLD, "solvers_cases.json"), "w") as f:
+    np.savez_compressed(os.path.join(GOLD, stem + ".npz"), **out)
+    with open(os.path.join(GOLD, stem + "_cases.json"), "w") as f:
         json.dump(meta, f, indent=0)
-    print("solvers: %d cases pinned" % len(meta))
+    print("%s: %d cases pinned" % (stem, len(meta)))
 
 
 def gen_generator():
@@ -252,10 +271,14 @@ def gen_generator():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    gen_generator()
-    gen_ops()
-    gen_pg()
-    gen_solvers()
+    only = sys.argv[1:]          # e.g. `gen_golden.py sparse` regenerates just that fixture set
+    steps = {"generator": gen_generator, "ops": gen_ops, "pg": gen_pg, "solvers": gen_solvers,
+             "sparse": lambda: gen_solvers(sparse=True)}
+    for name, fn in steps.items():
+        if not only or name in only:
+            fn()
+    if only:
+        return
     import platform
     meta = {"numpy": np.__version__, "python": platform.python_version(), "machine": platform.machine(),
             "note": "expected outputs are the reference's (palmerb4/CCQPpy @ /root/reference) outputs; "

@@ -88,3 +88,85 @@ def problem(n, seed):
     A = spd_rows(n, seed)
     xs = xstar(n, seed)
     return A, -A.dot(xs), xs
+
+
+# ------------------------------------------------------------------ sparse problems
+# The reference's solvers only call `A.dot(v)`, so a scipy.sparse matrix is a legal A for them.  Two
+# families are used by the sparse fixtures:
+#   * "sgen": the dense generator matrix above restricted to k symmetric off-diagonals (a circulant
+#     pattern: columns (i +- d_t) mod n for k/2 hashed distinct offsets d_t in [1, n/2 - 1]) with the
+#     off-diagonal entries rescaled to (2u - 1)/k and the diagonal kept at 2 -- Gershgorin puts the
+#     spectrum inside [1, 3].  Any row range can be produced independently (row-sharded runs).
+#   * "sirr": an irregular symmetric, strictly diagonally dominant matrix from scipy.sparse.random, with
+#     row lengths from 1 (diagonal only) to dozens of entries.
+_OFF_STREAM = np.uint64(0xA0761D6478BD642F)
+
+
+def sparse_offsets(n, k, seed):
+    """k/2 distinct positive offsets in [1, n/2 - 1] (hashed; collisions resolved by linear probing)."""
+    m = k // 2
+    span = n // 2 - 1
+    assert k % 2 == 0 and 1 <= m <= span
+    key = _key(seed, _OFF_STREAM)
+    with np.errstate(over="ignore"):
+        h = splitmix64(np.arange(m, dtype=np.uint64) + key)
+    used, out = set(), []
+    for t in range(m):
+        d = 1 + int(h[t] % np.uint64(span))
+        while d in used:
+            d = d % span + 1
+        used.add(d)
+        out.append(d)
+    return out
+
+
+def sparse_spd(n, k, seed, row0=0, rows=None):
+    """Rows [row0, row0+rows) of the n x n "sgen" matrix as scipy CSR (sorted columns, k+1 entries per row)."""
+    import scipy.sparse as sp
+    if rows is None:
+        rows = n - row0
+    offs = sparse_offsets(n, k, seed)
+    delta = np.array(sorted([-d for d in offs] + [0] + offs), dtype=np.int64)
+    i = np.arange(row0, row0 + rows, dtype=np.int64)[:, None]
+    cols = np.sort((i + delta[None, :]) % n, axis=1)
+    lo = np.minimum(i, cols).astype(np.uint64)
+    hi = np.maximum(i, cols).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        kk = lo * np.uint64(n) + hi
+    vals = (2.0 * uniform01(matrix_key(seed), kk) - 1.0) / np.float64(k)
+    vals[cols == i] = 2.0
+    w = delta.shape[0]
+    indptr = np.arange(rows + 1, dtype=np.int64) * w
+    return sp.csr_matrix((vals.reshape(-1), cols.reshape(-1).astype(np.int32), indptr), shape=(rows, n))
+
+
+def sparse_problem(n, k, seed):
+    """(A csr, b, xstar) with b = -A.xstar computed by scipy."""
+    A = sparse_spd(n, k, seed)
+    xs = xstar(n, seed)
+    return A, -A.dot(xs), xs
+
+
+def irregular_spd(n, seed, density=0.02):
+    """Irregular symmetric strictly diagonally dominant CSR matrix (row lengths vary; every 7th row and
+    column is cleared except for its diagonal)."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    R = sp.random(n, n, density=density, format="csr", random_state=rng, data_rvs=lambda s: rng.uniform(-1, 1, s))
+    S = (R + R.T).tolil()
+    for r in range(0, n, 7):
+        S[r, :] = 0
+        S[:, r] = 0
+    S = S.tocsr()
+    S.setdiag(0)
+    S.eliminate_zeros()
+    d = 1.0 + np.asarray(abs(S).sum(axis=1)).reshape(-1)
+    A = (S + sp.diags(d)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def irregular_problem(n, seed):
+    A = irregular_spd(n, seed)
+    xs = xstar(n, seed)
+    return A, -A.dot(xs), xs

@@ -1,0 +1,249 @@
+"""GPU parity of the sparse operator (ccqp_spmv_csr_f64 behind operators.SparseOperator).
+
+  * the matvec against scipy's `A.dot(x)` (what the reference would call) and, bit for bit, against the
+    summation order the header promises -- for every subgroup width, on irregular matrices with empty,
+    short and very long rows;
+  * the seven solvers on sparse A against the golden results of the REFERENCE run with scipy CSR input;
+  * row-sharded sparse solves (2 ranks, one device, gloo) bitwise equal to the single-GPU solve;
+  * index validation (the kernel does not bounds-check: bad input must be refused on the host)."""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import cases as C
+from oracle import gen_ref
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CASES, ARR = H.load_sparse()
+RTOL = 1e-10
+
+
+def _ragged(rows, cols, seed, long_rows=()):
+    """CSR with empty rows, rows of 1..90 entries in UNSORTED storage order, duplicates-free, plus a few
+    very long rows."""
+    rng = np.random.default_rng(seed)
+    indptr, indices, data = [0], [], []
+    for r in range(rows):
+        if r in long_rows:
+            m = min(cols, long_rows[r])
+        else:
+            m = 0 if r % 5 == 0 else int(rng.integers(1, min(cols, 90) + 1))
+        c = rng.choice(cols, size=m, replace=False)
+        indices.append(c)
+        data.append(rng.normal(size=m))
+        indptr.append(indptr[-1] + m)
+    return (np.array(indptr, dtype=np.int64), np.concatenate(indices).astype(np.int32), np.concatenate(data))
+
+
+@pytest.mark.parametrize("rows,cols,seed,long_rows", [(37, 50, 1, {}), (300, 211, 2, {7: 200, 150: 211}),
+                                                     (1, 1, 3, {}), (513, 4096, 4, {100: 4000, 101: 129, 102: 64, 103: 65})])
+def test_spmv_bits_follow_the_canonical_order_for_every_width(rows, cols, seed, long_rows):
+    from ccqppy_amd.operators import SparseOperator
+    indptr, indices, data = _ragged(rows, cols, seed, long_rows)
+    x = np.random.default_rng(seed + 100).normal(size=cols)
+    want = H.spmv_canonical(indptr, indices, data, x)
+    ref = sp.csr_matrix((data, indices, indptr), shape=(rows, cols)).dot(x)
+    np.testing.assert_allclose(want, ref, rtol=1e-12, atol=1e-13)
+    b = np.random.default_rng(seed + 200).normal(size=rows)
+    for width in (0, 4, 8, 16, 32, 64):
+        op = SparseOperator((indptr, indices, data), shape=(rows, cols), width=width)
+        eng = op.engine
+        eng.bind()
+        xd = eng.to_device(x)
+        y = torch.full((rows,), 7.0, dtype=torch.float64, device=eng.device)
+        g = torch.full((rows,), 7.0, dtype=torch.float64, device=eng.device)
+        op.matvec(xd, y)
+        assert H.same_bits(y.cpu().numpy(), want), width
+        y.fill_(3.0)
+        op.matvec(xd, y, eng.to_device(b), g)
+        assert H.same_bits(y.cpu().numpy(), want), width
+        assert H.same_bits(g.cpu().numpy(), want + b), width
+
+
+def test_input_formats_and_row_blocks():
+    from ccqppy_amd.operators import SparseOperator, as_operator
+    A = gen_ref.irregular_spd(700, 11)
+    x = np.random.default_rng(5).normal(size=700)
+    base = as_operator(A)                                   # scipy CSR
+    assert isinstance(base, SparseOperator) and base.shape == (700, 700) and base.nnz == A.nnz
+    y0 = base.dot(x).cpu().numpy()
+    np.testing.assert_allclose(y0, A.dot(x), rtol=1e-13, atol=1e-13)
+    for other in (A.tocoo(), A.tocsc(), sp.csr_array(A)):   # converted through .tocsr(): same sorted CSR
+        assert H.same_bits(as_operator(other).dot(x).cpu().numpy(), y0)
+    t = torch.sparse_csr_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
+                                torch.from_numpy(A.data), size=(700, 700))
+    assert H.same_bits(as_operator(t).dot(x).cpu().numpy(), y0)
+    assert H.same_bits(as_operator(t.cuda()).dot(x).cpu().numpy(), y0)
+    assert H.same_bits(as_operator(t.to_sparse_coo()).dot(x).cpu().numpy(), y0)
+    # any row block gives the bits of those rows of the full product (what row-sharding relies on)
+    for row0, rows in ((0, 700), (0, 1), (123, 400), (699, 1), (350, 0)):
+        blk = base.row_block(row0, rows)
+        assert blk.shape == (rows, 700)
+        assert H.same_bits(blk.dot(x).cpu().numpy(), y0[row0:row0 + rows])
+    with pytest.raises(ValueError):
+        SparseOperator((A.indptr, A.indices, A.data))       # triple without shape
+
+
+def test_invalid_csr_is_refused_before_any_matvec():
+    from ccqppy_amd.operators import SparseOperator
+    A = gen_ref.irregular_spd(100, 2)
+    ip, ix, dv = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data
+    bad_col = ix.copy()
+    bad_col[17] = 100
+    neg_col = ix.copy()
+    neg_col[3] = -1
+    not_mono = ip.copy()
+    not_mono[10], not_mono[11] = not_mono[11], not_mono[10] - 1
+    short = ip.copy()
+    short[-1] -= 1
+    shifted = ip + 1
+    for rowptr, col in ((ip, bad_col), (ip, neg_col), (not_mono, ix), (short, ix), (shifted, ix)):
+        with pytest.raises(ValueError, match="CSR invariants"):
+            SparseOperator((rowptr, col, dv), shape=(100, 100))
+    with pytest.raises(ValueError, match="inconsistent"):
+        SparseOperator((ip[:-1], ix, dv), shape=(100, 100))
+    SparseOperator((ip, ix, dv), shape=(100, 100))          # the untouched arrays pass
+
+
+def test_device_generator_matches_oracle_generator_bits():
+    from ccqppy_amd import problems
+    for n, k, seed, row0, rows in ((256, 8, 1234, 0, None), (4096, 100, 1234, 1000, 2000)):
+        K = gen_ref.sparse_spd(n, k, seed, row0, rows)
+        rowptr, col, val = problems.sparse_spd_csr(n, k, seed, row0, rows)
+        assert val.is_cuda
+        assert np.array_equal(K.indptr, rowptr.cpu().numpy())
+        assert np.array_equal(K.indices, col.cpu().numpy())
+        assert H.same_bits(K.data, val.cpu().numpy())
+    op, b, xs = problems.random_sparse_problem(4096, 32, 1234)
+    A, b_ref, xs_ref = gen_ref.sparse_problem(4096, 32, 1234)
+    assert H.same_bits(xs.cpu().numpy(), xs_ref)
+    np.testing.assert_allclose(b.cpu().numpy(), b_ref, rtol=1e-13, atol=1e-14)
+
+
+_OPS = {}
+
+
+def _operator(pid):
+    from ccqppy_amd import problems
+    from ccqppy_amd.operators import SparseOperator
+    if pid not in _OPS:
+        if pid.startswith("sgen:"):
+            _, n, k, seed = pid.split(":")
+            n = int(n)
+            _OPS[pid] = SparseOperator(problems.sparse_spd_csr(n, int(k), int(seed)), shape=(n, n))
+        else:
+            _OPS[pid] = H.sparse_fixture_matrix(pid, ARR)        # scipy input, converted by every solve()
+    return _OPS[pid]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_solver_golden_sparse(case):
+    from ccqppy_amd import solvers
+    A = _operator(case["problem"])
+    b = ARR[case["problem"] + ".b"]
+    n = b.shape[0]
+    P = None if case["op"] is None else C.build_op(case["op"], C.product_factory(), dict(C.SUITE_ARRAYS))
+    max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
+    np.random.seed(case["rng_seed"])
+    s = getattr(solvers, "CCQPSolver" + case["solver"])(case["tol"], max_mv, **case["kwargs"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        s.solve(A, b, x0=C.case_x0(case, n), convex_proj_op=P)
+    want = ARR[case["id"] + ".x"]
+    lo, hi = case["mv_band"]
+    if lo == hi:
+        assert s.solution_num_matrix_vector_multiplications == case["mv"]
+        assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+        rtol = RTOL
+    else:       # the reference's own count moves under 1-ulp perturbations of b (band in the fixture)
+        assert lo - (hi - lo) <= s.solution_num_matrix_vector_multiplications <= hi + (hi - lo)
+        rtol = max(RTOL, 8 * case["x_spread"])
+    assert bool(s.solution_converged) == case["converged"]
+    assert np.linalg.norm(s.solution - want) <= rtol * np.linalg.norm(want) + 1e-14
+    if case["converged"] and case["solver"] != "SPG":
+        assert float(s.solution_residual) < case["tol"]
+
+
+def test_sparse_in_both_batch_schedulers_matches_plain_solves():
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd.batch import solve_batch, solve_batch_fused
+    n = 2048
+    probs = []
+    for p in range(6):
+        op, b, _ = problems.random_sparse_problem(n, 16, 100 + p)
+        probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+    for make in (lambda: solvers.CCQPSolverMPRGP(1e-6, 300), lambda: solvers.CCQPSolverAPGD(1e-8, 5000)):
+        plain = []
+        for op, b, x0, P in probs:
+            with contextlib.redirect_stdout(io.StringIO()):
+                plain.append(make().solve(op, b, convex_proj_op=P))
+        for sched in (lambda: solve_batch(make, probs, lanes=3), lambda: solve_batch_fused(make, probs, lanes=4, groups=2)):
+            got = sched()
+            for a, c in zip(plain, got):
+                assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+                assert H.same_bits(a.solution.cpu().numpy(), c.solution.cpu().numpy())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _solve_set(op, b, n):
+    from ccqppy_amd import solvers, solution_spaces as ss
+    out = {}
+    box = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    for name, cls, args in (("APGD", solvers.CCQPSolverAPGD, (1e-8, 5000)), ("BBPGD", solvers.CCQPSolverBBPGD, (1e-8, 5000)),
+                            ("SPG", solvers.CCQPSolverSPG, (1e-8, 5000)), ("MPRGP", solvers.CCQPSolverMPRGP, (1e-6, 300))):
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = cls(*args).solve(op, b, convex_proj_op=box)
+        out[name] = (r.solution.cpu().numpy().copy(), int(r.solution_num_matrix_vector_multiplications))
+    return out
+
+
+def _worker(rank, world, port, n, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from ccqppy_amd import problems
+        op, b, _ = problems.random_sparse_problem(n, k, 1234, device=0, group=dist.group.WORLD)
+        assert op.sparse and op.rows < n
+        q.put((rank, _solve_set(op, b, n)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(4096, 32), (1001, 8)])
+def test_row_sharded_sparse_equals_single_gpu_bitwise(n, k):
+    import torch.multiprocessing as mp
+    from ccqppy_amd import problems
+    op, b, _ = problems.random_sparse_problem(n, k, 1234, device=0)
+    single = _solve_set(op, b, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        for name, (x, mv) in res.items():
+            assert mv == single[name][1], (name, rank)
+            assert H.same_bits(x, single[name][0]), (name, rank)
