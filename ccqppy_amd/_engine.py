@@ -162,7 +162,19 @@ class Engine:
             ev[1].record(self.torch_stream)
             self.gemv_events.append(ev)
 
-    def spmv_csr(self, rowptr, col, val, cols, x, y, b=None, g=None, width=0):
+    def spmv_plan(self, rowptr, nnz):
+        """One-time analysis of a CSR matrix -> (plan tensor, host summary {rows on the wave-per-row path,
+        windows in transposed gather order} as a ctypes int64[2])."""
+        rows = rowptr.numel() - 1
+        words = self.lib.ccqp_spmv_plan_words(rows, nnz)
+        plan = torch.empty(words, dtype=torch.int64, device=self.device)
+        summary = (ctypes.c_int64 * 2)()
+        rc = self.lib.ccqp_spmv_plan_csr(self.ctx, rowptr.data_ptr(), rows, nnz, plan.data_ptr(), summary, self.stream)
+        if rc:
+            _lib.check(rc)
+        return plan, summary
+
+    def spmv_csr(self, rowptr, col, val, plan, summary, cols, x, y, b=None, g=None, width=0):
         """y = A.x for a CSR matrix (rowptr int64[rows+1], col int32[nnz], val float64[nnz]); g = y + b."""
         rows = rowptr.numel() - 1
         assert x.numel() >= cols and y.numel() >= rows
@@ -171,8 +183,8 @@ class Engine:
         if self.gemv_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(self.torch_stream)
-        rc = self.lib.ccqp_spmv_csr_f64(self.ctx, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), x.data_ptr(),
-                                        None if g is None else b.data_ptr(), y.data_ptr(),
+        rc = self.lib.ccqp_spmv_csr_f64(self.ctx, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), plan.data_ptr(),
+                                        summary, x.data_ptr(), None if g is None else b.data_ptr(), y.data_ptr(),
                                         None if g is None else g.data_ptr(), rows, cols, val.numel(), width,
                                         self.stream)
         if rc:

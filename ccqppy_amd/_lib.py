@@ -100,7 +100,9 @@ SIGNATURES = {
     "ccqp_scalars_gather_host": [_P, _I, _c.POINTER(_D)],
     "ccqp_symv_workspace_doubles": [_I64],
     "ccqp_symv_upper_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
-    "ccqp_spmv_csr_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P],
+    "ccqp_spmv_plan_words": [_I64, _I64],
+    "ccqp_spmv_plan_csr": [_P, _P, _I64, _I64, _P, _c.POINTER(_I64), _P],
+    "ccqp_spmv_csr_f64": [_P, _P, _P, _P, _P, _c.POINTER(_I64), _P, _P, _P, _P, _I64, _I64, _I64, _I, _P],
     "ccqp_csr_validate": [_P, _P, _P, _I64, _I64, _I64, _I, _P],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],
     "ccqp_gen_vec_f64": [_P, _P, _I64, _c.c_uint64, _P],
@@ -130,7 +132,7 @@ def load():
                                      % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "ccqp_last_error" else
-                      ctypes.c_int64 if name == "ccqp_symv_workspace_doubles" else ctypes.c_int)
+                      ctypes.c_int64 if name in ("ccqp_symv_workspace_doubles", "ccqp_spmv_plan_words") else ctypes.c_int)
     if lib.ccqp_abi_version() != 1:
         raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib

@@ -1,62 +1,322 @@
 // Sparse (CSR, fp64) form of the solvers' `A.dot(v)` (reference: src/ccqppy/solvers.py:25 -- the solver
 // only ever calls `A.dot`, so a scipy.sparse matrix is a legal `A` there).
 //
-// HBM-bound streaming kernel: every stored entry is read once (8 B value + 4 B column), x is gathered
-// through L2 / Infinity Cache, one 8-B row pointer and one 8-B result per row.
+// HBM-bound: every stored entry is read once (8 B value + 4 B column), x is gathered through L2 /
+// Infinity Cache, one 8-B row pointer and one 8-B result per row.
+//
+// Structure ("CSR-stream"): the entry range is cut into windows of SPMV_CAP entries; workgroup i owns
+// the rows that START in window i (a plan computed once per matrix, ccqp_spmv_plan_csr).  It streams its
+// entries with all 256 threads -- fully coalesced whatever the row lengths, 8 independent (value, column)
+// loads per thread in flight, then 8 gathers -- parks the products in LDS, and subgroups of W lanes reduce
+// one row each out of LDS.  Where the rows of a window have (nearly) the same length and at least ~28
+// entries (plan word 4), the x gathers are issued in TRANSPOSED order -- consecutive lanes take the same
+// entry position of consecutive rows, (value, column) coming through LDS -- because banded / stencil-like
+// matrices then gather consecutive x, which the L1 merges; in entry order every lane of a gather is a cache
+// access of its own.  A window's last row bypasses LDS when it is longer than SPMV_LONG entries (one wave
+// per row, second launch).
+//
+// Measured (profiles/r01_spmv_*): 4.0-4.6 TB/s of algorithmic bytes on banded matrices with 8..128 entries
+// per row, 0.7-1.3 TB/s when the columns are scrambled (every gather a cache miss).  The same kernel with
+// the gather replaced by arithmetic streams at 7.2 TB/s, and the PMC counters of the full kernel show the
+// texture-address / L1 pipe 76 % busy with 1.5 cache accesses per entry: the x gathers are the bound, not
+// HBM.  Variants that were built and measured slower: a CSR-vector kernel (subgroup per row straight from
+// global memory: 2-3 TB/s, one load per lane in flight and half-empty load instructions), several rows per
+// subgroup, and two persistent software-pipelined forms (next window's loads in flight during the reduce:
+// 100+ VGPRs, 4 workgroups per CU, 2.6-3.3 TB/s).
 //
 // Determinism contract (same as the dense matvec): the bits of y[i] are a function of row i's stored
-// entries and x ONLY.  The canonical order is: entry e of the row (0-based, in storage order) belongs to
-// canonical lane L = e mod 64; lane L accumulates its entries in order with one fma each, starting from
-// +0.0; the 64 lane sums are combined by the xor butterfly 32,16,8,4,2,1.  A row is worked on by a
-// SUBGROUP of W lanes (W = 4..64, picked from the mean row length); lane l of the subgroup then carries
-// the 64/W canonical lanes l, l+W, l+2W, ... in separate accumulators and performs the butterfly steps
-// >= W inside its registers, so every W yields the same bits and W is a pure tuning knob -- and so is
-// any row-sharding of the matrix.
+// entries (in storage order) and x ONLY: product p_e = fl(val_e * x[col_e]); canonical lane L = e mod 64
+// adds its products in order starting from +0.0; the 64 lane sums are combined by the xor butterfly
+// 32,16,8,4,2,1.  Lane l of a W-lane subgroup carries the 64/W canonical lanes l, l+W, ... in separate
+// accumulators and does the butterfly steps >= W in registers, so W, the window plan and any
+// row-sharding of the matrix are pure tuning / layout choices.
 #include "ccqp_internal.h"
 
-template <int W, bool EPI>
-__global__ __launch_bounds__(CCQP_BLOCK) void spmv_csr_kernel(const int64_t* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ col,
-                                                              const double* __restrict__ val,
-                                                              const double* __restrict__ x,
-                                                              const double* __restrict__ b, double* __restrict__ y,
-                                                              double* __restrict__ g, int64_t rows) {
-  constexpr int K = 64 / W;                 // canonical lanes per physical lane
-  constexpr int ROWS_PER_BLOCK = CCQP_BLOCK / W;
-  const int l = threadIdx.x % W;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / W;
-  int64_t beg = 0, end = 0;
-  if (row < rows) {                         // no early exit: every lane takes part in the shuffles
-    beg = rowptr[row];
-    end = rowptr[row + 1];
+#define SPMV_LDS 2048              // products a workgroup parks in LDS (8 per thread)
+#define SPMV_LONG 256              // a window's last row bypasses LDS (one wave per row) if it is longer than this
+#define SPMV_CAP (SPMV_LDS - SPMV_LONG)   // window size in entries: rows starting in it hold < SPMV_LDS entries
+#define SPMV_SLOTS (SPMV_LDS / CCQP_BLOCK)   // entries per thread in the streaming phase
+#define SPMV_PLAN_WORDS 5          // per window: first row, end row (LDS path), first entry, end entry (LDS path),
+                                   // longest row if the window takes the transposed gather order, else 0
+#define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order
+#define SPMV_ROWS_LDS 1790         // row starts of a window live in LDS (16-bit) up to this many rows: with the
+                                   // products 19.9 KB per workgroup = 8 workgroups per CU
+
+// ------------------------------------------------------------------------------------------ plan
+// first row r in [0, rows] whose start rowptr[r] is >= target (rows if none)
+__device__ __forceinline__ int64_t spmv_lower_bound(const int64_t* __restrict__ rowptr, int64_t rows, int64_t target) {
+  int64_t lo = 0, hi = rows;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
   }
-  double acc[K];
+  return lo;
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_kernel(const int64_t* __restrict__ rowptr, int64_t rows,
+                                                               int64_t nwin, int64_t* __restrict__ plan,
+                                                               unsigned long long* __restrict__ nlong,
+                                                               unsigned long long* __restrict__ ntransposed,
+                                                               int64_t* __restrict__ long_rows) {
+  const int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x;
+  if (i >= nwin) return;
+  const int64_t rb = spmv_lower_bound(rowptr, rows, i * SPMV_CAP);
+  int64_t re = spmv_lower_bound(rowptr, rows, (i + 1) * SPMV_CAP);
+  // LDS capacity: the rows before the window's last row span < SPMV_CAP entries, so only the LAST row can
+  // overflow the SPMV_LDS products a workgroup parks; if it is longer than SPMV_LONG it takes the
+  // wave-per-row path instead (a row longer than SPMV_CAP is always the last row of its window)
+  if (re > rb && rowptr[re] - rowptr[re - 1] > SPMV_LONG) {
+    re -= 1;
+    long_rows[atomicAdd(nlong, 1ull)] = re;
+  }
+  const int64_t nzb = rowptr[rb], nze = rowptr[re];
+  // transposed gather order: the (position, row) grid of the window must fit the 8 grid points per thread,
+  // i.e. the rows have (nearly) the same length; measured to pay from ~28 entries per row on
+  int64_t longest = 0;
+  const int64_t nr = re - rb;
+  if (nr > 0 && nr <= SPMV_TRANSPOSE_ROWS && nze > nzb) {
+    for (int64_t r = rb; r < re; ++r) {
+      const int64_t len = rowptr[r + 1] - rowptr[r];
+      longest = len > longest ? len : longest;
+    }
+    if (nr * longest > SPMV_LDS) longest = 0;
+    if (longest > 0) atomicAdd(ntransposed, 1ull);
+  }
+  plan[SPMV_PLAN_WORDS * i + 0] = rb;
+  plan[SPMV_PLAN_WORDS * i + 1] = re;
+  plan[SPMV_PLAN_WORDS * i + 2] = nzb;
+  plan[SPMV_PLAN_WORDS * i + 3] = nze;
+  plan[SPMV_PLAN_WORDS * i + 4] = longest;
+}
+
+static inline int64_t spmv_windows(int64_t nnz) { return nnz / SPMV_CAP + 1; }
+
+extern "C" int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz) {
+  if (rows < 0 || nnz < 0) return -1;
+  const int64_t nwin = spmv_windows(nnz);
+  return SPMV_PLAN_WORDS * nwin + 2 + nwin;      // windows, two counters (summary), long-row list
+}
+
+extern "C" int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, int64_t rows, int64_t nnz, int64_t* plan,
+                                  int64_t* summary, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(rows >= 0 && nnz >= 0, "negative size");
+  CCQP_REQUIRE(rowptr != nullptr && plan != nullptr, "NULL rowptr / plan");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nwin = spmv_windows(nnz);
+  int64_t* count = plan + SPMV_PLAN_WORDS * nwin;
+  CCQP_HIP(hipMemsetAsync(count, 0, 2 * sizeof(int64_t), s));
+  const int64_t grid = (nwin + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  CCQP_REQUIRE(grid <= (int64_t)INT32_MAX, "matrix too large for one plan launch");
+  hipLaunchKernelGGL(spmv_plan_kernel, dim3((unsigned)grid), dim3(CCQP_BLOCK), 0, s, rowptr, rows, nwin, plan,
+                     (unsigned long long*)count, (unsigned long long*)count + 1, count + 2);
+  CCQP_LAUNCH_CHECK();
+  if (summary) {                             // blocking: lets the matvec skip launches / pick the lean kernel
+    CCQP_HIP(hipMemcpyAsync(summary, count, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    CCQP_HIP(hipStreamSynchronize(s));
+  }
+  return CCQP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ matvec
+// v of the lane `s` places up, for the butterfly steps inside a 16-lane row: DPP register moves instead of
+// two ds_bpermute round trips per step.  Lane 0 of a subgroup (the only lane whose sum is stored) sees the
+// same operands as in the xor butterfly, and a + b == b + a bitwise.
+template <int CTRL>
+__device__ __forceinline__ double spmv_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int W>
+__device__ __forceinline__ double spmv_subgroup_sum(double v) {
 #pragma unroll
-  for (int a = 0; a < K; ++a) acc[a] = 0.0;
-  for (int64_t e = beg + l; e < end; e += 64) {
+  for (int s = W / 2; s >= 16; s >>= 1) v = v + __shfl_xor(v, s, W);
+  if (W >= 16) v = v + spmv_dpp<0x128>(v);   // row_ror:8   == lane ^ 8 within the row
+  if (W >= 8) v = v + spmv_dpp<0x104>(v);    // row_shl:4   lane l <- lane l + 4
+  if (W >= 4) v = v + spmv_dpp<0x4E>(v);     // quad_perm [2,3,0,1] == lane ^ 2
+  if (W >= 2) v = v + spmv_dpp<0xB1>(v);     // quad_perm [1,0,3,2] == lane ^ 1
+  return v;
+}
+
+// TR: the kernel can run windows in transposed gather order (8 KB more LDS: 6 instead of 8 workgroups per
+// CU); without it such windows are streamed in entry order like the others.
+template <int W, bool EPI, bool TR>
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const double* __restrict__ val,
+                                                                 const int64_t* __restrict__ plan,
+                                                                 const double* __restrict__ x,
+                                                                 const double* __restrict__ b, double* __restrict__ y,
+                                                                 double* __restrict__ g, int64_t last) {
+  constexpr int K = 64 / W;                 // canonical lanes per physical lane
+  constexpr int SUBGROUPS = CCQP_BLOCK / W;
+  __shared__ double prod[SPMV_LDS];
+  __shared__ uint16_t rstart[SPMV_ROWS_LDS + 2];      // row starts relative to the window
+  __shared__ int32_t colv[TR ? SPMV_LDS : 1];         // transposed windows: the column indices
+  const int64_t* pw = plan + (int64_t)SPMV_PLAN_WORDS * blockIdx.x;
+  const int64_t rb = pw[0], re = pw[1], nzb = pw[2];
+  const int E = (int)(pw[3] - nzb);          // < SPMV_LDS by construction of the plan
+  const int longest = TR ? (int)pw[4] : 0;
+  const int t = threadIdx.x;
+  const int l = t % W;
+  const int64_t nrows = re - rb;
+  const bool rows_in_lds = nrows <= SPMV_ROWS_LDS;
+  // phase 1: ALL (value, column) loads of the window and its row pointers back to back, then all
+  // gathers -- one pass through the load -> gather latency chain per workgroup.  Every load is
+  // unconditional with a clamped index (a slot past the end of the window re-reads its last entry, one
+  // cache line for the whole wave): loads inside conditional code make the compiler wait for them one by
+  // one, and this kernel lives on the number of loads in flight.
+  double v[SPMV_SLOTS];
+  int32_t c[SPMV_SLOTS];
+  // an empty window (E == 0) may sit at the very end of the arrays: clamp to the last stored entry
+  const int64_t elast = E > 0 ? nzb + E - 1 : (nzb < last ? nzb : last);
 #pragma unroll
-    for (int a = 0; a < K; ++a) {
-      const int64_t idx = e + (int64_t)a * W;
-      if (idx < end) {
-        const double v = __builtin_nontemporal_load(val + idx);
-        const int32_t c = __builtin_nontemporal_load(col + idx);
-        acc[a] = fma(v, x[c], acc[a]);
+  for (int j = 0; j < SPMV_SLOTS; ++j) {
+    const int64_t e = nzb + t + j * CCQP_BLOCK;
+    const int64_t es = e < elast ? e : elast;
+    v[j] = __builtin_nontemporal_load(val + es);
+    c[j] = __builtin_nontemporal_load(col + es);
+  }
+  int64_t rp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t i = t + j * CCQP_BLOCK;
+    rp[j] = rowptr[rb + (i < nrows ? i : nrows)];
+  }
+  if (rows_in_lds) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (t + j * CCQP_BLOCK <= nrows) rstart[t + j * CCQP_BLOCK] = (uint16_t)(rp[j] - nzb);
+    for (int i = t + 2 * CCQP_BLOCK; i <= (int)nrows; i += CCQP_BLOCK)      // > 511 rows in one window: rare
+      rstart[i] = (uint16_t)(rowptr[rb + i] - nzb);
+  }
+  if (TR && longest > 0) {
+    // transposed window: (a) park values and columns in LDS
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int e = t + j * CCQP_BLOCK;
+      if (e < E) {
+        prod[e] = v[j];
+        colv[e] = c[j];
       }
     }
+    __syncthreads();
+    // (b) thread p of the (position, row) grid takes position p / nr of row p % nr: consecutive lanes
+    // gather for consecutive rows (banded / stencil matrices: consecutive x, which the L1 merges -- in
+    // entry order every lane of a gather is a cache access of its own).  nr * longest <= SPMV_LDS, so the
+    // 8 grid points per thread cover the grid; gathers unconditional (clamped) as above.
+    const int nr = (int)nrows;
+    const int q = CCQP_BLOCK / nr, m = CCQP_BLOCK % nr;
+    int row = t % nr, pos = t / nr;
+    int e[SPMV_SLOTS];
+    bool ok[SPMV_SLOTS];
+    int32_t cc[SPMV_SLOTS];
+    double xv[SPMV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int s0 = rstart[row], s1 = rstart[row + 1];
+      ok[j] = pos < s1 - s0;
+      e[j] = ok[j] ? s0 + pos : 0;
+      cc[j] = colv[e[j]];
+      row += m;
+      pos += q;
+      if (row >= nr) {
+        row -= nr;
+        pos += 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) xv[j] = x[cc[j]];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j)
+      if (ok[j]) prod[e[j]] = prod[e[j]] * xv[j];
+  } else {
+    double xv[SPMV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) xv[j] = x[c[j]];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int e = t + j * CCQP_BLOCK;
+      if (e < E) prod[e] = v[j] * xv[j];
+    }
   }
-  // butterfly steps 32 .. W: both partners live in this lane
+  __syncthreads();
+  // phase 2: one row per subgroup out of LDS, canonical order
+  for (int64_t i = t / W; i < nrows; i += SUBGROUPS) {
+    int beg, end;
+    if (rows_in_lds) {
+      beg = rstart[i];
+      end = rstart[i + 1];
+    } else {                                // a window with thousands of empty rows
+      beg = (int)(rowptr[rb + i] - nzb);
+      end = (int)(rowptr[rb + i + 1] - nzb);
+    }
+    double acc[K];
 #pragma unroll
-  for (int s = K / 2; s >= 1; s >>= 1) {
+    for (int a = 0; a < K; ++a) acc[a] = 0.0;
+    for (int e = beg + l; e < end; e += 64) {
 #pragma unroll
-    for (int a = 0; a < s; ++a) acc[a] = acc[a] + acc[a + s];
+      for (int a = 0; a < K; ++a)
+        if (e + a * W < end) acc[a] = acc[a] + prod[e + a * W];
+    }
+    // butterfly steps 32 .. W: both partners live in this lane
+#pragma unroll
+    for (int s = K / 2; s >= 1; s >>= 1) {
+#pragma unroll
+      for (int a = 0; a < s; ++a) acc[a] = acc[a] + acc[a + s];
+    }
+    // butterfly steps W/2 .. 1 across the subgroup
+    const double sum = spmv_subgroup_sum<W>(acc[0]);
+    if (l == 0) {
+      y[rb + i] = sum;
+      if (EPI) g[rb + i] = sum + b[rb + i];
+    }
   }
-  double v = acc[0];
-  // butterfly steps W/2 .. 1 across the subgroup
+}
+
+// rows longer than SPMV_CAP entries: one wave per row, straight from global memory, same canonical order
+template <bool EPI>
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_long_rows_kernel(const int64_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ col,
+                                                                    const double* __restrict__ val,
+                                                                    const int64_t* __restrict__ nlong,
+                                                                    const int64_t* __restrict__ long_rows,
+                                                                    const double* __restrict__ x,
+                                                                    const double* __restrict__ b,
+                                                                    double* __restrict__ y, double* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  const int64_t n = *nlong;
+  for (int64_t i = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const int64_t r = long_rows[i];
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    double acc = 0.0;
+    for (int64_t base = beg; base < end; base += 4 * 64) {
+      double v[4], xv[4];
+      int32_t c[4];
 #pragma unroll
-  for (int s = W / 2; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, W);
-  if (l == 0 && row < rows) {
-    y[row] = v;
-    if (EPI) g[row] = v + b[row];
+      for (int j = 0; j < 4; ++j) {
+        const int64_t e = base + j * 64 + lane;
+        const int64_t es = e < end ? e : end - 1;
+        v[j] = __builtin_nontemporal_load(val + es);
+        c[j] = __builtin_nontemporal_load(col + es);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double p = v[j] * xv[j];
+        if (base + j * 64 + lane < end) acc = acc + p;
+      }
+    }
+    const double sum = ccqp_wave_sum(acc);
+    if (lane == 0) {
+      y[r] = sum;
+      if (EPI) g[r] = sum + b[r];
+    }
   }
 }
 
@@ -69,7 +329,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void csr_check_rows_kernel(const int64_
     const int64_t a = rowptr[r], c = rowptr[r + 1];
     bad = (a < 0) || (c < a) || (c > nnz);
   }
-  if (r == 0 && rows > 0) bad |= (rowptr[0] != 0) || (rowptr[rows] != nnz);
+  if (r == 0) bad |= (rowptr[0] != 0) || (rowptr[rows] != nnz);
   if (bad) atomicAdd(slot, 1.0);
 }
 
@@ -87,33 +347,38 @@ __global__ __launch_bounds__(CCQP_BLOCK) void csr_check_cols_kernel(const int32_
 static int spmv_pick_width(int64_t rows, int64_t nnz, int width) {
   if (width == 4 || width == 8 || width == 16 || width == 32 || width == 64) return width;
   const double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
-  if (mean <= 6.0) return 4;
-  if (mean <= 12.0) return 8;
-  if (mean <= 24.0) return 16;
-  if (mean <= 48.0) return 32;
+  // phase 2 wants (rows of a window) x W ~ the 256 threads: W ~ mean / 7 (measured: 4 at 9 entries per
+  // row, 8-16 at 33, 16 at 129, flat beyond)
+  if (mean <= 12.0) return 4;
+  if (mean <= 48.0) return 8;
+  if (mean <= 192.0) return 16;
+  if (mean <= 512.0) return 32;
   return 64;
 }
 
 template <int W>
-static void spmv_launch(const int64_t* rowptr, const int32_t* col, const double* val, const double* x,
-                        const double* b, double* y, double* g, int64_t rows, hipStream_t s) {
-  const int64_t rpb = CCQP_BLOCK / W;
-  const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-  if (g)
-    hipLaunchKernelGGL((spmv_csr_kernel<W, true>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, x, b, y, g,
-                       rows);
-  else
-    hipLaunchKernelGGL((spmv_csr_kernel<W, false>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, x, b, y,
-                       g, rows);
+static void spmv_launch(unsigned grid, bool tr, const int64_t* rowptr, const int32_t* col, const double* val,
+                        const int64_t* plan, const double* x, const double* b, double* y, double* g, int64_t nnz,
+                        hipStream_t s) {
+#define SPMV_GO(EPI, TR)                                                                                          \
+  hipLaunchKernelGGL((spmv_stream_kernel<W, EPI, TR>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, \
+                     x, b, y, g, nnz - 1)
+  if (g) {
+    if (tr) SPMV_GO(true, true); else SPMV_GO(true, false);
+  } else {
+    if (tr) SPMV_GO(false, true); else SPMV_GO(false, false);
+  }
+#undef SPMV_GO
 }
 
 extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
-                                 const double* x, const double* b, double* y, double* g, int64_t rows,
-                                 int64_t cols, int64_t nnz, int width, void* stream) {
+                                 const int64_t* plan, const int64_t* summary, const double* x, const double* b,
+                                 double* y, double* g, int64_t rows, int64_t cols, int64_t nnz, int width,
+                                 void* stream) {
   CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
   CCQP_REQUIRE(rows >= 0 && cols >= 0 && nnz >= 0, "negative size");
   CCQP_REQUIRE(cols <= INT32_MAX, "cols exceeds the 32-bit column index");
-  CCQP_REQUIRE(rows == 0 || (rowptr != nullptr && y != nullptr), "NULL rowptr / y");
+  CCQP_REQUIRE(rows == 0 || (rowptr != nullptr && y != nullptr && plan != nullptr), "NULL rowptr / y / plan");
   CCQP_REQUIRE(nnz == 0 || (col != nullptr && val != nullptr && x != nullptr), "NULL col / val / x");
   CCQP_REQUIRE(y != x, "y must not alias x");
   CCQP_REQUIRE(g == nullptr || b != nullptr, "g requested but b is NULL");
@@ -121,14 +386,36 @@ extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int
   CCQP_REQUIRE(width == 0 || width == 4 || width == 8 || width == 16 || width == 32 || width == 64,
                "width must be 0 (auto), 4, 8, 16, 32 or 64");
   if (rows == 0) return CCQP_OK;
-  CCQP_REQUIRE((rows + 3) / 4 <= (int64_t)INT32_MAX, "too many rows for one launch");
+  const int64_t nwin = spmv_windows(nnz);
+  CCQP_REQUIRE(nwin <= (int64_t)INT32_MAX, "matrix too large for one launch");
   hipStream_t s = (hipStream_t)stream;
+  if (nnz == 0) {                            // all rows empty: nothing to stream
+    CCQP_HIP(hipMemsetAsync(y, 0, (size_t)rows * sizeof(double), s));
+    if (g) CCQP_HIP(hipMemcpyAsync(g, b, (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return CCQP_OK;
+  }
+  const unsigned grid = (unsigned)nwin;
+  // summary (host copy of the plan's two counters) unknown: assume long rows and transposed windows exist.
+  // The transposed-capable kernel holds fewer workgroups per CU: worth it from a quarter of the windows on.
+  const int64_t n_long_rows = summary ? summary[0] : -1;
+  const bool tr = summary ? 4 * summary[1] >= nwin : true;
   switch (spmv_pick_width(rows, nnz, width)) {
-    case 4: spmv_launch<4>(rowptr, col, val, x, b, y, g, rows, s); break;
-    case 8: spmv_launch<8>(rowptr, col, val, x, b, y, g, rows, s); break;
-    case 16: spmv_launch<16>(rowptr, col, val, x, b, y, g, rows, s); break;
-    case 32: spmv_launch<32>(rowptr, col, val, x, b, y, g, rows, s); break;
-    default: spmv_launch<64>(rowptr, col, val, x, b, y, g, rows, s); break;
+    case 4: spmv_launch<4>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 8: spmv_launch<8>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 16: spmv_launch<16>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 32: spmv_launch<32>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    default: spmv_launch<64>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+  }
+  if (n_long_rows != 0) {                    // < 0: unknown to the caller, the kernel reads the count
+    const int64_t* count = plan + SPMV_PLAN_WORDS * nwin;
+    int64_t lg = n_long_rows < 0 ? ctx->num_cu : (n_long_rows + 3) / 4;
+    if (lg > (int64_t)ctx->num_cu * 8) lg = (int64_t)ctx->num_cu * 8;
+    if (g)
+      hipLaunchKernelGGL((spmv_long_rows_kernel<true>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
+                         count, count + 2, x, b, y, g);
+    else
+      hipLaunchKernelGGL((spmv_long_rows_kernel<false>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
+                         count, count + 2, x, b, y, g);
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

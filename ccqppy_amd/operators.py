@@ -169,12 +169,14 @@ class SparseOperator:
         self.nnz = self.val.numel()
         self.width = width
         self.A = self                      # what `op.A` means for a dense operator: the stored matrix
+        self.engine.bind()
         if check:
-            self.engine.bind()
             bad = self.engine.csr_violations(self.rowptr, self.col, self.n)
             if bad:
                 raise ValueError("SparseOperator: %d violated CSR invariants (row pointers not monotone / "
                                  "not ending at nnz, or column index outside [0, %d))" % (bad, self.n))
+        # one-time analysis: which rows each workgroup streams, which rows are too long for the LDS path
+        self.plan, self.summary = self.engine.spmv_plan(self.rowptr, self.nnz)
 
     @property
     def shape(self):
@@ -190,7 +192,7 @@ class SparseOperator:
                               check=False, width=self.width)
 
     def apply(self, eng, x, y, b=None, g=None):
-        eng.spmv_csr(self.rowptr, self.col, self.val, self.n, x, y, b, g, self.width)
+        eng.spmv_csr(self.rowptr, self.col, self.val, self.plan, self.summary, self.n, x, y, b, g, self.width)
 
     def matvec(self, x, y, b=None, g=None, engine=None):
         self.apply(engine or self.engine, x, y, b, g)

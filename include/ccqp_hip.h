@@ -223,14 +223,24 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  * The reference only calls `A.dot(v)` (solvers.py:25,133,...), so a scipy.sparse matrix is a legal A
  * there; this is that call for a CSR matrix resident in HBM: y = A.x for rows [0, rows) of a
  * rows x cols matrix (rowptr: rows+1 int64, rowptr[0] == 0; col: nnz int32; val: nnz doubles), with
- * the optional epilogue g = y + b.  The bits of y[i] depend on row i's stored entries (in storage
- * order) and x only -- not on `width`, the subgroup size working on one row (0 = pick from the mean
- * row length; 4, 8, 16, 32, 64 to force), and not on how the rows are sharded over GPUs: entry e goes
- * to canonical lane e mod 64 (fma chain from +0.0), lanes are combined by the xor butterfly 32..1.
- * Traffic per call: 12 B per stored entry + 16 B per row (+ x once). */
+ * the optional epilogue g = y + b.
+ *   plan: ccqp_spmv_plan_words(rows, nnz) int64 words of device memory owned by the caller, filled ONCE
+ *         per matrix by ccqp_spmv_plan_csr: which rows each workgroup streams through LDS, which windows
+ *         gather x in transposed order, and the list of rows that take the wave-per-row launch instead.
+ *   summary (optional, 2 host words): {rows on the wave-per-row path, windows in transposed order}.
+ *         Asking for it makes the plan call blocking; handing it to the matvec lets it skip the second
+ *         launch and pick the leaner kernel (NULL = unknown: both are assumed to exist).
+ * Bits of y[i]: a function of row i's stored entries (in storage order) and x only -- not of the plan,
+ * not of `width` (lanes that reduce one row: 0 = from the mean row length; 4, 8, 16, 32, 64 to force),
+ * not of how the rows are sharded over GPUs: p_e = fl(val_e * x[col_e]); canonical lane e mod 64 adds its
+ * products in order from +0.0; the 64 lanes are combined by the xor butterfly 32, 16, 8, 4, 2, 1.
+ * Traffic per call: 12 B per stored entry + 16 B per row + 8 B per column (x once). */
+int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz);
+int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, int64_t rows, int64_t nnz, int64_t* plan,
+                       int64_t* summary, void* stream);
 int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
-                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
-                      int64_t nnz, int width, void* stream);
+                      const int64_t* plan, const int64_t* summary, const double* x, const double* b, double* y,
+                      double* g, int64_t rows, int64_t cols, int64_t nnz, int width, void* stream);
 /* Counts violated CSR invariants into scalar slot `slot` (0.0 = valid): rowptr[0] == 0, rowptr
  * non-decreasing, rowptr[rows] == nnz, 0 <= col[e] < cols.  Call once before the first matvec on
  * untrusted index arrays: the matvec itself does not bounds-check its gathers. */

@@ -44,7 +44,9 @@ def _ragged(rows, cols, seed, long_rows=()):
 
 
 @pytest.mark.parametrize("rows,cols,seed,long_rows", [(37, 50, 1, {}), (300, 211, 2, {7: 200, 150: 211}),
-                                                     (1, 1, 3, {}), (513, 4096, 4, {100: 4000, 101: 129, 102: 64, 103: 65})])
+                                                     (1, 1, 3, {}), (513, 4096, 4, {100: 4000, 101: 129, 102: 64, 103: 65}),
+                                                     (64, 3000, 5, {0: 1024, 1: 1025, 2: 2047, 3: 2049, 62: 3000, 63: 1500}),
+                                                     (4000, 64, 6, {})])
 def test_spmv_bits_follow_the_canonical_order_for_every_width(rows, cols, seed, long_rows):
     from ccqppy_amd.operators import SparseOperator
     indptr, indices, data = _ragged(rows, cols, seed, long_rows)
@@ -66,6 +68,46 @@ def test_spmv_bits_follow_the_canonical_order_for_every_width(rows, cols, seed, 
         op.matvec(xd, y, eng.to_device(b), g)
         assert H.same_bits(y.cpu().numpy(), want), width
         assert H.same_bits(g.cpu().numpy(), want + b), width
+
+
+def test_unknown_plan_summary_and_forced_kernels_give_the_same_bits():
+    """C-ABI callers may pass summary = NULL (both extra code paths are then launched); the plan itself and
+    the lean / transposed-capable kernel choice must not change a bit either."""
+    from ccqppy_amd.operators import SparseOperator
+    for A in (gen_ref.sparse_spd(4096, 64, 3), gen_ref.irregular_spd(3000, 4)):
+        # one row far beyond the LDS path
+        A = A.tolil()
+        A[5, :] = np.random.default_rng(1).normal(size=A.shape[1])
+        A = A.tocsr()
+        x = np.random.default_rng(2).normal(size=A.shape[1])
+        op = SparseOperator(A)
+        assert op.summary[0] >= 1
+        y0 = op.dot(x).cpu().numpy()
+        np.testing.assert_allclose(y0, A.dot(x), rtol=1e-12, atol=1e-12)
+        keep = op.summary
+        op.summary = None
+        assert H.same_bits(op.dot(x).cpu().numpy(), y0)
+        import ctypes
+        for fake in ((keep[0], 0), (keep[0], 10 ** 9)):          # lean kernel / transposed-capable kernel
+            op.summary = (ctypes.c_int64 * 2)(*fake)
+            assert H.same_bits(op.dot(x).cpu().numpy(), y0)
+
+
+def test_empty_matrix_and_empty_rows():
+    from ccqppy_amd.operators import SparseOperator
+    x = np.arange(1.0, 6.0)
+    op = SparseOperator((np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0)), shape=(3, 5))
+    assert op.dot(x).cpu().numpy().tolist() == [0.0, 0.0, 0.0]
+    # 5000 rows, only three of them non-empty (many more rows than entries in every window)
+    indptr = np.zeros(5001, dtype=np.int64)
+    indptr[11:] = 2
+    indptr[2500:] = 3
+    indptr[5000:] = 5
+    op = SparseOperator((indptr, np.array([0, 4, 2, 1, 3], dtype=np.int32), np.array([1.0, 2.0, 3.0, 4.0, 5.0])),
+                        shape=(5000, 5))
+    y = op.dot(x).cpu().numpy()
+    assert y[10] == 1.0 * 1 + 2.0 * 5 and y[2499] == 9.0 and y[4999] == 4.0 * 2 + 5.0 * 4
+    assert np.count_nonzero(y) == 3
 
 
 def test_input_formats_and_row_blocks():
