@@ -76,6 +76,62 @@ int main(void) {
   }
   if (fabs(xy - s[0]) > 1e-12 * fabs(xy) + 1e-12) bad++;
   if (fabs(gg - s[1]) > 1e-12 * fabs(gg)) bad++;
+  /* sparse operator: validate -> plan -> CSR matvec with epilogue, against a C loop.  Rows of 0..7 entries
+   * plus one row of 2500 entries (longer than a window: wave-per-row path); columns (5 i + 3 j) mod n. */
+  {
+    const int64_t rows = n, cols = n;
+    int64_t* hrp = malloc((rows + 1) * sizeof(int64_t));
+    hrp[0] = 0;
+    for (int64_t i = 0; i < rows; ++i) hrp[i + 1] = hrp[i] + (i == 77 ? 2500 : i % 8);
+    const int64_t nnz = hrp[rows];
+    int32_t* hc = malloc(nnz * sizeof(int32_t));
+    double* hv = malloc(nnz * sizeof(double));
+    for (int64_t i = 0; i < rows; ++i)
+      for (int64_t e = hrp[i]; e < hrp[i + 1]; ++e) {
+        hc[e] = (int32_t)((5 * i + 3 * (e - hrp[i])) % cols);
+        hv[e] = 0.25 + (double)((i + 7 * e) % 13) / 16.0;
+      }
+    int64_t *rp, *plan;
+    int32_t* cidx;
+    double* vals;
+    const int64_t words = ccqp_spmv_plan_words(rows, nnz);
+    if (words <= 0 || hipMalloc((void**)&rp, (rows + 1) * sizeof(int64_t)) || hipMalloc((void**)&cidx, nnz * sizeof(int32_t)) ||
+        hipMalloc((void**)&vals, nnz * sizeof(double)) || hipMalloc((void**)&plan, words * sizeof(int64_t)))
+      return 4;
+    hipMemcpy(rp, hrp, (rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    hipMemcpy(cidx, hc, nnz * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipMemcpy(vals, hv, nnz * sizeof(double), hipMemcpyHostToDevice);
+    double viol = -1.0;
+    CHECK(ccqp_csr_validate(ctx, rp, cidx, rows, cols, nnz, 5, NULL));
+    CHECK(ccqp_scalars_read(ctx, 5, 1, &viol, NULL));
+    if (viol != 0.0) bad++;
+    int64_t summary[2] = {-1, -1};
+    CHECK(ccqp_spmv_plan_csr(ctx, rp, rows, nnz, plan, summary, NULL));
+    if (summary[0] != 1) bad++;                              /* exactly the 2500-entry row */
+    CHECK(ccqp_spmv_csr_f64(ctx, rp, cidx, vals, plan, summary, x, b, y, g, rows, cols, nnz, 0, NULL));
+    hipMemcpy(hy, y, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipMemcpy(hg, g, n * sizeof(double), hipMemcpyDeviceToHost);
+    for (int64_t i = 0; i < rows; ++i) {
+      double acc = 0.0, mag = 0.0;
+      for (int64_t e = hrp[i]; e < hrp[i + 1]; ++e) {
+        acc += hv[e] * hx[hc[e]];
+        mag += fabs(hv[e] * hx[hc[e]]);
+      }
+      if (fabs(acc - hy[i]) > 1e-13 * mag + 1e-300) bad++;
+      if (hrp[i + 1] - hrp[i] == 1 && hy[i] != hv[hrp[i]] * hx[hc[hrp[i]]]) bad++;   /* one entry: exact */
+      if (hg[i] != hy[i] + hb[i]) bad++;
+    }
+    /* an out-of-range column must be counted by the validator */
+    int32_t oob = (int32_t)cols;
+    hipMemcpy(cidx + 3, &oob, sizeof(int32_t), hipMemcpyHostToDevice);
+    CHECK(ccqp_csr_validate(ctx, rp, cidx, rows, cols, nnz, 5, NULL));
+    CHECK(ccqp_scalars_read(ctx, 5, 1, &viol, NULL));
+    if (viol != 1.0) bad++;
+    printf("sparse: nnz = %lld, plan words = %lld, long rows = %lld\n", (long long)nnz, (long long)words,
+           (long long)summary[0]);
+    hipFree(rp); hipFree(cidx); hipFree(vals); hipFree(plan);
+    free(hrp); free(hc); free(hv);
+  }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;
   printf("x.Ax = %.15g, |g|^2 = %.15g, mismatches = %d, last error: %s\n", s[0], s[1], bad, ccqp_last_error());
