@@ -91,7 +91,7 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
     """One process per GPU: this rank generates and solves problems p = rank, rank+world, ...
     (`make_problem(p)` -> (A, b, x0, op) on this rank's GPU).  Returns {p: solver} for the local
     problems; no collective is issued.  fused=True uses the lock-step scheduler with batched launches
-    (solve_batch_fused, 32 lanes in 4 groups by default), fused=False the one-stream-per-solve scheduler."""
+    (solve_batch_fused, 32 lanes in 2 groups by default), fused=False the one-stream-per-solve scheduler."""
     world, rank = 1, 0
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size(group)
@@ -99,7 +99,7 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
     mine = batch_partition(nproblems, world, rank)
     probs = [make_problem(p) for p in mine]
     if fused:
-        solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=4, device=device)
+        solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=2, device=device)
     else:
         solved = solve_batch(make_solver, probs, lanes=lanes or 4, device=device)
     return dict(zip(mine, solved))

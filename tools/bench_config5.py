@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--problems", type=int, default=None, help="total problems (default 128 per rank)")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--lanes", type=int, default=32)
-    ap.add_argument("--groups", type=int, default=4)
+    ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--scheduler", default="fused", choices=["fused", "lanes", "sequential"])
     args = ap.parse_args()
