@@ -217,9 +217,19 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
       // caller's stream): matvecs of different lane groups then run one after the other at full
       // bandwidth instead of overlapping and splitting it, while the small kernels of the other
       // groups still overlap with them.
-      static hipStream_t mv_stream = nullptr;
+      // (one stream per device; the host side of this library is driven by one thread per process)
+      static hipStream_t mv_streams[64] = {nullptr};
+      CCQP_REQUIRE(!ctx->mv_serialize || (ctx->device >= 0 && ctx->device < 64), "device index out of range");
+      hipStream_t& mv_stream = mv_streams[ctx->mv_serialize ? ctx->device : 0];
       if (ctx->mv_serialize) {
-        if (!mv_stream) CCQP_HIP(hipStreamCreateWithFlags(&mv_stream, hipStreamNonBlocking));
+        if (!mv_stream) {
+          int prev = 0;
+          CCQP_HIP(hipGetDevice(&prev));
+          CCQP_HIP(hipSetDevice(ctx->device));
+          const hipError_t e = hipStreamCreateWithFlags(&mv_stream, hipStreamNonBlocking);
+          (void)hipSetDevice(prev);
+          CCQP_HIP(e);
+        }
         if (!ctx->mv_ev_in) {
           CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_in, hipEventDisableTiming));
           CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_out, hipEventDisableTiming));
