@@ -271,6 +271,21 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
     // butterfly steps W/2 .. 1 across the subgroup
     const double sum = spmv_subgroup_sum<W>(acc[0]);
     if (l == 0) {
+      if (rows_in_lds) {
+        if (end > beg) prod[beg] = sum;     // parked in the row's own first slot (nobody reads it any more)
+      } else {
+        y[rb + i] = sum;
+        if (EPI) g[rb + i] = sum + b[rb + i];
+      }
+    }
+  }
+  if (rows_in_lds) {
+    // phase 3: coalesced output -- lane 0 of every W-lane subgroup storing 8 bytes costs ~20 % of the kernel
+    // at 9 entries per row
+    __syncthreads();
+    for (int i = t; i < (int)nrows; i += CCQP_BLOCK) {
+      const int beg = rstart[i], end = rstart[i + 1];
+      const double sum = end > beg ? prod[beg] : 0.0;
       y[rb + i] = sum;
       if (EPI) g[rb + i] = sum + b[rb + i];
     }
