@@ -16,6 +16,7 @@ from oracle import cpu_ref, gen_ref
 pytestmark = pytest.mark.gpu
 
 NCASES = 240
+NSPARSE = 80
 
 
 def _rand_leaf(rng, d, arrays, tag, allow_cone=True):
@@ -75,6 +76,17 @@ def _run(fn):
 
 @pytest.mark.parametrize("case_id", range(NCASES))
 def test_fuzz_case(case_id):
+    _fuzz(case_id, sparse=False)
+
+
+@pytest.mark.parametrize("case_id", range(NSPARSE))
+def test_fuzz_sparse_case(case_id):
+    """Same differential test with A an irregular scipy.sparse matrix (rows of 1..dozens of entries) handed to
+    solve() as such: SparseOperator / ccqp_spmv_csr_f64 on the product side, scipy's CSR dot in the oracle."""
+    _fuzz(50000 + case_id, sparse=True)
+
+
+def _fuzz(case_id, sparse):
     from ccqppy_amd import problems, solvers
     rng = np.random.default_rng(9000 + case_id)
     n = int(rng.choice([5, 17, 64, 100, 200, 333]))
@@ -89,9 +101,14 @@ def test_fuzz_case(case_id):
     kwargs = {"step_size": 0.3} if sname == "PGD" else {}
     x0 = None if rng.random() < 0.6 else rng.uniform(-0.5, 0.5, size=n)
 
-    A = gen_ref.spd_rows(n, seed)
-    op_dev, b_dev, _ = problems.random_problem(n, seed)
-    b = b_dev.cpu().numpy()
+    if sparse:
+        A = gen_ref.irregular_spd(n, seed % 1000, density=float(rng.choice([0.02, 0.1, 0.3])))
+        op_dev = A                                       # scipy matrix straight into solve()
+        b = -A.dot(gen_ref.xstar(n, seed))
+    else:
+        A = gen_ref.spd_rows(n, seed)
+        op_dev, b_dev, _ = problems.random_problem(n, seed)
+        b = b_dev.cpu().numpy()
     Po = C.build_op(spec, C.oracle_factory(), arrays)
     Pp = C.build_op(spec, C.product_factory(), arrays)
 
@@ -116,7 +133,11 @@ def test_fuzz_case(case_id):
     prng = np.random.default_rng(case_id)
     for _ in range(4):
         bp = b * (1 + prng.integers(-1, 2, size=n) * 2.0 ** -52)
-        Ap = A * (1 + prng.integers(-1, 2, size=A.shape) * 2.0 ** -52)
+        if sparse:
+            Ap = A.copy()
+            Ap.data = A.data * (1 + prng.integers(-1, 2, size=A.data.shape) * 2.0 ** -52)
+        else:
+            Ap = A * (1 + prng.integers(-1, 2, size=A.shape) * 2.0 ** -52)
         po, perr = _run(lambda: oracle(Ap, bp))
         if perr is None:
             mvs.append(po.solution_num_matrix_vector_multiplications)
