@@ -3,6 +3,8 @@
 The reference only ever calls `A.dot(v)` (solvers.py:25,133,...).  Here that call is one of
   * DenseOperator        -- the whole matrix on one GPU, `ccqp_gemv_f64`;
   * SparseOperator       -- a CSR matrix on one GPU (scipy.sparse / torch sparse input), `ccqp_spmv_csr_f64`;
+  * ComposedOperator     -- matrix-free product of dense / sparse / diagonal factors (+ shift * I), e.g. the
+                            Delassus operator D M^-1 D^T of a contact problem;
   * RowShardedOperator   -- one process per GPU (torch.distributed, backend "nccl" = RCCL over
                             xGMI): rank r owns the contiguous row block [r*n/G, (r+1)*n/G), all
                             n-vectors are replicated, every rank runs the same host loop.  One
@@ -44,6 +46,9 @@ class DenseOperator:
     def matvec(self, x, y, b=None, g=None, engine=None):
         """y = A.x (and g = y + b); `engine` = the lane to launch on (default: the operator's)."""
         (engine or self.engine).gemv(self.A, x, y, b, g)
+
+    def apply(self, eng, x, y, b=None, g=None):
+        eng.gemv(self.A, x, y, b, g)
 
 
 class VectorExchange:
@@ -194,6 +199,21 @@ class SparseOperator:
     def apply(self, eng, x, y, b=None, g=None):
         eng.spmv_csr(self.rowptr, self.col, self.val, self.plan, self.summary, self.n, x, y, b, g, self.width)
 
+    @property
+    def T(self):
+        """The transposed matrix as a SparseOperator of its own (built once on the device: a stable sort of
+        the entries by column keeps the rows of A in order inside every row of A^T)."""
+        if getattr(self, "_transposed", None) is None:
+            counts = self.rowptr[1:] - self.rowptr[:-1]
+            row_of = torch.repeat_interleave(torch.arange(self.rows, device=self.val.device), counts)
+            order = torch.argsort(self.col.long(), stable=True)
+            rp = torch.zeros(self.n + 1, dtype=torch.int64, device=self.val.device)
+            rp[1:] = torch.cumsum(torch.bincount(self.col.long(), minlength=self.n), 0)
+            self._transposed = SparseOperator((rp, row_of[order].to(torch.int32), self.val[order]),
+                                              shape=(self.n, self.rows), engine=self.engine, check=False,
+                                              width=self.width)
+        return self._transposed
+
     def matvec(self, x, y, b=None, g=None, engine=None):
         self.apply(engine or self.engine, x, y, b, g)
 
@@ -203,6 +223,78 @@ class SparseOperator:
         eng.bind()
         y = torch.empty(self.rows, dtype=torch.float64, device=eng.device)
         self.apply(eng, eng.to_device(x), y)
+        return y
+
+
+class DiagonalOperator:
+    """y = d * x for a diagonal factor (e.g. an inverse mass matrix): one elementwise multiply, rounded once
+    like numpy's `d * x`."""
+
+    def __init__(self, d, engine=None):
+        self.engine = engine or get_engine(d.device if isinstance(d, torch.Tensor) and d.is_cuda else None)
+        self.d = self.engine.to_device(d).reshape(-1)
+        self.rows = self.n = self.d.numel()
+
+    @property
+    def shape(self):
+        return (self.rows, self.n)
+
+    def apply(self, eng, x, y, b=None, g=None):
+        eng.mul(self.d, x, y)
+        if g is not None:
+            eng.axpby(1.0, y, 1.0, b, g)
+
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        self.apply(engine or self.engine, x, y, b, g)
+
+
+class ComposedOperator:
+    """Matrix-free A = F_1 . F_2 ... F_k (+ shift * I): the product is never formed, one matvec applies the
+    factors right to left.  This is the shape of the Hessians CCQPs come from -- e.g. the
+    Delassus operator D M^-1 D^T of a contact problem: `ComposedOperator(D, Minv, D.T, shift=eps)` with D a
+    SparseOperator and Minv a DiagonalOperator.  Factors are DenseOperator / SparseOperator /
+    DiagonalOperator (anything with `apply(engine, x, y)`, `rows`, `n`).  The reference needs only
+    `A.dot(v)`, so the same object-with-a-dot can be handed to it; every intermediate is rounded where
+    numpy rounds (`shift * v` and the final sum are separate operations).  Counts as ONE matvec."""
+
+    def __init__(self, *factors, shift=0.0, engine=None):
+        if not factors:
+            raise ValueError("ComposedOperator needs at least one factor")
+        for left, right in zip(factors[:-1], factors[1:]):
+            if left.n != right.rows:
+                raise ValueError("ComposedOperator: inner dimensions do not match (%d vs %d)" % (left.n, right.rows))
+        if shift != 0.0 and factors[0].rows != factors[-1].n:
+            raise ValueError("ComposedOperator: a shift needs a square product")
+        self.factors = factors
+        self.shift = float(shift)
+        self.engine = engine or factors[-1].engine
+        self.rows, self.n = factors[0].rows, factors[-1].n
+        self.A = self
+
+    @property
+    def shape(self):
+        return (self.rows, self.n)
+
+    def matvec(self, x, y, b=None, g=None, engine=None):
+        eng = engine or self.engine
+        mv0 = eng.mv_executed
+        cur = x
+        last = len(self.factors) - 1
+        for i, f in enumerate(reversed(self.factors)):
+            out = y if (i == last and self.shift == 0.0) else eng.empty(f.rows)
+            f.apply(eng, cur, out)
+            cur = out
+        if self.shift != 0.0:
+            eng.axpby(1.0, cur, self.shift, x, y)          # t + shift * x, `shift * x` rounded first
+        eng.mv_executed = mv0 + 1
+        if g is not None:
+            eng.axpby(1.0, y, 1.0, b, g)
+
+    def dot(self, x):
+        eng = self.engine
+        eng.bind()
+        y = torch.empty(self.rows, dtype=torch.float64, device=eng.device)
+        self.matvec(eng.to_device(x), y)
         return y
 
 

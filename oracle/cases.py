@@ -418,3 +418,34 @@ def sparse_solver_cases():
         add("sirr%d.BBPGDf.lower" % n, p, "BBPGDf", 1e-8, 3000, {"kind": "Lower", "dim": n, "lb": {"fill": -0.25}})
     add("sgen256k8.warm.BBPGD", "sgen:256:8:7", "BBPGD", 1e-9, None, _box_half(256), x0="ramp")
     return cases
+
+
+# ------------------------------------------------------------------ matrix-free (composed) operator cases
+def contact_solver_cases():
+    """Problems 'contact:<m>:<n>:<seed>': A = D diag(minv) D^T + eps I handed to the reference as an object
+    with `.dot` only (oracle/gen_ref.py:ContactHessian).  m constraints, n body coordinates."""
+    cases = []
+
+    def add(cid, problem, solver, tol, mx, op):
+        cases.append(dict(id=cid, problem=problem, solver=solver, tol=tol, max_mv=mx,
+                          kwargs={"step_size": 0.05} if solver == "PGD" else {}, op=op, rng_seed=1234))
+
+    def nonneg(m):
+        return {"kind": "Lower", "dim": m, "lb": {"fill": 0.0}}
+
+    for m, n, seed in ((300, 200, 3), (2000, 3000, 5), (4096, 1024, 7)):
+        p = "contact:%d:%d:%d" % (m, n, seed)
+        tag = "contact%dx%d" % (m, n)
+        add(tag + ".BBPGD.nonneg", p, "BBPGD", 1e-8, 3000, nonneg(m))
+        add(tag + ".APGD.nonneg", p, "APGD", 1e-8, 3000, nonneg(m))
+        add(tag + ".SPG.box", p, "SPG", 1e-8, 3000, _box_half(m))
+        add(tag + ".MPRGP.box", p, "MPRGP", 1e-6, 1500, _box_half(m))
+        add(tag + ".BBPGDf.identity", p, "BBPGDf", 1e-8, 3000, None)
+    for s in ("PGD", "APGDAntiRelaxation"):
+        add("contact300x200.%s.nonneg" % s, "contact:300:200:3", s, 1e-8, 3000, nonneg(300))
+    m = 2000
+    add("contact2000x3000.BBPGD.friction", "contact:2000:3000:5", "BBPGD", 1e-8, 3000,
+        {"kind": "Disjoint", "ops": [{"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 2, "radius": 0.3},
+                                                                    "count": 500}},
+                                     nonneg(m - 1000)]})
+    return cases

@@ -146,6 +146,9 @@ def get_problem(pid):
     elif pid.startswith("sgen:"):
         _, n, k, seed = pid.split(":")
         A, b, _ = gen_ref.sparse_problem(int(n), int(k), int(seed))
+    elif pid.startswith("contact:"):
+        _, m, n, seed = pid.split(":")
+        A, b, _ = gen_ref.contact_problem(int(m), int(n), int(seed))
     elif pid.startswith("sirr:"):
         _, n, seed = pid.split(":")
         A, b, _ = gen_ref.irregular_problem(int(n), int(seed))
@@ -156,18 +159,19 @@ def get_problem(pid):
     return A, b
 
 
-def gen_solvers(sparse=False):
+def gen_solvers(sparse=False, contact=False):
     """sparse=False: the dense cases -> solvers.npz; sparse=True: the reference run with A =
     scipy.sparse.csr_matrix (it only calls `A.dot`) -> sparse.npz, which also holds the CSR arrays of the
     irregular matrices and of one small generated matrix (known-answer vectors for the product generator)."""
-    cases = C.sparse_solver_cases() if sparse else C.solver_cases()
-    stem = "sparse" if sparse else "solvers"
+    cases = C.contact_solver_cases() if contact else C.sparse_solver_cases() if sparse else C.solver_cases()
+    stem = "contact" if contact else "sparse" if sparse else "solvers"
+    sparse = sparse or contact                   # both: A is not a dense array (no entrywise perturbation of A)
     ofac = C.oracle_factory()
     arrays = dict(C.SUITE_ARRAYS)
     out = {}
     meta = []
     t0 = time.time()
-    if sparse:
+    if sparse and not contact:
         K = gen_ref.sparse_spd(64, 4, 5)
         out["kat.sgen:64:4:5.indptr"], out["kat.sgen:64:4:5.indices"], out["kat.sgen:64:4:5.data"] = \
             K.indptr, K.indices, K.data
@@ -177,6 +181,11 @@ def gen_solvers(sparse=False):
         A, b = get_problem(c["problem"])
         n = b.shape[0]
         out[c["problem"] + ".b"] = b
+        if c["problem"].startswith("contact:"):
+            pid = c["problem"]
+            out[pid + ".D.indptr"], out[pid + ".D.indices"], out[pid + ".D.data"] = A.D.indptr, A.D.indices, A.D.data
+            out[pid + ".D.shape"] = np.array(A.D.shape)
+            out[pid + ".minv"], out[pid + ".eps"] = A.minv, np.array(A.eps)
         if c["problem"].startswith("sirr:"):
             out[c["problem"] + ".indptr"], out[c["problem"] + ".indices"], out[c["problem"] + ".data"] = \
                 A.indptr, A.indices, A.data
@@ -273,7 +282,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     only = sys.argv[1:]          # e.g. `gen_golden.py sparse` regenerates just that fixture set
     steps = {"generator": gen_generator, "ops": gen_ops, "pg": gen_pg, "solvers": gen_solvers,
-             "sparse": lambda: gen_solvers(sparse=True)}
+             "sparse": lambda: gen_solvers(sparse=True), "contact": lambda: gen_solvers(contact=True)}
     for name, fn in steps.items():
         if not only or name in only:
             fn()

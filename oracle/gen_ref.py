@@ -170,3 +170,40 @@ def irregular_problem(n, seed):
     A = irregular_spd(n, seed)
     xs = xstar(n, seed)
     return A, -A.dot(xs), xs
+
+
+# ------------------------------------------------------------------ matrix-free "contact" Hessians
+class ContactHessian:
+    """A = D . diag(minv) . D^T + eps * I, never formed: the only thing the reference's solvers need from A is
+    `A.dot(v)` (solvers.py:25), so this object is a legal A for them.  Evaluated exactly as written below --
+    the product-side ComposedOperator(D, Minv, D.T, shift=eps) performs the same sequence of roundings."""
+
+    def __init__(self, D, minv, eps):
+        self.D = D.tocsr()
+        self.Dt = D.T.tocsr()
+        self.minv = np.asarray(minv, dtype=np.float64)
+        self.eps = float(eps)
+        self.shape = (D.shape[0], D.shape[0])
+
+    def dot(self, v):
+        t = self.Dt.dot(v)
+        t = self.minv * t
+        t = self.D.dot(t)
+        return t + self.eps * v
+
+    def toarray(self):
+        return (self.D @ np.diag(self.minv) @ self.D.T.toarray()) + self.eps * np.eye(self.shape[0])
+
+
+def contact_problem(m, n, seed, per_row=6, eps=0.05):
+    """(ContactHessian, b, xstar): D is m x n with ~per_row entries per row (a constraint touches a few
+    bodies), minv in [0.5, 1.5); b = -A.xstar."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    D = sp.random(m, n, density=min(1.0, per_row / n), format="csr", random_state=rng,
+                  data_rvs=lambda s: rng.uniform(-1, 1, s))
+    D.sort_indices()
+    minv = 0.5 + uniform01(vector_key(seed + 1), np.arange(n, dtype=np.uint64))
+    A = ContactHessian(D, minv, eps)
+    xs = xstar(m, seed)
+    return A, -A.dot(xs), xs
