@@ -12,14 +12,17 @@
 // entries (plan word 4), the x gathers are issued in TRANSPOSED order -- consecutive lanes take the same
 // entry position of consecutive rows, (value, column) coming through LDS -- because banded / stencil-like
 // matrices then gather consecutive x, which the L1 merges; in entry order every lane of a gather is a cache
-// access of its own.  A window's last row bypasses LDS when it is longer than SPMV_LONG entries (one wave
+// access of its own.  The columns travel through the LDS region that later holds the products, the gathered x
+// travel back through it to the threads that hold the values: no LDS beyond the products themselves.  A window's last row bypasses LDS when it is longer than SPMV_LONG entries (one wave
 // per row, second launch).
 //
 // Measured (profiles/r01_spmv_*): 4.0-4.6 TB/s of algorithmic bytes on banded matrices with 8..128 entries
-// per row, 0.7-1.3 TB/s when the columns are scrambled (every gather a cache miss).  The same kernel with
-// the gather replaced by arithmetic streams at 7.2 TB/s, and the PMC counters of the full kernel show the
-// texture-address / L1 pipe 76 % busy with 1.5 cache accesses per entry: the x gathers are the bound, not
-// HBM.  Variants that were built and measured slower: a CSR-vector kernel (subgroup per row straight from
+// per row (4.9 TB/s when x fits one XCD's L2, n <= 512k), 0.7-1.3 TB/s when the columns are scrambled (every
+// gather a cache miss).  The same kernel with the gather replaced by arithmetic streams at 7.2 TB/s; with
+// it the time scales with ALL bytes delivered through the vector-memory path -- 12 B of stream + 8 B gathered
+// per entry: 7 TB/s x 12/20 = 4.2 TB/s -- and does not respond to the gather order (1.6 vs 0.85 L1 accesses
+// per entry), to occupancy (5 vs 8 workgroups per CU) or to W: the gathered x is the bound, not the HBM
+// stream.  Variants that were built and measured slower: a CSR-vector kernel (subgroup per row straight from
 // global memory: 2-3 TB/s, one load per lane in flight and half-empty load instructions), several rows per
 // subgroup, and two persistent software-pipelined forms (next window's loads in flight during the reduce:
 // 100+ VGPRs, 4 workgroups per CU, 2.6-3.3 TB/s).
@@ -148,9 +151,7 @@ __device__ __forceinline__ double spmv_subgroup_sum(double v) {
   return v;
 }
 
-// TR: the kernel can run windows in transposed gather order (8 KB more LDS: 6 instead of 8 workgroups per
-// CU); without it such windows are streamed in entry order like the others.
-template <int W, bool EPI, bool TR>
+template <int W, bool EPI>
 __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* __restrict__ rowptr,
                                                                  const int32_t* __restrict__ col,
                                                                  const double* __restrict__ val,
@@ -162,12 +163,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   constexpr int SUBGROUPS = CCQP_BLOCK / W;
   __shared__ double prod[SPMV_LDS];
   __shared__ uint16_t rstart[SPMV_ROWS_LDS + 2];      // row starts relative to the window
-  __shared__ int32_t colv[TR ? SPMV_LDS : 1];         // transposed windows: the column indices
+  // transposed windows pass the column indices through the first half of `prod` before any product exists
+  int32_t* const colv = reinterpret_cast<int32_t*>(prod);
   const int64_t* pw = plan + (int64_t)SPMV_PLAN_WORDS * blockIdx.x;
   const int64_t rb = pw[0], re = pw[1], nzb = pw[2];
   const int E = (int)(pw[3] - nzb);          // < SPMV_LDS by construction of the plan
-  const int longest = TR ? (int)(pw[4] & 0xffffffff) : 0;
-  const bool uniform = TR && (pw[4] & SPMV_UNIFORM);
+  const int longest = (int)(pw[4] & 0xffffffff);
+  const bool uniform = (pw[4] & SPMV_UNIFORM) != 0;
   const int t = threadIdx.x;
   const int l = t % W;
   const int64_t nrows = re - rb;
@@ -201,15 +203,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
     for (int i = t + 2 * CCQP_BLOCK; i <= (int)nrows; i += CCQP_BLOCK)      // > 511 rows in one window: rare
       rstart[i] = (uint16_t)(rowptr[rb + i] - nzb);
   }
-  if (TR && longest > 0) {
-    // transposed window: (a) park values and columns in LDS
+  if (longest > 0) {
+    // transposed window: (a) the column indices -> LDS
 #pragma unroll
     for (int j = 0; j < SPMV_SLOTS; ++j) {
       const int e = t + j * CCQP_BLOCK;
-      if (e < E) {
-        prod[e] = v[j];
-        colv[e] = c[j];
-      }
+      if (e < E) colv[e] = c[j];
     }
     __syncthreads();
     // (b) thread p of the (position, row) grid takes position p / nr of row p % nr: consecutive lanes
@@ -243,9 +242,17 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
     }
 #pragma unroll
     for (int j = 0; j < SPMV_SLOTS; ++j) xv[j] = x[cc[j]];
+    __syncthreads();                          // every column index has been read: `prod` may be overwritten
+    // (c) the gathered x travel back to the entries' owners (who hold the values), again through LDS
 #pragma unroll
     for (int j = 0; j < SPMV_SLOTS; ++j)
-      if (ok[j]) prod[e[j]] = prod[e[j]] * xv[j];
+      if (ok[j]) prod[e[j]] = xv[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int eo = t + j * CCQP_BLOCK;
+      if (eo < E) prod[eo] = v[j] * prod[eo];
+    }
   } else {
     double xv[SPMV_SLOTS];
 #pragma unroll
@@ -385,18 +392,15 @@ static int spmv_pick_width(int64_t rows, int64_t nnz, int width) {
 }
 
 template <int W>
-static void spmv_launch(unsigned grid, bool tr, const int64_t* rowptr, const int32_t* col, const double* val,
+static void spmv_launch(unsigned grid, const int64_t* rowptr, const int32_t* col, const double* val,
                         const int64_t* plan, const double* x, const double* b, double* y, double* g, int64_t nnz,
                         hipStream_t s) {
-#define SPMV_GO(EPI, TR)                                                                                          \
-  hipLaunchKernelGGL((spmv_stream_kernel<W, EPI, TR>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, \
-                     x, b, y, g, nnz - 1)
-  if (g) {
-    if (tr) SPMV_GO(true, true); else SPMV_GO(true, false);
-  } else {
-    if (tr) SPMV_GO(false, true); else SPMV_GO(false, false);
-  }
-#undef SPMV_GO
+  if (g)
+    hipLaunchKernelGGL((spmv_stream_kernel<W, true>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, x,
+                       b, y, g, nnz - 1);
+  else
+    hipLaunchKernelGGL((spmv_stream_kernel<W, false>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, x,
+                       b, y, g, nnz - 1);
 }
 
 extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
@@ -423,16 +427,14 @@ extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int
     return CCQP_OK;
   }
   const unsigned grid = (unsigned)nwin;
-  // summary (host copy of the plan's two counters) unknown: assume long rows and transposed windows exist.
-  // The transposed-capable kernel holds fewer workgroups per CU: worth it from a quarter of the windows on.
+  // summary (host copy of the plan's two counters) unknown: assume rows for the wave-per-row launch exist
   const int64_t n_long_rows = summary ? summary[0] : -1;
-  const bool tr = summary ? 4 * summary[1] >= nwin : true;
   switch (spmv_pick_width(rows, nnz, width)) {
-    case 4: spmv_launch<4>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 8: spmv_launch<8>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 16: spmv_launch<16>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 32: spmv_launch<32>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    default: spmv_launch<64>(grid, tr, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 4: spmv_launch<4>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 8: spmv_launch<8>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 16: spmv_launch<16>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 32: spmv_launch<32>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    default: spmv_launch<64>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
   }
   if (n_long_rows != 0) {                    // < 0: unknown to the caller, the kernel reads the count
     const int64_t* count = plan + SPMV_PLAN_WORDS * nwin;

@@ -229,7 +229,7 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  *         gather x in transposed order, and the list of rows that take the wave-per-row launch instead.
  *   summary (optional, 2 host words): {rows on the wave-per-row path, windows in transposed order}.
  *         Asking for it makes the plan call blocking; handing it to the matvec lets it skip the second
- *         launch and pick the leaner kernel (NULL = unknown: both are assumed to exist).
+ *         launch when no row needs it (NULL = unknown: launched, the kernel reads the count).
  * Bits of y[i]: a function of row i's stored entries (in storage order) and x only -- not of the plan,
  * not of `width` (lanes that reduce one row: 0 = from the mean row length; 4, 8, 16, 32, 64 to force),
  * not of how the rows are sharded over GPUs: p_e = fl(val_e * x[col_e]); canonical lane e mod 64 adds its
