@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
-    ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=65536, help="size of the CPU-baseline sample (0 = skip); 65536: ~20 s of host work")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
