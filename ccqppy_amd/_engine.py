@@ -208,6 +208,20 @@ class Engine:
         if rc:
             _lib.check(rc)
 
+    def axpby2(self, a1, x1, b1, y1, out1, a2, x2, b2, y2, out2):
+        """out1 = a1*x1 + b1*y1 and out2 = a2*x2 + b2*y2 in one launch."""
+        rc = self.lib.ccqp_axpby2_f64(self.ctx, a1, x1.data_ptr(), b1, y1.data_ptr(), out1.data_ptr(), a2,
+                                      x2.data_ptr(), b2, y2.data_ptr(), out2.data_ptr(), out1.numel(), self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def proj_elementwise_sub(self, seg, x, out, a, b, y, z):
+        """out = P(a*x + b*y) - z for an elementwise set."""
+        rc = self.lib.ccqp_proj_elementwise_sub_f64(self.ctx, seg, a, x.data_ptr(), b, y.data_ptr(), z.data_ptr(),
+                                                    out.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
+
     def scale(self, a, x, out):
         rc = self.lib.ccqp_scale_f64(self.ctx, a, x.data_ptr(), out.data_ptr(), out.numel(), self.stream)
         if rc:
@@ -276,6 +290,37 @@ class Engine:
     def residual_sq_elementwise(self, seg, x, g, c, gd, slot):
         rc = self.lib.ccqp_residual_sq_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), c, gd, slot,
                                                        self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def fused_dots(self, pairs, slot0=0, residual=None):
+        """pairs: [(a, b)] where a / b is a vector or a tuple (u, v) standing for u - v; slots slot0.. get the dot
+        products, and with residual=(seg, x, g, c, gd, slot) that slot gets the Eq. 25 residual^2 -- one launch."""
+        k = len(pairs)
+        tabs = [(ctypes.c_void_p * k)() for _ in range(4)]
+        n = None
+        for j, (a, b) in enumerate(pairs):
+            for base, opnd in ((0, a), (2, b)):
+                if isinstance(opnd, tuple):
+                    tabs[base][j], tabs[base + 1][j] = opnd[0].data_ptr(), opnd[1].data_ptr()
+                    n = opnd[0].numel()
+                else:
+                    tabs[base][j], tabs[base + 1][j] = opnd.data_ptr(), None
+                    n = opnd.numel()
+        if residual is None:
+            rc = self.lib.ccqp_fused_dots_f64(self.ctx, k, tabs[0], tabs[1], tabs[2], tabs[3], n, slot0, None, None,
+                                              None, 0.0, 0.0, 0, self.stream)
+        else:
+            seg, rx, rg, c, gd, rslot = residual
+            rc = self.lib.ccqp_fused_dots_f64(self.ctx, k, tabs[0], tabs[1], tabs[2], tabs[3], n, slot0, seg,
+                                              rx.data_ptr(), rg.data_ptr(), c, gd, rslot, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def bb_tail_elementwise(self, seg, x_new, x_old, g_new, g_old, c, gd, slot0):
+        """slots [slot0, slot0+3) = residual^2(x_new, g_new), dx.dx, dx.dg in one launch."""
+        rc = self.lib.ccqp_bb_tail_elementwise_f64(self.ctx, seg, x_new.data_ptr(), x_old.data_ptr(),
+                                                   g_new.data_ptr(), g_old.data_ptr(), c, gd, slot0, self.stream)
         if rc:
             _lib.check(rc)
 

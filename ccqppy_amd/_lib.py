@@ -70,6 +70,7 @@ SIGNATURES = {
     "ccqp_gemv_f64": [_P, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
     "ccqp_axpby_f64": [_P, _D, _P, _D, _P, _P, _I64, _P],
+    "ccqp_axpby2_f64": [_P, _D, _P, _D, _P, _P, _D, _P, _D, _P, _P, _I64, _P],
     "ccqp_scale_f64": [_P, _D, _P, _P, _I64, _P],
     "ccqp_copy_f64": [_P, _P, _P, _I64, _P],
     "ccqp_fill_f64": [_P, _D, _P, _I64, _P],
@@ -78,9 +79,13 @@ SIGNATURES = {
     "ccqp_submul_f64": [_P, _P, _P, _P, _P, _I64, _P],
     "ccqp_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _I64, _I, _P],
     "ccqp_proj_elementwise_f64": [_P, _c.POINTER(Seg), _D, _P, _D, _P, _P, _P],
+    "ccqp_proj_elementwise_sub_f64": [_P, _c.POINTER(Seg), _D, _P, _D, _P, _P, _P, _P],
     "ccqp_proj_normscale_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
     "ccqp_proj_small_segments_f64": [_P, _P, _I64, _P, _P, _I, _P],
     "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
+    "ccqp_fused_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _I64, _I,
+                            _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
+    "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],
     "ccqp_feasible_steps_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _I, _I, _P],

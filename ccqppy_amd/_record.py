@@ -94,6 +94,15 @@ class RecordingEngine(Engine):
         n = out.numel()
         self._rec(_lib.BOP_AXPBY, (_lib.BOP_AXPBY, n), (x, y, out), (a, b), n=n)
 
+    def axpby2(self, a1, x1, b1, y1, out1, a2, x2, b2, y2, out2):
+        self.axpby(a1, x1, b1, y1, out1)
+        self.axpby(a2, x2, b2, y2, out2)
+
+    def proj_elementwise_sub(self, seg, x, out, a, b, y, z):
+        t = self.empty(out.numel())
+        self.proj_elementwise(seg, x, t, a, b, y)
+        self.axpby(1.0, t, -1.0, z, out)
+
     def scale(self, a, x, out):
         n = out.numel()
         self._rec(_lib.BOP_SCALE, (_lib.BOP_SCALE, n), (x, out), (a,), n=n)
@@ -125,6 +134,31 @@ class RecordingEngine(Engine):
     def residual_sq_elementwise(self, seg, x, g, c, gd, slot):
         self._rec(_lib.BOP_RESIDUAL_ELEM, (_lib.BOP_RESIDUAL_ELEM, seg.dim), (x, g), (c, gd), slots=(slot,), k=1,
                   seg=seg)
+
+    def fused_dots(self, pairs, slot0=0, residual=None):
+        # batched form: materialise the differences, then the plain batched dots / residual (same bits)
+        flat = []
+        for a, b in pairs:
+            ops = []
+            for opnd in (a, b):
+                if isinstance(opnd, tuple):
+                    d = self.empty(opnd[0].numel())
+                    self.axpby(1.0, opnd[0], -1.0, opnd[1], d)
+                    opnd = d
+                ops.append(opnd)
+            flat.append(tuple(ops))
+        self.dots(flat, slot0)
+        if residual is not None:
+            seg, rx, rg, c, gd, rslot = residual
+            self.residual_sq_elementwise(seg, rx, rg, c, gd, rslot)
+
+    def bb_tail_elementwise(self, seg, x_new, x_old, g_new, g_old, c, gd, slot0):
+        # the batched form keeps the four operations the fused kernel stands for (bitwise the same results)
+        self.residual_sq_elementwise(seg, x_new, g_new, c, gd, slot0)
+        dx, dg = self.empty(x_new.numel()), self.empty(x_new.numel())
+        self.axpby(1.0, x_new, -1.0, x_old, dx)
+        self.axpby(1.0, g_new, -1.0, g_old, dg)
+        self.dots([(dx, dx), (dx, dg)], slot0 + 1)
 
     def feasible_steps_elementwise(self, seg, x, p, alpha0, K, slot0):
         self._rec(_lib.BOP_FEASIBLE_ELEM, (_lib.BOP_FEASIBLE_ELEM, seg.dim, K), (x, p), (alpha0,), slots=(slot0,),

@@ -128,21 +128,17 @@ __global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage1(const ccqp_bop* t,
         dst[bx] = sb;
         dst[nblk + bx] = sp;
       }
+      if (nblk > 1) ccqp_reduce_finish(dst, nblk, 2, ccqp_red_counters(o.partials), o.slab + o.slot[0], lds4);
       return;
     }
     default:
       break;
   }
   if (threadIdx.x == 0) dst[(int64_t)j * nblk + bx] = s;
-}
-
-// grid (k, count): slab[slot0 + j] = sum of the problem's partials of reduction j
-__global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage2(const ccqp_bop* t, int nblk) {
-  __shared__ double lds4[4];
-  const ccqp_bop& o = t[blockIdx.y];
-  const int j = blockIdx.x;
-  const double s = partial_sum_body(o.partials + (int64_t)j * nblk, nblk, lds4);
-  if (threadIdx.x == 0) o.slab[o.slot[0] + j] = s;
+  // several blocks per reduction: the block of this problem's reduction j that finishes last adds the partials
+  if (nblk > 1)
+    ccqp_reduce_finish(dst + (int64_t)j * nblk, nblk, 1, ccqp_red_counters(o.partials) + j, o.slab + o.slot[0] + j,
+                       lds4);
 }
 
 // ------------------------------------------------------------------ matvec group
@@ -206,10 +202,9 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
       int64_t chunk;
       int nblk;
       ccqp_red_geometry(n, &chunk, &nblk);
-      CCQP_REQUIRE((int64_t)k * nblk <= (int64_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK, "k * blocks exceeds the workspace");
+      CCQP_REQUIRE((int64_t)k * nblk <= (int64_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK, "k * blocks exceeds the workspace");
       const int gy = opcode == CCQP_BOP_MPRGP_PROPORTION ? 1 : k;
       hipLaunchKernelGGL(b_reduce_stage1, dim3(nblk, gy, count), dim3(CCQP_BLOCK), 0, s, dev, opcode, chunk, nblk);
-      if (nblk > 1) hipLaunchKernelGGL(b_reduce_stage2, dim3(k, count), dim3(CCQP_BLOCK), 0, s, dev, nblk);
       return CCQP_OK;
     }
     case CCQP_BOP_GEMV: {

@@ -111,6 +111,37 @@ __device__ __forceinline__ double residual_body(const ccqp_segk& sg, const doubl
   return ccqp_block_sum(acc, lds4);
 }
 
+// Fused tail of a Barzilai-Borwein iteration (solvers.py:647-656 and the BBPGDf / PGD analogues): ONE pass
+// over (x_new, x_old, g_new, g_old) yields the three block sums that residual_body on (x_new, g_new),
+// dot_body(dx, dx) and dot_body(dx, dg) would give with dx = x_new - x_old, dg = g_new - g_old materialised
+// first (each difference is rounded once, exactly like the axpby it replaces): same thread -> element map, same
+// fma chains, so the bits are those of the four separate launches.
+__device__ __forceinline__ void bb_tail_body(const ccqp_segk& sg, const double* xn, const double* xo,
+                                             const double* gn, const double* go, double c, double gd,
+                                             int64_t chunk, int bx, double* lds4, double* res2, double* dxdx,
+                                             double* dxdg) {
+  CHUNK_RANGE(sg.dim)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double xi = xn[i], gi = gn[i];
+    const double t = gd * gi;
+    const double u = xi - t;
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+    const double d = xi - p;
+    const double v = c * d;
+    a0 = fma(v, v, a0);
+    const double dx = xi - xo[i];
+    const double dg = gi - go[i];
+    a1 = fma(dx, dx, a1);
+    a2 = fma(dx, dg, a2);
+  }
+  *res2 = ccqp_block_sum(a0, lds4);
+  *dxdx = ccqp_block_sum(a1, lds4);
+  *dxdg = ccqp_block_sum(a2, lds4);
+}
+
 // count of i with not isclose(yf_i, P(yf)_i), yf = x - (alpha0 * 0.5^k)*p
 __device__ __forceinline__ double feasible_body(const ccqp_segk& sg, const double* x, const double* p,
                                                 double alpha0, int k, int64_t chunk, int bx, double* lds4) {

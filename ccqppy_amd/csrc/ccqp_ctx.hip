@@ -12,6 +12,20 @@ void ccqp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Blocking scalar read without the copy engine and without an interrupt-driven stream wait: one wave
+// copies the requested slots into the pinned, coherent host mirror and then raises a sequence flag; the host
+// polls the flag (ccqp_scalars_read).  13.5 us -> ~5 us per read on an idle stream, and every solver
+// iteration has one to three of them.
+__global__ void publish_slots_kernel(const double* __restrict__ slots, double* __restrict__ host, int slot0,
+                                     int count, unsigned long long seq) {
+  const int i = threadIdx.x;
+  if (i < count) host[slot0 + i] = slots[slot0 + i];
+  __threadfence_system();                       // the wave's stores have reached host memory ...
+  if (i == 0)                                   // ... before the flag does
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + CCQP_NUM_SLOTS), seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" int ccqp_abi_version(void) { return CCQP_ABI_VERSION; }
 
 extern "C" const char* ccqp_last_error(void) { return g_err; }
@@ -35,6 +49,8 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->slots = nullptr;
   c->partials = nullptr;
   c->host_slots = nullptr;
+  c->host_slots_dev = nullptr;
+  c->read_seq = 0;
   c->read_event = nullptr;
   c->batch = nullptr;
   c->mv_serialize = 0;
@@ -43,8 +59,12 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->gather_dev = nullptr;
   c->gather_host = nullptr;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&c->partials, (size_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK * sizeof(double));
-  if (e == hipSuccess) e = hipHostMalloc(&c->host_slots, CCQP_NUM_SLOTS * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&c->partials, CCQP_PARTIALS_DOUBLES * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(c->partials, 0, CCQP_PARTIALS_DOUBLES * sizeof(double));
+  if (e == hipSuccess)
+    e = hipHostMalloc(&c->host_slots, (CCQP_NUM_SLOTS + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) memset(c->host_slots, 0, (CCQP_NUM_SLOTS + 8) * sizeof(double));
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->host_slots_dev, c->host_slots, 0);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->read_event, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(c->slots, 0, CCQP_NUM_SLOTS * sizeof(double));
   if (e != hipSuccess) {
@@ -93,10 +113,26 @@ extern "C" int ccqp_scalars_read(ccqp_ctx* c, int slot0, int count, double* host
   CCQP_REQUIRE(host_out != nullptr, "host_out is NULL");
   CCQP_REQUIRE(ccqp_slot_ok(slot0, count), "slot range outside the slab");
   hipStream_t s = (hipStream_t)stream;
-  if (count > 0)
-    CCQP_HIP(hipMemcpyAsync(c->host_slots + slot0, c->slots + slot0, (size_t)count * sizeof(double),
-                            hipMemcpyDeviceToHost, s));
-  CCQP_HIP(hipStreamSynchronize(s));
+  CCQP_REQUIRE(count <= 64, "at most 64 slots per read");
+  const unsigned long long seq = ++c->read_seq;
+  hipLaunchKernelGGL(publish_slots_kernel, dim3(1), dim3(64), 0, s, c->slots, c->host_slots_dev, slot0, count, seq);
+  CCQP_LAUNCH_CHECK();
+  // poll briefly (the common case at small and medium n: the GPU is a few microseconds behind), then
+  // fall back to a sleeping wait -- the flag is certainly up once the stream has drained
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->host_slots + CCQP_NUM_SLOTS);
+  bool up = false;
+  for (int spin = 0; spin < 20000; ++spin) {
+    if (*flag == seq) {
+      up = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!up) {
+    CCQP_HIP(hipStreamSynchronize(s));
+    CCQP_REQUIRE(*flag == seq, "published scalars did not arrive");
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int i = 0; i < count; ++i) host_out[i] = c->host_slots[slot0 + i];
   return CCQP_OK;
 }

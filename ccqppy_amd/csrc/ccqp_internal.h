@@ -10,6 +10,9 @@
 #define CCQP_BLOCK 256          // 4 wave64 per workgroup
 #define CCQP_RED_CHUNK 2048     // elements per stage-1 reduction block (8 per thread)
 #define CCQP_RED_MAXBLK 1024    // stage-1 blocks per reduction (partials per dot)
+#define CCQP_RED_COUNTERS 32    // arrival counters behind the partials (one per reduction of a launch)
+#define CCQP_RED_ROWS (CCQP_MAX_STEPS + 1)   // rows of CCQP_RED_MAXBLK partials: up to 16 sums per launch + 1
+#define CCQP_PARTIALS_DOUBLES ((size_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK + CCQP_RED_COUNTERS / 2)
 
 struct ccqp_batch;                 // descriptor ring of the batched launch form (ccqp_batch.hip)
 void ccqp_batch_free(struct ccqp_ctx* ctx);
@@ -24,8 +27,10 @@ struct ccqp_ctx {
   int num_cu;
   char arch[64];
   double* slots;      // device, CCQP_NUM_SLOTS doubles
-  double* partials;   // device, CCQP_MAX_DOTS * CCQP_RED_MAXBLK doubles
-  double* host_slots; // pinned host mirror
+  double* partials;   // device, CCQP_PARTIALS_DOUBLES doubles: partial sums, then the arrival counters
+  double* host_slots; // pinned, coherent host mirror (CCQP_NUM_SLOTS doubles + the publish flag behind them)
+  double* host_slots_dev;       // the same memory as the device sees it
+  unsigned long long read_seq;  // sequence number of the last published read
   hipEvent_t read_event;  // marks the end of the last ccqp_scalars_read_async copy
 };
 
@@ -92,6 +97,36 @@ __device__ __forceinline__ double ccqp_block_sum(double v, double* lds4) {
   if (threadIdx.x == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
   __syncthreads();
   return s;
+}
+
+// Arrival counters of a reduction workspace (`partials` of a context): they sit behind the partial sums.
+__device__ __forceinline__ unsigned* ccqp_red_counters(double* partials) {
+  return reinterpret_cast<unsigned*>(partials + (size_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK);
+}
+
+// Single-launch reductions.  Thread 0 of every block has just stored the block's partial sum(s); the block
+// that arrives LAST at the counter adds the `nred` rows of `nblk` partials -- always in index order, whichever
+// block that is, so the result is the one the former second kernel produced -- and writes out[0..nred).
+// Protocol (guide, "inter-workgroup visibility"): release fence by the storing thread, agent-scope counter,
+// acquire fence by one lane, barrier, then plain loads.  The counter is left at zero for the next launch.
+__device__ __forceinline__ void ccqp_reduce_finish(const double* partials, int nblk, int nred, unsigned* counter,
+                                                   double* out, double* lds4) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned prev = atomicAdd(counter, 1u);
+    is_last = prev + 1u == (unsigned)nblk;
+    if (is_last) __threadfence();
+  }
+  __syncthreads();
+  if (!is_last) return;
+  for (int r = 0; r < nred; ++r) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += partials[(int64_t)r * nblk + i];
+    const double s = ccqp_block_sum(acc, lds4);
+    if (threadIdx.x == 0) out[r] = s;
+  }
+  if (threadIdx.x == 0) *counter = 0u;
 }
 
 // np.isclose(a, b) with the default rtol=1e-5, atol=1e-8 (numpy/_core/numeric.py):

@@ -6,7 +6,6 @@
 // tests/test_gpu_batch.py) in 5 launches instead of 14.
 #include "ccqp_bodies.h"
 
-int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s);
 
 static inline int vec_grid(int64_t n) {
   int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
@@ -37,10 +36,11 @@ static int elementwise_seg_ok(const ccqp_seg* seg) {
 // ---- K1: xp = P(x); delta = isclose(x, xp); psi = delta*g; w = 1-delta; sum (x-xp)^2 -> dst
 __global__ __launch_bounds__(CCQP_BLOCK) void split_stage1(ccqp_segk sg, const double* x, const double* g,
                                                            double* xp, double* psi, double* w, int64_t chunk,
-                                                           double* dst) {
+                                                           double* dst, int nblk, double* slot) {
   __shared__ double lds4[4];
   const double s = split_body(sg, x, g, xp, psi, w, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 1, ccqp_red_counters(dst), slot, lds4);
 }
 
 extern "C" int ccqp_mprgp_split_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, const double* g,
@@ -58,8 +58,7 @@ extern "C" int ccqp_mprgp_split_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const do
   ccqp_red_geometry(k.dim, &chunk, &nblk);
   double* dst = nblk == 1 ? ctx->slots + dist2_slot : ctx->partials;
   hipLaunchKernelGGL(split_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, x + o, g + o, xp + o, psi + o, w + o,
-                     chunk, dst);
-  if (nblk > 1) ccqp_launch_stage2(ctx, 1, nblk, dist2_slot, s);
+                     chunk, dst, nblk, ctx->slots + dist2_slot);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -67,10 +66,12 @@ extern "C" int ccqp_mprgp_split_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const do
 // ---- K2: nv = normal_vector from xp (+ the "outside => zeros" rule); sum nv*g -> dst
 __global__ __launch_bounds__(CCQP_BLOCK) void normal_dot_stage1(ccqp_segk sg, const double* xp, const double* g,
                                                                 double* nvout, const double* dist2,
-                                                                int64_t chunk, double* dst) {
+                                                                int64_t chunk, double* dst, int nblk,
+                                                                double* slot) {
   __shared__ double lds4[4];
   const double s = normal_dot_body(sg, xp, g, nvout, *dist2, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 1, ccqp_red_counters(dst), slot, lds4);
 }
 
 extern "C" int ccqp_mprgp_normal_dot_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* xp, const double* g,
@@ -88,8 +89,7 @@ extern "C" int ccqp_mprgp_normal_dot_f64(ccqp_ctx* ctx, const ccqp_seg* seg, con
   ccqp_red_geometry(k.dim, &chunk, &nblk);
   double* dst = nblk == 1 ? ctx->slots + ng_slot : ctx->partials;
   hipLaunchKernelGGL(normal_dot_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, xp + o, g + o, nv + o,
-                     ctx->slots + dist2_slot, chunk, dst);
-  if (nblk > 1) ccqp_launch_stage2(ctx, 1, nblk, ng_slot, s);
+                     ctx->slots + dist2_slot, chunk, dst, nblk, ctx->slots + ng_slot);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -98,7 +98,7 @@ extern "C" int ccqp_mprgp_normal_dot_f64(ccqp_ctx* ctx, const ccqp_seg* seg, con
 __global__ __launch_bounds__(CCQP_BLOCK) void proportion_stage1(const double* w, const double* g,
                                                                 const double* nv, const double* psi,
                                                                 const double* ng, int64_t n, int64_t chunk,
-                                                                double* dst, int nblk) {
+                                                                double* dst, int nblk, double* slots) {
   __shared__ double lds4[4];
   double sb, sp;
   proportion_body(w, g, nv, psi, *ng, n, chunk, blockIdx.x, lds4, &sb, &sp);
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void proportion_stage1(const double* w,
     dst[blockIdx.x] = sb;
     dst[nblk + blockIdx.x] = sp;
   }
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 2, ccqp_red_counters(dst), slots, lds4);
 }
 
 extern "C" int ccqp_mprgp_proportion_f64(ccqp_ctx* ctx, const double* w, const double* g, const double* nv,
@@ -120,8 +121,7 @@ extern "C" int ccqp_mprgp_proportion_f64(ccqp_ctx* ctx, const double* w, const d
   ccqp_red_geometry(n, &chunk, &nblk);
   double* dst = nblk == 1 ? ctx->slots + slot0 : ctx->partials;
   hipLaunchKernelGGL(proportion_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, w, g, nv, psi, ctx->slots + ng_slot, n,
-                     chunk, dst, nblk);
-  if (nblk > 1) ccqp_launch_stage2(ctx, 2, nblk, slot0, s);
+                     chunk, dst, nblk, ctx->slots + slot0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -5,7 +5,6 @@
 // Built with -ffp-contract=off: every elementwise expression rounds once per operation like numpy.
 #include "ccqp_bodies.h"
 
-int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s);
 
 static inline int vec_grid(int64_t n) {
   int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
@@ -56,6 +55,36 @@ extern "C" int ccqp_proj_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, dou
   const ccqp_segk k = seg_by_value(seg);
   hipLaunchKernelGGL(proj_elem_kernel, dim3(vec_grid(k.dim)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, k,
                      a, x + seg->offset, b, y ? y + seg->offset : nullptr, out + seg->offset);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// out = P(a*x + b*y) - z : the SPG search direction d = P(x - alpha*g) - x (solvers.py:937) in one launch
+__global__ __launch_bounds__(CCQP_BLOCK) void proj_elem_sub_kernel(ccqp_segk sg, double a, const double* x, double b,
+                                                                   const double* y, const double* z, double* out) {
+  VEC_LOOP(i, sg.dim) {
+    const double t1 = a * x[i];
+    const double t2 = b * y[i];
+    const double u = t1 + t2;
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double p = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+    out[i] = p - z[i];
+  }
+}
+
+extern "C" int ccqp_proj_elementwise_sub_f64(ccqp_ctx* ctx, const ccqp_seg* seg, double a, const double* x,
+                                             double b, const double* y, const double* z, double* out,
+                                             void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = seg_check(seg, true);
+  if (rc) return rc;
+  if (seg->dim == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && y && z && out, "NULL vector");
+  const ccqp_segk k = seg_by_value(seg);
+  const int64_t o = seg->offset;
+  hipLaunchKernelGGL(proj_elem_sub_kernel, dim3(vec_grid(k.dim)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, k, a,
+                     x + o, b, y + o, z + o, out + o);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -222,10 +251,11 @@ extern "C" int ccqp_proj_small_segments_f64(ccqp_ctx* ctx, const ccqp_seg* table
 // ------------------------------------------------------------------ residual^2 (elementwise ops)
 __global__ __launch_bounds__(CCQP_BLOCK) void residual_stage1(ccqp_segk sg, const double* x, const double* g,
                                                               double c, double gd, int64_t chunk,
-                                                              double* dst) {
+                                                              double* dst, int nblk, double* slot) {
   __shared__ double lds4[4];
   const double s = residual_body(sg, x, g, c, gd, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 1, ccqp_red_counters(dst), slot, lds4);
 }
 
 extern "C" int ccqp_residual_sq_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
@@ -243,14 +273,8 @@ extern "C" int ccqp_residual_sq_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* s
   ccqp_red_geometry(k.dim, &chunk, &nblk);
   const double* xs = x ? x + seg->offset : x;
   const double* gs = g ? g + seg->offset : g;
-  if (nblk == 1) {
-    hipLaunchKernelGGL(residual_stage1, dim3(1), dim3(CCQP_BLOCK), 0, s, k, xs, gs, c, gd, chunk,
-                       ctx->slots + slot);
-  } else {
-    hipLaunchKernelGGL(residual_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, xs, gs, c, gd, chunk,
-                       ctx->partials);
-    ccqp_launch_stage2(ctx, 1, nblk, slot, s);
-  }
+  hipLaunchKernelGGL(residual_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, xs, gs, c, gd, chunk,
+                     nblk == 1 ? ctx->slots + slot : ctx->partials, nblk, ctx->slots + slot);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -279,7 +303,8 @@ extern "C" int ccqp_isclose_mask_mul_f64(ccqp_ctx* ctx, const double* a, const d
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void count_notclose_stage1(const double* a, const double* b,
-                                                                    int64_t n, int64_t chunk, double* dst) {
+                                                                    int64_t n, int64_t chunk, double* dst,
+                                                                    int nblk, double* slot) {
   __shared__ double lds4[4];
   const int64_t lo = (int64_t)blockIdx.x * chunk;
   int64_t hi = lo + chunk;
@@ -288,6 +313,137 @@ __global__ __launch_bounds__(CCQP_BLOCK) void count_notclose_stage1(const double
   for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) acc += ccqp_isclose(a[i], b[i]) ? 0.0 : 1.0;
   const double s = ccqp_block_sum(acc, lds4);
   if (threadIdx.x == 0) dst[blockIdx.x] = s;
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 1, ccqp_red_counters(dst), slot, lds4);
+}
+
+// ---- fused dots (+ residual): k dot products whose operands may be DIFFERENCES of two vectors, and
+// optionally the Eq. 25 residual^2, in one pass.  Pair j: a = a1[j] - a2[j] (a2[j] NULL: a = a1[j]), same for
+// b; every difference is rounded once and every pair keeps its own fma chain over the same thread -> element
+// map as dot_body, so slab[slot0 + j] has the bits ccqp_dots_f64 gives on materialised differences, and
+// slab[slot0 + k] those of ccqp_residual_sq_elementwise_f64.
+struct fused_dots_args {
+  const double* a1[CCQP_MAX_DOTS];
+  const double* a2[CCQP_MAX_DOTS];
+  const double* b1[CCQP_MAX_DOTS];
+  const double* b2[CCQP_MAX_DOTS];
+};
+
+// grid (nblk, k + RES): row j < k is dot pair j, row k the residual -- the rows run side by side like the
+// (nblk, k) grid of ccqp_dots_f64; each row has its own arrival counter.
+template <bool RES>
+__global__ __launch_bounds__(CCQP_BLOCK) void fused_dots_stage1(fused_dots_args a, int k, ccqp_segk sg,
+                                                                const double* rx, const double* rg, double c,
+                                                                double gd, int64_t n, int64_t chunk, double* dst,
+                                                                int nblk, double* slots, double* rslot) {
+  __shared__ double lds4[4];
+  const int bx = blockIdx.x, j = blockIdx.y;
+  double s;
+  if (RES && j == k) {
+    s = residual_body(sg, rx, rg, c, gd, chunk, bx, lds4);
+  } else {
+    const int64_t lo = (int64_t)bx * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    const double* __restrict__ a1 = a.a1[j];
+    const double* __restrict__ a2 = a.a2[j];
+    const double* __restrict__ b1 = a.b1[j];
+    const double* __restrict__ b2 = a.b2[j];
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      double u = a1[i], v = b1[i];
+      if (a2) u = u - a2[i];
+      if (b2) v = v - b2[i];
+      acc = fma(u, v, acc);
+    }
+    s = ccqp_block_sum(acc, lds4);
+  }
+  // nblk == 1: dst is the slab itself (row j -> slot0 + j; the residual row -> its own slot)
+  double* out = (RES && j == k) ? rslot : slots + j;
+  if (nblk == 1) {
+    if (threadIdx.x == 0) *out = s;
+    return;
+  }
+  if (threadIdx.x == 0) dst[(int64_t)j * nblk + bx] = s;
+  ccqp_reduce_finish(dst + (int64_t)j * nblk, nblk, 1, ccqp_red_counters(dst) + j, out, lds4);
+}
+
+extern "C" int ccqp_fused_dots_f64(ccqp_ctx* ctx, int k, const double* const* a1, const double* const* a2,
+                                   const double* const* b1, const double* const* b2, int64_t n, int slot0,
+                                   const ccqp_seg* res_seg, const double* res_x, const double* res_g, double c,
+                                   double gd, int res_slot, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(k >= 1 && k <= CCQP_MAX_DOTS, "k outside [1, CCQP_MAX_DOTS]");
+  CCQP_REQUIRE(n >= 0, "negative size");
+  const bool res = res_seg != nullptr;
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, k) && (!res || ccqp_slot_ok(res_slot, 1)), "slot range outside the slab");
+  CCQP_REQUIRE(!res || res_slot < slot0 || res_slot >= slot0 + k, "residual slot overlaps the dot slots");
+  CCQP_REQUIRE(a1 && a2 && b1 && b2, "NULL pointer table");
+  fused_dots_args a;
+  for (int j = 0; j < CCQP_MAX_DOTS; ++j) {
+    a.a1[j] = j < k ? a1[j] : nullptr;
+    a.a2[j] = j < k ? a2[j] : nullptr;
+    a.b1[j] = j < k ? b1[j] : nullptr;
+    a.b2[j] = j < k ? b2[j] : nullptr;
+    CCQP_REQUIRE(j >= k || n == 0 || (a.a1[j] && a.b1[j]), "NULL vector");
+  }
+  ccqp_segk sg;
+  memset(&sg, 0, sizeof(sg));
+  if (res) {
+    int rc = seg_check(res_seg, true);
+    if (rc) return rc;
+    CCQP_REQUIRE(res_seg->offset == 0 && res_seg->dim == n, "the fused residual works on whole vectors of length n");
+    CCQP_REQUIRE(n == 0 || (res_x && res_g), "NULL residual operand");
+    sg = seg_by_value(res_seg);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  double* rslot = ctx->slots + (res ? res_slot : 0);
+  if (res)
+    hipLaunchKernelGGL((fused_dots_stage1<true>), dim3(nblk, k + 1), dim3(CCQP_BLOCK), 0, s, a, k, sg, res_x, res_g,
+                       c, gd, n, chunk, ctx->partials, nblk, ctx->slots + slot0, rslot);
+  else
+    hipLaunchKernelGGL((fused_dots_stage1<false>), dim3(nblk, k), dim3(CCQP_BLOCK), 0, s, a, k, sg, res_x, res_g, c,
+                       gd, n, chunk, ctx->partials, nblk, ctx->slots + slot0, rslot);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// grid (nblk): three sums per block -> dst[0*nblk + b], dst[1*nblk + b], dst[2*nblk + b]
+__global__ __launch_bounds__(CCQP_BLOCK) void bb_tail_stage1(ccqp_segk sg, const double* xn, const double* xo,
+                                                             const double* gn, const double* go, double c,
+                                                             double gd, int64_t chunk, double* dst, int nblk,
+                                                             double* slots) {
+  __shared__ double lds4[4];
+  double r, s1, s2;
+  bb_tail_body(sg, xn, xo, gn, go, c, gd, chunk, blockIdx.x, lds4, &r, &s1, &s2);
+  if (threadIdx.x == 0) {
+    dst[blockIdx.x] = r;
+    dst[nblk + blockIdx.x] = s1;
+    dst[2 * nblk + blockIdx.x] = s2;
+  }
+  if (nblk > 1) ccqp_reduce_finish(dst, nblk, 3, ccqp_red_counters(dst), slots, lds4);
+}
+
+extern "C" int ccqp_bb_tail_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x_new,
+                                            const double* x_old, const double* g_new, const double* g_old,
+                                            double c, double gd, int slot0, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  int rc = seg_check(seg, true);
+  if (rc) return rc;
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, 3), "slot range outside the slab");
+  CCQP_REQUIRE(seg->offset == 0, "the fused tail works on whole vectors (offset must be 0)");
+  CCQP_REQUIRE(seg->dim == 0 || (x_new && x_old && g_new && g_old), "NULL vector");
+  hipStream_t s = (hipStream_t)stream;
+  const ccqp_segk k = seg_by_value(seg);
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(k.dim, &chunk, &nblk);
+  hipLaunchKernelGGL(bb_tail_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, k, x_new, x_old, g_new, g_old, c, gd, chunk,
+                     nblk == 1 ? ctx->slots + slot0 : ctx->partials, nblk, ctx->slots + slot0);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
 }
 
 extern "C" int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const double* b, int64_t n, int slot,
@@ -300,14 +456,8 @@ extern "C" int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const dou
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  if (nblk == 1) {
-    hipLaunchKernelGGL(count_notclose_stage1, dim3(1), dim3(CCQP_BLOCK), 0, s, a, b, n, chunk,
-                       ctx->slots + slot);
-  } else {
-    hipLaunchKernelGGL(count_notclose_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, a, b, n, chunk,
-                       ctx->partials);
-    ccqp_launch_stage2(ctx, 1, nblk, slot, s);
-  }
+  hipLaunchKernelGGL(count_notclose_stage1, dim3(nblk), dim3(CCQP_BLOCK), 0, s, a, b, n, chunk,
+                     nblk == 1 ? ctx->slots + slot : ctx->partials, nblk, ctx->slots + slot);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -315,11 +465,13 @@ extern "C" int ccqp_count_notclose_f64(ccqp_ctx* ctx, const double* a, const dou
 // grid (nblk, K): block (b, k) counts the not-close entries of yf = x - alpha_k*p over its chunk.
 __global__ __launch_bounds__(CCQP_BLOCK) void feasible_steps_stage1(ccqp_segk sg, const double* x,
                                                                     const double* p, double alpha0,
-                                                                    int64_t chunk, double* dst, int nblk) {
+                                                                    int64_t chunk, double* dst, int nblk,
+                                                                    double* slots) {
   __shared__ double lds4[4];
   const int k = blockIdx.y;
   const double s = feasible_body(sg, x, p, alpha0, k, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[(int64_t)k * nblk + blockIdx.x] = s;
+  if (nblk > 1) ccqp_reduce_finish(dst + (int64_t)k * nblk, nblk, 1, ccqp_red_counters(dst) + k, slots + k, lds4);
 }
 
 extern "C" int ccqp_feasible_steps_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
@@ -336,18 +488,12 @@ extern "C" int ccqp_feasible_steps_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(k.dim, &chunk, &nblk);
-  // partials area holds CCQP_MAX_DOTS * CCQP_RED_MAXBLK doubles: K * nblk must fit
-  CCQP_REQUIRE((int64_t)K * nblk <= (int64_t)CCQP_MAX_DOTS * CCQP_RED_MAXBLK, "K * blocks exceeds the workspace");
+  // partials area holds CCQP_RED_ROWS * CCQP_RED_MAXBLK doubles: K * nblk must fit
+  CCQP_REQUIRE((int64_t)K * nblk <= (int64_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK, "K * blocks exceeds the workspace");
   const double* xs = x ? x + seg->offset : x;
   const double* ps = p ? p + seg->offset : p;
-  if (nblk == 1) {
-    hipLaunchKernelGGL(feasible_steps_stage1, dim3(1, K), dim3(CCQP_BLOCK), 0, s, k, xs, ps, alpha0, chunk,
-                       ctx->slots + slot0, 1);
-  } else {
-    hipLaunchKernelGGL(feasible_steps_stage1, dim3(nblk, K), dim3(CCQP_BLOCK), 0, s, k, xs, ps, alpha0, chunk,
-                       ctx->partials, nblk);
-    ccqp_launch_stage2(ctx, K, nblk, slot0, s);
-  }
+  hipLaunchKernelGGL(feasible_steps_stage1, dim3(nblk, K), dim3(CCQP_BLOCK), 0, s, k, xs, ps, alpha0, chunk,
+                     nblk == 1 ? ctx->slots + slot0 : ctx->partials, nblk, ctx->slots + slot0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

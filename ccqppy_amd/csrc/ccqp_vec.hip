@@ -20,6 +20,16 @@ __global__ __launch_bounds__(CCQP_BLOCK) void axpby_kernel(double a, const doubl
   axpby_body(a, x, b, y, out, n, blockIdx.x, gridDim.x);
 }
 
+// two independent axpby of the same length in one launch (blockIdx.y picks the operation)
+__global__ __launch_bounds__(CCQP_BLOCK) void axpby2_kernel(double a1, const double* x1, double b1, const double* y1,
+                                                            double* out1, double a2, const double* x2, double b2,
+                                                            const double* y2, double* out2, int64_t n) {
+  if (blockIdx.y == 0)
+    axpby_body(a1, x1, b1, y1, out1, n, blockIdx.x, gridDim.x);
+  else
+    axpby_body(a2, x2, b2, y2, out2, n, blockIdx.x, gridDim.x);
+}
+
 __global__ __launch_bounds__(CCQP_BLOCK) void scale_kernel(double a, const double* x, double* out, int64_t n) {
   scale_body(a, x, out, n, blockIdx.x, gridDim.x);
 }
@@ -64,6 +74,18 @@ extern "C" int ccqp_axpby_f64(ccqp_ctx* ctx, double a, const double* x, double b
                               double* out, int64_t n, void* stream) {
   VEC_PROLOGUE(x && y && out)
   hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(CCQP_BLOCK), 0, s, a, x, b, y, out, n);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_axpby2_f64(ccqp_ctx* ctx, double a1, const double* x1, double b1, const double* y1,
+                               double* out1, double a2, const double* x2, double b2, const double* y2,
+                               double* out2, int64_t n, void* stream) {
+  VEC_PROLOGUE(x1 && y1 && out1 && x2 && y2 && out2)
+  CCQP_REQUIRE(out1 != out2 && out1 != x2 && out1 != y2 && out2 != x1 && out2 != y1,
+               "the two updates must not depend on each other");
+  hipLaunchKernelGGL(axpby2_kernel, dim3(vec_grid(n), 2), dim3(CCQP_BLOCK), 0, s, a1, x1, b1, y1, out1, a2, x2, b2, y2,
+                     out2, n);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -122,25 +144,12 @@ struct dot_args {
 // grid (nblk, k).  Block (b, j) reduces elements [b*chunk, (b+1)*chunk) of pair j: thread t takes
 // t, t+256, ... with one fma chain, then wave butterfly, then waves 0..3 in order.
 __global__ __launch_bounds__(CCQP_BLOCK) void dots_stage1(dot_args a, int64_t n, int64_t chunk,
-                                                          double* dst, int nblk) {
+                                                          double* dst, int nblk, double* slots) {
   __shared__ double lds4[4];
   const int j = blockIdx.y;
   const double s = dot_body(a.x[j], a.y[j], n, chunk, blockIdx.x, lds4);
   if (threadIdx.x == 0) dst[(int64_t)j * nblk + blockIdx.x] = s;
-}
-
-// grid (k).  Sums the nblk partials of pair j in a fixed order -> slab[slot0 + j].
-__global__ __launch_bounds__(CCQP_BLOCK) void reduce_stage2(const double* partials, int nblk,
-                                                            double* slots, int slot0) {
-  __shared__ double lds4[4];
-  const int j = blockIdx.x;
-  const double s = partial_sum_body(partials + (int64_t)j * nblk, nblk, lds4);
-  if (threadIdx.x == 0) slots[slot0 + j] = s;
-}
-
-int ccqp_launch_stage2(ccqp_ctx* ctx, int k, int nblk, int slot0, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_stage2, dim3(k), dim3(CCQP_BLOCK), 0, s, ctx->partials, nblk, ctx->slots, slot0);
-  return CCQP_OK;
+  if (nblk > 1) ccqp_reduce_finish(dst + (int64_t)j * nblk, nblk, 1, ccqp_red_counters(dst) + j, slots + j, lds4);
 }
 
 extern "C" int ccqp_dots_f64(ccqp_ctx* ctx, int k, const double* const* xs, const double* const* ys,
@@ -160,12 +169,9 @@ extern "C" int ccqp_dots_f64(ccqp_ctx* ctx, int k, const double* const* xs, cons
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  if (nblk == 1) {
-    hipLaunchKernelGGL(dots_stage1, dim3(1, k), dim3(CCQP_BLOCK), 0, s, a, n, chunk, ctx->slots + slot0, 1);
-  } else {
-    hipLaunchKernelGGL(dots_stage1, dim3(nblk, k), dim3(CCQP_BLOCK), 0, s, a, n, chunk, ctx->partials, nblk);
-    ccqp_launch_stage2(ctx, k, nblk, slot0, s);
-  }
+  // one launch either way: with several blocks per dot, the block that finishes last adds the partials
+  hipLaunchKernelGGL(dots_stage1, dim3(nblk, k), dim3(CCQP_BLOCK), 0, s, a, n, chunk,
+                     nblk == 1 ? ctx->slots + slot0 : ctx->partials, nblk, ctx->slots + slot0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -209,6 +209,18 @@ class _ElementwiseOp(ProjOpBase):
     def _dev_residual_sq(self, eng, x, g, c, gd, slot):
         eng.residual_sq_elementwise(self._seg(eng, 0, x.numel()), x, g, c, gd, slot)
 
+    def _dev_step_project_minus(self, eng, x, b, y, out):
+        """out = P(x + b*y) - x in one launch."""
+        eng.proj_elementwise_sub(self._seg(eng, 0, x.numel()), x, out, 1.0, b, y, x)
+
+    def _dev_fused_dots_residual(self, eng, pairs, slot0, x, g, c, gd, res_slot):
+        """dot products (operands may be (u, v) = u - v) + residual^2(x, g) in one launch."""
+        eng.fused_dots(pairs, slot0, (self._seg(eng, 0, x.numel()), x, g, c, gd, res_slot))
+
+    def _dev_bb_tail(self, eng, x_new, x_old, g_new, g_old, c, gd, slot0):
+        """residual^2 + the two Barzilai-Borwein dots in one launch (elementwise sets only)."""
+        eng.bb_tail_elementwise(self._seg(eng, 0, x_new.numel()), x_new, x_old, g_new, g_old, c, gd, slot0)
+
     def _scalar_bound_names(self):
         lb, ub = self._bounds()
         return [type(b).__name__ for b in (ub, lb) if b is not None and _is_scalar(b)]

@@ -295,16 +295,20 @@ class _APGDCore(CCQPSolverBase):
                         eng.dots([(gk, run.lin(1.0, xkp1, -1.0, xk))], 6)
                     res2 = yield from run.read(6, 2)
                     break
-                d = run.lin(1.0, xkp1, -1.0, yk)
+                fused = hasattr(run.P, "_dev_fused_dots_residual")
+                d = (xkp1, yk) if fused else run.lin(1.0, xkp1, -1.0, yk)     # fused: formed on the fly
                 pairs = [(xkp1, Ax1), (xkp1, b), (gk, d), (d, d)]
                 if AR:
-                    pairs.append((gk, run.lin(1.0, xkp1, -1.0, xk)))
+                    pairs.append((gk, (xkp1, xk) if fused else run.lin(1.0, xkp1, -1.0, xk)))
                 if first:
-                    eng.dots([(yk, Ayk), (yk, b)] + pairs, 0)
+                    pairs = [(yk, Ayk), (yk, b)] + pairs
+                # speculative: the residual needs xkp1 and A.xkp1 only -> same sync as the dots; for
+                # elementwise sets dots, differences and residual are ONE launch with identical bits
+                if fused:
+                    run.P._dev_fused_dots_residual(eng, pairs, 0 if first else 2, xkp1, g1, run.c, _GD, 7)
                 else:
-                    eng.dots(pairs, 2)
-                # speculative: the residual needs xkp1 and A.xkp1 only -> same sync as the dots
-                run.residual_sq(xkp1, g1, 7)
+                    eng.dots(pairs, 0 if first else 2)
+                    run.residual_sq(xkp1, g1, 7)
                 if first:
                     sc = yield from run.read(0, 8)
                     r1 = sc[0] * 0.5
@@ -398,17 +402,22 @@ class _BBPGDCore(CCQPSolverBase):
                 mv_count += 1
                 if mv_count >= max_mv:
                     break
-                run.residual_sq(xk, gk, 0)
                 if not self._fallback:
-                    # speculative BB dots share the residual's sync
-                    dx = run.lin(1.0, xk, -1.0, xkm1)
-                    dg = run.lin(1.0, gk, -1.0, gkm1)
-                    eng.dots([(dx, dx), (dx, dg)], 1)
+                    # speculative BB dots share the residual's sync; for elementwise sets residual and
+                    # dots are ONE launch (no dx / dg vectors at all), with identical bits
+                    if hasattr(run.P, "_dev_bb_tail"):
+                        run.P._dev_bb_tail(eng, xk, xkm1, gk, gkm1, run.c, _GD, 0)
+                    else:
+                        run.residual_sq(xk, gk, 0)
+                        dx = run.lin(1.0, xk, -1.0, xkm1)
+                        dg = run.lin(1.0, gk, -1.0, gkm1)
+                        eng.dots([(dx, dx), (dx, dg)], 1)
                     sc = yield from run.read(0, 3)
                     res = np.sqrt(sc[0])
                     if res < tol:
                         break
                 else:
+                    run.residual_sq(xk, gk, 0)
                     res = np.sqrt((yield from run.read(0, 1))[0])
                     if res < tol:
                         break
@@ -478,8 +487,12 @@ class CCQPSolverSPG(CCQPSolverBase):
         fk_queue.append(fk)
         dkdotdk = None
         while True:
-            tproj = run.step_project(xk, alpha, gk)
-            dk = run.lin(1.0, tproj, -1.0, xk)
+            if hasattr(run.P, "_dev_step_project_minus"):
+                dk = run.new()                              # P(xk - alpha*gk) - xk in one launch
+                run.P._dev_step_project_minus(eng, xk, -alpha, gk, dk)
+            else:
+                tproj = run.step_project(xk, alpha, gk)
+                dk = run.lin(1.0, tproj, -1.0, xk)
             Adk = run.mv(dk)
             mv_count += 1
             if mv_count >= max_mv:
@@ -492,8 +505,7 @@ class CCQPSolverSPG(CCQPSolverBase):
             beta = -dkdotgk / dkdotAdk
             betahat = tau * beta + np.sqrt((tau ** 2) * (beta ** 2) + 2 * xi)
             betak = (self.rng or np.random).uniform(low=sig1, high=min(betahat, sig2))
-            eng.axpby(1.0, xk, betak, dk, xk)           # xk += betak*dk
-            eng.axpby(1.0, gk, betak, Adk, gk)          # gk += betak*Adk
+            eng.axpby2(1.0, xk, betak, dk, xk, 1.0, gk, betak, Adk, gk)   # xk += betak*dk; gk += betak*Adk
             fk += betak * betak * dkdotgk + 0.5 * (betak ** 2) * dkdotAdk   # sic, :963
             fk_queue.append(fk)
             alpha = dkdotdk / dkdotAdk

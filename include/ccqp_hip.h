@@ -86,6 +86,11 @@ int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const do
  * bit for bit.  out may alias x or y. */
 int ccqp_axpby_f64(ccqp_ctx* ctx, double a, const double* x, double b, const double* y,
                    double* out, int64_t n, void* stream);
+/* Two independent updates of the same length in one launch (SPG's `xk += beta*dk; gk += beta*Adk`,
+ * solvers.py:961-962); neither output may be an operand of the other update. */
+int ccqp_axpby2_f64(ccqp_ctx* ctx, double a1, const double* x1, double b1, const double* y1, double* out1,
+                    double a2, const double* x2, double b2, const double* y2, double* out2, int64_t n,
+                    void* stream);
 /* out = a*x (one rounding) -- the `c * (...)` of the residual, solvers.py:138 */
 int ccqp_scale_f64(ccqp_ctx* ctx, double a, const double* x, double* out, int64_t n, void* stream);
 int ccqp_copy_f64(ccqp_ctx* ctx, const double* x, double* out, int64_t n, void* stream);
@@ -138,6 +143,10 @@ typedef struct ccqp_seg {
  * 638,778,937,1148,1167) with the projection; literal expression order => bit-exact. */
 int ccqp_proj_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, double a, const double* x,
                               double b, const double* y, double* out, void* stream);
+/* out[seg] = P(a*x + b*y)[seg] - z[seg]: SPG's direction `P(xk - alpha*gk) - xk` (solvers.py:937) without the
+ * intermediate vector; the subtraction is a separate rounding, as in numpy. */
+int ccqp_proj_elementwise_sub_f64(ccqp_ctx* ctx, const ccqp_seg* seg, double a, const double* x, double b,
+                                  const double* y, const double* z, double* out, void* stream);
 /* Sphere / Cone, second phase: slab[norm2_slot] must already hold |x[seg]|^2 (ccqp_dots_f64 on the
  * block).  Computes r = sqrt(slab[norm2_slot]) on the device and applies the op's branches. */
 int ccqp_proj_normscale_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, double* out,
@@ -156,6 +165,24 @@ int ccqp_proj_small_segments_f64(ccqp_ctx* ctx, const ccqp_seg* table, int64_t n
  * the caller takes the square root (np.linalg.norm = sqrt(v.v)). */
 int ccqp_residual_sq_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
                                      const double* g, double c, double gd, int slot, void* stream);
+/* k dot products whose operands may be DIFFERENCES of two vectors, plus (res_seg != NULL) the Eq. 25
+ * residual^2 of (res_x, res_g), in ONE launch: slab[slot0 + j] = (a1[j] - a2[j]) . (b1[j] - b2[j]) with a NULL
+ * a2[j] / b2[j] meaning "no subtraction"; slab[res_slot] = residual^2.  Each difference is rounded once (like
+ * the axpby that would materialise it) and each pair keeps the fma chain of ccqp_dots_f64, so the results are
+ * bit for bit those of the separate launches.  Used for the per-iteration probes of APGD (solvers.py:296-302,
+ * 321-323).  res_seg must describe the whole vector (offset 0, dim n). */
+int ccqp_fused_dots_f64(ccqp_ctx* ctx, int k, const double* const* a1, const double* const* a2,
+                        const double* const* b1, const double* const* b2, int64_t n, int slot0,
+                        const ccqp_seg* res_seg, const double* res_x, const double* res_g, double c, double gd,
+                        int res_slot, void* stream);
+/* Fused tail of a Barzilai-Borwein iteration (solvers.py:647-656; BBPGDf :787-806): ONE launch gives
+ *   slab[slot0]   = the Eq. 25 residual^2 of (x_new, g_new)     (as ccqp_residual_sq_elementwise_f64)
+ *   slab[slot0+1] = dx . dx,   slab[slot0+2] = dx . dg          (as ccqp_dots_f64 on the differences)
+ * with dx = x_new - x_old, dg = g_new - g_old formed on the fly (each rounded once, like the axpby they
+ * replace): bit for bit the results of the four separate launches.  Whole vectors only (seg->offset == 0). */
+int ccqp_bb_tail_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x_new, const double* x_old,
+                                 const double* g_new, const double* g_old, double c, double gd, int slot0,
+                                 void* stream);
 
 /* ---- a12: MPRGP helpers (solvers.py:1081-1182; np.isclose rtol=1e-5, atol=1e-8) -----------
  * mask_i = isclose(a_i, b_i) = (|a-b| <= 1e-8 + 1e-5*|b| and isfinite(b)) or a == b.

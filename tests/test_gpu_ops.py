@@ -273,3 +273,55 @@ def test_projected_gradient_golden(case, eng):
             assert isinstance(r, tuple) and len(r) == 2
             assert H.same_bits(r[0], PG_ARR[case["id"] + ".free"])
             assert H.same_bits(r[1], PG_ARR[case["id"] + ".chop"])
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 8192, 100003, (1 << 21) + 5])
+def test_fused_iteration_kernels_have_the_bits_of_the_separate_launches(n, eng):
+    """ccqp_fused_dots_f64, ccqp_bb_tail_elementwise_f64, ccqp_axpby2_f64 and ccqp_proj_elementwise_sub_f64 exist
+    only to save launches: every result must be bit for bit what the sequence of plain kernels gives (one and
+    several reduction blocks, with and without the last-block finish)."""
+    from ccqppy_amd import solution_spaces as ss
+    rng = np.random.default_rng(n)
+    eng.bind()
+    v = [eng.to_device(rng.normal(size=n)) for _ in range(6)]
+    lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
+    lb[::3] = -0.1
+    op = ss.BoxProjOp(n, lb, ub)
+    seg = op._seg(eng, 0, n)
+    c, gd = 1.0 / (3 * n * 1e-6), 1e-6
+
+    def bits(slot0, count):
+        return H.bits(np.array(eng.read(slot0, count)))
+
+    # --- fused dots with differences + residual vs axpby / dots / residual
+    d01 = eng.empty(n)
+    eng.axpby(1.0, v[0], -1.0, v[1], d01)
+    d23 = eng.empty(n)
+    eng.axpby(1.0, v[2], -1.0, v[3], d23)
+    eng.dots([(v[4], v[5]), (v[4], d01), (d01, d01), (d01, d23), (v[0], v[0])], 10)
+    eng.residual_sq_elementwise(seg, v[0], v[2], c, gd, 20)
+    want = np.concatenate([bits(10, 5), bits(20, 1)])
+    eng.fused_dots([(v[4], v[5]), (v[4], (v[0], v[1])), ((v[0], v[1]), (v[0], v[1])), ((v[0], v[1]), (v[2], v[3])),
+                    (v[0], v[0])], 30, (seg, v[0], v[2], c, gd, 40))
+    assert np.array_equal(np.concatenate([bits(30, 5), bits(40, 1)]), want)
+    eng.fused_dots([(v[4], v[5]), (v[4], (v[0], v[1]))], 50)          # without the residual row
+    assert np.array_equal(bits(50, 2), want[:2])
+    # --- BB tail vs residual + two dots on materialised differences
+    eng.residual_sq_elementwise(seg, v[0], v[2], c, gd, 0)
+    eng.dots([(d01, d01), (d01, d23)], 1)
+    want = bits(0, 3)
+    eng.bb_tail_elementwise(seg, v[0], v[1], v[2], v[3], c, gd, 5)
+    assert np.array_equal(bits(5, 3), want)
+    # --- two updates in one launch, in place like SPG's
+    a, b_ = v[0].clone(), v[2].clone()
+    a2, b2 = v[0].clone(), v[2].clone()
+    eng.axpby(1.0, a, 0.37, v[1], a)
+    eng.axpby(1.0, b_, 0.37, v[3], b_)
+    eng.axpby2(1.0, a2, 0.37, v[1], a2, 1.0, b2, 0.37, v[3], b2)
+    assert torch.equal(a, a2) and torch.equal(b_, b2)
+    # --- P(x - alpha g) - x
+    t, want_d, got_d = eng.empty(n), eng.empty(n), eng.empty(n)
+    eng.proj_elementwise(seg, v[0], t, 1.0, -0.3, v[2])
+    eng.axpby(1.0, t, -1.0, v[0], want_d)
+    eng.proj_elementwise_sub(seg, v[0], got_d, 1.0, -0.3, v[2], v[0])
+    assert H.same_bits(got_d.cpu().numpy(), want_d.cpu().numpy())
