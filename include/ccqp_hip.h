@@ -105,7 +105,8 @@ int ccqp_submul_f64(ccqp_ctx* ctx, const double* x, const double* y, const doubl
                     int64_t n, void* stream);
 
 /* ---- a3: dot / norm reductions ------------------------------------------------------------
- * slab[slot0 + j] = xs[j] . ys[j]  for j < k <= CCQP_MAX_DOTS, one launch pair for all k.
+ * slab[slot0 + j] = xs[j] . ys[j]  for j < k <= CCQP_MAX_DOTS, ONE launch for all k (with several blocks per
+ * dot, the block that finishes last adds the partial sums in index order).
  * xs / ys are HOST arrays of device pointers.  Replaces `.dot` / `np.dot` / the squared
  * `np.linalg.norm` at solvers.py:264-265,285-286,296-301,510,635,655-656,923-924,944-946,
  * 1077,1098,1106,1129,1146-1147,1163,1171-1172. */
