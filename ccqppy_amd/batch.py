@@ -87,11 +87,14 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
     return solvers
 
 
-def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=None, device=None, fused=True):
+def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=None, device=None, fused=True,
+                        gather=False):
     """One process per GPU: this rank generates and solves problems p = rank, rank+world, ...
     (`make_problem(p)` -> (A, b, x0, op) on this rank's GPU).  Returns {p: solver} for the local
-    problems; no collective is issued.  fused=True uses the lock-step scheduler with batched launches
-    (solve_batch_fused, 32 lanes in 2 groups by default), fused=False the one-stream-per-solve scheduler."""
+    problems; no collective is issued on the data path.  fused=True uses the lock-step scheduler with batched
+    launches (solve_batch_fused, 32 lanes in 2 groups by default), fused=False the one-stream-per-solve scheduler.
+    gather=True adds ONE exchange after all solves ("host gathers the result vectors at the
+    end"): every rank then gets {p: BatchResult} for ALL problems, results as host arrays."""
     world, rank = 1, 0
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size(group)
@@ -102,7 +105,45 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
         solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=2, device=device)
     else:
         solved = solve_batch(make_solver, probs, lanes=lanes or 4, device=device)
-    return dict(zip(mine, solved))
+    local = dict(zip(mine, solved))
+    if not gather:
+        return local
+    packed = {p: BatchResult.of(s) for p, s in local.items()}
+    if world == 1:
+        return packed
+    parts = [None] * world
+    torch.distributed.all_gather_object(parts, packed, group=group)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return merged
+
+
+class BatchResult:
+    """Host-side copy of a finished solve (what travels in the end-of-job gather): the reference's six result
+    properties, `solution` as a numpy array."""
+    __slots__ = ("solution", "solution_residual", "solution_converged", "solution_time",
+                 "solution_num_matrix_vector_multiplications", "executed_matrix_vector_multiplications", "name")
+
+    @classmethod
+    def of(cls, solver):
+        r = cls()
+        x = solver.solution
+        r.solution = x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        r.solution_residual = float(solver.solution_residual)
+        r.solution_converged = bool(solver.solution_converged)
+        r.solution_time = float(solver.solution_time)
+        r.solution_num_matrix_vector_multiplications = int(solver.solution_num_matrix_vector_multiplications)
+        r.executed_matrix_vector_multiplications = int(solver.executed_matrix_vector_multiplications)
+        r.name = solver.name
+        return r
+
+    def __getstate__(self):
+        return {k: getattr(self, k) for k in self.__slots__}
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            setattr(self, k, v)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -32,12 +32,13 @@ def xstar(n, seed, device=None):
 def random_problem(n, seed, device=None, group=None, mode="allgather"):
     """(operator, b, xstar): b = -A.xstar computed with the engine's own matvec.
 
-    With `group` (a torch.distributed process group with > 1 rank) the matrix is row-sharded:
-    this rank generates and keeps only rows row_partition(n, world, rank)."""
+    With `group` (a torch.distributed process group with > 1 rank, e.g. `dist.group.WORLD`) the matrix is
+    row-sharded: this rank generates and keeps only rows row_partition(n, world, rank).  Without it the
+    problem is local to this process even if torch.distributed is initialised (batch-sharded mode)."""
     eng = get_engine(device)
     xs = xstar(n, seed, eng.device)
     world = 1
-    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+    if group is not None:                      # sharding is opt-in: batch-sharded ranks build LOCAL problems
         world = torch.distributed.get_world_size(group)
     if world > 1:
         rank = torch.distributed.get_rank(group)
@@ -123,7 +124,7 @@ def random_sparse_problem(n, k, seed, device=None, group=None, mode="allgather")
     eng = get_engine(device)
     xs = xstar(n, seed, eng.device)
     world = 1
-    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+    if group is not None:                      # sharding is opt-in: batch-sharded ranks build LOCAL problems
         world = torch.distributed.get_world_size(group)
     if world > 1:
         rank = torch.distributed.get_rank(group)

@@ -67,7 +67,7 @@ def test_row_sharded_equals_single_gpu_bitwise(n, mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(2)]
+    results = [q.get(timeout=120) for _ in range(2)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -121,7 +121,59 @@ def test_rccl_backend_single_rank_collectives():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    same, conv, mv = q.get(timeout=300)
+    same, conv, mv = q.get(timeout=120)
     p.join(60)
     assert p.exitcode == 0
     assert same and conv and mv > 0
+
+
+def _batch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from ccqppy_amd import problems, solvers, solution_spaces as ss
+        from ccqppy_amd.batch import solve_batch_sharded
+        n = 1024
+
+        def make(p):
+            op, b, _ = problems.random_problem(n, 300 + p)
+            return op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+        res = solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), make, 7, group=dist.group.WORLD,
+                                  lanes=4, gather=True)
+        q.put((rank, {p: (r.solution, r.solution_num_matrix_vector_multiplications, r.solution_converged, r.name)
+                      for p, r in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_sharded_two_ranks_with_final_gather():
+    """Batch-sharded mode over 2 ranks (problem p -> rank p % 2, no collective while solving) + the one
+    end-of-job gather: every rank ends up with all 7 results, equal to plain single-process solves."""
+    import torch.multiprocessing as mp
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    n = 1024
+    want = {}
+    for p in range(7):
+        op, b, _ = problems.random_problem(n, 300 + p)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = solvers.CCQPSolverMPRGP(1e-6, 300).solve(op, b, convex_proj_op=ss.BoxProjOp(n, -0.5 * np.ones(n),
+                                                                                           0.5 * np.ones(n)))
+        want[p] = (r.solution.cpu().numpy(), int(r.solution_num_matrix_vector_multiplications))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert sorted(res) == list(range(7))
+        for p, (x, mv, conv, name) in res.items():
+            assert mv == want[p][1] and conv and name == "MPRGP"
+            assert np.array_equal(x.view(np.uint64), want[p][0].view(np.uint64)), (rank, p)

@@ -281,7 +281,7 @@ def test_row_sharded_sparse_equals_single_gpu_bitwise(n, k):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, k, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(2)]
+    results = [q.get(timeout=120) for _ in range(2)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
