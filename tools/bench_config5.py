@@ -31,9 +31,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("CCQP_DIST_BACKEND", "nccl")   # gloo: rehearsal of N ranks on a 1-GPU box
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     from ccqppy_amd.batch import solve_batch, solve_batch_fused
     from ccqppy_amd.operators import batch_partition
@@ -61,7 +68,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         if rep and (best is None or dt < best):
@@ -69,7 +76,7 @@ def main():
     mv = sum(r.executed_matrix_vector_multiplications for r in res)
     conv = sum(bool(r.solution_converged) for r in res)
     if world > 1:
-        t = torch.tensor([mv, conv], dtype=torch.float64, device="cuda")
+        t = torch.tensor([mv, conv], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t)
         mv, conv = int(t[0].item()), int(t[1].item())
     if rank == 0:
