@@ -113,10 +113,18 @@ __device__ __forceinline__ void ccqp_reduce_finish(const double* partials, int n
                                                    double* out, double* lds4) {
   __shared__ int is_last;
   if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned prev = atomicAdd(counter, 1u);
+    // the guide's counter hand-off (cdna_hip_programming.md, in-launch reduction / Guideline 16), to the letter:
+    // drain the store, agent-scope release, drain again (ROCm 7.2 can drop the fence's own wait), relaxed
+    // agent-scope ticket; the last arriver takes an agent-scope acquire before anybody loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = prev + 1u == (unsigned)nblk;
-    if (is_last) __threadfence();
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
   if (!is_last) return;
@@ -126,7 +134,7 @@ __device__ __forceinline__ void ccqp_reduce_finish(const double* partials, int n
     const double s = ccqp_block_sum(acc, lds4);
     if (threadIdx.x == 0) out[r] = s;
   }
-  if (threadIdx.x == 0) *counter = 0u;
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // np.isclose(a, b) with the default rtol=1e-5, atol=1e-8 (numpy/_core/numeric.py):
