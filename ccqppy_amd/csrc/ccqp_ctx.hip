@@ -20,8 +20,12 @@ __global__ void publish_slots_kernel(const double* __restrict__ slots, double* _
                                      int count, unsigned long long seq) {
   const int i = threadIdx.x;
   if (i < count) host[slot0 + i] = slots[slot0 + i];
-  __threadfence_system();                       // the wave's stores have reached host memory ...
-  if (i == 0)                                   // ... before the flag does
+  // the wave's stores have reached host memory before the flag does: drain, system-scope release, drain again
+  // (ROCm 7.2 can drop the fence's own wait -- guide, Guideline 16 pitfall 12)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (i == 0)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + CCQP_NUM_SLOTS), seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
