@@ -16,8 +16,12 @@
 // travel back through it to the threads that hold the values: no LDS beyond the products themselves.  A window's last row bypasses LDS when it is longer than SPMV_LONG entries (one wave
 // per row, second launch).
 //
-// Measured (profiles/r01_spmv_*): 4.0-4.6 TB/s of algorithmic bytes on banded matrices with 8..128 entries
-// per row (4.9 TB/s when x fits one XCD's L2, n <= 512k), 0.7-1.3 TB/s when the columns are scrambled (every
+// Windows whose entries reuse their columns (plan word 4, SPMV_LOCALX) gather each DISTINCT x once into LDS and
+// read a 16-bit local column per entry ("local x" mode).
+//
+// Measured (profiles/r01_spmv_*): 5.8-6.3 TB/s of algorithmic bytes on a 27-point-stencil pattern (local-x
+// windows); 4.0-4.6 TB/s on hashed-circulant matrices with 8..128 entries per row, which reuse no column inside
+// a window (4.9 TB/s when x fits one XCD's L2, n <= 512k); 0.7-1.3 TB/s when the columns are scrambled (every
 // gather a cache miss).  The same kernel with the gather replaced by arithmetic streams at 7.2 TB/s; with
 // it the time scales with ALL bytes delivered through the vector-memory path -- 12 B of stream + 8 B gathered
 // per entry: 7 TB/s x 12/20 = 4.2 TB/s -- and does not respond to the gather order (1.6 vs 0.85 L1 accesses
@@ -42,6 +46,10 @@
 #define SPMV_PLAN_WORDS 5          // per window: first row, end row (LDS path), first entry, end entry (LDS path),
                                    // longest row if the window takes the transposed gather order, else 0
 #define SPMV_UNIFORM (1ll << 32)   // flag in plan word 4: all rows of the window have the same length
+#define SPMV_LOCALX (1ll << 33)    // flag in plan word 4: the window gathers x through LDS ("local x" mode); the
+                                   // number of distinct columns sits in bits 40-55
+#define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
+                                   // products: 8 KB)
 #define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order: measured
                                    // slower in transposed order even with the uniform-length shortcut (9 entries
                                    // per row: 0.57 vs 0.49 ms at n = 16.8M)
@@ -100,29 +108,100 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_kernel(const int64_t* __
 }
 
 static inline int64_t spmv_windows(int64_t nnz) { return nnz / SPMV_CAP + 1; }
+// plan layout (int64 words): [5 per window][3 counters: long rows, transposed windows, local-x windows]
+// [long-row list, one slot per window][distinct columns, SPMV_XS int32 per window][16-bit local column per entry]
+static inline int64_t spmv_off_counts(int64_t nwin) { return SPMV_PLAN_WORDS * nwin; }
+static inline int64_t spmv_off_long(int64_t nwin) { return spmv_off_counts(nwin) + 3; }
+static inline int64_t spmv_off_ucol(int64_t nwin) { return spmv_off_long(nwin) + nwin; }
+static inline int64_t spmv_off_lcol(int64_t nwin) { return spmv_off_ucol(nwin) + nwin * (SPMV_XS / 2); }
 
 extern "C" int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz) {
   if (rows < 0 || nnz < 0) return -1;
   const int64_t nwin = spmv_windows(nnz);
-  return SPMV_PLAN_WORDS * nwin + 2 + nwin;      // windows, two counters (summary), long-row list
+  return spmv_off_lcol(nwin) + (nnz + 3) / 4;
 }
 
-extern "C" int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, int64_t rows, int64_t nnz, int64_t* plan,
-                                  int64_t* summary, void* stream) {
+// Local-x analysis, one workgroup per window: sort the window's column indices (bitonic, in LDS), keep the
+// distinct ones, and -- if they fit SPMV_XS and every x value is used 1.5 times or more -- store them
+// (sorted) plus, for every entry, the 16-bit position of its column in that list.  The matvec then loads
+// each distinct x ONCE with coalesced gathers, parks it in LDS, and reads 2 bytes instead of 4 per entry.
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int32_t* __restrict__ col,
+                                                                      int64_t* __restrict__ plan,
+                                                                      int32_t* __restrict__ ucol,
+                                                                      uint16_t* __restrict__ lcol,
+                                                                      unsigned long long* __restrict__ nlocal) {
+  __shared__ int32_t key[SPMV_LDS];
+  __shared__ int ndistinct;
+  const int64_t w = blockIdx.x;
+  const int64_t nzb = plan[SPMV_PLAN_WORDS * w + 2];
+  const int E = (int)(plan[SPMV_PLAN_WORDS * w + 3] - nzb);
+  if (E <= 0) return;
+  const int t = threadIdx.x;
+  for (int i = t; i < SPMV_LDS; i += CCQP_BLOCK) key[i] = i < E ? col[nzb + i] : INT32_MAX;
+  __syncthreads();
+  for (int k = 2; k <= SPMV_LDS; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < SPMV_LDS; i += CCQP_BLOCK) {
+        const int partner = i ^ j;
+        if (partner > i) {
+          const int32_t a = key[i], b = key[partner];
+          const bool ascending = (i & k) == 0;
+          if ((a > b) == ascending) {
+            key[i] = b;
+            key[partner] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t == 0) {
+    int u = 0;
+    for (int i = 0; i < E; ++i)
+      if (i == 0 || key[i] != key[i - 1]) key[u++] = key[i];      // u <= i: in place
+    ndistinct = u;
+  }
+  __syncthreads();
+  const int cnt = ndistinct;
+  if (cnt > SPMV_XS || 2 * E < 3 * cnt) return;                   // too many columns, or too little reuse
+  int32_t* uc = ucol + w * SPMV_XS;
+  for (int i = t; i < cnt; i += CCQP_BLOCK) uc[i] = key[i];
+  for (int i = t; i < E; i += CCQP_BLOCK) {
+    const int32_t c = col[nzb + i];
+    int lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (key[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    lcol[nzb + i] = (uint16_t)lo;
+  }
+  if (t == 0) {
+    plan[SPMV_PLAN_WORDS * w + 4] |= SPMV_LOCALX | ((int64_t)cnt << 40);
+    atomicAdd(nlocal, 1ull);
+  }
+}
+
+extern "C" int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, int64_t rows,
+                                  int64_t nnz, int64_t* plan, int64_t* summary, void* stream) {
   CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
   CCQP_REQUIRE(rows >= 0 && nnz >= 0, "negative size");
   CCQP_REQUIRE(rowptr != nullptr && plan != nullptr, "NULL rowptr / plan");
   hipStream_t s = (hipStream_t)stream;
   const int64_t nwin = spmv_windows(nnz);
-  int64_t* count = plan + SPMV_PLAN_WORDS * nwin;
-  CCQP_HIP(hipMemsetAsync(count, 0, 2 * sizeof(int64_t), s));
+  int64_t* count = plan + spmv_off_counts(nwin);
+  CCQP_HIP(hipMemsetAsync(count, 0, 3 * sizeof(int64_t), s));
   const int64_t grid = (nwin + CCQP_BLOCK - 1) / CCQP_BLOCK;
   CCQP_REQUIRE(grid <= (int64_t)INT32_MAX, "matrix too large for one plan launch");
   hipLaunchKernelGGL(spmv_plan_kernel, dim3((unsigned)grid), dim3(CCQP_BLOCK), 0, s, rowptr, rows, nwin, plan,
-                     (unsigned long long*)count, (unsigned long long*)count + 1, count + 2);
+                     (unsigned long long*)count, (unsigned long long*)count + 1, plan + spmv_off_long(nwin));
+  CCQP_REQUIRE(nwin <= (int64_t)INT32_MAX, "matrix too large for one plan launch");
+  if (col != nullptr && nnz > 0)             // local-x analysis (optional: without col the windows keep their mode)
+    hipLaunchKernelGGL(spmv_plan_localx_kernel, dim3((unsigned)nwin), dim3(CCQP_BLOCK), 0, s, col, plan,
+                       reinterpret_cast<int32_t*>(plan + spmv_off_ucol(nwin)),
+                       reinterpret_cast<uint16_t*>(plan + spmv_off_lcol(nwin)), (unsigned long long*)count + 2);
   CCQP_LAUNCH_CHECK();
-  if (summary) {                             // blocking: lets the matvec skip launches / pick the lean kernel
-    CCQP_HIP(hipMemcpyAsync(summary, count, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  if (summary) {                             // blocking: lets the matvec skip the wave-per-row launch
+    CCQP_HIP(hipMemcpyAsync(summary, count, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CCQP_HIP(hipStreamSynchronize(s));
   }
   return CCQP_OK;
@@ -156,6 +235,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
                                                                  const int32_t* __restrict__ col,
                                                                  const double* __restrict__ val,
                                                                  const int64_t* __restrict__ plan,
+                                                                 const int32_t* __restrict__ ucol,
+                                                                 const uint16_t* __restrict__ lcol,
                                                                  const double* __restrict__ x,
                                                                  const double* __restrict__ b, double* __restrict__ y,
                                                                  double* __restrict__ g, int64_t last) {
@@ -170,10 +251,68 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   const int E = (int)(pw[3] - nzb);          // < SPMV_LDS by construction of the plan
   const int longest = (int)(pw[4] & 0xffffffff);
   const bool uniform = (pw[4] & SPMV_UNIFORM) != 0;
+  const bool localx = (pw[4] & SPMV_LOCALX) != 0;
   const int t = threadIdx.x;
   const int l = t % W;
   const int64_t nrows = re - rb;
   const bool rows_in_lds = nrows <= SPMV_ROWS_LDS;
+  // an empty window (E == 0) may sit at the very end of the arrays: clamp to the last stored entry
+  const int64_t elast = E > 0 ? nzb + E - 1 : (nzb < last ? nzb : last);
+  // row pointers of the window: first in the load queue, needed last
+  int64_t rp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t i = t + j * CCQP_BLOCK;
+    rp[j] = rowptr[rb + (i < nrows ? i : nrows)];
+  }
+  if (localx) {
+    // ---- "local x" window: the distinct columns of the window (sorted, from the plan) are gathered ONCE,
+    // coalesced, into LDS; every entry then multiplies its value with an LDS read through a 16-bit local
+    // index.  Per entry 8 B + 2 B are streamed instead of 8 B + 4 B + an 8-B global gather.
+    const int ucnt = (int)((pw[4] >> 40) & 0xffff);
+    const int32_t* __restrict__ uc = ucol + (int64_t)blockIdx.x * SPMV_XS;
+    int32_t ucv[SPMV_XS / CCQP_BLOCK];
+#pragma unroll
+    for (int q = 0; q < SPMV_XS / CCQP_BLOCK; ++q) {
+      const int k = t + q * CCQP_BLOCK;
+      ucv[q] = uc[k < ucnt ? k : ucnt - 1];
+    }
+    double v[SPMV_SLOTS];
+    uint16_t lc[SPMV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int64_t e = nzb + t + j * CCQP_BLOCK;
+      const int64_t es = e < elast ? e : elast;
+      v[j] = __builtin_nontemporal_load(val + es);
+      lc[j] = __builtin_nontemporal_load(lcol + es);
+    }
+    if (rows_in_lds) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (t + j * CCQP_BLOCK <= nrows) rstart[t + j * CCQP_BLOCK] = (uint16_t)(rp[j] - nzb);
+      for (int i = t + 2 * CCQP_BLOCK; i <= (int)nrows; i += CCQP_BLOCK)
+        rstart[i] = (uint16_t)(rowptr[rb + i] - nzb);
+    }
+    double xg[SPMV_XS / CCQP_BLOCK];
+#pragma unroll
+    for (int q = 0; q < SPMV_XS / CCQP_BLOCK; ++q) xg[q] = x[ucv[q]];
+    double* const xs = prod;                  // the first SPMV_XS doubles of `prod`, until the products exist
+#pragma unroll
+    for (int q = 0; q < SPMV_XS / CCQP_BLOCK; ++q) {
+      const int k = t + q * CCQP_BLOCK;
+      if (k < ucnt) xs[k] = xg[q];
+    }
+    __syncthreads();
+    double pr[SPMV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) pr[j] = v[j] * xs[lc[j]];
+    __syncthreads();                          // every x value has been read: `prod` may be overwritten
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int e = t + j * CCQP_BLOCK;
+      if (e < E) prod[e] = pr[j];
+    }
+  } else {
   // phase 1: ALL (value, column) loads of the window and its row pointers back to back, then all
   // gathers -- one pass through the load -> gather latency chain per workgroup.  Every load is
   // unconditional with a clamped index (a slot past the end of the window re-reads its last entry, one
@@ -181,20 +320,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   // one, and this kernel lives on the number of loads in flight.
   double v[SPMV_SLOTS];
   int32_t c[SPMV_SLOTS];
-  // an empty window (E == 0) may sit at the very end of the arrays: clamp to the last stored entry
-  const int64_t elast = E > 0 ? nzb + E - 1 : (nzb < last ? nzb : last);
 #pragma unroll
   for (int j = 0; j < SPMV_SLOTS; ++j) {
     const int64_t e = nzb + t + j * CCQP_BLOCK;
     const int64_t es = e < elast ? e : elast;
     v[j] = __builtin_nontemporal_load(val + es);
     c[j] = __builtin_nontemporal_load(col + es);
-  }
-  int64_t rp[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t i = t + j * CCQP_BLOCK;
-    rp[j] = rowptr[rb + (i < nrows ? i : nrows)];
   }
   if (rows_in_lds) {
 #pragma unroll
@@ -262,6 +393,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
       const int e = t + j * CCQP_BLOCK;
       if (e < E) prod[e] = v[j] * xv[j];
     }
+  }
   }
   __syncthreads();
   // phase 2: one row per subgroup out of LDS, canonical order
@@ -395,12 +527,15 @@ template <int W>
 static void spmv_launch(unsigned grid, const int64_t* rowptr, const int32_t* col, const double* val,
                         const int64_t* plan, const double* x, const double* b, double* y, double* g, int64_t nnz,
                         hipStream_t s) {
+  const int64_t nwin = spmv_windows(nnz);
+  const int32_t* ucol = reinterpret_cast<const int32_t*>(plan + spmv_off_ucol(nwin));
+  const uint16_t* lcol = reinterpret_cast<const uint16_t*>(plan + spmv_off_lcol(nwin));
   if (g)
-    hipLaunchKernelGGL((spmv_stream_kernel<W, true>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, x,
-                       b, y, g, nnz - 1);
+    hipLaunchKernelGGL((spmv_stream_kernel<W, true>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan,
+                       ucol, lcol, x, b, y, g, nnz - 1);
   else
-    hipLaunchKernelGGL((spmv_stream_kernel<W, false>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan, x,
-                       b, y, g, nnz - 1);
+    hipLaunchKernelGGL((spmv_stream_kernel<W, false>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan,
+                       ucol, lcol, x, b, y, g, nnz - 1);
 }
 
 extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
@@ -437,15 +572,15 @@ extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int
     default: spmv_launch<64>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
   }
   if (n_long_rows != 0) {                    // < 0: unknown to the caller, the kernel reads the count
-    const int64_t* count = plan + SPMV_PLAN_WORDS * nwin;
+    const int64_t* count = plan + spmv_off_counts(nwin);
     int64_t lg = n_long_rows < 0 ? ctx->num_cu : (n_long_rows + 3) / 4;
     if (lg > (int64_t)ctx->num_cu * 8) lg = (int64_t)ctx->num_cu * 8;
     if (g)
       hipLaunchKernelGGL((spmv_long_rows_kernel<true>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
-                         count, count + 2, x, b, y, g);
+                         count, plan + spmv_off_long(nwin), x, b, y, g);
     else
       hipLaunchKernelGGL((spmv_long_rows_kernel<false>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
-                         count, count + 2, x, b, y, g);
+                         count, plan + spmv_off_long(nwin), x, b, y, g);
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

@@ -133,7 +133,7 @@ class SparseOperator:
     (include/ccqp_hip.h), so row-sharded and single-GPU runs agree bitwise.
     `check=True` validates the index arrays on the device once (the matvec does not bounds-check)."""
 
-    def __init__(self, A, shape=None, engine=None, check=True, width=0):
+    def __init__(self, A, shape=None, engine=None, check=True, width=0, local_x=True):
         if isinstance(A, torch.Tensor) and A.is_cuda:
             self.engine = engine or get_engine(A.device)
         elif isinstance(A, (tuple, list)) and isinstance(A[2], torch.Tensor) and A[2].is_cuda:
@@ -181,7 +181,9 @@ class SparseOperator:
                 raise ValueError("SparseOperator: %d violated CSR invariants (row pointers not monotone / "
                                  "not ending at nnz, or column index outside [0, %d))" % (bad, self.n))
         # one-time analysis: which rows each workgroup streams, which rows are too long for the LDS path
-        self.plan, self.summary = self.engine.spmv_plan(self.rowptr, self.nnz)
+        # (local_x=False keeps every window on the global-gather paths: a tuning / testing switch, same bits)
+        self.local_x = local_x
+        self.plan, self.summary = self.engine.spmv_plan(self.rowptr, self.col, self.nnz, local_x)
 
     @property
     def shape(self):
@@ -194,7 +196,7 @@ class SparseOperator:
         hi = int(self.rowptr[row0 + rows].item())
         rp = (self.rowptr[row0:row0 + rows + 1] - lo).contiguous()
         return SparseOperator((rp, self.col[lo:hi], self.val[lo:hi]), shape=(rows, self.n), engine=self.engine,
-                              check=False, width=self.width)
+                              check=False, width=self.width, local_x=self.local_x)
 
     def apply(self, eng, x, y, b=None, g=None):
         eng.spmv_csr(self.rowptr, self.col, self.val, self.plan, self.summary, self.n, x, y, b, g, self.width)
@@ -211,7 +213,7 @@ class SparseOperator:
             rp[1:] = torch.cumsum(torch.bincount(self.col.long(), minlength=self.n), 0)
             self._transposed = SparseOperator((rp, row_of[order].to(torch.int32), self.val[order]),
                                               shape=(self.n, self.rows), engine=self.engine, check=False,
-                                              width=self.width)
+                                              width=self.width, local_x=self.local_x)
         return self._transposed
 
     def matvec(self, x, y, b=None, g=None, engine=None):

@@ -254,18 +254,22 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  * the optional epilogue g = y + b.
  *   plan: ccqp_spmv_plan_words(rows, nnz) int64 words of device memory owned by the caller, filled ONCE
  *         per matrix by ccqp_spmv_plan_csr: which rows each workgroup streams through LDS, which windows
- *         gather x in transposed order, and the list of rows that take the wave-per-row launch instead.
- *   summary (optional, 2 host words): {rows on the wave-per-row path, windows in transposed order}.
- *         Asking for it makes the plan call blocking; handing it to the matvec lets it skip the second
- *         launch when no row needs it (NULL = unknown: launched, the kernel reads the count).
+ *         gather x in transposed order, the list of rows that take the wave-per-row launch instead, and --
+ *         when `col` is given -- for every window whose entries reuse their columns (each distinct column
+ *         1.5 times or more, at most 1024 of them) the sorted distinct columns plus a 16-bit local column
+ *         per entry: such "local-x" windows load each x value once into LDS and stream 10 instead of 12
+ *         bytes per entry.  The plan takes ~2.3 + 2 bytes per stored entry.
+ *   summary (optional, 3 host words): {rows on the wave-per-row path, windows in transposed order,
+ *         local-x windows}.  Asking for it makes the plan call blocking; handing it to the matvec lets it
+ *         skip the second launch when no row needs it (NULL = unknown: launched, the kernel reads the count).
  * Bits of y[i]: a function of row i's stored entries (in storage order) and x only -- not of the plan,
  * not of `width` (lanes that reduce one row: 0 = from the mean row length; 4, 8, 16, 32, 64 to force),
  * not of how the rows are sharded over GPUs: p_e = fl(val_e * x[col_e]); canonical lane e mod 64 adds its
  * products in order from +0.0; the 64 lanes are combined by the xor butterfly 32, 16, 8, 4, 2, 1.
  * Traffic per call: 12 B per stored entry + 16 B per row + 8 B per column (x once). */
 int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz);
-int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, int64_t rows, int64_t nnz, int64_t* plan,
-                       int64_t* summary, void* stream);
+int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, int64_t rows, int64_t nnz,
+                       int64_t* plan, int64_t* summary, void* stream);
 int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
                       const int64_t* plan, const int64_t* summary, const double* x, const double* b, double* y,
                       double* g, int64_t rows, int64_t cols, int64_t nnz, int width, void* stream);

@@ -88,9 +88,43 @@ def test_unknown_plan_summary_and_forced_kernels_give_the_same_bits():
         op.summary = None
         assert H.same_bits(op.dot(x).cpu().numpy(), y0)
         import ctypes
-        for fake in ((keep[0], 0), (keep[0], 10 ** 9)):          # lean kernel / transposed-capable kernel
-            op.summary = (ctypes.c_int64 * 2)(*fake)
+        for fake in ((keep[0], 0, 0), (keep[0], 10 ** 9, 0)):
+            op.summary = (ctypes.c_int64 * 3)(*fake)
             assert H.same_bits(op.dot(x).cpu().numpy(), y0)
+
+
+def test_local_x_windows_are_used_where_columns_repeat_and_change_no_bit():
+    """Banded / stencil-like matrices reuse their columns inside a 1792-entry window: the plan then switches
+    those windows to the local-x mode (distinct x values through LDS, 16-bit local columns).  Same bits as the
+    global-gather modes and as the canonical order; matrices without reuse keep their mode."""
+    from ccqppy_amd import problems
+    from ccqppy_amd.operators import SparseOperator
+    n, side = 32768, 32
+    offs = sorted({dz * side * side + dy * side + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
+    i = np.arange(n)[:, None]
+    cols = np.sort((i + np.array(offs)[None, :]) % n, axis=1)
+    rng = np.random.default_rng(3)
+    data = rng.normal(size=cols.shape)
+    indptr = np.arange(n + 1, dtype=np.int64) * len(offs)
+    x = rng.normal(size=n)
+    on = SparseOperator((indptr, cols.reshape(-1).astype(np.int32), data.reshape(-1)), shape=(n, n))
+    off = SparseOperator((indptr, cols.reshape(-1).astype(np.int32), data.reshape(-1)), shape=(n, n), local_x=False)
+    assert on.summary[2] > 0.9 * (on.nnz // 1792) and off.summary[2] == 0
+    y_on, y_off = on.dot(x).cpu().numpy(), off.dot(x).cpu().numpy()
+    assert H.same_bits(y_on, y_off)
+    rows = slice(1000, 1200)
+    want = H.spmv_canonical(indptr[rows.start:rows.stop + 1] - indptr[rows.start], cols[rows].reshape(-1),
+                            data[rows].reshape(-1), x)
+    assert H.same_bits(y_on[rows], want)
+    for width in (4, 8, 16, 32, 64):
+        assert H.same_bits(SparseOperator((indptr, cols.reshape(-1).astype(np.int32), data.reshape(-1)), shape=(n, n),
+                                          width=width).dot(x).cpu().numpy(), y_on)
+    # no reuse (hashed circulant offsets): nothing switches
+    circ = SparseOperator(problems.sparse_spd_csr(65536, 32, 1234), shape=(65536, 65536))
+    assert circ.summary[2] == 0
+    # transposes and row blocks re-plan for themselves
+    assert H.same_bits(on.T.dot(x).cpu().numpy(), off.T.dot(x).cpu().numpy())
+    assert H.same_bits(on.row_block(5000, 3000).dot(x).cpu().numpy(), y_on[5000:8000])
 
 
 def test_empty_matrix_and_empty_rows():

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--shapes", default="1048576:8,1048576:32,1048576:128,4194304:32,16777216:8")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--scramble", action="store_true", help="also time a column-scrambled copy (random gathers)")
+    ap.add_argument("--stencil", action="store_true", help="with k = 26: also a 27-point-stencil pattern (column reuse)")
     args = ap.parse_args()
     from ccqppy_amd import problems
     from ccqppy_amd.operators import SparseOperator
@@ -25,6 +26,14 @@ def main():
         n, k = (int(v) for v in shape.split(":"))
         rowptr, col, val = problems.sparse_spd_csr(n, k, 1234)
         variants = [("circulant", col)]
+        if args.stencil:
+            # banded pattern with column reuse inside a window (27-point-stencil-like: offsets {-1,0,1} x 9 planes)
+            side = max(4, int(round(n ** (1.0 / 3.0))))
+            offs = sorted({dz * side * side + dy * side + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
+            if len(offs) == k + 1:
+                i = torch.arange(n, device=col.device, dtype=torch.int64)[:, None]
+                d = torch.tensor(offs, device=col.device, dtype=torch.int64)[None, :]
+                variants.append(("stencil27", torch.sort(torch.remainder(i + d, n), dim=1).values.reshape(-1).to(torch.int32)))
         if args.scramble:
             perm = torch.randperm(n, device=col.device, dtype=torch.int64)
             variants.append(("scrambled", perm[col.long()].to(torch.int32)))
@@ -36,6 +45,7 @@ def main():
             row = {"n": n, "k": k, "nnz": nnz, "pattern": pname, "GB": nbytes / 1e9}
             for width, r in [(w, 0) for w in (0, 4, 8, 16, 32, 64)]:
                 op = SparseOperator((rowptr, c, val), shape=(n, n), width=width, check=False)
+                row.setdefault("plan_summary", [int(v) for v in op.summary])
                 for _ in range(3):
                     op.matvec(x, y)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
