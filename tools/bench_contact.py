@@ -42,9 +42,11 @@ def main():
     for shape in args.shapes.split(","):
         m, n = (int(v) for v in shape.split(":"))
         D = SparseOperator(device_jacobian(m, n, args.per_row, 1, eng.device), shape=(m, n), engine=eng)
-        minv = 0.5 + torch.rand(n, device=eng.device, dtype=torch.float64)
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(7)
+        minv = 0.5 + torch.rand(n, device=eng.device, dtype=torch.float64, generator=gen)
         op = ComposedOperator(D, DiagonalOperator(minv), D.T, shift=0.05)
-        xs = torch.rand(m, device=eng.device, dtype=torch.float64) * 2 - 1
+        xs = torch.rand(m, device=eng.device, dtype=torch.float64, generator=gen) * 2 - 1
         b = -op.dot(xs)
         P = ss.LowerBoundProjOp(m, 0.0)
 
