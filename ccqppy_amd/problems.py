@@ -95,14 +95,30 @@ def sparse_offsets(n, k, seed):
     return out
 
 
-def sparse_spd_csr(n, k, seed, row0=0, rows=None, device=None):
+def stencil_offsets(n):
+    """The 13 positive offsets of a periodic 27-point stencil on a side^3 grid, side = round(n^(1/3))."""
+    side = int(round(n ** (1.0 / 3.0)))
+    if side < 4 or 2 * (side * side + side + 1) >= n:
+        raise ValueError("stencil27 pattern needs n ~ side^3 with side >= 4")
+    offs = sorted({dz * side * side + dy * side + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
+    return [d for d in offs if d > 0]
+
+
+def sparse_spd_csr(n, k, seed, row0=0, rows=None, device=None, pattern="hashed"):
     """Rows [row0, row0+rows) of the sparse SPD test matrix as device CSR arrays (rowptr int64, col int32,
     val float64): the entries of the dense generator matrix on k hashed symmetric off-diagonals
     (columns (i +- d_t) mod n), rescaled to (2u - 1)/k, diagonal 2 => spectrum inside [1, 3] (Gershgorin).
-    Columns are sorted within a row; every row holds k + 1 entries."""
+    Columns are sorted within a row; every row holds k + 1 entries.  pattern="stencil27" (k = 26) takes the
+    offsets of a periodic 27-point stencil on a side^3 grid instead of hashed ones: neighbouring rows then share
+    columns, the case the matvec's local-x windows are made for."""
     rows = n - row0 if rows is None else rows
     dev = torch.device("cpu") if device == "cpu" else get_engine(device).device
-    offs = sparse_offsets(n, k, seed)
+    if pattern == "stencil27":
+        if k != 26:
+            raise ValueError("stencil27 has k = 26 off-diagonals")
+        offs = stencil_offsets(n)
+    else:
+        offs = sparse_offsets(n, k, seed)
     delta = torch.tensor(sorted([-d for d in offs] + [0] + offs), dtype=torch.int64, device=dev)
     i = torch.arange(row0, row0 + rows, dtype=torch.int64, device=dev)[:, None]
     cols = torch.sort(torch.remainder(i + delta[None, :], n), dim=1).values
@@ -116,7 +132,7 @@ def sparse_spd_csr(n, k, seed, row0=0, rows=None, device=None):
     return rowptr, cols.reshape(-1).to(torch.int32), vals.reshape(-1)
 
 
-def random_sparse_problem(n, k, seed, device=None, group=None, mode="allgather"):
+def random_sparse_problem(n, k, seed, device=None, group=None, mode="allgather", pattern="hashed"):
     """(operator, b, xstar) for the sparse SPD test matrix with k off-diagonal entries per row;
     b = -A.xstar by the engine's own sparse matvec.  With a process group of > 1 rank the matrix is
     row-sharded (each rank builds only its own rows)."""
@@ -129,10 +145,10 @@ def random_sparse_problem(n, k, seed, device=None, group=None, mode="allgather")
     if world > 1:
         rank = torch.distributed.get_rank(group)
         row0, rows, _ = row_partition(n, world, rank)
-        local = SparseOperator(sparse_spd_csr(n, k, seed, row0, rows, eng.device), shape=(rows, n), engine=eng)
+        local = SparseOperator(sparse_spd_csr(n, k, seed, row0, rows, eng.device, pattern), shape=(rows, n), engine=eng)
         op = RowShardedOperator(local, n, group, mode, eng)
     else:
-        op = SparseOperator(sparse_spd_csr(n, k, seed, 0, n, eng.device), shape=(n, n), engine=eng)
+        op = SparseOperator(sparse_spd_csr(n, k, seed, 0, n, eng.device, pattern), shape=(n, n), engine=eng)
     Ax = eng.empty(n)
     op.matvec(xs, Ax)
     b = eng.empty(n)

@@ -417,6 +417,10 @@ def sparse_solver_cases():
         add("sirr%d.BBPGD.identity" % n, p, "BBPGD", 1e-8, 3000, None)
         add("sirr%d.BBPGDf.lower" % n, p, "BBPGDf", 1e-8, 3000, {"kind": "Lower", "dim": n, "lb": {"fill": -0.25}})
     add("sgen256k8.warm.BBPGD", "sgen:256:8:7", "BBPGD", 1e-9, None, _box_half(256), x0="ramp")
+    for n in (4096, 32768):                      # 27-point stencil (side 16 / 32): local-x windows on the GPU
+        p = "sstencil:%d:1234" % n
+        for s in ("APGD", "BBPGD", "SPG", "MPRGP"):
+            add("sstencil%d.%s.box" % (n, s), p, s, 1e-6 if s == "MPRGP" else 1e-8, 3000, _box_half(n))
     return cases
 
 

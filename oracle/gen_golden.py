@@ -146,6 +146,9 @@ def get_problem(pid):
     elif pid.startswith("sgen:"):
         _, n, k, seed = pid.split(":")
         A, b, _ = gen_ref.sparse_problem(int(n), int(k), int(seed))
+    elif pid.startswith("sstencil:"):
+        _, n, seed = pid.split(":")
+        A, b, _ = gen_ref.sparse_problem(int(n), 26, int(seed), pattern="stencil27")
     elif pid.startswith("contact:"):
         _, m, n, seed = pid.split(":")
         A, b, _ = gen_ref.contact_problem(int(m), int(n), int(seed))

@@ -120,12 +120,26 @@ def sparse_offsets(n, k, seed):
     return out
 
 
-def sparse_spd(n, k, seed, row0=0, rows=None):
-    """Rows [row0, row0+rows) of the n x n "sgen" matrix as scipy CSR (sorted columns, k+1 entries per row)."""
+def stencil_offsets(n):
+    """The 13 positive offsets of a periodic 27-point stencil on a side^3 grid, side = round(n^(1/3)) >= 4
+    (dz*side^2 + dy*side + dx over {-1,0,1}^3): a banded pattern whose neighbouring rows share columns."""
+    side = int(round(n ** (1.0 / 3.0)))
+    assert side >= 4 and 2 * (side * side + side + 1) < n
+    offs = sorted({dz * side * side + dy * side + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
+    return [d for d in offs if d > 0]
+
+
+def sparse_spd(n, k, seed, row0=0, rows=None, pattern="hashed"):
+    """Rows [row0, row0+rows) of the n x n "sgen" matrix as scipy CSR (sorted columns, k+1 entries per row).
+    pattern "hashed": k/2 hashed offsets spread over the whole vector; "stencil27": k = 26, the 27-point stencil."""
     import scipy.sparse as sp
     if rows is None:
         rows = n - row0
-    offs = sparse_offsets(n, k, seed)
+    if pattern == "stencil27":
+        assert k == 26
+        offs = stencil_offsets(n)
+    else:
+        offs = sparse_offsets(n, k, seed)
     delta = np.array(sorted([-d for d in offs] + [0] + offs), dtype=np.int64)
     i = np.arange(row0, row0 + rows, dtype=np.int64)[:, None]
     cols = np.sort((i + delta[None, :]) % n, axis=1)
@@ -140,9 +154,9 @@ def sparse_spd(n, k, seed, row0=0, rows=None):
     return sp.csr_matrix((vals.reshape(-1), cols.reshape(-1).astype(np.int32), indptr), shape=(rows, n))
 
 
-def sparse_problem(n, k, seed):
+def sparse_problem(n, k, seed, pattern="hashed"):
     """(A csr, b, xstar) with b = -A.xstar computed by scipy."""
-    A = sparse_spd(n, k, seed)
+    A = sparse_spd(n, k, seed, pattern=pattern)
     xs = xstar(n, seed)
     return A, -A.dot(xs), xs
 

@@ -215,6 +215,11 @@ def _operator(pid):
             _, n, k, seed = pid.split(":")
             n = int(n)
             _OPS[pid] = SparseOperator(problems.sparse_spd_csr(n, int(k), int(seed)), shape=(n, n))
+        elif pid.startswith("sstencil:"):
+            _, n, seed = pid.split(":")
+            n = int(n)
+            _OPS[pid] = SparseOperator(problems.sparse_spd_csr(n, 26, int(seed), pattern="stencil27"), shape=(n, n))
+            assert _OPS[pid].summary[2] > 0                      # local-x windows in play
         else:
             _OPS[pid] = H.sparse_fixture_matrix(pid, ARR)        # scipy input, converted by every solve()
     return _OPS[pid]

@@ -18,13 +18,15 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="1048576:8,4194304:32,16777216:8,2097152:64")
+    ap.add_argument("--shapes", default="1048576:8,4194304:32,16777216:8,2097152:64,2097152:26s,16777216:26s",
+                    help="n:k with k off-diagonals per row; a trailing s = 27-point-stencil pattern (k = 26)")
     ap.add_argument("--cpu-n", type=int, default=1048576, help="largest n also solved by the scipy-based oracle")
     args = ap.parse_args()
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     for shape in args.shapes.split(","):
-        n, k = (int(v) for v in shape.split(":"))
-        op, b, _ = problems.random_sparse_problem(n, k, 1234)
+        pattern = "stencil27" if shape.endswith("s") else "hashed"
+        n, k = (int(v) for v in shape.rstrip("s").split(":"))
+        op, b, _ = problems.random_sparse_problem(n, k, 1234, pattern=pattern)
         P = ss.BoxProjOp(n, -0.5, 0.5)
         eng = op.engine
 
@@ -43,7 +45,8 @@ def main():
         ms = [a.elapsed_time(b_) for a, b_ in eng.gemv_events]
         eng.gemv_events = None
         nbytes = 12 * op.nnz + 24 * n + 8 * n
-        row = {"workload": "sparse box-QP, APGD tol 1e-8", "n": n, "offdiag_per_row": k, "nnz": op.nnz,
+        row = {"workload": "sparse box-QP, APGD tol 1e-8", "n": n, "offdiag_per_row": k, "pattern": pattern,
+               "local_x_windows": int(op.summary[2]), "nnz": op.nnz,
                "wall_s": wall, "executed_mv": mv, "reported_mv": int(r.solution_num_matrix_vector_multiplications),
                "converged": bool(r.solution_converged), "matvecs_per_s": mv / wall,
                "spmv_ms": float(np.mean(ms)), "spmv_algorithmic_GBps": nbytes / np.mean(ms) / 1e6,
@@ -51,7 +54,7 @@ def main():
                "solve_level_GBps": nbytes * mv / wall / 1e9}
         if n <= args.cpu_n:
             from oracle import cpu_ref, gen_ref
-            A, bb, _ = gen_ref.sparse_problem(n, k, 1234)
+            A, bb, _ = gen_ref.sparse_problem(n, k, 1234, pattern=pattern)
             t0 = time.perf_counter()
             o = cpu_ref.SOLVERS["APGD"](A, bb, 1e-8, 5000, P=cpu_ref.Box(n, -0.5, 0.5))
             row["cpu_oracle_wall_s"] = time.perf_counter() - t0
