@@ -127,6 +127,25 @@ def test_local_x_windows_are_used_where_columns_repeat_and_change_no_bit():
     assert H.same_bits(on.row_block(5000, 3000).dot(x).cpu().numpy(), y_on[5000:8000])
 
 
+def test_duplicate_and_unsorted_columns_inside_rows():
+    """CSR does not forbid repeated or unsorted columns within a row: every stored entry contributes, in storage
+    order, on every path (entry order, transposed, local-x)."""
+    from ccqppy_amd.operators import SparseOperator
+    rng = np.random.default_rng(11)
+    for rows, cols, per_row in ((3000, 40, 7), (500, 5000, 40), (64, 64, 64)):
+        indptr = np.arange(rows + 1, dtype=np.int64) * per_row
+        indices = rng.integers(0, cols, size=rows * per_row).astype(np.int32)     # repeats, any order
+        data = rng.normal(size=rows * per_row)
+        x = rng.normal(size=cols)
+        want = H.spmv_canonical(indptr, indices, data, x)
+        for local_x in (True, False):
+            op = SparseOperator((indptr, indices, data), shape=(rows, cols), local_x=local_x)
+            assert H.same_bits(op.dot(x).cpu().numpy(), want), (rows, cols, local_x)
+        dense = np.zeros((rows, cols))
+        np.add.at(dense, (np.repeat(np.arange(rows), per_row), indices), data)
+        np.testing.assert_allclose(want, dense.dot(x), rtol=1e-11, atol=1e-12)
+
+
 def test_empty_matrix_and_empty_rows():
     from ccqppy_amd.operators import SparseOperator
     x = np.arange(1.0, 6.0)
