@@ -85,6 +85,15 @@ SIGNATURES = {
     "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
     "ccqp_fused_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _I64, _I,
                             _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
+    "ccqp_pipe_reset": [_P, _D, _P],
+    "ccqp_pipe_step_project_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
+    "ccqp_pipe_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
+    "ccqp_pipe_bb_tail_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _D, _D, _P],
+    "ccqp_pipe_poll": [_P, _c.POINTER(_D)],
+    "ccqp_pipe_capture_begin": [_P, _P],
+    "ccqp_pipe_capture_end": [_P, _P, _c.POINTER(_P)],
+    "ccqp_pipe_graph_launch": [_P, _P, _P],
+    "ccqp_pipe_graph_destroy": [_P],
     "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void b_reduce_stage1(const ccqp_bop* t,
 // ~2 us, the kernel runs 83 us).  So a matvec group is issued as `count` launches of the
 // single-problem kernel from this C loop: no Python between them, identical bits by construction.
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b, double* y,
-                     double* g, int64_t rows, int64_t cols, int variant, hipStream_t s);
+                     double* g, int64_t rows, int64_t cols, int variant, hipStream_t s,
+                     const double* skip);
 
 static inline int vec_grid(int64_t n) {
   int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
@@ -240,7 +241,7 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
         CCQP_REQUIRE(o.p[0] && o.p[3] && (o.n2 == 0 || o.p[1]), "batched matvec: NULL operand");
         CCQP_REQUIRE(o.p[4] == nullptr || o.p[2] != nullptr, "batched matvec: g requested but b is NULL");
         int rc = ccqp_gemv_launch(ctx, o.p[0], o.lda, o.p[1], o.p[2], const_cast<double*>(o.p[3]),
-                                  const_cast<double*>(o.p[4]), o.n, o.n2, 0, ms);
+                                  const_cast<double*>(o.p[4]), o.n, o.n2, 0, ms, nullptr);
         if (rc) return rc;
       }
       if (ctx->mv_serialize) {

@@ -20,7 +20,9 @@ template <int R, int U, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(CCQP_BLOCK) void gemv_stream_kernel(
     const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
     const double* __restrict__ b, double* __restrict__ y, double* __restrict__ g,
-    int64_t rows, int64_t cols, int64_t ntasks) {
+    int64_t rows, int64_t cols, int64_t ntasks, const double* __restrict__ skip) {
+  // pipelined solves (ccqp_pipe_*): launches queued behind a converged iteration find the flag set and leave
+  if (skip != nullptr && *skip != 0.0) return;
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   gemv_body<R, U, ALIGNED, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves);
@@ -28,31 +30,33 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_stream_kernel(
 
 template <int R, int U, bool ALIGNED, bool NT>
 static void launch_one(hipStream_t s, int grid, const double* A, int64_t lda, const double* x,
-                       const double* b, double* y, double* g, int64_t rows, int64_t cols) {
+                       const double* b, double* y, double* g, int64_t rows, int64_t cols, const double* skip) {
   const int64_t ntasks = (rows + R - 1) / R;
   hipLaunchKernelGGL((gemv_stream_kernel<R, U, ALIGNED, NT>), dim3(grid), dim3(CCQP_BLOCK), 0, s, A, lda,
-                     x, b, y, g, rows, cols, ntasks);
+                     x, b, y, g, rows, cols, ntasks, skip);
 }
 
 template <int R, int U>
 static void launch_ru(bool aligned, bool nt, hipStream_t s, int grid, const double* A, int64_t lda,
-                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols) {
+                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                      const double* skip) {
   if (aligned) {
-    if (nt) launch_one<R, U, true, true>(s, grid, A, lda, x, b, y, g, rows, cols);
-    else launch_one<R, U, true, false>(s, grid, A, lda, x, b, y, g, rows, cols);
+    if (nt) launch_one<R, U, true, true>(s, grid, A, lda, x, b, y, g, rows, cols, skip);
+    else launch_one<R, U, true, false>(s, grid, A, lda, x, b, y, g, rows, cols, skip);
   } else {
-    if (nt) launch_one<R, U, false, true>(s, grid, A, lda, x, b, y, g, rows, cols);
-    else launch_one<R, U, false, false>(s, grid, A, lda, x, b, y, g, rows, cols);
+    if (nt) launch_one<R, U, false, true>(s, grid, A, lda, x, b, y, g, rows, cols, skip);
+    else launch_one<R, U, false, false>(s, grid, A, lda, x, b, y, g, rows, cols, skip);
   }
 }
 
 template <int R>
 static int launch_r(int U, bool aligned, bool nt, hipStream_t s, int grid, const double* A, int64_t lda,
-                    const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols) {
+                    const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                    const double* skip) {
   switch (U) {
-    case 1: launch_ru<R, 1>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols); return 0;
-    case 2: launch_ru<R, 2>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols); return 0;
-    case 4: launch_ru<R, 4>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols); return 0;
+    case 1: launch_ru<R, 1>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols, skip); return 0;
+    case 2: launch_ru<R, 2>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols, skip); return 0;
+    case 4: launch_ru<R, 4>(aligned, nt, s, grid, A, lda, x, b, y, g, rows, cols, skip); return 0;
     default: return 1;
   }
 }
@@ -62,7 +66,8 @@ static int launch_r(int U, bool aligned, bool nt, hipStream_t s, int grid, const
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
 // yields the same bits, so this is speed only.
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
-                     double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s) {
+                     double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s,
+                     const double* skip) {
   int R = variant & 0xF, U = (variant >> 4) & 0xF;
   const bool nt = !((variant >> 8) & 1);
   int bpc = (variant >> 12) & 0xFF;
@@ -76,10 +81,10 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
   if (blocks < 1) blocks = 1;
   int bad = 0;
   switch (R) {
-    case 1: bad = launch_r<1>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols); break;
-    case 2: bad = launch_r<2>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols); break;
-    case 4: bad = launch_r<4>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols); break;
-    case 8: bad = launch_r<8>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols); break;
+    case 1: bad = launch_r<1>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
+    case 2: bad = launch_r<2>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
+    case 4: bad = launch_r<4>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
+    case 8: bad = launch_r<8>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
     default: bad = 1;
   }
   if (bad) {
@@ -105,7 +110,7 @@ extern "C" int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const 
   int rc = gemv_check(ctx, A, lda, x, y, rows, cols);
   if (rc) return rc;
   if (rows == 0) return CCQP_OK;
-  rc = ccqp_gemv_launch(ctx, A, lda, x, nullptr, y, nullptr, rows, cols, variant, (hipStream_t)stream);
+  rc = ccqp_gemv_launch(ctx, A, lda, x, nullptr, y, nullptr, rows, cols, variant, (hipStream_t)stream, nullptr);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -119,7 +124,7 @@ extern "C" int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t ld
   CCQP_REQUIRE(g == nullptr || b != nullptr, "g requested but b is NULL");
   CCQP_REQUIRE(g == nullptr || g != x, "g must not alias x");
   if (rows == 0) return CCQP_OK;
-  rc = ccqp_gemv_launch(ctx, A, lda, x, b, y, g, rows, cols, variant, (hipStream_t)stream);
+  rc = ccqp_gemv_launch(ctx, A, lda, x, b, y, g, rows, cols, variant, (hipStream_t)stream, nullptr);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

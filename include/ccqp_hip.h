@@ -238,6 +238,31 @@ int ccqp_projected_gradient_elementwise_f64(ccqp_ctx* ctx, const ccqp_seg* seg, 
                                             const double* g, const double* nv, double* free_g,
                                             double* chopped_g, void* stream);
 
+/* ---- opt-in: pipelined Barzilai-Borwein iterations (same bits, fewer host round trips) ------------------
+ * A BBPGD iteration (solvers.py:636-660) whose scalars stay on the device: ccqp_pipe_bb_tail_f64 derives
+ * alpha = dx.dx / (dx.dg + eps10) and the exit test sqrt(res2) < tol in its last block, keeps them in slab slots
+ * 48..51 {alpha, converged, iterations, res2} (and 0..2 as ccqp_bb_tail_elementwise_f64) and mirrors them into
+ * pinned host memory; ccqp_pipe_step_project_f64 (out = P(x - alpha g), alpha from the slab) and
+ * ccqp_pipe_gemv_epilogue_f64 can therefore be queued for the NEXT iterations without waiting -- every pipe
+ * kernel leaves at once when the slab says "converged".  ccqp_pipe_poll is a non-blocking look at the mirror:
+ * out[0..3] = {iterations finished, converged (0/1), res2, alpha}.  Elementwise sets, whole vectors only. */
+int ccqp_pipe_reset(ccqp_ctx* ctx, double alpha0, void* stream);
+int ccqp_pipe_step_project_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x, const double* g, double* out,
+                               void* stream);
+int ccqp_pipe_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
+                                double* y, double* g, int64_t rows, int64_t cols, int variant, void* stream);
+int ccqp_pipe_bb_tail_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x_new, const double* x_old,
+                          const double* g_new, const double* g_old, double c, double gd, double tol, double eps10,
+                          void* stream);
+int ccqp_pipe_poll(ccqp_ctx* ctx, double* out);
+/* hipGraph form of the same: bracket the ccqp_pipe_* calls of THREE consecutive iterations (a ring of three x / g
+ * buffers makes iteration k+3 a repeat of iteration k, argument for argument) with capture_begin / capture_end on
+ * `stream`, then replay with ccqp_pipe_graph_launch -- one launch instead of nine. */
+int ccqp_pipe_capture_begin(ccqp_ctx* ctx, void* stream);
+int ccqp_pipe_capture_end(ccqp_ctx* ctx, void* stream, void** graph_exec);
+int ccqp_pipe_graph_launch(ccqp_ctx* ctx, void* graph_exec, void* stream);
+int ccqp_pipe_graph_destroy(void* graph_exec);
+
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
  * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from

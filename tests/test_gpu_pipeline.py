@@ -1,0 +1,111 @@
+"""GPU: the pipelined BBPGD iteration (CCQPSolverBBPGD(..., pipeline=True); ccqp_pipe_* in ccqp_pipe.hip) keeps the
+step length and the exit test on the device and queues iterations ahead.  It is an execution strategy only: x,
+the residual, the converged flag, the reported and the executed MV counts must be those of the host-driven loop,
+bit for bit -- for every elementwise set, at reduction sizes with one and several blocks, under an MV cap at
+every position, and when the very first residual already meets the tolerance."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, gen_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(op, b, P, tol, max_mv, x0=None):
+    from ccqppy_amd import solvers
+    out = []
+    for pipe in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out.append(solvers.CCQPSolverBBPGD(tol, max_mv, pipeline=pipe).solve(op, b, x0=x0, convex_proj_op=P))
+    return out
+
+
+def _same(a, c):
+    assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+    assert bool(a.solution_converged) == bool(c.solution_converged)
+    assert float(a.solution_residual) == float(c.solution_residual)
+    xa, xc = a.solution, c.solution
+    xa = xa.cpu().numpy() if hasattr(xa, "cpu") else xa
+    xc = xc.cpu().numpy() if hasattr(xc, "cpu") else xc
+    assert np.array_equal(xa.view(np.uint64), xc.view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [64, 1024, 2048, 2049, 8192, 20000])
+@pytest.mark.parametrize("kind", ["Box", "Lower", "Upper", "Identity"])
+def test_pipelined_bbpgd_equals_host_driven_loop(n, kind):
+    from ccqppy_amd import problems, solution_spaces as ss
+    op, b, _ = problems.random_problem(n, 4321)
+    lo, hi = -0.3 * np.ones(n), 0.4 * np.ones(n)
+    P = {"Box": ss.BoxProjOp(n, lo, hi), "Lower": ss.LowerBoundProjOp(n, lo), "Upper": ss.UpperBoundProjOp(n, hi),
+         "Identity": ss.IdentityProjOp(n)}[kind]
+    a, c = _pair(op, b, P, 1e-8, 5000)
+    assert c.solution_converged
+    _same(a, c)
+
+
+def test_pipelined_bbpgd_under_every_mv_cap_and_trivial_start():
+    from ccqppy_amd import problems, solution_spaces as ss
+    n = 4096
+    op, b, _ = problems.random_problem(n, 99)
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    full, _ = _pair(op, b, P, 1e-10, 5000)
+    total = full.solution_num_matrix_vector_multiplications
+    assert total >= 8
+    for cap in range(1, total + 3):                          # cap before, at and after convergence
+        a, c = _pair(op, b, P, 1e-10, cap)
+        _same(a, c)
+    # numpy in, numpy out; warm start at the solution: the loop is never entered
+    A = gen_ref.spd_rows(512, 5)
+    bb = -A.dot(gen_ref.xstar(512, 5))
+    Pn = ss.BoxProjOp(512, -2.0 * np.ones(512), 2.0 * np.ones(512))
+    a, c = _pair(A, bb, Pn, 1e-8, 5000)
+    _same(a, c)
+    assert isinstance(c.solution, np.ndarray)
+    a2, c2 = _pair(A, bb, Pn, 1e-6, 5000, x0=c.solution)
+    _same(a2, c2)
+    assert c2.solution_num_matrix_vector_multiplications == 1
+    # and against the oracle
+    o = cpu_ref.solve_bbpgd(A, bb, 1e-8, 5000, P=cpu_ref.Box(512, -2.0 * np.ones(512), 2.0 * np.ones(512)))
+    assert o.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert np.linalg.norm(c.solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+
+
+def test_graph_replay_of_three_iterations_gives_the_same_bits():
+    """pipeline="graph": three captured iterations replayed as one hipGraph launch (plus single iterations near
+    an MV cap) -- same results again, also when torch's current stream is the default stream."""
+    import torch
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    n = 2048
+    op, b, _ = problems.random_problem(n, 31)
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    for cap in (5000, 11, 7, 6, 5, 4, 3, 2):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = solvers.CCQPSolverBBPGD(1e-10, cap).solve(op, b, convex_proj_op=P)
+            got = solvers.CCQPSolverBBPGD(1e-10, cap, pipeline="graph").solve(op, b, convex_proj_op=P)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                got2 = solvers.CCQPSolverBBPGD(1e-10, cap, pipeline="graph").solve(op, b, convex_proj_op=P)
+        _same(ref, got)
+        _same(ref, got2)
+
+
+def test_pipeline_request_falls_back_where_it_does_not_apply():
+    """Sphere sets, sparse operators, the fallback variant and the batch schedulers take the host-driven loop."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd.batch import solve_batch_fused
+    n = 1024
+    op, b, _ = problems.random_problem(n, 7)
+    a, c = _pair(op, b, ss.SphereProjOp(n, 3.0), 1e-8, 5000)
+    _same(a, c)
+    sop, sb, _ = problems.random_sparse_problem(4096, 8, 7)
+    a, c = _pair(sop, sb, ss.BoxProjOp(4096, -0.5 * np.ones(4096), 0.5 * np.ones(4096)), 1e-8, 5000)
+    _same(a, c)
+    probs = [(op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n)))] * 3
+    got = solve_batch_fused(lambda: solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=True), probs, lanes=3, groups=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = solvers.CCQPSolverBBPGD(1e-8, 5000).solve(*probs[0][:2], convex_proj_op=probs[0][3])
+    for g in got:
+        _same(ref, g)
