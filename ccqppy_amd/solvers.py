@@ -467,8 +467,14 @@ class _BBPGDCore(CCQPSolverBase):
                         break
                     tail(k)
                 lib.ccqp_pipe_poll(ctx, state)
+                spins = 0
                 while state[1] == 0.0 and k - state[0] >= ahead:
                     lib.ccqp_pipe_poll(ctx, state)
+                    spins += 1
+                    if spins > 200000:                      # mirror silent for ~0.1 s: ask the device itself
+                        d_, it_, _ = eng.read(49, 3)        # (blocking; everything queued so far has then run)
+                        state[0], state[1] = it_, d_
+                        spins = 0
                 if state[1] != 0.0:
                     break
             done, iters, res2 = eng.read(49, 3)             # blocking: the queue has drained
