@@ -89,6 +89,9 @@ SIGNATURES = {
     "ccqp_pipe_step_project_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P],
     "ccqp_pipe_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
     "ccqp_pipe_bb_tail_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _D, _D, _P],
+    "ccqp_pipe_spmv_csr_f64": [_P, _P, _P, _P, _P, _c.POINTER(_I64), _P, _P, _P, _P, _I64, _I64, _I64, _I, _P],
+    "ccqp_pipe_mul_f64": [_P, _P, _P, _P, _I64, _P],
+    "ccqp_pipe_axpby_f64": [_P, _D, _P, _D, _P, _P, _I64, _P],
     "ccqp_pipe_poll": [_P, _c.POINTER(_D)],
     "ccqp_pipe_capture_begin": [_P, _P],
     "ccqp_pipe_capture_end": [_P, _P, _c.POINTER(_P)],

@@ -187,6 +187,42 @@ extern "C" int ccqp_pipe_bb_tail_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const d
   return CCQP_OK;
 }
 
+// elementwise factors of a composed operator, behind the same word
+__global__ __launch_bounds__(CCQP_BLOCK) void pipe_mul_kernel(const double* x, const double* y, double* out, int64_t n,
+                                                              const double* slots) {
+  if (slots[PIPE_DONE] != 0.0) return;
+  const int64_t stride = (int64_t)gridDim.x * CCQP_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += stride) out[i] = x[i] * y[i];
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void pipe_axpby_kernel(double a, const double* x, double b, const double* y,
+                                                                double* out, int64_t n, const double* slots) {
+  if (slots[PIPE_DONE] != 0.0) return;
+  axpby_body(a, x, b, y, out, n, blockIdx.x, gridDim.x);
+}
+
+extern "C" int ccqp_pipe_mul_f64(ccqp_ctx* ctx, const double* x, const double* y, double* out, int64_t n,
+                                 void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && n >= 0, "bad argument");
+  if (n == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && y && out, "NULL vector");
+  hipLaunchKernelGGL(pipe_mul_kernel, dim3(pipe_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, x, y, out, n,
+                     ctx->slots);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_pipe_axpby_f64(ccqp_ctx* ctx, double a, const double* x, double b, const double* y, double* out,
+                                   int64_t n, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && n >= 0, "bad argument");
+  if (n == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && y && out, "NULL vector");
+  hipLaunchKernelGGL(pipe_axpby_kernel, dim3(pipe_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, a, x, b, y,
+                     out, n, ctx->slots);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 // Non-blocking look at the host mirror: out = {iterations finished, converged (0/1), res2, alpha}.
 extern "C" int ccqp_pipe_poll(ccqp_ctx* ctx, double* out) {
   CCQP_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");

@@ -241,9 +241,11 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
                                                                  const uint16_t* __restrict__ lcol,
                                                                  const double* __restrict__ x,
                                                                  const double* __restrict__ b, double* __restrict__ y,
-                                                                 double* __restrict__ g, int64_t last) {
+                                                                 double* __restrict__ g, int64_t last,
+                                                                 const double* __restrict__ skip) {
   constexpr int K = 64 / W;                 // canonical lanes per physical lane
   constexpr int SUBGROUPS = CCQP_BLOCK / W;
+  if (skip != nullptr && *skip != 0.0) return;      // pipelined solves: queued behind a converged iteration
   __shared__ double prod[SPMV_LDS];
   __shared__ uint16_t rstart[SPMV_ROWS_LDS + 2];      // row starts relative to the window
   // transposed windows pass the column indices through the first half of `prod` before any product exists
@@ -455,7 +457,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_long_rows_kernel(const int64_
                                                                     const int64_t* __restrict__ long_rows,
                                                                     const double* __restrict__ x,
                                                                     const double* __restrict__ b,
-                                                                    double* __restrict__ y, double* __restrict__ g) {
+                                                                    double* __restrict__ y, double* __restrict__ g,
+                                                                    const double* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0.0) return;
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   const int64_t n = *nlong;
@@ -528,22 +532,22 @@ static int spmv_pick_width(int64_t rows, int64_t nnz, int width) {
 template <int W>
 static void spmv_launch(unsigned grid, const int64_t* rowptr, const int32_t* col, const double* val,
                         const int64_t* plan, const double* x, const double* b, double* y, double* g, int64_t nnz,
-                        hipStream_t s) {
+                        hipStream_t s, const double* skip) {
   const int64_t nwin = spmv_windows(nnz);
   const int32_t* ucol = reinterpret_cast<const int32_t*>(plan + spmv_off_ucol(nwin));
   const uint16_t* lcol = reinterpret_cast<const uint16_t*>(plan + spmv_off_lcol(nwin));
   if (g)
     hipLaunchKernelGGL((spmv_stream_kernel<W, true>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan,
-                       ucol, lcol, x, b, y, g, nnz - 1);
+                       ucol, lcol, x, b, y, g, nnz - 1, skip);
   else
     hipLaunchKernelGGL((spmv_stream_kernel<W, false>), dim3(grid), dim3(CCQP_BLOCK), 0, s, rowptr, col, val, plan,
-                       ucol, lcol, x, b, y, g, nnz - 1);
+                       ucol, lcol, x, b, y, g, nnz - 1, skip);
 }
 
-extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
-                                 const int64_t* plan, const int64_t* summary, const double* x, const double* b,
-                                 double* y, double* g, int64_t rows, int64_t cols, int64_t nnz, int width,
-                                 void* stream) {
+static int spmv_csr_impl(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
+                         const int64_t* plan, const int64_t* summary, const double* x, const double* b, double* y,
+                         double* g, int64_t rows, int64_t cols, int64_t nnz, int width, void* stream,
+                         const double* skip) {
   CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
   CCQP_REQUIRE(rows >= 0 && cols >= 0 && nnz >= 0, "negative size");
   CCQP_REQUIRE(cols <= INT32_MAX, "cols exceeds the 32-bit column index");
@@ -567,11 +571,11 @@ extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int
   // summary (host copy of the plan's two counters) unknown: assume rows for the wave-per-row launch exist
   const int64_t n_long_rows = summary ? summary[0] : -1;
   switch (spmv_pick_width(rows, nnz, width)) {
-    case 4: spmv_launch<4>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 8: spmv_launch<8>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 16: spmv_launch<16>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    case 32: spmv_launch<32>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
-    default: spmv_launch<64>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s); break;
+    case 4: spmv_launch<4>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s, skip); break;
+    case 8: spmv_launch<8>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s, skip); break;
+    case 16: spmv_launch<16>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s, skip); break;
+    case 32: spmv_launch<32>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s, skip); break;
+    default: spmv_launch<64>(grid, rowptr, col, val, plan, x, b, y, g, nnz, s, skip); break;
   }
   if (n_long_rows != 0) {                    // < 0: unknown to the caller, the kernel reads the count
     const int64_t* count = plan + spmv_off_counts(nwin);
@@ -579,13 +583,30 @@ extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int
     if (lg > (int64_t)ctx->num_cu * 8) lg = (int64_t)ctx->num_cu * 8;
     if (g)
       hipLaunchKernelGGL((spmv_long_rows_kernel<true>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
-                         count, plan + spmv_off_long(nwin), x, b, y, g);
+                         count, plan + spmv_off_long(nwin), x, b, y, g, skip);
     else
       hipLaunchKernelGGL((spmv_long_rows_kernel<false>), dim3((unsigned)lg), dim3(CCQP_BLOCK), 0, s, rowptr, col, val,
-                         count, plan + spmv_off_long(nwin), x, b, y, g);
+                         count, plan + spmv_off_long(nwin), x, b, y, g, skip);
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
+}
+
+extern "C" int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
+                                 const int64_t* plan, const int64_t* summary, const double* x, const double* b,
+                                 double* y, double* g, int64_t rows, int64_t cols, int64_t nnz, int width,
+                                 void* stream) {
+  return spmv_csr_impl(ctx, rowptr, col, val, plan, summary, x, b, y, g, rows, cols, nnz, width, stream, nullptr);
+}
+
+// the same behind the pipeline's "converged" word (ccqp_pipe.hip): a no-op once slab slot 49 is set
+extern "C" int ccqp_pipe_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
+                                      const int64_t* plan, const int64_t* summary, const double* x, const double* b,
+                                      double* y, double* g, int64_t rows, int64_t cols, int64_t nnz, int width,
+                                      void* stream) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  return spmv_csr_impl(ctx, rowptr, col, val, plan, summary, x, b, y, g, rows, cols, nnz, width, stream,
+                       ctx->slots + 49);
 }
 
 extern "C" int ccqp_csr_validate(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, int64_t rows,

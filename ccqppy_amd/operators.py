@@ -17,6 +17,7 @@ and therefore the control flow and MV counts on every rank.
 import torch
 
 from ._engine import get_engine
+from ._lib import check as _check
 
 
 def row_partition(n, world, rank):
@@ -49,6 +50,15 @@ class DenseOperator:
 
     def apply(self, eng, x, y, b=None, g=None):
         eng.gemv(self.A, x, y, b, g)
+
+    def pipe_apply(self, eng, x, y, b=None, g=None):
+        """apply() behind the pipeline's "converged" word (solvers.CCQPSolverBBPGD(pipeline=True))."""
+        A = self.A
+        if g is None:
+            raise NotImplementedError("the pipelined dense matvec is the whole operator (it needs b and g)")
+        _check(eng.lib.ccqp_pipe_gemv_epilogue_f64(eng.ctx, A.data_ptr(), A.stride(0), x.data_ptr(), b.data_ptr(),
+                                                   y.data_ptr(), g.data_ptr(), A.shape[0], A.shape[1],
+                                                   eng.gemv_variant, eng.stream))
 
 
 class VectorExchange:
@@ -201,6 +211,14 @@ class SparseOperator:
     def apply(self, eng, x, y, b=None, g=None):
         eng.spmv_csr(self.rowptr, self.col, self.val, self.plan, self.summary, self.n, x, y, b, g, self.width)
 
+    def pipe_apply(self, eng, x, y, b=None, g=None):
+        """apply() behind the pipeline's "converged" word."""
+        _check(eng.lib.ccqp_pipe_spmv_csr_f64(eng.ctx, self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(),
+                                              self.plan.data_ptr(), self.summary, x.data_ptr(),
+                                              None if g is None else b.data_ptr(), y.data_ptr(),
+                                              None if g is None else g.data_ptr(), self.rows, self.n, self.nnz,
+                                              self.width, eng.stream))
+
     @property
     def T(self):
         """The transposed matrix as a SparseOperator of its own (built once on the device: a stable sort of
@@ -248,6 +266,12 @@ class DiagonalOperator:
 
     def matvec(self, x, y, b=None, g=None, engine=None):
         self.apply(engine or self.engine, x, y, b, g)
+
+    def pipe_apply(self, eng, x, y, b=None, g=None):
+        _check(eng.lib.ccqp_pipe_mul_f64(eng.ctx, self.d.data_ptr(), x.data_ptr(), y.data_ptr(), y.numel(), eng.stream))
+        if g is not None:
+            _check(eng.lib.ccqp_pipe_axpby_f64(eng.ctx, 1.0, y.data_ptr(), 1.0, b.data_ptr(), g.data_ptr(), g.numel(),
+                                               eng.stream))
 
 
 class ComposedOperator:
@@ -298,6 +322,24 @@ class ComposedOperator:
         y = torch.empty(self.rows, dtype=torch.float64, device=eng.device)
         self.matvec(eng.to_device(x), y)
         return y
+
+    def pipe_apply(self, eng, x, y, b=None, g=None):
+        """matvec() with every kernel behind the pipeline's "converged" word; sparse and diagonal factors only."""
+        cur = x
+        last = len(self.factors) - 1
+        for i, f in enumerate(reversed(self.factors)):
+            out = y if (i == last and self.shift == 0.0) else eng.empty(f.rows)
+            f.pipe_apply(eng, cur, out)
+            cur = out
+        if self.shift != 0.0:
+            _check(eng.lib.ccqp_pipe_axpby_f64(eng.ctx, 1.0, cur.data_ptr(), self.shift, x.data_ptr(), y.data_ptr(),
+                                               y.numel(), eng.stream))
+        if g is not None:
+            _check(eng.lib.ccqp_pipe_axpby_f64(eng.ctx, 1.0, y.data_ptr(), 1.0, b.data_ptr(), g.data_ptr(), g.numel(),
+                                               eng.stream))
+
+    def can_pipeline(self):
+        return all(isinstance(f, (SparseOperator, DiagonalOperator)) for f in self.factors)
 
 
 class RowShardedOperator:

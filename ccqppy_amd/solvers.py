@@ -380,7 +380,7 @@ class _BBPGDCore(CCQPSolverBase):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         # Extension, OFF by default, SAME results bit for bit: keep the per-iteration scalars (BB step length, exit
         # test) on the device and queue iterations ahead instead of one host round trip per iteration
-        # (ccqp_pipe_*; dense A, elementwise sets, plain solve()).  1.1-1.6x on 13-iteration solves with n <= 8k,
+        # (ccqp_pipe_*; dense, sparse and sparse/diagonal composed operators, elementwise sets, plain solve()).  1.1-1.6x on 13-iteration solves with n <= 8k,
         # 1.7-1.9x on 125-iteration ones.  pipeline="graph" additionally replays three captured iterations as one
         # hipGraph launch: measured no faster than the direct launches (the host is no longer the bottleneck) and
         # 0.3 ms of capture + instantiation per solve -- kept for the record.
@@ -388,8 +388,11 @@ class _BBPGDCore(CCQPSolverBase):
 
     def _can_pipeline(self, run):
         from ._record import RecordingEngine
-        from .operators import DenseOperator
-        return (self.pipeline and not self._fallback and isinstance(run.op, DenseOperator)
+        from .operators import ComposedOperator, DenseOperator, SparseOperator
+        op = run.op
+        ok_op = isinstance(op, (DenseOperator, SparseOperator)) or \
+            (isinstance(op, ComposedOperator) and op.can_pipeline())
+        return (self.pipeline and not self._fallback and ok_op
                 and hasattr(run.P, "_dev_bb_tail") and not isinstance(run.eng, RecordingEngine)
                 and run.eng.gemv_events is None)
 
@@ -401,7 +404,6 @@ class _BBPGDCore(CCQPSolverBase):
         X = [x0, run.new(), run.new()]
         G = [g0, run.new(), run.new()]
         y = run.new()
-        A = op.A
         check = _lib_check
         # stream capture is not possible on the legacy default stream: run the loop on a side stream that is
         # ordered behind the caller's work, and hand the results back the same way (the blocking read at the end
@@ -414,13 +416,13 @@ class _BBPGDCore(CCQPSolverBase):
             torch.cuda.set_stream(side)
             eng.bind()
         try:
-            return self._pipelined_loop(run, eng, seg, X, G, y, A, check, alpha, res, tol, max_mv)
+            return self._pipelined_loop(run, eng, seg, X, G, y, op, check, alpha, res, tol, max_mv)
         finally:
             if side is not None:
                 torch.cuda.set_stream(caller)
                 eng.bind()
 
-    def _pipelined_loop(self, run, eng, seg, X, G, y, A, check, alpha, res, tol, max_mv):
+    def _pipelined_loop(self, run, eng, seg, X, G, y, op, check, alpha, res, tol, max_mv):
         import ctypes
         n = run.n
         lib, ctx, st = eng.lib, eng.ctx, eng.stream
@@ -431,9 +433,7 @@ class _BBPGDCore(CCQPSolverBase):
         def step(k):
             new, cur = k % 3, (k - 1) % 3
             check(lib.ccqp_pipe_step_project_f64(ctx, seg, X[cur].data_ptr(), G[cur].data_ptr(), X[new].data_ptr(), st))
-            check(lib.ccqp_pipe_gemv_epilogue_f64(ctx, A.data_ptr(), A.stride(0), X[new].data_ptr(), run.b.data_ptr(),
-                                                  y.data_ptr(), G[new].data_ptr(), A.shape[0], A.shape[1],
-                                                  eng.gemv_variant, st))
+            op.pipe_apply(eng, X[new], y, run.b, G[new])    # A.x + b, a no-op once the slab says "converged"
 
         def tail(k):
             new, cur = k % 3, (k - 1) % 3
@@ -444,7 +444,9 @@ class _BBPGDCore(CCQPSolverBase):
         # device): capture them once as a hipGraph and replay it -- one launch instead of nine -- whenever the MV
         # cap is at least three full iterations away (pipeline="graph").
         graph = ctypes.c_void_p()
-        use_graph = self.pipeline == "graph"    # capture + instantiation cost ~0.3 ms: pays from ~40 iterations on
+        # (capture + instantiation cost ~0.3 ms; dense operators only: the other forms allocate intermediates)
+        from .operators import DenseOperator
+        use_graph = self.pipeline == "graph" and isinstance(op, DenseOperator)
         k, capped = 0, False
         try:
             while True:

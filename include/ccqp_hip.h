@@ -254,6 +254,13 @@ int ccqp_pipe_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, con
 int ccqp_pipe_bb_tail_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x_new, const double* x_old,
                           const double* g_new, const double* g_old, double c, double gd, double tol, double eps10,
                           void* stream);
+/* the other matvec forms and the elementwise factors of a composed operator behind the same "converged" word */
+int ccqp_pipe_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
+                           const int64_t* plan, const int64_t* summary, const double* x, const double* b, double* y,
+                           double* g, int64_t rows, int64_t cols, int64_t nnz, int width, void* stream);
+int ccqp_pipe_mul_f64(ccqp_ctx* ctx, const double* x, const double* y, double* out, int64_t n, void* stream);
+int ccqp_pipe_axpby_f64(ccqp_ctx* ctx, double a, const double* x, double b, const double* y, double* out, int64_t n,
+                        void* stream);
 int ccqp_pipe_poll(ccqp_ctx* ctx, double* out);
 /* hipGraph form of the same: bracket the ccqp_pipe_* calls of THREE consecutive iterations (a ring of three x / g
  * buffers makes iteration k+3 a repeat of iteration k, argument for argument) with capture_begin / capture_end on

@@ -92,17 +92,47 @@ def test_graph_replay_of_three_iterations_gives_the_same_bits():
         _same(ref, got2)
 
 
+def test_pipelined_bbpgd_on_sparse_and_matrix_free_operators():
+    """The CSR matvec (all its window modes, incl. the wave-per-row launch) and the factors of a composed operator
+    sit behind the same "converged" word."""
+    import scipy.sparse as sp
+    from ccqppy_amd import problems, solution_spaces as ss
+    from ccqppy_amd.operators import ComposedOperator, DiagonalOperator, SparseOperator
+    for n, k, pattern in ((4096, 8, "hashed"), (32768, 26, "stencil27"), (65536, 32, "hashed")):
+        op, b, _ = problems.random_sparse_problem(n, k, 1234, pattern=pattern)
+        a, c = _pair(op, b, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n)), 1e-8, 5000)
+        assert c.solution_converged
+        _same(a, c)
+    irr = gen_ref.irregular_spd(3000, 4).tolil()
+    irr[5, :] = 0.001 * np.random.default_rng(1).normal(size=3000)       # one row on the wave-per-row path
+    irr[:, 5] = irr[5, :].T
+    irr[5, 5] = 50.0
+    irr = sp.csr_matrix(irr)
+    bb = -irr.dot(gen_ref.xstar(3000, 4))
+    op = SparseOperator(irr)
+    assert op.summary[0] >= 1
+    a, c = _pair(op, bb, ss.BoxProjOp(3000, -0.5 * np.ones(3000), 0.5 * np.ones(3000)), 1e-8, 5000)
+    _same(a, c)
+    A, b, _ = gen_ref.contact_problem(2000, 3000, 5)
+    D = SparseOperator(A.D)
+    op = ComposedOperator(D, DiagonalOperator(A.minv), D.T, shift=A.eps)
+    for cap in (5000, 40, 7):
+        a, c = _pair(op, b, ss.LowerBoundProjOp(2000, np.zeros(2000)), 1e-8, cap)
+        _same(a, c)
+
+
 def test_pipeline_request_falls_back_where_it_does_not_apply():
-    """Sphere sets, sparse operators, the fallback variant and the batch schedulers take the host-driven loop."""
+    """Sphere sets, the fallback variant and the batch schedulers take the host-driven loop."""
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     from ccqppy_amd.batch import solve_batch_fused
     n = 1024
     op, b, _ = problems.random_problem(n, 7)
     a, c = _pair(op, b, ss.SphereProjOp(n, 3.0), 1e-8, 5000)
     _same(a, c)
-    sop, sb, _ = problems.random_sparse_problem(4096, 8, 7)
-    a, c = _pair(sop, sb, ss.BoxProjOp(4096, -0.5 * np.ones(4096), 0.5 * np.ones(4096)), 1e-8, 5000)
-    _same(a, c)
+    with contextlib.redirect_stdout(io.StringIO()):
+        f1 = solvers.CCQPSolverBBPGDf(1e-8, 5000).solve(op, b, convex_proj_op=ss.BoxProjOp(n, -0.5, 0.5))
+        f2 = solvers.CCQPSolverBBPGDf(1e-8, 5000, pipeline=True).solve(op, b, convex_proj_op=ss.BoxProjOp(n, -0.5, 0.5))
+    _same(f1, f2)
     probs = [(op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n)))] * 3
     got = solve_batch_fused(lambda: solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=True), probs, lanes=3, groups=1)
     with contextlib.redirect_stdout(io.StringIO()):
