@@ -15,8 +15,11 @@ from oracle import cpu_ref, gen_ref
 
 pytestmark = pytest.mark.gpu
 
-NCASES = 240
-NSPARSE = 80
+import os
+
+# CCQP_FUZZ_CASES / CCQP_FUZZ_SPARSE widen the sweep for a one-off soak run (defaults: what the suite runs)
+NCASES = int(os.environ.get("CCQP_FUZZ_CASES", "240"))
+NSPARSE = int(os.environ.get("CCQP_FUZZ_SPARSE", "80"))
 
 
 def _rand_leaf(rng, d, arrays, tag, allow_cone=True):

@@ -139,3 +139,25 @@ def test_pipeline_request_falls_back_where_it_does_not_apply():
         ref = solvers.CCQPSolverBBPGD(1e-8, 5000).solve(*probs[0][:2], convex_proj_op=probs[0][3])
     for g in got:
         _same(ref, g)
+
+
+@pytest.mark.parametrize("case_id", range(40))
+def test_pipelined_bbpgd_randomised(case_id):
+    """Random size, set (array / scalar / default bounds), tolerance, MV cap and starting point."""
+    from ccqppy_amd import problems, solution_spaces as ss
+    rng = np.random.default_rng(700 + case_id)
+    n = int(rng.integers(2, 6000))
+    op, b, _ = problems.random_problem(n, int(rng.integers(1, 10 ** 6)))
+    kind = ["Box", "Lower", "Upper", "Identity"][rng.integers(4)]
+    mode = rng.integers(3)
+    lo = -rng.uniform(0.1, 1.0, size=n) if mode == 0 else (-float(rng.uniform(0.1, 1.0)) if mode == 1 else None)
+    hi = rng.uniform(0.1, 1.0, size=n) if mode == 0 else (float(rng.uniform(0.1, 1.0)) if mode == 1 else None)
+    P = {"Box": ss.BoxProjOp(n, *[v for v in (lo, hi) if v is not None]) if mode != 2 else ss.BoxProjOp(n),
+         "Lower": ss.LowerBoundProjOp(n, lo) if lo is not None else ss.LowerBoundProjOp(n),
+         "Upper": ss.UpperBoundProjOp(n, hi) if hi is not None else ss.UpperBoundProjOp(n),
+         "Identity": ss.IdentityProjOp(n)}[kind]
+    tol = float(rng.choice([1e-5, 1e-8, 1e-11]))
+    cap = int(rng.choice([2, 3, 5, 9, 17, 5000]))
+    x0 = None if rng.random() < 0.5 else rng.uniform(-0.5, 0.5, size=n)
+    a, c = _pair(op, b, P, tol, cap, x0=x0)
+    _same(a, c)
