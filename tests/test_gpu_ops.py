@@ -253,6 +253,47 @@ def test_abi_error_reporting(eng):
         _lib.check(rc)
 
 
+def test_abi_error_reporting_of_the_fused_and_pipelined_entry_points(eng):
+    """Refused calls return CCQP_ERR_INVALID with a message and launch nothing."""
+    import ctypes
+    from ccqppy_amd import _lib, solution_spaces as ss
+    lib = _lib.load()
+    n = 100
+    eng.bind()
+    v = [eng.to_device(np.arange(n, dtype=np.float64) + i) for i in range(4)]
+    box = ss.BoxProjOp(n, -np.ones(n), np.ones(n))
+    seg = box._seg(eng, 0, n)
+    P = ctypes.c_void_p
+    one = (P * 1)(v[0].data_ptr())
+    none = (P * 1)(None)
+    # residual slot inside the dot slots
+    rc = lib.ccqp_fused_dots_f64(eng.ctx, 1, one, none, one, none, n, 5, seg, P(v[0].data_ptr()), P(v[1].data_ptr()),
+                                 1.0, 1e-6, 5, eng.stream)
+    assert rc == 1 and b"overlaps" in lib.ccqp_last_error()
+    # k out of range, residual on a sub-vector
+    assert lib.ccqp_fused_dots_f64(eng.ctx, 9, one, none, one, none, n, 0, None, None, None, 0.0, 0.0, 0, eng.stream) == 1
+    part = box._seg(eng, 10, 50)
+    rc = lib.ccqp_fused_dots_f64(eng.ctx, 1, one, none, one, none, n, 0, part, P(v[0].data_ptr()), P(v[1].data_ptr()),
+                                 1.0, 1e-6, 9, eng.stream)
+    assert rc == 1 and b"whole vectors" in lib.ccqp_last_error()
+    rc = lib.ccqp_bb_tail_elementwise_f64(eng.ctx, part, P(v[0].data_ptr()), P(v[1].data_ptr()), P(v[2].data_ptr()),
+                                          P(v[3].data_ptr()), 1.0, 1e-6, 0, eng.stream)
+    assert rc == 1 and b"offset must be 0" in lib.ccqp_last_error()
+    # the two updates of axpby2 must be independent
+    rc = lib.ccqp_axpby2_f64(eng.ctx, 1.0, P(v[0].data_ptr()), 1.0, P(v[1].data_ptr()), P(v[2].data_ptr()), 1.0,
+                             P(v[2].data_ptr()), 1.0, P(v[3].data_ptr()), P(v[3].data_ptr()), n, eng.stream)
+    assert rc == 1 and b"depend" in lib.ccqp_last_error()
+    # the pipelined iteration is for elementwise sets on whole vectors
+    sseg = _lib.Seg()
+    sseg.kind, sseg.dim, sseg.offset = _lib.OP_SPHERE, n, 0
+    rc = lib.ccqp_pipe_step_project_f64(eng.ctx, sseg, P(v[0].data_ptr()), P(v[1].data_ptr()), P(v[2].data_ptr()),
+                                        eng.stream)
+    assert rc == 1 and b"elementwise" in lib.ccqp_last_error()
+    rc = lib.ccqp_pipe_bb_tail_f64(eng.ctx, part, P(v[0].data_ptr()), P(v[1].data_ptr()), P(v[2].data_ptr()),
+                                   P(v[3].data_ptr()), 1.0, 1e-6, 1e-8, 1e-15, eng.stream)
+    assert rc == 1 and b"whole vectors" in lib.ccqp_last_error()
+
+
 import json as _json
 
 with open(H.GOLD + "/pg_cases.json") as _f:
