@@ -46,6 +46,14 @@ class Bop(ctypes.Structure):
                 ("seg", Seg)]
 
 
+class PProb(ctypes.Structure):
+    """struct ccqp_pprob (include/ccqp_hip.h): one problem of a batched pipelined BBPGD run."""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
+                ("x", ctypes.c_void_p * 3), ("g", ctypes.c_void_p * 3), ("y", ctypes.c_void_p),
+                ("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
+
+
 (BOP_GEMV, BOP_AXPBY, BOP_SCALE, BOP_COPY, BOP_FILL, BOP_DOTS, BOP_PROJ_ELEM, BOP_RESIDUAL_ELEM,
  BOP_FEASIBLE_ELEM, BOP_MPRGP_SPLIT, BOP_MPRGP_NORMAL_DOT, BOP_MPRGP_PROPORTION, BOP_FREE_GRADIENT_ELEM,
  BOP_CG_DIRECTION) = range(1, 15)
@@ -97,6 +105,10 @@ SIGNATURES = {
     "ccqp_pipe_capture_end": [_P, _P, _c.POINTER(_P)],
     "ccqp_pipe_graph_launch": [_P, _P, _P],
     "ccqp_pipe_graph_destroy": [_P],
+    "ccqp_bpipe_partials_doubles": [_I64],
+    "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
+    "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
+    "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
     "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],
@@ -149,7 +161,8 @@ def load():
                                      % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "ccqp_last_error" else
-                      ctypes.c_int64 if name in ("ccqp_symv_workspace_doubles", "ccqp_spmv_plan_words") else ctypes.c_int)
+                      ctypes.c_int64 if name in ("ccqp_symv_workspace_doubles", "ccqp_spmv_plan_words",
+                                                 "ccqp_bpipe_partials_doubles") else ctypes.c_int)
     if lib.ccqp_abi_version() != 1:
         raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib

@@ -313,3 +313,153 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
     if not quiet:
         print(out.getvalue(), end="")
     return solvers
+
+
+# ---------------------------------------------------------------------------------------------
+# Pipelined batch: equal-size dense BBPGD solves in lock-step with every scalar on the device.
+# ---------------------------------------------------------------------------------------------
+_BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
+
+
+def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4):
+    """Many SMALL dense problems of one size n, solved by BBPGD (solvers.py:560-693) in lock-step: three launches
+    per iteration for the whole batch, step lengths and exit tests computed on the device (ccqp_bpipe_*,
+    csrc/ccqp_bpipe.hip), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python
+    per problem and scalar read at n <= 4096; this one is not.
+
+    make_solver : () -> CCQPSolverBBPGD (no other solver); all with the same max_matrix_vector_multiplications
+    problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
+                  elementwise (Identity / Lower / Upper / Box) or None
+    Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
+    and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
+    the wall-clock of the whole batch."""
+    from . import _lib
+    from . import solution_spaces as ss
+    from .operators import DenseOperator, as_operator
+    from .solvers import CCQPSolverBBPGD
+    problems = list(problems)
+    solvers = [make_solver() for _ in problems]
+    if not problems:
+        return solvers
+    t0 = time.time()
+    eng = get_engine(device)
+    eng.bind()
+    max_mv = solvers[0].max_matrix_vector_multiplications
+    items = []
+    n = None
+    for s, (A, b, x0, P) in zip(solvers, problems):
+        if type(s) is not CCQPSolverBBPGD:
+            raise TypeError("solve_batch_pipelined runs CCQPSolverBBPGD only, got %s" % type(s).__name__)
+        if s.max_matrix_vector_multiplications != max_mv:
+            raise ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
+        op = as_operator(A)
+        if not isinstance(op, DenseOperator) or op.rows != op.n:
+            raise TypeError("solve_batch_pipelined needs square dense operators")
+        if n is None:
+            n = op.n
+        if op.n != n or b.shape[0] != n:
+            raise ValueError("solve_batch_pipelined: all problems must have the same size")
+        if op.A.device != eng.device:
+            raise ValueError("solve_batch_pipelined: operator on another device")
+        P = P if P is not None else ss.IdentityProjOp(n)
+        if not hasattr(P, "_dev_bb_tail"):
+            raise TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
+        bd = eng.to_device(b).reshape(-1)
+        items.append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
+                      isinstance(b, torch.Tensor)))
+    if not quiet:
+        for s in solvers:
+            print("solving " + s._label)
+    with np.errstate(all="ignore"):
+        for lo in range(0, len(items), _BPIPE_MAX):
+            _bpipe_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead)
+    dt = time.time() - t0
+    for s in solvers:
+        s._solution_time = dt
+    return solvers
+
+
+def _bpipe_group(eng, items, n, max_mv, ahead):
+    import ctypes
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(items)
+    pd = int(lib.ccqp_bpipe_partials_doubles(n))
+    vec = torch.empty((7, B, n), dtype=torch.float64, device=dev)       # x ring, g ring, y
+    vec[0].zero_()                                                      # x0 = 0 (solvers.py:125-126)
+    for p, it in enumerate(items):
+        if it[3] is not None:
+            vec[0, p].copy_(it[3])
+    slabs = torch.zeros((B, 64), dtype=torch.float64, device=dev)
+    partials = torch.empty((B, max(pd, 1)), dtype=torch.float64, device=dev)
+    words = torch.zeros(B + 2, dtype=torch.int32, device=dev)           # per-problem counters + 2 batch words
+    dt = np.dtype(_lib.PProb)
+    tab = np.zeros(B, dtype=dt)
+    rows = np.arange(B, dtype=np.uint64) * np.uint64(8 * n)
+    plane = np.uint64(8 * n * B)
+    base = np.uint64(vec.data_ptr())
+    tab["A"] = [it[1].A.data_ptr() for it in items]
+    tab["lda"] = [it[1].A.stride(0) for it in items]
+    tab["b"] = [it[2].data_ptr() for it in items]
+    for j in range(3):
+        tab["x"][:, j] = base + np.uint64(j) * plane + rows
+        tab["g"][:, j] = base + np.uint64(3 + j) * plane + rows
+    tab["y"] = base + np.uint64(6) * plane + rows
+    tab["seg"] = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=dt["seg"])
+    tab["slab"] = np.uint64(slabs.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * 64)
+    tab["partials"] = np.uint64(partials.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * max(pd, 1))
+    tab["counter"] = np.uint64(words.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(4)
+    tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
+    tab["tol"] = [it[0].desired_residual_tol for it in items]
+    aligned = int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2))
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
+    check = _lib.check
+    check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, aligned, batch, st))
+    state = (ctypes.c_double * 2)()
+    k, capped = 0, False
+    while True:
+        k += 1
+        tail = not (1 + k >= max_mv)                    # the reference breaks before the residual (:643-644)
+        check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), aligned, int(tail), batch, st))
+        if not tail:
+            capped = True
+            break
+        lib.ccqp_bpipe_poll(ctx, state)
+        spins = 0
+        while state[0] < B and k - state[1] >= ahead:
+            lib.ccqp_bpipe_poll(ctx, state)
+            spins += 1
+            if spins > 2000000:                         # mirror silent for ~1 s: wait for the queue itself
+                torch.cuda.current_stream(dev).synchronize()
+                lib.ccqp_bpipe_poll(ctx, state)
+                if state[1] != k:
+                    raise RuntimeError("solve_batch_pipelined: the device never reported iteration %d" % k)
+                spins = 0
+        if state[0] >= B:
+            break
+    h = slabs[:, 48:52].cpu().numpy()                   # blocking: the queue has drained
+    done, iters, res2 = h[:, 1] != 0.0, h[:, 2].astype(np.int64), h[:, 3]
+    if not capped and not done.all():
+        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+    last = np.where(done, iters, k)
+    sel = torch.from_numpy(last % 3).to(dev)
+    sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
+    host = None
+    res = np.sqrt(res2)
+    for p, it in enumerate(items):
+        s = it[0]
+        mv = 1 + int(last[p])
+        if it[5]:
+            s._solution = sols[p]
+        else:
+            if host is None:
+                host = sols.cpu().numpy()
+            s._solution = host[p]
+        s._solution_converged = mv < max_mv
+        s._solution_residual = res[p]
+        s._solution_num_matrix_vector_mults = mv
+        # start-up: A x0 and -- unless the start already satisfies the tolerance -- A g0 (executed, not counted)
+        s._executed_matrix_vector_mults = 1 if (done[p] and iters[p] == 0) else 2 + int(last[p])
+        eng.mv_executed += s._executed_matrix_vector_mults

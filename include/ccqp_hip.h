@@ -270,6 +270,38 @@ int ccqp_pipe_capture_end(ccqp_ctx* ctx, void* stream, void** graph_exec);
 int ccqp_pipe_graph_launch(ccqp_ctx* ctx, void* graph_exec, void* stream);
 int ccqp_pipe_graph_destroy(void* graph_exec);
 
+/* ---- opt-in: MANY equal-size dense BBPGD solves (solvers.py:560-693) in lock-step, scalars on the device ---
+ * The pipelined iteration above, batched: blockIdx.y = problem, three launches per iteration for the whole batch,
+ * a converged problem's blocks leave at once.  `dev_probs` is a DEVICE array of `count` descriptors; `dev_batch`
+ * two device words owned by the caller.  Per-problem slab (>= 52 doubles, zeroed before start): slots 0..2 as
+ * ccqp_bb_tail_elementwise_f64, 48..51 = {alpha, converged, iterations finished, res2}.  Each problem's results are
+ * bit for bit those of its own solve(): x = x[iterations % 3] (converged) or x[last iteration % 3] (budget). */
+typedef struct ccqp_pprob {
+  const double* A;   /* n x n, row-major, leading dimension lda */
+  int64_t lda;
+  const double* b;
+  double* x[3];      /* ring; x[0] holds x0 on entry */
+  double* g[3];
+  double* y;
+  ccqp_seg seg;      /* elementwise kind, offset 0, dim n */
+  double* slab;
+  double* partials;  /* ccqp_bpipe_partials_doubles(n) doubles */
+  uint32_t* counter; /* one word, zero on entry */
+  double c;          /* residual scale 1/(3 n gd), solvers.py:138 */
+  double tol;
+} ccqp_pprob;
+int64_t ccqp_bpipe_partials_doubles(int64_t n);
+/* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `aligned` != 0
+ * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even). */
+int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd, int aligned,
+                         uint32_t* dev_batch, void* stream);
+/* iteration >= 1: x[it%3] = P(x[(it-1)%3] - alpha g[..]); g[it%3] = A x[it%3] + b; with_tail != 0: residual, BB
+ * dots, alpha, exit test (with_tail == 0 where the matvec budget ends before the residual, solvers.py:643-644). */
+int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, int64_t iteration,
+                           double gd, double eps10, int aligned, int with_tail, uint32_t* dev_batch, void* stream);
+/* non-blocking: out[0..1] = {problems converged, last iteration every problem has finished (-1: none yet)} */
+int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out);
+
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
  * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from

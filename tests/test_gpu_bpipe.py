@@ -1,0 +1,152 @@
+"""GPU: solve_batch_pipelined (ccqp_bpipe_* in ccqp_bpipe.hip) advances many equal-size dense BBPGD solves in
+lock-step with every scalar on the device.  It is an execution strategy only: per problem x, the residual, the
+converged flag, the reported and the executed MV counts must be those of that problem's own solve(), bit for bit --
+for every elementwise set, with one and several reduction blocks, odd sizes (unaligned rows), warm starts, problems
+that finish at the start, mixed tolerances, and under an MV cap at every position."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, gen_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, c):
+    assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+    assert bool(a.solution_converged) == bool(c.solution_converged)
+    assert float(a.solution_residual) == float(c.solution_residual)
+    xa, xc = a.solution, c.solution
+    xa = xa.cpu().numpy() if hasattr(xa, "cpu") else xa
+    xc = xc.cpu().numpy() if hasattr(xc, "cpu") else xc
+    assert np.array_equal(xa.view(np.uint64), xc.view(np.uint64))
+
+
+def _sets(n, p):
+    from ccqppy_amd import solution_spaces as ss
+    lo, hi = -0.3 * np.ones(n) - 0.01 * (p % 5), 0.4 * np.ones(n) + 0.02 * (p % 3)
+    return [ss.BoxProjOp(n, lo, hi), ss.LowerBoundProjOp(n, lo), ss.UpperBoundProjOp(n, hi), None,
+            ss.BoxProjOp(n, -0.25, 0.5), ss.LowerBoundProjOp(n, 0)][p % 6]
+
+
+def _problems(n, count, seed):
+    from ccqppy_amd import problems
+    out = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, seed + p)
+        out.append((op, b, None, _sets(n, p)))
+    return out
+
+
+def _reference(probs, tols, max_mv):
+    from ccqppy_amd import solvers
+    ref = []
+    for (A, b, x0, P), tol in zip(probs, tols):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.append(solvers.CCQPSolverBBPGD(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
+    return ref
+
+
+def _batch(probs, tols, max_mv, **kw):
+    from ccqppy_amd import batch, solvers
+    it = iter(tols)
+    return batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(next(it), max_mv), probs, **kw)
+
+
+@pytest.mark.parametrize("n,count", [(37, 13), (256, 40), (1000, 12), (2049, 7), (4500, 5)])
+def test_batched_pipeline_equals_individual_solves(n, count):
+    probs = _problems(n, count, 700 + n)
+    tols = [1e-8] * count
+    ref = _reference(probs, tols, 5000)
+    got = _batch(probs, tols, 5000)
+    assert len(got) == count
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
+    assert len({r.solution_num_matrix_vector_multiplications for r in ref}) >= 1
+
+
+def test_mixed_tolerances_warm_starts_and_trivial_starts():
+    import torch
+    n, count = 512, 24
+    probs = _problems(n, count, 31)
+    tols = [[1e-10, 1e-6, 1e-3, 1e30][p % 4] for p in range(count)]       # 1e30: satisfied by x0 already
+    first = _reference(probs, [1e-9] * count, 5000)
+    # warm start every third problem at (nearly) its solution
+    for p in range(0, count, 3):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, first[p].solution.clone() if isinstance(first[p].solution, torch.Tensor)
+                    else first[p].solution.copy(), P)
+    ref = _reference(probs, tols, 5000)
+    got = _batch(probs, tols, 5000)
+    for a, c in zip(ref, got):
+        _same(a, c)
+    assert any(r.solution_num_matrix_vector_multiplications == 1 for r in ref)
+    assert any(r.solution_num_matrix_vector_multiplications > 5 for r in ref)
+
+
+def test_every_mv_cap():
+    n, count = 300, 9
+    probs = _problems(n, count, 5)
+    tols = [1e-9] * count
+    full = _reference(probs, tols, 5000)
+    longest = max(r.solution_num_matrix_vector_multiplications for r in full)
+    shortest = min(r.solution_num_matrix_vector_multiplications for r in full)
+    assert longest > shortest >= 3                       # the cap separates finished from unfinished problems
+    for cap in range(1, longest + 3):
+        ref = _reference(probs, tols, cap)
+        got = _batch(probs, tols, cap)
+        for a, c in zip(ref, got):
+            _same(a, c)
+
+
+def test_numpy_problems_and_the_oracle():
+    n, count = 192, 6
+    probs, tols = [], [1e-8] * count
+    for p in range(count):
+        A = gen_ref.spd_rows(n, 40 + p)
+        b = -A.dot(gen_ref.xstar(n, 40 + p))
+        from ccqppy_amd import solution_spaces as ss
+        probs.append((A, b, None, ss.BoxProjOp(n, -2.0 * np.ones(n), 2.0 * np.ones(n))))
+    got = _batch(probs, tols, 5000, ahead=1)
+    for (A, b, _, _), c in zip(probs, got):
+        assert isinstance(c.solution, np.ndarray)
+        o = cpu_ref.solve_bbpgd(A, b, 1e-8, 5000, P=cpu_ref.Box(n, -2.0 * np.ones(n), 2.0 * np.ones(n)))
+        assert o.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert np.linalg.norm(c.solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+    ref = _reference(probs, tols, 5000)
+    for a, c in zip(ref, got):
+        _same(a, c)
+
+
+def test_large_batch_and_back_to_back_batches():
+    """300 problems (more than one wave of workgroups per launch), then a second, smaller batch on the same context:
+    the progress mirror of the first must not leak into the second."""
+    n = 128
+    probs = _problems(n, 300, 9000)
+    tols = [1e-8] * len(probs)
+    got = _batch(probs, tols, 5000)
+    ref = _reference(probs[::25], tols[::25], 5000)
+    for a, c in zip(ref, got[::25]):
+        _same(a, c)
+    assert all(c.solution_converged for c in got)
+    probs2 = _problems(n, 300, 9000)[:7]
+    got2 = _batch(probs2, tols[:7], 5000)
+    for a, c in zip(got[:7], got2):
+        _same(a, c)
+
+
+def test_rejects_what_it_cannot_run():
+    from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
+    op, b, _ = problems.random_problem(64, 1)
+    op2, b2, _ = problems.random_problem(96, 2)
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGDf(1e-8), [(op, b, None, None)])
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, ss.ConeProjOp(64))])
+    with pytest.raises(ValueError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, None), (op2, b2, None, None)])
+    assert batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), []) == []
