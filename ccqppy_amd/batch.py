@@ -321,7 +321,7 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 
 
-def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4):
+def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0):
     """Many SMALL dense problems of one size n, solved by BBPGD (solvers.py:560-693) in lock-step: three launches
     per iteration for the whole batch, step lengths and exit tests computed on the device (ccqp_bpipe_*,
     csrc/ccqp_bpipe.hip), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python
@@ -372,14 +372,14 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
             print("solving " + s._label)
     with np.errstate(all="ignore"):
         for lo in range(0, len(items), _BPIPE_MAX):
-            _bpipe_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead)
+            _bpipe_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
     for s in solvers:
         s._solution_time = dt
     return solvers
 
 
-def _bpipe_group(eng, items, n, max_mv, ahead):
+def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
     import ctypes
     from . import _lib
     from .solvers import _EPS10, _GD
@@ -412,7 +412,8 @@ def _bpipe_group(eng, items, n, max_mv, ahead):
     tab["counter"] = np.uint64(words.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(4)
     tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
     tab["tol"] = [it[0].desired_residual_tol for it in items]
-    aligned = int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2))
+    # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
+    aligned = int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_step_kernel(const ccqp_pprob
 //   mode 0:  y = A x[i],  g[i] = y + b        mode 1:  y = A g[i]
 // The matrices of a batch are re-read every iteration and fit the 256 MiB of MALL for the sizes this path is
 // meant for, so the loads are ordinary (cacheable) ones, unlike the single big matvec's.
-template <bool ALIGNED>
+template <int U, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_gemv_kernel(const ccqp_pprob* __restrict__ probs, int i, int mode,
                                                                 int64_t n) {
   const ccqp_pprob& q = probs[blockIdx.y];
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_gemv_kernel(const ccqp_pprob
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   if (mode == 0)
-    gemv_body<1, 1, ALIGNED, false>(q.A, q.lda, q.x[i], q.b, q.y, q.g[i], n, n, n, wave, nwaves);
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.x[i], q.b, q.y, q.g[i], n, n, n, wave, nwaves);
   else
-    gemv_body<1, 1, ALIGNED, false>(q.A, q.lda, q.g[i], nullptr, q.y, nullptr, n, n, n, wave, nwaves);
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.g[i], nullptr, q.y, nullptr, n, n, n, wave, nwaves);
 }
 
 // start-up, first reduction: residual^2 of (x[0], g[0]) and g0.g0; the exit test of solvers.py `if res >= tol`
@@ -201,21 +201,39 @@ static inline int bp_vec_grid(int64_t n) {
   return (int)g;
 }
 
-static inline unsigned bp_mv_grid(int64_t n, int count) {
-  // one row per wave at a time; enough workgroups per problem that the batch fills the chip a few times over
-  int64_t per = (n + CCQP_BLOCK / 64 - 1) / (CCQP_BLOCK / 64);
-  int64_t want = (8192 + count - 1) / count;
-  if (want < 1) want = 1;
-  if (per > want) per = want;
-  return (unsigned)per;
-}
-
-static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int aligned, hipStream_t s) {
-  const dim3 grid(bp_mv_grid(n, count), count);
-  if (aligned)
-    hipLaunchKernelGGL((bpipe_gemv_kernel<true>), grid, dim3(CCQP_BLOCK), 0, s, probs, i, mode, n);
-  else
-    hipLaunchKernelGGL((bpipe_gemv_kernel<false>), grid, dim3(CCQP_BLOCK), 0, s, probs, i, mode, n);
+// `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
+// result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
+// per wave step in units of 128 (1, 2, 4), bits 8.. workgroups per problem.
+static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+  const bool aligned = flags & 1;
+  int nt = (flags >> 1) & 3, U = (flags >> 4) & 7;
+  int64_t per = flags >> 8;
+  const double bytes = 8.0 * (double)n * (double)n * count;
+  if (nt == 0) nt = bytes > 192.0 * 1048576.0 ? 2 : 1;      // a batch that fits the MALL is re-read from there
+  if (U == 0) U = n >= 4096 ? 4 : 1;
+  const int64_t rows_per_wg = CCQP_BLOCK / 64;
+  // many small workgroups: ~64k per launch measured best for n = 256..4096 (profiles/r01g_bpipe_sweep.txt)
+  if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
+  if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
+  if (per < 1) per = 1;
+  const dim3 grid((unsigned)per, count);
+#define BP_GEMV(UU, AL, NTT)                                                                              \
+  hipLaunchKernelGGL((bpipe_gemv_kernel<UU, AL, NTT>), grid, dim3(CCQP_BLOCK), 0, s, probs, i, mode, n)
+#define BP_GEMV_U(AL, NTT)            \
+  do {                                \
+    if (U >= 4) BP_GEMV(4, AL, NTT);  \
+    else if (U == 2) BP_GEMV(2, AL, NTT); \
+    else BP_GEMV(1, AL, NTT);         \
+  } while (0)
+  if (aligned) {
+    if (nt == 2) BP_GEMV_U(true, true);
+    else BP_GEMV_U(true, false);
+  } else {
+    if (nt == 2) BP_GEMV_U(false, true);
+    else BP_GEMV_U(false, false);
+  }
+#undef BP_GEMV_U
+#undef BP_GEMV
 }
 
 #define BP_CHECK_BATCH()                                                                          \
@@ -225,7 +243,7 @@ static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mo
 // Start-up of all solves (solvers.py:626-636): g0 = A x0 + b, residual, A g0, alpha0.  Expects x[0] staged, the
 // per-problem counters zero; sequence number 0 is published when every problem has its residual.
 extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd,
-                                    int aligned, uint32_t* dev_batch, void* stream) {
+                                    int flags, uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
@@ -238,10 +256,10 @@ extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
   hipLaunchKernelGGL(bpipe_begin_kernel, dim3(1), dim3(64), 0, s, dev_batch);
   // (DONE is read by the matvec: the caller zeroes the slabs before this call)
-  bp_gemv(dev_probs, count, n, 0, 0, aligned, s);
+  bp_gemv(dev_probs, count, n, 0, 0, flags, s);
   hipLaunchKernelGGL(bpipe_init_res_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, 0.0);
-  bp_gemv(dev_probs, count, n, 0, 1, aligned, s);
+  bp_gemv(dev_probs, count, n, 0, 1, flags, s);
   hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -250,14 +268,14 @@ extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
 // Iteration `iteration` >= 1 of all live solves: x[new] = P(x[cur] - alpha g[cur]); g[new] = A x[new] + b; and,
 // unless `with_tail` is 0 (the matvec budget ends here, solvers.py:643-644), the fused tail.
 extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n,
-                                      int64_t iteration, double gd, double eps10, int aligned, int with_tail,
+                                      int64_t iteration, double gd, double eps10, int flags, int with_tail,
                                       uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
   CCQP_REQUIRE(iteration >= 1, "iterations count from 1");
   hipStream_t s = (hipStream_t)stream;
   const int inew = (int)(iteration % 3), icur = (int)((iteration - 1) % 3);
   hipLaunchKernelGGL(bpipe_step_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur);
-  bp_gemv(dev_probs, count, n, inew, 0, aligned, s);
+  bp_gemv(dev_probs, count, n, inew, 0, flags, s);
   if (with_tail) {
     int64_t chunk;
     int nblk;

@@ -291,14 +291,15 @@ typedef struct ccqp_pprob {
   double tol;
 } ccqp_pprob;
 int64_t ccqp_bpipe_partials_doubles(int64_t n);
-/* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `aligned` != 0
- * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even). */
-int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd, int aligned,
+/* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
+ * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
+ * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_bpipe.hip). */
+int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd, int flags,
                          uint32_t* dev_batch, void* stream);
 /* iteration >= 1: x[it%3] = P(x[(it-1)%3] - alpha g[..]); g[it%3] = A x[it%3] + b; with_tail != 0: residual, BB
  * dots, alpha, exit test (with_tail == 0 where the matvec budget ends before the residual, solvers.py:643-644). */
 int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, int64_t iteration,
-                           double gd, double eps10, int aligned, int with_tail, uint32_t* dev_batch, void* stream);
+                           double gd, double eps10, int flags, int with_tail, uint32_t* dev_batch, void* stream);
 /* non-blocking: out[0..1] = {problems converged, last iteration every problem has finished (-1: none yet)} */
 int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out);
 
