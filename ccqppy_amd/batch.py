@@ -322,21 +322,23 @@ _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; ke
 
 
 def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0):
-    """Many SMALL dense problems of one size n, solved by BBPGD (solvers.py:560-693) in lock-step: three launches
-    per iteration for the whole batch, step lengths and exit tests computed on the device (ccqp_bpipe_*,
-    csrc/ccqp_bpipe.hip), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python
-    per problem and scalar read at n <= 4096; this one is not.
+    """Many SMALL dense problems of one size n, solved by BBPGD (solvers.py:560-693) or APGD (:197-367) in
+    lock-step: three launches per iteration (APGD: per matvec) for the whole batch, step lengths, line-search and
+    exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_*, csrc/ccqp_bpipe.hip), the host only polls a
+    progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
+    this one is not.
 
-    make_solver : () -> CCQPSolverBBPGD (no other solver); all with the same max_matrix_vector_multiplications
+    make_solver : () -> CCQPSolverBBPGD or CCQPSolverAPGD (plain: no fallback / anti-relaxation / matvec reuse),
+                  all of one class with the same max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
     and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
-    the wall-clock of the whole batch."""
-    from . import _lib
+    the wall-clock of the whole batch.  (APGD problems that would run into the matvec budget are handed to plain
+    solve(), whose exit path at the budget has quirks of its own.)"""
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
-    from .solvers import CCQPSolverBBPGD
+    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -344,12 +346,16 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     t0 = time.time()
     eng = get_engine(device)
     eng.bind()
+    kind = type(solvers[0])
+    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD) or getattr(solvers[0], "reuse_matvec", False):
+        raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD only, got %s"
+                        % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
     items = []
     n = None
     for s, (A, b, x0, P) in zip(solvers, problems):
-        if type(s) is not CCQPSolverBBPGD:
-            raise TypeError("solve_batch_pipelined runs CCQPSolverBBPGD only, got %s" % type(s).__name__)
+        if type(s) is not kind or getattr(s, "reuse_matvec", False):
+            raise TypeError("solve_batch_pipelined: one solver class for the whole batch")
         if s.max_matrix_vector_multiplications != max_mv:
             raise ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
         op = as_operator(A)
@@ -366,66 +372,31 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
             raise TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
         bd = eng.to_device(b).reshape(-1)
         items.append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
-                      isinstance(b, torch.Tensor)))
+                      isinstance(b, torch.Tensor), (A, b, x0, P)))
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
+    group = _bpipe_group if kind is CCQPSolverBBPGD else _bapgd_group
     with np.errstate(all="ignore"):
         for lo in range(0, len(items), _BPIPE_MAX):
-            _bpipe_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
+            group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
     for s in solvers:
         s._solution_time = dt
     return solvers
 
 
-def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
+def _bpipe_poll_loop(eng, B, launch, last_round, ahead):
+    """Queue rounds 1, 2, ... (`launch(k)`) at most `ahead` beyond the last one the device reported, until every
+    problem has converged or `last_round` has been queued.  Returns the number of rounds queued."""
     import ctypes
-    from . import _lib
-    from .solvers import _EPS10, _GD
-    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(items)
-    pd = int(lib.ccqp_bpipe_partials_doubles(n))
-    vec = torch.empty((7, B, n), dtype=torch.float64, device=dev)       # x ring, g ring, y
-    vec[0].zero_()                                                      # x0 = 0 (solvers.py:125-126)
-    for p, it in enumerate(items):
-        if it[3] is not None:
-            vec[0, p].copy_(it[3])
-    slabs = torch.zeros((B, 64), dtype=torch.float64, device=dev)
-    partials = torch.empty((B, max(pd, 1)), dtype=torch.float64, device=dev)
-    words = torch.zeros(B + 2, dtype=torch.int32, device=dev)           # per-problem counters + 2 batch words
-    dt = np.dtype(_lib.PProb)
-    tab = np.zeros(B, dtype=dt)
-    rows = np.arange(B, dtype=np.uint64) * np.uint64(8 * n)
-    plane = np.uint64(8 * n * B)
-    base = np.uint64(vec.data_ptr())
-    tab["A"] = [it[1].A.data_ptr() for it in items]
-    tab["lda"] = [it[1].A.stride(0) for it in items]
-    tab["b"] = [it[2].data_ptr() for it in items]
-    for j in range(3):
-        tab["x"][:, j] = base + np.uint64(j) * plane + rows
-        tab["g"][:, j] = base + np.uint64(3 + j) * plane + rows
-    tab["y"] = base + np.uint64(6) * plane + rows
-    tab["seg"] = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=dt["seg"])
-    tab["slab"] = np.uint64(slabs.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * 64)
-    tab["partials"] = np.uint64(partials.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * max(pd, 1))
-    tab["counter"] = np.uint64(words.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(4)
-    tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
-    tab["tol"] = [it[0].desired_residual_tol for it in items]
-    # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
-    aligned = int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
-    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
-    check = _lib.check
-    check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, aligned, batch, st))
+    lib, ctx = eng.lib, eng.ctx
     state = (ctypes.c_double * 2)()
-    k, capped = 0, False
-    while True:
+    k = 0
+    while k < last_round:
         k += 1
-        tail = not (1 + k >= max_mv)                    # the reference breaks before the residual (:643-644)
-        check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), aligned, int(tail), batch, st))
-        if not tail:
-            capped = True
+        launch(k)
+        if k >= last_round:                             # (the last round of a budget may report nothing)
             break
         lib.ccqp_bpipe_poll(ctx, state)
         spins = 0
@@ -433,25 +404,91 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
             lib.ccqp_bpipe_poll(ctx, state)
             spins += 1
             if spins > 2000000:                         # mirror silent for ~1 s: wait for the queue itself
-                torch.cuda.current_stream(dev).synchronize()
+                torch.cuda.current_stream(eng.device).synchronize()
                 lib.ccqp_bpipe_poll(ctx, state)
                 if state[1] != k:
-                    raise RuntimeError("solve_batch_pipelined: the device never reported iteration %d" % k)
+                    raise RuntimeError("solve_batch_pipelined: the device never reported round %d" % k)
                 spins = 0
         if state[0] >= B:
             break
+    return k
+
+
+def _bpipe_table(eng, items, n, struct, nvec, partial_rows):
+    """Workspace + descriptor table shared by the lock-step drivers: `nvec` (B, n) vector planes, zeroed slabs,
+    partial-sum areas, counters; returns (vec, slabs, words, tab, base, plane, rows)."""
+    from . import _lib
+    from .solvers import _GD
+    dev = eng.device
+    B = len(items)
+    nblk = max(int(eng.lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+    vec = torch.empty((nvec, B, n), dtype=torch.float64, device=dev)
+    slabs = torch.zeros((B, 64), dtype=torch.float64, device=dev)
+    partials = torch.empty((B, partial_rows * nblk), dtype=torch.float64, device=dev)
+    words = torch.zeros(B + 2, dtype=torch.int32, device=dev)           # per-problem counters + 2 batch words
+    dt = np.dtype(struct)
+    tab = np.zeros(B, dtype=dt)
+    idx = np.arange(B, dtype=np.uint64)
+    tab["A"] = [it[1].A.data_ptr() for it in items]
+    tab["lda"] = [it[1].A.stride(0) for it in items]
+    tab["b"] = [it[2].data_ptr() for it in items]
+    tab["seg"] = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=dt["seg"])
+    tab["slab"] = np.uint64(slabs.data_ptr()) + idx * np.uint64(8 * 64)
+    tab["partials"] = np.uint64(partials.data_ptr()) + idx * np.uint64(8 * partial_rows * nblk)
+    tab["counter"] = np.uint64(words.data_ptr()) + idx * np.uint64(4)
+    tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
+    tab["tol"] = [it[0].desired_residual_tol for it in items]
+    planes = [np.uint64(vec.data_ptr()) + np.uint64(j) * np.uint64(8 * n * B) + idx * np.uint64(8 * n)
+              for j in range(nvec)]
+    keep = (partials,)
+    return vec, slabs, words, tab, planes, keep
+
+
+def _bpipe_flags(tab, n, tune):
+    # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
+    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
+
+
+def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(items)
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PProb, 7, 3)   # x ring, g ring, y
+    vec[0].zero_()                                                      # x0 = 0 (solvers.py:125-126)
+    for p, it in enumerate(items):
+        if it[3] is not None:
+            vec[0, p].copy_(it[3])
+    for j in range(3):
+        tab["x"][:, j] = planes[j]
+        tab["g"][:, j] = planes[3 + j]
+    tab["y"] = planes[6]
+    flags = _bpipe_flags(tab, n, tune)
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
+    check = _lib.check
+    check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
+    # iteration k with 1 + k >= max_mv is the last one and has no tail: the reference breaks before the
+    # residual (:643-644)
+    last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
+
+    def launch(k):
+        check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
+
+    k = _bpipe_poll_loop(eng, B, launch, last, ahead)
+    capped = 1 + k >= max_mv
     h = slabs[:, 48:52].cpu().numpy()                   # blocking: the queue has drained
     done, iters, res2 = h[:, 1] != 0.0, h[:, 2].astype(np.int64), h[:, 3]
     if not capped and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    last = np.where(done, iters, k)
-    sel = torch.from_numpy(last % 3).to(dev)
+    final = np.where(done, iters, k)
+    sel = torch.from_numpy(final % 3).to(dev)
     sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
     host = None
     res = np.sqrt(res2)
     for p, it in enumerate(items):
         s = it[0]
-        mv = 1 + int(last[p])
+        mv = 1 + int(final[p])
         if it[5]:
             s._solution = sols[p]
         else:
@@ -462,5 +499,65 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_residual = res[p]
         s._solution_num_matrix_vector_mults = mv
         # start-up: A x0 and -- unless the start already satisfies the tolerance -- A g0 (executed, not counted)
-        s._executed_matrix_vector_mults = 1 if (done[p] and iters[p] == 0) else 2 + int(last[p])
+        s._executed_matrix_vector_mults = 1 if (done[p] and iters[p] == 0) else 2 + int(final[p])
         eng.mv_executed += s._executed_matrix_vector_mults
+    del keep
+
+
+def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
+    from . import _lib
+    from .solvers import _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(items)
+    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PApgd, 8, 7)
+    vec[0].zero_()
+    for p, it in enumerate(items):
+        if it[3] is not None:
+            vec[0, p].copy_(it[3])
+    vec[2].copy_(vec[0])                                                # yk = x0 (solvers.py:257-258)
+    tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
+    tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
+    tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"] = planes[4], planes[5], planes[6], planes[7]
+    flags = _bpipe_flags(tab, n, tune)
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
+    check = _lib.check
+    check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
+    # round r performs matvec number 1 + r; the rounds stop one short of the budget, where the reference's exit
+    # path takes over (:277-278, :288-289): such problems go to plain solve() below
+    last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
+
+    def launch(r):
+        check(lib.ccqp_bapgd_round_f64(ctx, dp, B, n, r, _GD, flags, batch, st))
+
+    _bpipe_poll_loop(eng, B, launch, last, ahead)
+    h = slabs[:, 32:52].cpu().numpy()                   # blocking: the queue has drained
+    done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
+    if not np.isfinite(max_mv) and not done.all():
+        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+    sel = torch.from_numpy((its + 1) % 2).to(dev)
+    sols = vec[0:2][sel, torch.arange(B, device=dev)]
+    host = None
+    res = np.sqrt(res2)
+    import contextlib
+    import io
+    for p, it in enumerate(items):
+        s = it[0]
+        if not done[p]:                                  # budget reached: the reference's own exit path
+            A, b, x0, P = it[6]
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            continue
+        if it[5]:
+            s._solution = sols[p]
+        else:
+            if host is None:
+                host = sols.cpu().numpy()
+            s._solution = host[p]
+        s._solution_converged = int(mvs[p]) < max_mv
+        s._solution_residual = res[p]
+        s._solution_num_matrix_vector_mults = int(mvs[p])
+        s._executed_matrix_vector_mults = int(mvs[p])
+        eng.mv_executed += int(mvs[p])
+    del keep

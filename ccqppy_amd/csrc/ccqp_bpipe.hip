@@ -204,36 +204,53 @@ static inline int bp_vec_grid(int64_t n) {
 // `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
 // result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
 // per wave step in units of 128 (1, 2, 4), bits 8.. workgroups per problem.
-static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
-  const bool aligned = flags & 1;
-  int nt = (flags >> 1) & 3, U = (flags >> 4) & 7;
+struct bp_mv_tuning {
+  bool aligned;
+  int nt, U;
+  dim3 grid;
+};
+
+static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
+  bp_mv_tuning t;
+  t.aligned = flags & 1;
+  t.nt = (flags >> 1) & 3;
+  t.U = (flags >> 4) & 7;
   int64_t per = flags >> 8;
   const double bytes = 8.0 * (double)n * (double)n * count;
-  if (nt == 0) nt = bytes > 192.0 * 1048576.0 ? 2 : 1;      // a batch that fits the MALL is re-read from there
-  if (U == 0) U = n >= 4096 ? 4 : 1;
+  if (t.nt == 0) t.nt = bytes > 192.0 * 1048576.0 ? 2 : 1;  // a batch that fits the MALL is re-read from there
+  if (t.U == 0) t.U = n >= 4096 ? 4 : 1;
   const int64_t rows_per_wg = CCQP_BLOCK / 64;
   // many small workgroups: ~64k per launch measured best for n = 256..4096 (profiles/r01g_bpipe_sweep.txt)
   if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
   if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
   if (per < 1) per = 1;
-  const dim3 grid((unsigned)per, count);
-#define BP_GEMV(UU, AL, NTT)                                                                              \
-  hipLaunchKernelGGL((bpipe_gemv_kernel<UU, AL, NTT>), grid, dim3(CCQP_BLOCK), 0, s, probs, i, mode, n)
-#define BP_GEMV_U(AL, NTT)            \
-  do {                                \
-    if (U >= 4) BP_GEMV(4, AL, NTT);  \
-    else if (U == 2) BP_GEMV(2, AL, NTT); \
-    else BP_GEMV(1, AL, NTT);         \
+  t.grid = dim3((unsigned)per, count);
+  return t;
+}
+
+// launches KERNEL<U, ALIGNED, NT>(args...) for the tuning `t`
+#define BP_MV_LAUNCH1(KERNEL, UU, AL, NTT, ...) \
+  hipLaunchKernelGGL((KERNEL<UU, AL, NTT>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
+#define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
+  do {                                                                \
+    if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__);     \
+    else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
+    else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
   } while (0)
-  if (aligned) {
-    if (nt == 2) BP_GEMV_U(true, true);
-    else BP_GEMV_U(true, false);
-  } else {
-    if (nt == 2) BP_GEMV_U(false, true);
-    else BP_GEMV_U(false, false);
-  }
-#undef BP_GEMV_U
-#undef BP_GEMV
+#define BP_MV_LAUNCH(KERNEL, ...)                                          \
+  do {                                                                     \
+    if (t.aligned) {                                                       \
+      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, true, true, __VA_ARGS__);      \
+      else BP_MV_LAUNCH_U(KERNEL, true, false, __VA_ARGS__);               \
+    } else {                                                               \
+      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, false, true, __VA_ARGS__);     \
+      else BP_MV_LAUNCH_U(KERNEL, false, false, __VA_ARGS__);              \
+    }                                                                      \
+  } while (0)
+
+static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bpipe_gemv_kernel, probs, i, mode, n);
 }
 
 #define BP_CHECK_BATCH()                                                                          \
@@ -304,4 +321,305 @@ extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
   int nblk;
   ccqp_red_geometry(n > 0 ? n : 1, &chunk, &nblk);
   return 3 * (int64_t)nblk;
+}
+
+// =====================================================================================================================
+// Lock-step APGD (solvers.py:220-343): the same idea for the accelerated method, whose iteration is a small state
+// machine -- one matvec of y_k, then one matvec per backtracking trial of x_{k+1}.  A ROUND is three launches for
+// the whole batch and advances every live problem by exactly one matvec:
+//   matvec   phase 0:  A y_k -> (Ayk, gk)            phase 1:  A x_{k+1} -> (Ax1, g1)
+//   decide   phase 0:  nothing to reduce; next action = trial step, phase 1
+//            phase 1:  the 6 (first trial: 8) dot products and the residual of solvers.py:296-301,321-323 in one
+//                      pass; the problem's last block evaluates the sufficient-decrease test and either accepts
+//                      (momentum scalars, exit test, L *= 0.9, phase 0) or rejects (L *= 2, another trial)
+//   apply    action 1: x_{k+1} = P(y_k - t g_k)       action 2: y_{k+1} = (1 + beta) x_{k+1} - beta x_k
+// x and y live in two buffers each, addressed by the parity of the accepted-iteration count `it`, so "swapping the
+// iterates" is the increment of `it` by the deciding thread.  State changes are made only by the LAST block of a
+// problem to arrive in `decide`, i.e. after every block of that launch has read the state.
+// The scalar arithmetic is the host loop's, operation for operation (fp contraction is off in this library).
+#define AP_L 32
+#define AP_T 33
+#define AP_THK 34
+#define AP_BETA 35
+#define AP_R1 36
+#define AP_R2 37
+#define AP_PHASE 38
+#define AP_ACT 39
+#define AP_IT 40
+#define AP_FIRST 44
+#define AP_DONE BP_DONE   // 49
+#define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
+#define AP_RES2 BP_RES2   // 51
+
+__device__ __forceinline__ ccqp_segk ap_segk(const ccqp_papgd& q) {
+  ccqp_segk k;
+  k.kind = q.seg.kind;
+  k.flags = q.seg.flags;
+  k.dim = q.seg.dim;
+  k.lb = q.seg.lb;
+  k.ub = q.seg.ub;
+  k.lb_s = q.seg.lb_s;
+  k.ub_s = q.seg.ub_s;
+  return k;
+}
+
+// all blocks of one problem meet here; true in the last one (sums of v[0..nred) over the blocks in v, thread 0)
+__device__ __forceinline__ bool ap_finish(const ccqp_papgd& q, int nblk, int nred, double* v, double* lds4,
+                                          int* is_last) {
+  if (nblk == 1) return true;
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < nred; ++k) q.partials[(int64_t)k * nblk + blockIdx.x] = v[k];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *is_last = prev + 1u == (unsigned)nblk;
+    if (*is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!*is_last) return false;
+  for (int k = 0; k < nred; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += q.partials[(int64_t)k * nblk + i];
+    v[k] = ccqp_block_sum(acc, lds4);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// d = x0 - ones (solvers.py:262) into the spare x buffer
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_d_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const double* __restrict__ x = q.X[0];
+  double* __restrict__ d = q.X[1];
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  BODY_LOOP(i, n) {
+    const double t1 = 1.0 * x[i];
+    const double t2 = -1.0 * 1.0;
+    d[i] = t1 + t2;
+  }
+}
+
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd* __restrict__ probs, int init,
+                                                                int64_t n) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  if (init) {
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, n, wave, nwaves);
+    return;
+  }
+  if (q.slab[AP_DONE] != 0.0) return;
+  const int it = (int)q.slab[AP_IT];
+  if (q.slab[AP_PHASE] == 0.0)
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.Y[it & 1], q.b, q.Ayk, q.gk, n, n, n, wave, nwaves);
+  else
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, n, wave, nwaves);
+}
+
+// L = |A d| / |d|, t = 1 / L (solvers.py:264-268) and the initial state
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
+                                                                  int64_t chunk, int nblk) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_papgd& q = probs[blockIdx.y];
+  double v[2];
+  v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, blockIdx.x, lds4);
+  v[1] = dot_body(q.X[1], q.X[1], n, chunk, blockIdx.x, lds4);
+  if (!ap_finish(q, nblk, 2, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    double* s = q.slab;
+    const double L = sqrt(v[0]) / sqrt(v[1]);
+    s[0] = v[0];
+    s[1] = v[1];
+    s[AP_L] = L;
+    s[AP_T] = 1.0 / L;
+    s[AP_THK] = 1.0;
+    s[AP_BETA] = 0.0;
+    s[AP_PHASE] = 0.0;
+    s[AP_ACT] = 0.0;
+    s[AP_IT] = 0.0;
+    s[AP_FIRST] = 0.0;
+    s[AP_DONE] = 0.0;
+    s[AP_MV] = 1.0;
+    s[AP_RES2] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_papgd* __restrict__ probs, double gd,
+                                                                  int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch,
+                                                                  double* __restrict__ host, unsigned count,
+                                                                  double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_papgd& q = probs[blockIdx.y];
+  double* s = q.slab;
+  if (s[AP_DONE] != 0.0) {                 // converged earlier: only the roll-call
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  double v[7];
+  if (s[AP_PHASE] == 0.0) {
+    // the matvec of y_k has run; next: the first trial step.  (All blocks meet so that the state changes only
+    // after every block has read it.)
+    if (!ap_finish(q, nblk, 0, v, lds4, &is_last)) return;
+    if (threadIdx.x == 0) {
+      s[AP_PHASE] = 1.0;
+      s[AP_ACT] = 1.0;
+      s[AP_FIRST] = 1.0;
+      s[AP_MV] = s[AP_MV] + 1.0;
+      bp_report(batch, host, count, seq);
+    }
+    return;
+  }
+  const ccqp_segk sg = ap_segk(q);
+  const int64_t n = sg.dim;
+  const int it = (int)s[AP_IT];
+  const bool first = s[AP_FIRST] != 0.0;
+  const double* __restrict__ x1 = q.X[(it + 1) & 1];
+  const double* __restrict__ yk = q.Y[it & 1];
+  const double* __restrict__ Ayk = q.Ayk;
+  const double* __restrict__ Ax1 = q.Ax1;
+  const double* __restrict__ gk = q.gk;
+  const double* __restrict__ bv = q.b;
+  {
+    const int bx = blockIdx.x;
+    CHUNK_RANGE(n)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double xi = x1[i], yi = yk[i], bi = bv[i];
+      if (first) {
+        a0 = fma(yi, Ayk[i], a0);
+        a1 = fma(yi, bi, a1);
+      }
+      a2 = fma(xi, Ax1[i], a2);
+      a3 = fma(xi, bi, a3);
+      const double d = xi - yi;
+      a4 = fma(gk[i], d, a4);
+      a5 = fma(d, d, a5);
+    }
+    v[0] = ccqp_block_sum(a0, lds4);
+    v[1] = ccqp_block_sum(a1, lds4);
+    v[2] = ccqp_block_sum(a2, lds4);
+    v[3] = ccqp_block_sum(a3, lds4);
+    v[4] = ccqp_block_sum(a4, lds4);
+    v[5] = ccqp_block_sum(a5, lds4);
+    v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, blockIdx.x, lds4);
+  }
+  if (!ap_finish(q, nblk, 7, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    double r1, r2;
+    if (first) {
+      r1 = v[0] * 0.5;
+      r2 = v[1];
+      s[AP_R1] = r1;
+      s[AP_R2] = r2;
+      s[0] = v[0];
+      s[1] = v[1];
+    } else {
+      r1 = s[AP_R1];
+      r2 = s[AP_R2];
+    }
+    for (int k = 2; k < 7; ++k) s[k] = v[k];
+    s[7] = v[6];
+    double L = s[AP_L];
+    const double l1 = v[2] * 0.5;
+    const double l2 = v[3];
+    const double r3 = v[4];
+    const double hL = 0.5 * L;
+    const double r4 = hL * v[5];
+    const double lhs = l1 + l2;
+    const double rhs = ((r1 + r2) + r3) + r4;
+    s[AP_MV] = s[AP_MV] + 1.0;
+    if (lhs <= rhs) {                                    // solvers.py:302
+      const double thk = s[AP_THK];
+      const double tt = thk * thk;
+      const double root = sqrt(4.0 + tt);
+      const double m1 = (-thk) * thk;
+      const double m2 = thk * root;
+      const double thk1 = 0.5 * (m1 + m2);               // :312
+      const double num = thk * (1.0 - thk);
+      const double beta = num / (tt + thk1);             // :313
+      const double res = sqrt(v[6]);
+      s[AP_RES2] = v[6];
+      if (res < q.tol) {
+        s[AP_DONE] = 1.0;
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        L = L * 0.9;
+        s[AP_L] = L;
+        s[AP_T] = 1.0 / L;
+        s[AP_THK] = thk1;
+        s[AP_BETA] = beta;
+        s[AP_IT] = (double)(it + 1);
+        s[AP_PHASE] = 0.0;
+        s[AP_ACT] = 2.0;
+      }
+    } else {
+      L = L * 2.0;
+      s[AP_L] = L;
+      s[AP_T] = 1.0 / L;
+      s[AP_ACT] = 1.0;
+      s[AP_FIRST] = 0.0;
+    }
+    bp_report(batch, host, count, seq);
+  }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papgd* __restrict__ probs) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[AP_DONE] != 0.0) return;
+  const int it = (int)s[AP_IT];
+  if (s[AP_ACT] == 1.0) {
+    const double mt = -s[AP_T];
+    proj_elem_body(ap_segk(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], blockIdx.x, gridDim.x);
+  } else {
+    const double beta = s[AP_BETA];
+    const double a = 1.0 + beta, b = -beta;
+    axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, blockIdx.x, gridDim.x);
+  }
+}
+
+// Start-up of all solves: d = x0 - 1, A d, L, t.  Expects X[0] = Y[0] = x0, slabs and counters zero.
+extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
+                                    uint32_t* dev_batch, void* stream) {
+  BP_CHECK_BATCH();
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  ctx->host_slots[BP_MIRROR] = 0.0;
+  ctx->host_slots[BP_MIRROR + 1] = -1.0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  hipLaunchKernelGGL(bpipe_begin_kernel, dim3(1), dim3(64), 0, s, dev_batch);
+  hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 1, n);
+  hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// Round `round` >= 1: one matvec for every live problem, the decision, the vector update it asks for.
+extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round,
+                                    double gd, int flags, uint32_t* dev_batch, void* stream) {
+  BP_CHECK_BATCH();
+  CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 0, n);
+  hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
+                     dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round);
+  hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
 }

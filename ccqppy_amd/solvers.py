@@ -424,7 +424,6 @@ class _BBPGDCore(CCQPSolverBase):
 
     def _pipelined_loop(self, run, eng, seg, X, G, y, op, check, alpha, res, tol, max_mv):
         import ctypes
-        n = run.n
         lib, ctx, st = eng.lib, eng.ctx, eng.stream
         check(lib.ccqp_pipe_reset(ctx, float(alpha), st))
         state = (ctypes.c_double * 4)()

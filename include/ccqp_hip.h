@@ -303,6 +303,35 @@ int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count
 /* non-blocking: out[0..1] = {problems converged, last iteration every problem has finished (-1: none yet)} */
 int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out);
 
+/* The same for APGD (solvers.py:220-343), whose iteration is a small state machine (one matvec of y_k, then one
+ * matvec per backtracking trial of x_{k+1}).  A ROUND advances every live problem by exactly one matvec: matvec,
+ * decide (all dot products + residual of :296-301,321-323 in one pass, sufficient-decrease test :302, momentum
+ * :312-313, exit test, L update), apply (trial step x_{k+1} = P(y_k - t g_k)  or  y_{k+1} = (1+beta) x_{k+1} -
+ * beta x_k).  Slab (>= 52 doubles, zeroed): 0..7 the host loop's eight scalars, 32..37 {L, t, theta_k, beta, r1,
+ * r2}, 38..40 {phase, action, accepted iterations}, 49..51 {converged, matvecs so far, res2}.  A converged
+ * problem's solution is X[(accepted iterations + 1) % 2].  ccqp_bpipe_poll reports {converged, round}. */
+typedef struct ccqp_papgd {
+  const double* A;
+  int64_t lda;
+  const double* b;
+  double* X[2];      /* x_k / x_{k+1} by parity of the accepted-iteration count; X[0] = x0 on entry */
+  double* Y[2];      /* y_k / y_{k+1};                                            Y[0] = x0 on entry */
+  double* gk;        /* A y_k + b */
+  double* g1;        /* A x_{k+1} + b */
+  double* Ayk;
+  double* Ax1;
+  ccqp_seg seg;      /* elementwise kind, offset 0, dim n */
+  double* slab;
+  double* partials;  /* 7 * ccqp_bpipe_partials_doubles(n) / 3 doubles */
+  uint32_t* counter; /* one word, zero on entry */
+  double c;
+  double tol;
+} ccqp_papgd;
+int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
+                         uint32_t* dev_batch, void* stream);
+int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
+                         int flags, uint32_t* dev_batch, void* stream);
+
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
  * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from

@@ -1,5 +1,5 @@
-"""GPU: solve_batch_pipelined (ccqp_bpipe_* in ccqp_bpipe.hip) advances many equal-size dense BBPGD solves in
-lock-step with every scalar on the device.  It is an execution strategy only: per problem x, the residual, the
+"""GPU: solve_batch_pipelined (ccqp_bpipe_* / ccqp_bapgd_* in ccqp_bpipe.hip) advances many equal-size dense BBPGD
+or APGD solves in lock-step with every scalar on the device.  It is an execution strategy only: per problem x, the residual, the
 converged flag, the reported and the executed MV counts must be those of that problem's own solve(), bit for bit --
 for every elementwise set, with one and several reduction blocks, odd sizes (unaligned rows), warm starts, problems
 that finish at the start, mixed tolerances, and under an MV cap at every position."""
@@ -41,19 +41,21 @@ def _problems(n, count, seed):
     return out
 
 
-def _reference(probs, tols, max_mv):
+def _reference(probs, tols, max_mv, solver="BBPGD"):
     from ccqppy_amd import solvers
+    cls = getattr(solvers, "CCQPSolver" + solver)
     ref = []
     for (A, b, x0, P), tol in zip(probs, tols):
         with contextlib.redirect_stdout(io.StringIO()):
-            ref.append(solvers.CCQPSolverBBPGD(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
+            ref.append(cls(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
     return ref
 
 
-def _batch(probs, tols, max_mv, **kw):
+def _batch(probs, tols, max_mv, solver="BBPGD", **kw):
     from ccqppy_amd import batch, solvers
+    cls = getattr(solvers, "CCQPSolver" + solver)
     it = iter(tols)
-    return batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(next(it), max_mv), probs, **kw)
+    return batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, **kw)
 
 
 @pytest.mark.parametrize("n,count", [(37, 13), (256, 40), (1000, 12), (2049, 7), (4500, 5)])
@@ -139,12 +141,73 @@ def test_large_batch_and_back_to_back_batches():
         _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(37, 13), (256, 40), (1000, 12), (2049, 7), (4500, 5)])
+def test_lockstep_apgd_equals_individual_solves(n, count):
+    probs = _problems(n, count, 1700 + n)
+    tols = [1e-8] * count
+    ref = _reference(probs, tols, 5000, "APGD")
+    got = _batch(probs, tols, 5000, "APGD")
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
+    assert max(r.solution_num_matrix_vector_multiplications for r in ref) > 20
+
+
+def test_lockstep_apgd_mixed_tolerances_warm_starts_numpy_and_ahead():
+    import torch
+    n, count = 384, 18
+    probs = _problems(n, count, 77)
+    first = _reference(probs, [1e-9] * count, 5000, "APGD")
+    for p in range(0, count, 3):                        # warm start every third problem at its solution
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, first[p].solution.clone(), P)
+    tols = [[1e-10, 1e-6, 1e-3, 1e30][p % 4] for p in range(count)]
+    ref = _reference(probs, tols, 5000, "APGD")
+    for ahead in (1, 4, 16):
+        got = _batch(probs, tols, 5000, "APGD", ahead=ahead)
+        for a, c in zip(ref, got):
+            _same(a, c)
+    assert min(r.solution_num_matrix_vector_multiplications for r in ref) <= 4
+    # numpy in, numpy out, and the oracle
+    from ccqppy_amd import solution_spaces as ss
+    A = gen_ref.spd_rows(192, 8)
+    b = -A.dot(gen_ref.xstar(192, 8))
+    lo, hi = -2.0 * np.ones(192), 2.0 * np.ones(192)
+    got = _batch([(A, b, None, ss.BoxProjOp(192, lo, hi))], [1e-8], 5000, "APGD")
+    assert isinstance(got[0].solution, np.ndarray)
+    o = cpu_ref.solve_apgd(A, b, 1e-8, 5000, P=cpu_ref.Box(192, lo, hi))
+    assert o.solution_num_matrix_vector_multiplications == got[0].solution_num_matrix_vector_multiplications
+    assert np.linalg.norm(got[0].solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+    assert isinstance(first[0].solution, torch.Tensor)
+
+
+def test_lockstep_apgd_under_a_matvec_budget():
+    """Problems that converge inside the budget come from the lock-step run, the others from the reference's own exit
+    path (plain solve()); either way the results are those of individual solves, at every budget."""
+    n, count = 200, 8
+    probs = _problems(n, count, 11)
+    tols = [1e-9] * count
+    full = _reference(probs, tols, 5000, "APGD")
+    longest = max(r.solution_num_matrix_vector_multiplications for r in full)
+    shortest = min(r.solution_num_matrix_vector_multiplications for r in full)
+    assert longest > shortest
+    for cap in list(range(3, 9)) + list(range(shortest - 2, longest + 3)):
+        ref = _reference(probs, tols, cap, "APGD")
+        got = _batch(probs, tols, cap, "APGD")
+        for a, c in zip(ref, got):
+            _same(a, c)
+
+
 def test_rejects_what_it_cannot_run():
     from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(64, 1)
     op2, b2, _ = problems.random_problem(96, 2)
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGDf(1e-8), [(op, b, None, None)])
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGDAntiRelaxation(1e-8), [(op, b, None, None)])
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(1e-8, reuse_matvec=True), [(op, b, None, None)])
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, ss.ConeProjOp(64))])
     with pytest.raises(ValueError):

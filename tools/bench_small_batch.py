@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput of MANY SMALL dense BBPGD solves (Box, tol 1e-8) under every scheduler of ccqppy_amd:
+"""Throughput of MANY SMALL dense BBPGD (or, with --apgd, APGD) solves (Box, tol 1e-8) under every scheduler of ccqppy_amd:
 sequential solve(), sequential with the pipelined iteration, the stream-lane and fused batch schedulers
 (host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device).  One JSON line per size.
-   python tools/bench_small_batch.py [n:B ...]"""
+   python tools/bench_small_batch.py [--apgd] [n:B ...]"""
 import contextlib
 import io
 import json
@@ -19,23 +19,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     from ccqppy_amd.batch import solve_batch, solve_batch_fused, solve_batch_pipelined
-    sizes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or \
+    args = [a for a in sys.argv[1:] if a != "--apgd"]
+    apgd = "--apgd" in sys.argv[1:]
+    cls = solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
+    sizes = [tuple(int(v) for v in a.split(":")) for a in args] or \
         [(64, 1024), (256, 1024), (1024, 512), (2048, 256), (4096, 128)]
     for n, B in sizes:
         probs = []
         for p in range(B):
             op, b, _ = problems.random_problem(n, 1234 + p)
             probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
-        mk = lambda: solvers.CCQPSolverBBPGD(1e-8, 5000)          # noqa: E731
+        mk = lambda: cls(1e-8, 5000)          # noqa: E731
 
         def seq(pipe):
             for op, b, x0, P in probs:
                 with contextlib.redirect_stdout(io.StringIO()):
-                    solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=pipe).solve(op, b, convex_proj_op=P)
+                    (cls(1e-8, 5000) if apgd else cls(1e-8, 5000, pipeline=pipe)).solve(op, b, convex_proj_op=P)
 
         out = {}
         res = {}
-        for name, fn in (("sequential", lambda: seq(False)), ("sequential_pipelined", lambda: seq(True)),
+        for name, fn in (("sequential", lambda: seq(False)),) + \
+                ((() if apgd else (("sequential_pipelined", lambda: seq(True)),))) + (
                          ("stream_lanes_8", lambda: solve_batch(mk, probs, lanes=8)),
                          ("fused_32x2", lambda: solve_batch_fused(mk, probs, lanes=32, groups=2)),
                          ("batch_pipelined", lambda: solve_batch_pipelined(mk, probs))):
@@ -52,9 +56,9 @@ def main():
                 res[name] = r
         mvs = [s.solution_num_matrix_vector_multiplications for s in res["batch_pipelined"]]
         same = all(torch.equal(a.solution, c.solution) for a, c in zip(res["fused_32x2"], res["batch_pipelined"]))
-        # bytes the matvecs of the batch must read: (2 + iterations) matvecs per problem, 8 n^2 bytes each
-        mv_bytes = sum((1 + m) * 8.0 * n * n for m in mvs)
-        print(json.dumps({"n": n, "problems": B, "problems_per_s": out, "mv_per_problem_mean": float(np.mean(mvs)),
+        # bytes the matvecs of the batch must read: executed matvecs per problem, 8 n^2 bytes each
+        mv_bytes = sum(s.executed_matrix_vector_multiplications * 8.0 * n * n for s in res["batch_pipelined"])
+        print(json.dumps({"solver": cls.__name__, "n": n, "problems": B, "problems_per_s": out, "mv_per_problem_mean": float(np.mean(mvs)),
                           "mv_per_problem_max": int(max(mvs)), "bitwise_equal_to_fused": bool(same),
                           "batch_pipelined_matrix_GBps": round(mv_bytes * out["batch_pipelined"] / B / 1e9, 1)}),
               flush=True)
