@@ -504,7 +504,9 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
     del keep
 
 
-def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
+def _bapgd_run(eng, items, n, max_mv, ahead, tune=0):
+    """Lock-step APGD over `items`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
+    matvec counts) -- rows of problems that did not converge inside the budget are meaningless."""
     from . import _lib
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
@@ -525,7 +527,7 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
     check = _lib.check
     check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
     # round r performs matvec number 1 + r; the rounds stop one short of the budget, where the reference's exit
-    # path takes over (:277-278, :288-289): such problems go to plain solve() below
+    # path takes over (:277-278, :288-289): such problems go to the host-driven loop
     last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
 
     def launch(r):
@@ -536,12 +538,20 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
     done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
     if not np.isfinite(max_mv) and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    sel = torch.from_numpy((its + 1) % 2).to(dev)
-    sols = vec[0:2][sel, torch.arange(B, device=dev)]
-    host = None
-    res = np.sqrt(res2)
+    if B == 1:
+        sols = vec[int((its[0] + 1) % 2)]
+    else:
+        sel = torch.from_numpy((its + 1) % 2).to(dev)
+        sols = vec[0:2][sel, torch.arange(B, device=dev)]
+    del keep
+    return done, sols, np.sqrt(res2), mvs
+
+
+def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
     import contextlib
     import io
+    done, sols, res, mvs = _bapgd_run(eng, items, n, max_mv, ahead, tune)
+    host = None
     for p, it in enumerate(items):
         s = it[0]
         if not done[p]:                                  # budget reached: the reference's own exit path
@@ -560,4 +570,3 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_num_matrix_vector_mults = int(mvs[p])
         s._executed_matrix_vector_mults = int(mvs[p])
         eng.mv_executed += int(mvs[p])
-    del keep

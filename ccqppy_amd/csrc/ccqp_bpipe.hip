@@ -218,12 +218,13 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   int64_t per = flags >> 8;
   const double bytes = 8.0 * (double)n * (double)n * count;
   if (t.nt == 0) t.nt = bytes > 192.0 * 1048576.0 ? 2 : 1;  // a batch that fits the MALL is re-read from there
-  if (t.U == 0) t.U = n >= 4096 ? 4 : 1;
   const int64_t rows_per_wg = CCQP_BLOCK / 64;
   // many small workgroups: ~64k per launch measured best for n = 256..4096 (profiles/r01g_bpipe_sweep.txt)
   if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
   if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
   if (per < 1) per = 1;
+  // few waves in flight (a batch of one, or few large problems): more loads per lane instead
+  if (t.U == 0) t.U = (n >= 4096 || per * count * rows_per_wg < 16384) ? 4 : 1;
   t.grid = dim3((unsigned)per, count);
   return t;
 }

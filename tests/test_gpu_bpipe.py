@@ -198,6 +198,28 @@ def test_lockstep_apgd_under_a_matvec_budget():
             _same(a, c)
 
 
+def test_single_solve_apgd_pipeline_option():
+    """CCQPSolverAPGD(..., pipeline=True) = the lock-step scheduler with a batch of one; where it does not apply
+    (anti-relaxation, cone, budget reached) the host-driven loop runs and the results are the same anyway."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    for n in (100, 1024, 3000):
+        for p, (A, b, x0, P) in enumerate(_problems(n, 6, 40 + n)):
+            for cap in (5000, 9, 30):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    a = solvers.CCQPSolverAPGD(1e-8, cap).solve(A, b, x0=x0, convex_proj_op=P)
+                    c = solvers.CCQPSolverAPGD(1e-8, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
+                _same(a, c)
+    op, b, _ = problems.random_problem(256, 3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = solvers.CCQPSolverAPGDAntiRelaxation(1e-8, 5000).solve(op, b, convex_proj_op=ss.BoxProjOp(256, -0.5, 0.5))
+        c = solvers.CCQPSolverAPGDAntiRelaxation(1e-8, 5000, pipeline=True).solve(
+            op, b, convex_proj_op=ss.BoxProjOp(256, -0.5, 0.5))
+        _same(a, c)
+        a = solvers.CCQPSolverAPGD(1e-8, 64).solve(op, b, convex_proj_op=ss.ConeProjOp(256))
+        c = solvers.CCQPSolverAPGD(1e-8, 64, pipeline=True).solve(op, b, convex_proj_op=ss.ConeProjOp(256))
+        _same(a, c)
+
+
 def test_rejects_what_it_cannot_run():
     from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(64, 1)

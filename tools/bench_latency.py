@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Single-solve latency of BBPGD at small and medium n: host-driven loop vs the pipelined form
+"""Single-solve latency of BBPGD and APGD at small and medium n: host-driven loop vs the pipelined form
 (CCQPSolverBBPGD(..., pipeline=True): scalars on the device, iterations queued ahead) vs pipeline="graph"
 (three captured iterations replayed as one hipGraph launch).  Random-SPD box QPs (13 matvecs each) and dense
 contact-type Hessians (~125 matvecs).  One JSON line per problem; results are bitwise identical by construction
@@ -45,6 +45,13 @@ def main():
         row = {"problem": label, "solver": "BBPGD tol 1e-8"}
         for key, pipe in (("host_driven_ms", False), ("pipelined_ms", True), ("pipelined_graph_ms", "graph")):
             dt, r = timed(lambda: solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=pipe).solve(op, b, convex_proj_op=P), 20)
+            row[key] = 1e3 * dt
+            row["executed_mv"] = int(r.executed_matrix_vector_multiplications)
+        row["speedup_pipelined"] = row["host_driven_ms"] / row["pipelined_ms"]
+        print(json.dumps(row), flush=True)
+        row = {"problem": label, "solver": "APGD tol 1e-8"}
+        for key, pipe in (("host_driven_ms", False), ("pipelined_ms", True)):
+            dt, r = timed(lambda: solvers.CCQPSolverAPGD(1e-8, 5000, pipeline=pipe).solve(op, b, convex_proj_op=P), 10)
             row[key] = 1e3 * dt
             row["executed_mv"] = int(r.executed_matrix_vector_multiplications)
         row["speedup_pipelined"] = row["host_driven_ms"] / row["pipelined_ms"]
