@@ -1,6 +1,6 @@
 /* Stand-alone C consumer of libccqp_hip.so: no Python, no torch.  Generates a small SPD problem on
- * the GPU, runs one matvec + epilogue + dots + Box projection through the C ABI and checks them
- * against plain C loops on the host.  Built and run by tests/test_gpu_cabi.py:
+ * the GPU, runs one matvec + epilogue + dots + Box projection, the CSR matvec and a lock-step batch of three
+ * BBPGD solves through the C ABI and checks them against plain C loops on the host.  Built and run by tests/test_gpu_cabi.py:
  *   gcc -std=c99 tests/c/abi_smoke.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
  *       -Lccqppy_amd -lccqp_hip -L/opt/rocm/lib -lamdhip64 -lm -o abi_smoke
  * (the define is what HIP's own headers require from a C translation unit; only hipMalloc/hipMemcpy
@@ -131,6 +131,75 @@ int main(void) {
            (long long)summary[0]);
     hipFree(rp); hipFree(cidx); hipFree(vals); hipFree(plan);
     free(hrp); free(hc); free(hv);
+  }
+  /* lock-step batch of three box-QPs (same A, different b) from plain C: descriptors in device memory, start,
+   * queue iterations while polling the progress mirror, then check the KKT conditions of every solution. */
+  {
+    enum { NB = 3 };
+    const double tol = 1e-8, gd = 1e-6, eps10 = 10.0 * 2.220446049250313e-16;
+    const int64_t pd = ccqp_bpipe_partials_doubles(n);
+    double *vecs, *slabs, *parts, *bs;
+    uint32_t* words;
+    ccqp_pprob hp3[NB], *dp3;
+    if (pd <= 0 || hipMalloc((void**)&vecs, 7 * NB * n * sizeof(double)) || hipMalloc((void**)&slabs, NB * 64 * sizeof(double)) ||
+        hipMalloc((void**)&parts, NB * pd * sizeof(double)) || hipMalloc((void**)&words, (NB + 2) * sizeof(uint32_t)) ||
+        hipMalloc((void**)&bs, NB * n * sizeof(double)) || hipMalloc((void**)&dp3, sizeof(hp3)))
+      return 5;
+    hipMemset(vecs, 0, 7 * NB * n * sizeof(double));      /* x0 = 0 */
+    hipMemset(slabs, 0, NB * 64 * sizeof(double));
+    hipMemset(words, 0, (NB + 2) * sizeof(uint32_t));
+    for (int q = 0; q < NB; ++q) {
+      CHECK(ccqp_gen_vec_f64(ctx, bs + q * n, n, 500 + q, NULL));
+      hp3[q].A = A;
+      hp3[q].lda = n;
+      hp3[q].b = bs + q * n;
+      for (int j = 0; j < 3; ++j) {
+        hp3[q].x[j] = vecs + ((int64_t)j * NB + q) * n;
+        hp3[q].g[j] = vecs + ((int64_t)(3 + j) * NB + q) * n;
+      }
+      hp3[q].y = vecs + ((int64_t)6 * NB + q) * n;
+      hp3[q].seg = seg;                                    /* Box [-0.5, 0.5] */
+      hp3[q].slab = slabs + q * 64;
+      hp3[q].partials = parts + q * pd;
+      hp3[q].counter = words + q;
+      hp3[q].c = 1.0 / (3 * n * gd);
+      hp3[q].tol = tol;
+    }
+    hipMemcpy(dp3, hp3, sizeof(hp3), hipMemcpyHostToDevice);
+    const int flags = 1;                                   /* hipMalloc + even n: 16-byte aligned rows */
+    CHECK(ccqp_bpipe_start_f64(ctx, dp3, NB, n, gd, flags, words + NB, NULL));
+    double st[2] = {0.0, -1.0};
+    int64_t k = 0;
+    while (st[0] < NB && k < 500) {
+      ++k;
+      CHECK(ccqp_bpipe_iterate_f64(ctx, dp3, NB, n, k, gd, eps10, flags, 1, words + NB, NULL));
+      do {
+        CHECK(ccqp_bpipe_poll(ctx, st));
+      } while (st[0] < NB && k - st[1] >= 4);              /* run at most 4 iterations ahead */
+    }
+    hipDeviceSynchronize();
+    if (st[0] < NB) bad++;
+    double hs[64];
+    for (int q = 0; q < NB; ++q) {
+      hipMemcpy(hs, slabs + q * 64, sizeof(hs), hipMemcpyDeviceToHost);
+      const int iters = (int)hs[50];
+      if (hs[49] != 1.0 || iters < 1 || sqrt(hs[51]) >= tol) bad++;
+      hipMemcpy(hx, hp3[q].x[iters % 3], n * sizeof(double), hipMemcpyDeviceToHost);
+      hipMemcpy(hb, hp3[q].b, n * sizeof(double), hipMemcpyDeviceToHost);
+      int kkt = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        double gi = hb[i];
+        for (int64_t j = 0; j < n; ++j) gi += hA[i * n + j] * hx[j];
+        if (hx[i] < -0.5 || hx[i] > 0.5) kkt++;
+        else if (hx[i] == -0.5) kkt += gi < -1e-4;
+        else if (hx[i] == 0.5) kkt += gi > 1e-4;
+        else kkt += fabs(gi) > 1e-4;
+      }
+      if (kkt) bad++;
+      printf("lock-step batch: problem %d converged after %d iterations, residual %.3g, KKT violations %d\n", q, iters,
+             sqrt(hs[51]), kkt);
+    }
+    hipFree(vecs); hipFree(slabs); hipFree(parts); hipFree(words); hipFree(bs); hipFree(dp3);
   }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;

@@ -220,6 +220,25 @@ def test_single_solve_apgd_pipeline_option():
         _same(a, c)
 
 
+def test_batch_sharded_driver_with_the_pipelined_scheduler():
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd.batch import solve_batch_sharded
+    n = 320
+
+    def make(p):
+        op, b, _ = problems.random_problem(n, 100 + p)
+        return op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    for cls in (solvers.CCQPSolverBBPGD, solvers.CCQPSolverAPGD):
+        res = solve_batch_sharded(lambda: cls(1e-8, 5000), make, 9, fused="pipelined", gather=True)
+        assert sorted(res) == list(range(9))
+        for p, r in res.items():
+            with contextlib.redirect_stdout(io.StringIO()):
+                a = cls(1e-8, 5000).solve(*make(p)[:2], convex_proj_op=make(p)[3])
+            assert r.solution_converged
+            assert r.solution_num_matrix_vector_multiplications == a.solution_num_matrix_vector_multiplications
+            assert np.array_equal(r.solution.view(np.uint64), a.solution.cpu().numpy().view(np.uint64))
+
+
 def test_rejects_what_it_cannot_run():
     from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(64, 1)
