@@ -16,7 +16,7 @@ CXXFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iincl
 
 all: $(LIB)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/ccqp_internal.h include/ccqp_hip.h
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/ccqp_hip.h
 	@mkdir -p build
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 

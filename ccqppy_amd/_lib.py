@@ -63,6 +63,15 @@ class PApgd(ctypes.Structure):
                 ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
 
 
+class PMprgp(ctypes.Structure):
+    """struct ccqp_pmprgp (include/ccqp_hip.h): one problem of a lock-step MPRGP run."""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
+                ("X", ctypes.c_void_p * 2), ("G", ctypes.c_void_p * 2)] + \
+               [(name, ctypes.c_void_p) for name in ("p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")] + \
+               [("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
+
+
 (BOP_GEMV, BOP_AXPBY, BOP_SCALE, BOP_COPY, BOP_FILL, BOP_DOTS, BOP_PROJ_ELEM, BOP_RESIDUAL_ELEM,
  BOP_FEASIBLE_ELEM, BOP_MPRGP_SPLIT, BOP_MPRGP_NORMAL_DOT, BOP_MPRGP_PROPORTION, BOP_FREE_GRADIENT_ELEM,
  BOP_CG_DIRECTION) = range(1, 15)
@@ -120,6 +129,8 @@ SIGNATURES = {
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
     "ccqp_bapgd_start_f64": [_P, _P, _I, _I64, _I, _P, _P],
     "ccqp_bapgd_round_f64": [_P, _P, _I, _I64, _I64, _D, _I, _P, _P],
+    "ccqp_bmprgp_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
+    "ccqp_bmprgp_round_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _P, _P],
     "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],

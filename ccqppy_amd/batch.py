@@ -326,23 +326,24 @@ _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; ke
 
 
 def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0):
-    """Many SMALL dense problems of one size n, solved by BBPGD (solvers.py:560-693) or APGD (:197-367) in
-    lock-step: three launches per iteration (APGD: per matvec) for the whole batch, step lengths, line-search and
-    exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_*, csrc/ccqp_bpipe.hip), the host only polls a
-    progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
+    """Many dense problems of one size n, solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
+    (:1002-1224) in lock-step: three launches per iteration (APGD: per matvec; MPRGP: five) for the whole batch, step
+    lengths, line search, branch decisions and exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_* /
+    ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
     this one is not.
 
-    make_solver : () -> CCQPSolverBBPGD or CCQPSolverAPGD (plain: no fallback / anti-relaxation / matvec reuse),
-                  all of one class with the same max_matrix_vector_multiplications
+    make_solver : () -> CCQPSolverBBPGD, CCQPSolverAPGD or CCQPSolverMPRGP (plain: no fallback / anti-relaxation /
+                  matvec reuse), all of one class with the same max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
     and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
-    the wall-clock of the whole batch.  (APGD problems that would run into the matvec budget are handed to plain
-    solve(), whose exit path at the budget has quirks of its own.)"""
+    the wall-clock of the whole batch.  (APGD / MPRGP problems that would run into the matvec budget are handed to
+    plain solve(), whose exit paths at the budget have quirks of their own.)"""
+    from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
-    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD
+    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD, CCQPSolverMPRGP
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -351,9 +352,9 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD) or getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD only, got %s"
-                        % kind.__name__)
+    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverMPRGP) or getattr(solvers[0], "reuse_matvec", False):
+        raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD / CCQPSolverMPRGP only, "
+                        "got %s" % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
     items = []
     n = None
@@ -374,13 +375,18 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         P = P if P is not None else ss.IdentityProjOp(n)
         if not hasattr(P, "_dev_bb_tail"):
             raise TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
+        if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
+            # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
+            # sequential-sum kernels of the literal path)
+            raise TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
+                            % _lib.SMALL_SEG_MAX)
         bd = eng.to_device(b).reshape(-1)
         items.append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
                       isinstance(b, torch.Tensor), (A, b, x0, P)))
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
-    group = _bpipe_group if kind is CCQPSolverBBPGD else _bapgd_group
+    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
     with np.errstate(all="ignore"):
         for lo in range(0, len(items), _BPIPE_MAX):
             group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
@@ -574,3 +580,72 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_num_matrix_vector_mults = int(mvs[p])
         s._executed_matrix_vector_mults = int(mvs[p])
         eng.mv_executed += int(mvs[p])
+
+
+def _bmprgp_run(eng, items, n, max_mv, ahead, tune=0):
+    """Lock-step MPRGP over `items`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
+    matvecs); status 1 = converged, anything else = not finished here (rows meaningless)."""
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(items)
+    names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PMprgp, len(names), 8)
+    vec[1].zero_()                                                      # x0 staged in X[1]
+    for p, it in enumerate(items):
+        if it[3] is not None:
+            vec[1, p].copy_(it[3])
+    tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
+    tab["G"][:, 0], tab["G"][:, 1] = planes[2], planes[3]
+    for j, name in enumerate(names[4:]):
+        tab[name] = planes[4 + j]
+    flags = _bpipe_flags(tab, n, tune)
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
+    check = _lib.check
+    check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
+    # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where a problem
+    # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
+    last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
+
+    def launch(r):
+        check(lib.ccqp_bmprgp_round_f64(ctx, dp, B, n, r, _GD, float(_EPS10), flags, batch, st))
+
+    _bpipe_poll_loop(eng, B, launch, last, ahead)
+    h = slabs[:, 32:56].cpu().numpy()                   # blocking: the queue has drained
+    status, its = h[:, 17], h[:, 8].astype(np.int64)
+    mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
+    if not np.isfinite(max_mv) and not (status != 0.0).all():
+        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+    if B == 1:
+        sols = vec[int((its[0] + 1) % 2)]
+    else:
+        sel = torch.from_numpy((its + 1) % 2).to(dev)
+        sols = vec[0:2][sel, torch.arange(B, device=dev)]
+    del keep
+    return status, sols, np.sqrt(res2), mvs, execd
+
+
+def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0):
+    import contextlib
+    import io
+    status, sols, res, mvs, execd = _bmprgp_run(eng, items, n, max_mv, ahead, tune)
+    host = None
+    for p, it in enumerate(items):
+        s = it[0]
+        if status[p] != 1.0:                             # budget reached (or the search that cannot terminate)
+            A, b, x0, P = it[6]
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            continue
+        if it[5]:
+            s._solution = sols[p]
+        else:
+            if host is None:
+                host = sols.cpu().numpy()
+            s._solution = host[p]
+        s._solution_converged = int(mvs[p]) < max_mv
+        s._solution_residual = res[p]
+        s._solution_num_matrix_vector_mults = int(mvs[p])
+        s._executed_matrix_vector_mults = int(execd[p])
+        eng.mv_executed += int(execd[p])

@@ -1,0 +1,469 @@
+// Lock-step MPRGP (solvers.py:1026-1200; README's "MPRGP-BB", BASELINE config 5): many equal-size dense problems,
+// every scalar and every branch decision on the device.  MPRGP's iteration is a state machine with 2-4 matvecs --
+//     g = A x_k + b;  proportioning test  ->  CG step: A p; feasible?  full step + A dx  |  expansion half-step,
+//     A x_{k+1} + b, A dx
+// -- so, as for APGD (ccqp_bpipe.hip), a ROUND advances every live problem by ONE matvec (none while a problem
+// repeats its feasibility search) and is the same five launches whatever the states of the problems:
+//     matvec | stage 1 | stage 2 | stage 3 | apply
+// where a stage is a reduction over the problem's vectors whose LAST block takes the decisions of the host loop with
+// the host loop's arithmetic, and `apply` is the elementwise update the decisions ask for.  Which stage does what:
+//     state                 matvec            stage 1                    stage 2           stage 3
+//     M1                    A x_k + b -> g_k  split: P(x), psi, 1-delta  normal, n.g       beta.beta, psi.psi -> branch
+//     AP                    A p               psi.p, p.Ap -> alpha_cg    feasible steps    [half step: BB dots]
+//     FEAS (search again)   --                --                         feasible steps    [half step: BB dots]
+//     G1   (half step)      A x_{k+1} + b     --
+//     ADXC / ADXH           A dx              dx.dx, dx.Adx, residual -> BB step, exit test, swap
+// (The proportioning step needs psi.psi <= 0 or NaN -- the iterates are always feasible, so beta.beta = 0 -- and does
+// not occur on finite data: a problem that asks for it leaves the lock-step run for the host-driven loop.)
+// x_k / x_{k+1} and g_k / g_{k+1} live in two buffers each, addressed by the parity of the outer-iteration count.
+// The bodies are those of the single-problem kernels (ccqp_bodies.h), so every problem gets bit for bit the result
+// of its own CCQPSolverMPRGP.solve() (tests/test_gpu_bmprgp.py).
+#include "ccqp_lockstep.h"
+
+// slab slots of one problem
+#define MP_S0 0          // dx.dx | beta.beta
+#define MP_S1 1          // dx.Adx | psi.psi
+#define MP_S2 2          // residual^2 of the tail
+#define MP_NG 8          // n(x).g
+#define MP_DIST2 10      // |x - P(x)|^2
+#define MP_COUNTS 16     // 8 feasibility counts
+#define MP_ABB 32        // alpha_bb
+#define MP_ACG 33        // alpha_cg
+#define MP_PAP 34        // p.Ap
+#define MP_AF 35         // feasibility search: first candidate of the next pass / the accepted alpha_f
+#define MP_AHALF 36      // BB step of the expansion half-step
+#define MP_TRIED 37
+#define MP_STATE 38
+#define MP_ACT 39
+#define MP_IT 40         // outer iterations finished (parity addresses x_k / g_k)
+#define MP_EXEC 52       // matvecs executed (the reference's count skips A dx)
+#define MP_DONE BP_DONE  // 49: 1 converged, 2 the feasibility search cannot terminate (:1113-1118), 3 proportioning step
+#define MP_MV BP_ITERS   // 50: the reference's mv_count
+#define MP_RES2 BP_RES2  // 51
+
+enum { ST_M1 = 0, ST_M1_N, ST_M1_P, ST_AP, ST_FEAS_NOW, ST_FEAS_WAIT, ST_HALF3, ST_G1, ST_ADXC, ST_ADXH };
+enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
+
+#define MP_STEPS 8       // candidate steps per feasibility pass (solvers.py CCQPSolverMPRGP._STEPS)
+
+__device__ __forceinline__ double mp_lin(double a, double x, double b, double y) {   // axpby_body, one element
+  const double t1 = a * x;
+  const double t2 = b * y;
+  return t1 + t2;
+}
+
+__device__ __forceinline__ double mp_free(const ccqp_segk& sg, double xi, double gi, int64_t i) {  // free_gradient_body
+  const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+  const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+  const double p = ccqp_proj_elem(sg.kind, sg.flags, xi, lb, ub);
+  return (ccqp_isclose(xi, p) ? 1.0 : 0.0) * gi;
+}
+
+// ---------------------------------------------------------------------------------------------------- start-up
+// x_k = P(x0), x_{k+1} = copy (solvers.py:1063-1064)
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_x_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const ccqp_segk sg = bp_segk_of(q);
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  const double* __restrict__ x0 = q.X[1];     // staged by the caller
+  BODY_LOOP(i, sg.dim) {
+    const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+    const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+    const double v = ccqp_proj_elem(sg.kind, sg.flags, x0[i], lb, ub);
+    q.X[0][i] = v;
+    q.X[1][i] = v;
+  }
+}
+
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmprgp* __restrict__ probs, int init,
+                                                                 int64_t n) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  if (init == 1) {                            // g_k = A x_k + b
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[0], q.b, q.ytmp, q.G[0], n, n, n, wave, nwaves);
+    return;
+  }
+  if (q.slab[MP_DONE] != 0.0) return;
+  if (init == 2) {                            // A g_k (solvers.py:1077)
+    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.G[0], nullptr, q.Adx, nullptr, n, n, n, wave, nwaves);
+    return;
+  }
+  const int it = (int)q.slab[MP_IT];
+  switch ((int)q.slab[MP_STATE]) {
+    case ST_M1:
+      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[it & 1], q.b, q.ytmp, q.G[it & 1], n, n, n, wave, nwaves);
+      break;
+    case ST_AP:
+      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.p, nullptr, q.Ap, nullptr, n, n, n, wave, nwaves);
+      break;
+    case ST_G1:
+      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.ytmp, q.G[(it + 1) & 1], n, n, n, wave, nwaves);
+      break;
+    case ST_ADXC:
+    case ST_ADXH:
+      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.dx, nullptr, q.Adx, nullptr, n, n, n, wave, nwaves);
+      break;
+    default:
+      break;                                  // ST_FEAS_WAIT: no matvec this round
+  }
+}
+
+// residual of the start (exit test :1070-1073)
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
+                                                                     int64_t chunk, int nblk,
+                                                                     unsigned* __restrict__ batch) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  double v[1];
+  v[0] = residual_body(bp_segk_of(q), q.X[0], q.G[0], q.c, gd, chunk, blockIdx.x, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    double* s = q.slab;
+    s[MP_S2] = v[0];
+    s[MP_RES2] = v[0];
+    s[MP_MV] = 1.0;
+    s[MP_EXEC] = 1.0;
+    s[MP_IT] = 0.0;
+    s[MP_STATE] = (double)ST_M1;
+    s[MP_ACT] = (double)ACT_NONE;
+    if (sqrt(v[0]) >= q.tol) {               // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
+      s[MP_DONE] = 0.0;
+    } else {
+      s[MP_DONE] = 1.0;
+      __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// alpha_bb = g.g / g.Ag (:1077), then g_{k+1} = copy(g_k) and p = phi(x_k, g_k) (:1066, :1081)
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_alpha_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n,
+                                                                       int64_t chunk, int nblk) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  if (q.slab[MP_DONE] != 0.0) return;
+  double v[2];
+  v[0] = dot_body(q.G[0], q.G[0], n, chunk, blockIdx.x, lds4);
+  v[1] = dot_body(q.G[0], q.Adx, n, chunk, blockIdx.x, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    double* s = q.slab;
+    s[MP_S0] = v[0];
+    s[MP_S1] = v[1];
+    s[MP_ABB] = v[0] / v[1];
+    s[MP_MV] = 2.0;
+    s[MP_EXEC] = 2.0;
+  }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  if (q.slab[MP_DONE] != 0.0) return;
+  const ccqp_segk sg = bp_segk_of(q);
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  BODY_LOOP(i, sg.dim) {
+    const double gi = q.G[0][i];
+    q.G[1][i] = gi;
+    q.p[i] = mp_free(sg, q.X[0][i], gi, i);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- the stages
+// tail of an outer iteration (solvers.py:1184-1192): BB step length, exit test, swap of the iterates
+__device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double s1, double r2, double eps10,
+                                        unsigned* batch) {
+  double* s = q.slab;
+  const double den = s1 + eps10;
+  s[MP_ABB] = s0 / den;
+  s[MP_S2] = r2;
+  s[MP_RES2] = r2;
+  if (sqrt(r2) < q.tol) {
+    s[MP_DONE] = 1.0;
+    __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    s[MP_IT] = s[MP_IT] + 1.0;
+    s[MP_STATE] = (double)ST_M1;
+  }
+}
+
+// stage = 1, 2, 3; grid (nblk, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmprgp* __restrict__ probs, int stage,
+                                                                  double gd, double eps10, int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch,
+                                                                  double* __restrict__ host, unsigned count,
+                                                                  double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  double* s = q.slab;
+  const bool rollcall = stage == 3;           // every problem reports once per round, in the last stage
+  if (s[MP_DONE] != 0.0) {
+    if (rollcall && blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  const ccqp_segk sg = bp_segk_of(q);
+  const int64_t n = sg.dim;
+  const int st = (int)s[MP_STATE];
+  const int it = (int)s[MP_IT];
+  double* xk = q.X[it & 1];
+  double* xk1 = q.X[(it + 1) & 1];
+  double* gk = q.G[it & 1];
+  double* gk1 = q.G[(it + 1) & 1];
+  const int bx = blockIdx.x;
+  double v[MP_STEPS];
+  if (stage == 1) {
+    switch (st) {
+      case ST_M1: {                           // :1090-1094
+        v[0] = split_body(sg, xk, gk, q.txk, q.psi, q.w, chunk, bx, lds4);
+        if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+        if (threadIdx.x == 0) {
+          s[MP_DIST2] = v[0];
+          s[MP_ACT] = (double)ACT_NONE;
+          s[MP_MV] = s[MP_MV] + 1.0;
+          s[MP_EXEC] = s[MP_EXEC] + 1.0;
+          s[MP_STATE] = (double)ST_M1_N;
+        }
+        return;
+      }
+      case ST_AP: {                           // :1100-1106
+        v[0] = dot_body(q.psi, q.p, n, chunk, bx, lds4);
+        v[1] = dot_body(q.p, q.Ap, n, chunk, bx, lds4);
+        if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+        if (threadIdx.x == 0) {
+          const double acg = v[0] / v[1];
+          s[MP_S0] = v[0];
+          s[MP_S1] = v[1];
+          s[MP_ACG] = acg;
+          s[MP_PAP] = v[1];
+          s[MP_AF] = acg + eps10;             // :1111
+          s[MP_TRIED] = 0.0;
+          s[MP_ACT] = (double)ACT_NONE;
+          s[MP_MV] = s[MP_MV] + 1.0;
+          s[MP_EXEC] = s[MP_EXEC] + 1.0;
+          s[MP_STATE] = (double)ST_FEAS_NOW;
+        }
+        return;
+      }
+      case ST_FEAS_WAIT:
+      case ST_G1: {
+        if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+        if (threadIdx.x == 0) {
+          if (st == ST_G1) {
+            s[MP_ACT] = (double)ACT_AFTER_G1;
+            s[MP_MV] = s[MP_MV] + 1.0;
+            s[MP_EXEC] = s[MP_EXEC] + 1.0;
+            s[MP_STATE] = (double)ST_ADXH;
+          } else {
+            s[MP_ACT] = (double)ACT_NONE;
+            s[MP_STATE] = (double)ST_FEAS_NOW;
+          }
+        }
+        return;
+      }
+      case ST_ADXC:
+      case ST_ADXH: {                         // :1129 / :1163, and the tail's residual
+        v[0] = dot_body(q.dx, q.dx, n, chunk, bx, lds4);
+        v[1] = dot_body(q.dx, q.Adx, n, chunk, bx, lds4);
+        v[2] = residual_body(sg, xk1, gk1, q.c, gd, chunk, bx, lds4);
+        if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, &is_last)) return;
+        if (threadIdx.x == 0) {
+          s[MP_S0] = v[0];
+          s[MP_S1] = v[1];
+          s[MP_ACT] = (double)ACT_NONE;
+          s[MP_EXEC] = s[MP_EXEC] + 1.0;
+          mp_tail(q, v[0], v[1], v[2], eps10, batch);
+        }
+        return;
+      }
+      default:
+        return;
+    }
+  }
+  if (stage == 2) {
+    if (st == ST_M1_N) {                      // :1095
+      v[0] = normal_dot_body(sg, q.txk, gk, q.nv, s[MP_DIST2], chunk, bx, lds4);
+      if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        s[MP_NG] = v[0];
+        s[MP_STATE] = (double)ST_M1_P;
+      }
+    } else if (st == ST_FEAS_NOW) {           // :1112-1118, MP_STEPS candidates per pass
+      const double a0 = s[MP_AF];
+      for (int k = 0; k < MP_STEPS; ++k) v[k] = feasible_body(sg, xk, q.p, a0, k, chunk, bx, lds4);
+      if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        double af = a0;
+        int found = 0;
+        for (int k = 0; k < MP_STEPS; ++k) {
+          s[MP_COUNTS + k] = v[k];
+          if (!found) {
+            if (v[k] == 0.0) found = 1;
+            else af *= 0.5;
+          }
+        }
+        s[MP_AF] = af;
+        if (found) {
+          if (s[MP_ACG] <= af) {              // :1120
+            s[MP_ACT] = (double)ACT_CGFULL;
+            s[MP_STATE] = (double)ST_ADXC;
+          } else {
+            s[MP_STATE] = (double)ST_HALF3;
+          }
+        } else {
+          const double tried = s[MP_TRIED] + (double)MP_STEPS;
+          s[MP_TRIED] = tried;
+          if (tried > 1200.0) {               // alpha_f has underflowed: the reference never exits either
+            s[MP_DONE] = 2.0;
+            __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            s[MP_STATE] = (double)ST_FEAS_WAIT;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // stage 3
+  if (st == ST_M1_P) {                        // :1096-1099
+    proportion_body(q.w, gk, q.nv, q.psi, s[MP_NG], n, chunk, bx, lds4, &v[0], &v[1]);
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (threadIdx.x == 0) {
+      s[MP_S0] = v[0];
+      s[MP_S1] = v[1];
+      if (v[0] < v[1]) {
+        s[MP_STATE] = (double)ST_AP;
+      } else {
+        // The proportioning step (:1165-1182).  beta is masked by 1 - isclose(x, P(x)) and the iterates are always
+        // feasible, so beta.beta = 0 and this needs psi.psi <= 0 or NaN: it does not occur on finite data.  Such a
+        // problem leaves the lock-step run and is solved by the host-driven loop.
+        s[MP_DONE] = 3.0;
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bp_report(batch, host, count, seq);
+    }
+    return;
+  }
+  if (st == ST_HALF3) {                       // :1140-1147: xh, gh, dx, dg formed on the fly, rounded as the axpbys
+    const double maf = -s[MP_AF];
+    CHUNK_RANGE(n)
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double xi = xk[i], gi = gk[i];
+      const double xh = mp_lin(1.0, xi, maf, q.p[i]);
+      const double gh = mp_lin(1.0, gi, maf, q.Ap[i]);
+      const double dx = mp_lin(1.0, xh, -1.0, xi);
+      const double dg = mp_lin(1.0, gh, -1.0, gi);
+      a0 = fma(dx, dx, a0);
+      a1 = fma(dx, dg, a1);
+    }
+    v[0] = ccqp_block_sum(a0, lds4);
+    v[1] = ccqp_block_sum(a1, lds4);
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (threadIdx.x == 0) {
+      const double den = v[1] + eps10;
+      s[MP_S0] = v[0];
+      s[MP_S1] = v[1];
+      s[MP_AHALF] = v[0] / den;
+      s[MP_ACT] = (double)ACT_HALF;
+      s[MP_STATE] = (double)ST_G1;
+      bp_report(batch, host, count, seq);
+    }
+    return;
+  }
+  // nothing to reduce in this stage: the roll-call only.  (One designated thread: no state is written here.)
+  if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[MP_DONE] != 0.0) return;
+  const int act = (int)s[MP_ACT];
+  if (act == ACT_NONE) return;
+  const ccqp_segk sg = bp_segk_of(q);
+  const int it = (int)s[MP_IT];
+  const double* __restrict__ xk = q.X[it & 1];
+  double* __restrict__ xk1 = q.X[(it + 1) & 1];
+  const double* __restrict__ gk = q.G[it & 1];
+  double* __restrict__ gk1 = q.G[(it + 1) & 1];
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  if (act == ACT_CGFULL) {             // :1125-1135
+    const double macg = -s[MP_ACG];
+    const double pAp = s[MP_PAP];
+    BODY_LOOP(i, sg.dim) {
+      const double xi = xk[i], pi = q.p[i], Api = q.Ap[i];
+      const double y = mp_lin(1.0, xi, macg, pi);
+      const double g1 = mp_lin(1.0, gk[i], macg, Api);
+      xk1[i] = y;
+      gk1[i] = g1;
+      q.dx[i] = mp_lin(1.0, y, -1.0, xi);
+      const double ps = mp_free(sg, y, g1, i);
+      const double t1 = ps * Api;             // cg_direction_body
+      const double beta = t1 / pAp;
+      const double t2 = beta * pi;
+      q.p[i] = ps - t2;
+    }
+  } else if (act == ACT_HALF) {               // :1140-1141, :1148
+    const double maf = -s[MP_AF];
+    const double mal = -s[MP_AHALF];
+    BODY_LOOP(i, sg.dim) {
+      const double xh = mp_lin(1.0, xk[i], maf, q.p[i]);
+      const double gh = mp_lin(1.0, gk[i], maf, q.Ap[i]);
+      const double u = mp_lin(1.0, xh, mal, gh);
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      xk1[i] = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+    }
+  } else if (act == ACT_AFTER_G1) {           // :1157-1162
+    BODY_LOOP(i, sg.dim) {
+      const double x1 = xk1[i];
+      q.p[i] = mp_free(sg, x1, gk1[i], i);
+      q.dx[i] = mp_lin(1.0, x1, -1.0, xk[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- entry points
+// Start-up of all solves (solvers.py:1063-1081).  Expects x0 staged in X[1], slabs and counters zero.
+extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd,
+                                     int flags, uint32_t* dev_batch, void* stream) {
+  BP_CHECK_BATCH();
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const dim3 vgrid(bp_vec_grid(n), count), rgrid(nblk, count), blk(CCQP_BLOCK);
+  ccqp_lockstep_begin(ctx, dev_batch, s);
+  hipLaunchKernelGGL(bmprgp_init_x_kernel, vgrid, blk, 0, s, dev_probs);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 1, n);
+  hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 2, n);
+  hipLaunchKernelGGL(bmprgp_init_alpha_kernel, rgrid, blk, 0, s, dev_probs, n, chunk, nblk);
+  hipLaunchKernelGGL(bmprgp_init_p_kernel, vgrid, blk, 0, s, dev_probs);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// Round `round` >= 1: at most one matvec for every live problem, the three decision stages, the vector update.
+extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round,
+                                     double gd, double eps10, int flags, uint32_t* dev_batch, void* stream) {
+  BP_CHECK_BATCH();
+  CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 0, n);
+  for (int stage = 1; stage <= 3; ++stage)
+    hipLaunchKernelGGL(bmprgp_stage_kernel, rgrid, blk, 0, s, dev_probs, stage, gd, eps10, chunk, nblk, dev_batch,
+                       ctx->host_slots_dev, (unsigned)count, (double)round);
+  hipLaunchKernelGGL(bmprgp_apply_kernel, dim3(bp_vec_grid(n), count), blk, 0, s, dev_probs);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

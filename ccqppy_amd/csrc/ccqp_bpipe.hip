@@ -12,73 +12,7 @@
 // Bits: the bodies are those of the single-problem kernels (proj_elem_body, gemv_task, residual_body, dot_body,
 // bb_tail_body), the reduction geometry is the same function of n and the matvec's bits do not depend on its
 // tiling, so every problem gets exactly the result of its own CCQPSolverBBPGD.solve() (tests/test_gpu_bpipe.py).
-#include "ccqp_bodies.h"
-
-#define BP_ALPHA 48
-#define BP_DONE 49
-#define BP_ITERS 50
-#define BP_RES2 51
-#define BP_GG 3                            // g0.g0 between the two start-up reductions
-#define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
-
-__device__ __forceinline__ ccqp_segk bp_segk(const ccqp_pprob& q) {
-  ccqp_segk k;
-  k.kind = q.seg.kind;
-  k.flags = q.seg.flags;
-  k.dim = q.seg.dim;
-  k.lb = q.seg.lb;
-  k.ub = q.seg.ub;
-  k.lb_s = q.seg.lb_s;
-  k.ub_s = q.seg.ub_s;
-  return k;
-}
-
-// Block sums v[0..nred) of this block -> sums over the problem's nblk blocks, in the LAST block to arrive (the
-// pattern of ccqp_reduce_finish with a per-problem area and counter).  Returns true in that block only.
-__device__ __forceinline__ bool bp_finish(const ccqp_pprob& q, int nblk, int nred, double* v, double* lds4,
-                                          int* is_last) {
-  if (nblk == 1) return true;
-  if (threadIdx.x == 0) {
-    for (int k = 0; k < nred; ++k) q.partials[(int64_t)k * nblk + blockIdx.x] = v[k];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned prev = __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *is_last = prev + 1u == (unsigned)nblk;
-    if (*is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!*is_last) return false;
-  for (int k = 0; k < nred; ++k) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += q.partials[(int64_t)k * nblk + i];
-    v[k] = ccqp_block_sum(acc, lds4);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
-
-// One thread per problem and launch calls this: the last of `count` publishes the progress of the whole batch.
-__device__ __forceinline__ void bp_report(unsigned* batch, double* host, unsigned count, double seq) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned prev = __hip_atomic_fetch_add(batch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (prev + 1u == count) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(batch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned conv = __hip_atomic_load(batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    host[BP_MIRROR] = (double)conv;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(host + BP_MIRROR + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
+#include "ccqp_lockstep.h"
 
 __global__ void bpipe_begin_kernel(unsigned* batch) {
   if (threadIdx.x == 0) {
@@ -87,13 +21,22 @@ __global__ void bpipe_begin_kernel(unsigned* batch) {
   }
 }
 
+void ccqp_lockstep_begin(ccqp_ctx* ctx, uint32_t* dev_batch, hipStream_t s) {
+  // the mirror is reset from the host side: a poll issued before the first kernel runs must not see the final
+  // state of an earlier batch (whose solves have all been read back by then)
+  ctx->host_slots[BP_MIRROR] = 0.0;
+  ctx->host_slots[BP_MIRROR + 1] = -1.0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  hipLaunchKernelGGL(bpipe_begin_kernel, dim3(1), dim3(64), 0, s, dev_batch);
+}
+
 // x_new = P(x_cur - alpha g_cur), grid (blocks, problems)
 __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_step_kernel(const ccqp_pprob* __restrict__ probs, int inew,
                                                                 int icur) {
   const ccqp_pprob& q = probs[blockIdx.y];
   if (q.slab[BP_DONE] != 0.0) return;
   const double b = -q.slab[BP_ALPHA];
-  proj_elem_body(bp_segk(q), 1.0, q.x[icur], b, q.g[icur], q.x[inew], blockIdx.x, gridDim.x);
+  proj_elem_body(bp_segk_of(q), 1.0, q.x[icur], b, q.g[icur], q.x[inew], blockIdx.x, gridDim.x);
 }
 
 // grid (blocks, problems); the waves of a problem stride over ITS rows, one row per wave at a time.
@@ -122,22 +65,22 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_res_kernel(const ccqp_p
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  const ccqp_segk sg = bp_segk(q);
+  const ccqp_segk sg = bp_segk_of(q);
   double v[2];
   v[0] = residual_body(sg, q.x[0], q.g[0], q.c, gd, chunk, blockIdx.x, lds4);
   v[1] = dot_body(q.g[0], q.g[0], sg.dim, chunk, blockIdx.x, lds4);
-  if (!bp_finish(q, nblk, 2, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     q.slab[0] = v[0];
     q.slab[BP_GG] = v[1];
     q.slab[BP_RES2] = v[0];
     q.slab[BP_ITERS] = 0.0;
     q.slab[BP_ALPHA] = 0.0;
-    if (sqrt(v[0]) < q.tol) {
+    if (sqrt(v[0]) >= q.tol) {               // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
+      q.slab[BP_DONE] = 0.0;
+    } else {
       q.slab[BP_DONE] = 1.0;
       __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      q.slab[BP_DONE] = 0.0;
     }
     bp_report(batch, host, count, seq);
   }
@@ -152,7 +95,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_alpha_kernel(const ccqp
   if (q.slab[BP_DONE] != 0.0) return;
   double v[1];
   v[0] = dot_body(q.g[0], q.y, n, chunk, blockIdx.x, lds4);
-  if (!bp_finish(q, nblk, 1, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     q.slab[1] = v[0];
     q.slab[BP_ALPHA] = q.slab[BP_GG] / v[0];
@@ -173,9 +116,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
     return;
   }
   double v[3];
-  bb_tail_body(bp_segk(q), q.x[inew], q.x[icur], q.g[inew], q.g[icur], q.c, gd, chunk, blockIdx.x, lds4, &v[0], &v[1],
+  bb_tail_body(bp_segk_of(q), q.x[inew], q.x[icur], q.g[inew], q.g[icur], q.c, gd, chunk, blockIdx.x, lds4, &v[0], &v[1],
                &v[2]);
-  if (!bp_finish(q, nblk, 3, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     // the host loop's scalar step (solvers.py:647-656): res = sqrt(res2); alpha = dx.dx / (dx.dg + 10 eps)
     const double res = sqrt(v[0]);
@@ -194,69 +137,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
   }
 }
 
-static inline int bp_vec_grid(int64_t n) {
-  int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
-  if (g > 256) g = 256;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
-// `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
-// result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
-// per wave step in units of 128 (1, 2, 4), bits 8.. workgroups per problem.
-struct bp_mv_tuning {
-  bool aligned;
-  int nt, U;
-  dim3 grid;
-};
-
-static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
-  bp_mv_tuning t;
-  t.aligned = flags & 1;
-  t.nt = (flags >> 1) & 3;
-  t.U = (flags >> 4) & 7;
-  int64_t per = flags >> 8;
-  const double bytes = 8.0 * (double)n * (double)n * count;
-  if (t.nt == 0) t.nt = bytes > 192.0 * 1048576.0 ? 2 : 1;  // a batch that fits the MALL is re-read from there
-  const int64_t rows_per_wg = CCQP_BLOCK / 64;
-  // many small workgroups: ~64k per launch measured best for n = 256..4096 (profiles/r01g_bpipe_sweep.txt)
-  if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
-  if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
-  if (per < 1) per = 1;
-  // few waves in flight (a batch of one, or few large problems): more loads per lane instead
-  if (t.U == 0) t.U = (n >= 4096 || per * count * rows_per_wg < 16384) ? 4 : 1;
-  t.grid = dim3((unsigned)per, count);
-  return t;
-}
-
-// launches KERNEL<U, ALIGNED, NT>(args...) for the tuning `t`
-#define BP_MV_LAUNCH1(KERNEL, UU, AL, NTT, ...) \
-  hipLaunchKernelGGL((KERNEL<UU, AL, NTT>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
-#define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
-  do {                                                                \
-    if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__);     \
-    else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
-    else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
-  } while (0)
-#define BP_MV_LAUNCH(KERNEL, ...)                                          \
-  do {                                                                     \
-    if (t.aligned) {                                                       \
-      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, true, true, __VA_ARGS__);      \
-      else BP_MV_LAUNCH_U(KERNEL, true, false, __VA_ARGS__);               \
-    } else {                                                               \
-      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, false, true, __VA_ARGS__);     \
-      else BP_MV_LAUNCH_U(KERNEL, false, false, __VA_ARGS__);              \
-    }                                                                      \
-  } while (0)
-
 static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   BP_MV_LAUNCH(bpipe_gemv_kernel, probs, i, mode, n);
 }
-
-#define BP_CHECK_BATCH()                                                                          \
-  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument"); \
-  CCQP_REQUIRE(count >= 1 && count <= 65535 && n >= 1, "bad batch shape")
 
 // Start-up of all solves (solvers.py:626-636): g0 = A x0 + b, residual, A g0, alpha0.  Expects x[0] staged, the
 // per-problem counters zero; sequence number 0 is published when every problem has its residual.
@@ -267,12 +151,7 @@ extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  // the mirror is reset from the host side: a poll issued before the first kernel runs must not see the final
-  // state of an earlier batch (whose solves have all been read back by then)
-  ctx->host_slots[BP_MIRROR] = 0.0;
-  ctx->host_slots[BP_MIRROR + 1] = -1.0;
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  hipLaunchKernelGGL(bpipe_begin_kernel, dim3(1), dim3(64), 0, s, dev_batch);
+  ccqp_lockstep_begin(ctx, dev_batch, s);
   // (DONE is read by the matvec: the caller zeroes the slabs before this call)
   bp_gemv(dev_probs, count, n, 0, 0, flags, s);
   hipLaunchKernelGGL(bpipe_init_res_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
@@ -352,45 +231,6 @@ extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
 #define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
 #define AP_RES2 BP_RES2   // 51
 
-__device__ __forceinline__ ccqp_segk ap_segk(const ccqp_papgd& q) {
-  ccqp_segk k;
-  k.kind = q.seg.kind;
-  k.flags = q.seg.flags;
-  k.dim = q.seg.dim;
-  k.lb = q.seg.lb;
-  k.ub = q.seg.ub;
-  k.lb_s = q.seg.lb_s;
-  k.ub_s = q.seg.ub_s;
-  return k;
-}
-
-// all blocks of one problem meet here; true in the last one (sums of v[0..nred) over the blocks in v, thread 0)
-__device__ __forceinline__ bool ap_finish(const ccqp_papgd& q, int nblk, int nred, double* v, double* lds4,
-                                          int* is_last) {
-  if (nblk == 1) return true;
-  if (threadIdx.x == 0) {
-    for (int k = 0; k < nred; ++k) q.partials[(int64_t)k * nblk + blockIdx.x] = v[k];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned prev = __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *is_last = prev + 1u == (unsigned)nblk;
-    if (*is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!*is_last) return false;
-  for (int k = 0; k < nred; ++k) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += q.partials[(int64_t)k * nblk + i];
-    v[k] = ccqp_block_sum(acc, lds4);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
-
 // d = x0 - ones (solvers.py:262) into the spare x buffer
 __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_d_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
   const ccqp_papgd& q = probs[blockIdx.y];
@@ -431,7 +271,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
   double v[2];
   v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, blockIdx.x, lds4);
   v[1] = dot_body(q.X[1], q.X[1], n, chunk, blockIdx.x, lds4);
-  if (!ap_finish(q, nblk, 2, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     double* s = q.slab;
     const double L = sqrt(v[0]) / sqrt(v[1]);
@@ -468,7 +308,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
   if (s[AP_PHASE] == 0.0) {
     // the matvec of y_k has run; next: the first trial step.  (All blocks meet so that the state changes only
     // after every block has read it.)
-    if (!ap_finish(q, nblk, 0, v, lds4, &is_last)) return;
+    if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
     if (threadIdx.x == 0) {
       s[AP_PHASE] = 1.0;
       s[AP_ACT] = 1.0;
@@ -478,7 +318,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
     }
     return;
   }
-  const ccqp_segk sg = ap_segk(q);
+  const ccqp_segk sg = bp_segk_of(q);
   const int64_t n = sg.dim;
   const int it = (int)s[AP_IT];
   const bool first = s[AP_FIRST] != 0.0;
@@ -512,7 +352,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
     v[5] = ccqp_block_sum(a5, lds4);
     v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, blockIdx.x, lds4);
   }
-  if (!ap_finish(q, nblk, 7, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 7, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     double r1, r2;
     if (first) {
@@ -579,7 +419,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papg
   const int it = (int)s[AP_IT];
   if (s[AP_ACT] == 1.0) {
     const double mt = -s[AP_T];
-    proj_elem_body(ap_segk(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], blockIdx.x, gridDim.x);
+    proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], blockIdx.x, gridDim.x);
   } else {
     const double beta = s[AP_BETA];
     const double a = 1.0 + beta, b = -beta;
@@ -595,10 +435,7 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  ctx->host_slots[BP_MIRROR] = 0.0;
-  ctx->host_slots[BP_MIRROR + 1] = -1.0;
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  hipLaunchKernelGGL(bpipe_begin_kernel, dim3(1), dim3(64), 0, s, dev_batch);
+  ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 1, n);

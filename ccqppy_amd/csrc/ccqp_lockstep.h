@@ -1,0 +1,139 @@
+// Shared pieces of the lock-step batch drivers (ccqp_bpipe.hip: BBPGD and APGD; ccqp_bmprgp.hip: MPRGP): slab slots,
+// the per-problem meeting point, the batch-wide roll-call with its host mirror, the batched matvec's tuning.
+#pragma once
+#include "ccqp_bodies.h"
+
+#define BP_ALPHA 48
+#define BP_DONE 49
+#define BP_ITERS 50
+#define BP_RES2 51
+#define BP_GG 3                            // g0.g0 between the two start-up reductions
+#define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
+
+#ifdef __HIPCC__
+// Block sums v[0..nred) of this block -> sums over the problem's nblk blocks, in the LAST block to arrive (the
+// pattern of ccqp_reduce_finish with a per-problem area and counter).  Returns true in that block only, with the
+// sums valid in thread 0.  nred == 0: a plain "all blocks have passed" meeting point -- state that every block reads
+// at the start of a launch may be changed by the block this returns true in.
+__device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int nblk, int nred, double* v,
+                                        double* lds4, int* is_last) {
+  if (nblk == 1) return true;
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < nred; ++k) partials[(int64_t)k * nblk + blockIdx.x] = v[k];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *is_last = prev + 1u == (unsigned)nblk;
+    if (*is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!*is_last) return false;
+  for (int k = 0; k < nred; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += partials[(int64_t)k * nblk + i];
+    v[k] = ccqp_block_sum(acc, lds4);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+template <typename PROB>
+__device__ __forceinline__ ccqp_segk bp_segk_of(const PROB& q) {
+  ccqp_segk k;
+  k.kind = q.seg.kind;
+  k.flags = q.seg.flags;
+  k.dim = q.seg.dim;
+  k.lb = q.seg.lb;
+  k.ub = q.seg.ub;
+  k.lb_s = q.seg.lb_s;
+  k.ub_s = q.seg.ub_s;
+  return k;
+}
+
+// One thread per problem and launch calls this: the last of `count` publishes the progress of the whole batch.
+__device__ __forceinline__ void bp_report(unsigned* batch, double* host, unsigned count, double seq) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned prev = __hip_atomic_fetch_add(batch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev + 1u == count) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(batch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned conv = __hip_atomic_load(batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host[BP_MIRROR] = (double)conv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(host + BP_MIRROR + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+#endif  // __HIPCC__
+
+static inline int bp_vec_grid(int64_t n) {
+  int64_t g = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
+// result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
+// per wave step in units of 128 (1, 2, 4), bits 8.. workgroups per problem.
+struct bp_mv_tuning {
+  bool aligned;
+  int nt, U;
+  dim3 grid;
+};
+
+static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
+  bp_mv_tuning t;
+  t.aligned = flags & 1;
+  t.nt = (flags >> 1) & 3;
+  t.U = (flags >> 4) & 7;
+  int64_t per = flags >> 8;
+  const double bytes = 8.0 * (double)n * (double)n * count;
+  if (t.nt == 0) t.nt = bytes > 192.0 * 1048576.0 ? 2 : 1;  // a batch that fits the MALL is re-read from there
+  const int64_t rows_per_wg = CCQP_BLOCK / 64;
+  // many small workgroups: ~64k per launch measured best for n = 256..4096 (profiles/r01g_bpipe_sweep.txt)
+  if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
+  if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
+  if (per < 1) per = 1;
+  // few waves in flight (a batch of one, or few large problems): more loads per lane instead
+  if (t.U == 0) t.U = (n >= 4096 || per * count * rows_per_wg < 16384) ? 4 : 1;
+  t.grid = dim3((unsigned)per, count);
+  return t;
+}
+
+// launches KERNEL<U, ALIGNED, NT>(args...) for the tuning `t`
+#define BP_MV_LAUNCH1(KERNEL, UU, AL, NTT, ...) \
+  hipLaunchKernelGGL((KERNEL<UU, AL, NTT>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
+#define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
+  do {                                                                \
+    if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__);     \
+    else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
+    else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
+  } while (0)
+#define BP_MV_LAUNCH(KERNEL, ...)                                          \
+  do {                                                                     \
+    if (t.aligned) {                                                       \
+      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, true, true, __VA_ARGS__);      \
+      else BP_MV_LAUNCH_U(KERNEL, true, false, __VA_ARGS__);               \
+    } else {                                                               \
+      if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, false, true, __VA_ARGS__);     \
+      else BP_MV_LAUNCH_U(KERNEL, false, false, __VA_ARGS__);              \
+    }                                                                      \
+  } while (0)
+
+#define BP_CHECK_BATCH()                                                                          \
+  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument"); \
+  CCQP_REQUIRE(count >= 1 && count <= 65535 && n >= 1, "bad batch shape")
+
+
+// zeroes the two batch words and resets the host mirror (ccqp_bpipe.hip)
+void ccqp_lockstep_begin(ccqp_ctx* ctx, uint32_t* dev_batch, hipStream_t s);

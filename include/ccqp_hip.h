@@ -332,6 +332,42 @@ int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
 int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
                          int flags, uint32_t* dev_batch, void* stream);
 
+/* And for MPRGP (solvers.py:1026-1200, README's "MPRGP-BB", BASELINE config 5), elementwise sets with array
+ * bounds.  A ROUND = at most one matvec per live problem (A x_k + b | A p | A x_{k+1} + b | A dx, by the problem's
+ * state), three decision stages (proportioning test :1090-1099; alpha_cg :1106 and the feasible-step search
+ * :1112-1118; the expansion half-step's BB dots :1146-1147; the tail :1184-1192) and the elementwise update they
+ * ask for.  Slab (>= 56 doubles, zeroed): 0..2 the tail's three scalars, 8 n.g, 10 |x - P(x)|^2, 16..23 feasibility
+ * counts, 32..37 {alpha_bb, alpha_cg, p.Ap, alpha_f, half-step alpha, candidates tried}, 38..40 {state, action,
+ * outer iterations}, 49 {0 running | 1 converged | 2 the feasibility search cannot terminate | 3 a proportioning step
+ * (:1165-1182, unreachable on finite data) is due: left to the host-driven loop}, 50 the reference's
+ * mv_count, 51 res2, 52 matvecs executed.  A converged problem's solution is X[(outer iterations + 1) % 2]. */
+typedef struct ccqp_pmprgp {
+  const double* A;
+  int64_t lda;
+  const double* b;
+  double* X[2];      /* x_k / x_{k+1} by parity of the outer-iteration count; x0 staged in X[1] on entry */
+  double* G[2];      /* g_k / g_{k+1} */
+  double* p;
+  double* Ap;
+  double* psi;
+  double* w;
+  double* nv;
+  double* txk;
+  double* dx;
+  double* Adx;
+  double* ytmp;      /* A x of the "+ b" matvecs (unused by the loop, written by the matvec kernel) */
+  ccqp_seg seg;      /* elementwise kind, offset 0, dim n */
+  double* slab;
+  double* partials;  /* 8 * ccqp_bpipe_partials_doubles(n) / 3 doubles */
+  uint32_t* counter; /* one word, zero on entry */
+  double c;
+  double tol;
+} ccqp_pmprgp;
+int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
+                          uint32_t* dev_batch, void* stream);
+int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,
+                          double eps10, int flags, uint32_t* dev_batch, void* stream);
+
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
  * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=32)
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--scheduler", default="fused", choices=["fused", "lanes", "sequential"])
+    ap.add_argument("--scheduler", default="pipelined", choices=["fused", "lanes", "sequential", "pipelined"])
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -42,7 +42,7 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
     from ccqppy_amd import problems, solvers, solution_spaces as ss
-    from ccqppy_amd.batch import solve_batch, solve_batch_fused
+    from ccqppy_amd.batch import solve_batch, solve_batch_fused, solve_batch_pipelined
     from ccqppy_amd.operators import batch_partition
     n = args.size
     total = args.problems if args.problems is not None else 128 * world
@@ -59,7 +59,9 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         t0 = time.perf_counter()
-        if args.scheduler == "fused":
+        if args.scheduler == "pipelined":
+            res = solve_batch_pipelined(make, probs, device=local)
+        elif args.scheduler == "fused":
             res = solve_batch_fused(make, probs, lanes=args.lanes, groups=args.groups, device=local)
         elif args.scheduler == "lanes":
             res = solve_batch(make, probs, lanes=4, device=local)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput of MANY SMALL dense BBPGD (or, with --apgd, APGD) solves (Box, tol 1e-8) under every scheduler of ccqppy_amd:
+"""Throughput of MANY SMALL dense BBPGD (--apgd: APGD, --mprgp: MPRGP) solves (Box, tol 1e-8; MPRGP: 1e-6 / 300 matvecs) under every scheduler of ccqppy_amd:
 sequential solve(), sequential with the pipelined iteration, the stream-lane and fused batch schedulers
 (host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device).  One JSON line per size.
-   python tools/bench_small_batch.py [--apgd] [n:B ...]"""
+   python tools/bench_small_batch.py [--apgd | --mprgp] [n:B ...]"""
 import contextlib
 import io
 import json
@@ -19,9 +19,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     from ccqppy_amd.batch import solve_batch, solve_batch_fused, solve_batch_pipelined
-    args = [a for a in sys.argv[1:] if a != "--apgd"]
-    apgd = "--apgd" in sys.argv[1:]
-    cls = solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
+    args = [a for a in sys.argv[1:] if a not in ("--apgd", "--mprgp")]
+    mprgp = "--mprgp" in sys.argv[1:]
+    apgd = "--apgd" in sys.argv[1:] or mprgp          # (no single-solve pipeline column for these)
+    cls = solvers.CCQPSolverMPRGP if mprgp else solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
     sizes = [tuple(int(v) for v in a.split(":")) for a in args] or \
         [(64, 1024), (256, 1024), (1024, 512), (2048, 256), (4096, 128)]
     for n, B in sizes:
@@ -29,12 +30,13 @@ def main():
         for p in range(B):
             op, b, _ = problems.random_problem(n, 1234 + p)
             probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
-        mk = lambda: cls(1e-8, 5000)          # noqa: E731
+        tol, cap = (1e-6, 300) if mprgp else (1e-8, 5000)          # MPRGP: BASELINE config 5's settings
+        mk = lambda: cls(tol, cap)          # noqa: E731
 
         def seq(pipe):
             for op, b, x0, P in probs:
                 with contextlib.redirect_stdout(io.StringIO()):
-                    (cls(1e-8, 5000) if apgd else cls(1e-8, 5000, pipeline=pipe)).solve(op, b, convex_proj_op=P)
+                    (cls(tol, cap) if apgd else cls(tol, cap, pipeline=pipe)).solve(op, b, convex_proj_op=P)
 
         out = {}
         res = {}
