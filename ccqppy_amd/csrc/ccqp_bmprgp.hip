@@ -82,28 +82,28 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmpr
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   if (init == 1) {                            // g_k = A x_k + b
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[0], q.b, q.ytmp, q.G[0], n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[0], q.b, q.ytmp, q.G[0], n, n, BP_TASKS(U, n), wave, nwaves);
     return;
   }
   if (q.slab[MP_DONE] != 0.0) return;
   if (init == 2) {                            // A g_k (solvers.py:1077)
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.G[0], nullptr, q.Adx, nullptr, n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.G[0], nullptr, q.Adx, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
     return;
   }
   const int it = (int)q.slab[MP_IT];
   switch ((int)q.slab[MP_STATE]) {
     case ST_M1:
-      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[it & 1], q.b, q.ytmp, q.G[it & 1], n, n, n, wave, nwaves);
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[it & 1], q.b, q.ytmp, q.G[it & 1], n, n, BP_TASKS(U, n), wave, nwaves);
       break;
     case ST_AP:
-      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.p, nullptr, q.Ap, nullptr, n, n, n, wave, nwaves);
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.p, nullptr, q.Ap, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
       break;
     case ST_G1:
-      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.ytmp, q.G[(it + 1) & 1], n, n, n, wave, nwaves);
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.ytmp, q.G[(it + 1) & 1], n, n, BP_TASKS(U, n), wave, nwaves);
       break;
     case ST_ADXC:
     case ST_ADXH:
-      gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.dx, nullptr, q.Adx, nullptr, n, n, n, wave, nwaves);
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.dx, nullptr, q.Adx, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
       break;
     default:
       break;                                  // ST_FEAS_WAIT: no matvec this round

@@ -51,9 +51,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_gemv_kernel(const ccqp_pprob
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   if (mode == 0)
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.x[i], q.b, q.y, q.g[i], n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.x[i], q.b, q.y, q.g[i], n, n, BP_TASKS(U, n), wave, nwaves);
   else
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.g[i], nullptr, q.y, nullptr, n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.g[i], nullptr, q.y, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
 }
 
 // start-up, first reduction: residual^2 of (x[0], g[0]) and g0.g0; the exit test of solvers.py `if res >= tol`
@@ -251,15 +251,15 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd
   const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
   if (init) {
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
     return;
   }
   if (q.slab[AP_DONE] != 0.0) return;
   const int it = (int)q.slab[AP_IT];
   if (q.slab[AP_PHASE] == 0.0)
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.Y[it & 1], q.b, q.Ayk, q.gk, n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.Y[it & 1], q.b, q.Ayk, q.gk, n, n, BP_TASKS(U, n), wave, nwaves);
   else
-    gemv_body<1, U, ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, n, wave, nwaves);
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, BP_TASKS(U, n), wave, nwaves);
 }
 
 // L = |A d| / |d|, t = 1 / L (solvers.py:264-268) and the initial state

@@ -84,7 +84,7 @@ static inline int bp_vec_grid(int64_t n) {
 
 // `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
 // result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
-// per wave step in units of 128 (1, 2, 4), bits 8.. workgroups per problem.
+// per wave step in units of 128 (1, 2, 4; 7 = two rows per wave, one step), bits 8.. workgroups per problem.
 struct bp_mv_tuning {
   bool aligned;
   int nt, U;
@@ -104,18 +104,25 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   if (per == 0) per = (65536 + count - 1) / count < 8 ? 8 : (65536 + count - 1) / count;
   if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
   if (per < 1) per = 1;
-  // few waves in flight (a batch of one, or few large problems): more loads per lane instead
-  if (t.U == 0) t.U = (n >= 4096 || per * count * rows_per_wg < 16384) ? 4 : 1;
+  // few waves in flight (a batch of one, or few problems): more loads per lane; large matrices: two rows per wave
+  if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : 1);
   t.grid = dim3((unsigned)per, count);
   return t;
 }
 
-// launches KERNEL<U, ALIGNED, NT>(args...) for the tuning `t`
+// The matvec kernels' first template argument is a CODE: 1, 2, 4 = one row per wave and that many 128-column
+// steps in flight; 8 = two rows per wave, one step (the large-matrix form of ccqp_gemv.hip).
+#define BP_R(C) ((C) == 8 ? 2 : 1)
+#define BP_U(C) ((C) == 8 ? 1 : (C))
+#define BP_TASKS(C, n) (((n) + BP_R(C) - 1) / BP_R(C))
+
+// launches KERNEL<code, ALIGNED, NT>(args...) for the tuning `t`
 #define BP_MV_LAUNCH1(KERNEL, UU, AL, NTT, ...) \
   hipLaunchKernelGGL((KERNEL<UU, AL, NTT>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
 #define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
   do {                                                                \
-    if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__);     \
+    if (t.U == 7) BP_MV_LAUNCH1(KERNEL, 8, AL, NTT, __VA_ARGS__);     \
+    else if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__); \
     else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
     else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
   } while (0)
