@@ -129,6 +129,7 @@ SIGNATURES = {
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
     "ccqp_bapgd_start_f64": [_P, _P, _I, _I64, _I, _P, _P],
     "ccqp_bapgd_round_f64": [_P, _P, _I, _I64, _I64, _D, _I, _P, _P],
+    "ccqp_bmprgp_partial_rows": [],
     "ccqp_bmprgp_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bmprgp_round_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _P, _P],
     "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],

@@ -590,7 +590,8 @@ def _bmprgp_run(eng, items, n, max_mv, ahead, tune=0):
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(items)
     names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PMprgp, len(names), 8)
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PMprgp, len(names),
+                                                         int(lib.ccqp_bmprgp_partial_rows()))
     vec[1].zero_()                                                      # x0 staged in X[1]
     for p, it in enumerate(items):
         if it[3] is not None:

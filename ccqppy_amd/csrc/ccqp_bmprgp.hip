@@ -44,7 +44,11 @@
 enum { ST_M1 = 0, ST_M1_N, ST_M1_P, ST_AP, ST_FEAS_NOW, ST_FEAS_WAIT, ST_HALF3, ST_G1, ST_ADXC, ST_ADXH };
 enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 
-#define MP_STEPS 8       // candidate steps per feasibility pass (solvers.py CCQPSolverMPRGP._STEPS)
+// Candidate steps alpha_f * 0.5^k per feasibility pass.  The host-driven loop tries 8 per launch; the values visited
+// and the first feasible one are the same whatever the pass size, and a larger pass saves whole rounds (the search
+// typically needs ~20 halvings).  The host loop gives up after 151 passes of 8 = candidates 0..1207.
+#define MP_STEPS 24
+#define MP_MAX_CANDIDATES 1208
 
 __device__ __forceinline__ double mp_lin(double a, double x, double b, double y) {   // axpby_body, one element
   const double t1 = a * x;
@@ -296,31 +300,34 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
       if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, &is_last)) return;
       if (threadIdx.x == 0) {
         double af = a0;
-        int found = 0;
+        int found = 0, at = 0;
         for (int k = 0; k < MP_STEPS; ++k) {
-          s[MP_COUNTS + k] = v[k];
+          if (k < 8) s[MP_COUNTS + k] = v[k];
           if (!found) {
-            if (v[k] == 0.0) found = 1;
-            else af *= 0.5;
+            if (v[k] == 0.0) {
+              found = 1;
+              at = k;
+            } else {
+              af *= 0.5;
+            }
           }
         }
         s[MP_AF] = af;
-        if (found) {
+        const double tried = s[MP_TRIED];
+        if (found && tried + (double)at < (double)MP_MAX_CANDIDATES) {
           if (s[MP_ACG] <= af) {              // :1120
             s[MP_ACT] = (double)ACT_CGFULL;
             s[MP_STATE] = (double)ST_ADXC;
           } else {
             s[MP_STATE] = (double)ST_HALF3;
           }
+        } else if (found || tried + (double)MP_STEPS >= (double)MP_MAX_CANDIDATES) {
+          // alpha_f has underflowed without a feasible candidate: the reference never exits, the host loop raises
+          s[MP_DONE] = 2.0;
+          __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-          const double tried = s[MP_TRIED] + (double)MP_STEPS;
-          s[MP_TRIED] = tried;
-          if (tried > 1200.0) {               // alpha_f has underflowed: the reference never exits either
-            s[MP_DONE] = 2.0;
-            __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            s[MP_STATE] = (double)ST_FEAS_WAIT;
-          }
+          s[MP_TRIED] = tried + (double)MP_STEPS;
+          s[MP_STATE] = (double)ST_FEAS_WAIT;
         }
       }
     }
@@ -467,3 +474,6 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
+
+// rows of partial sums (each ccqp_bpipe_partials_doubles(n) / 3 doubles long) one MPRGP problem needs
+extern "C" int ccqp_bmprgp_partial_rows(void) { return MP_STEPS; }

@@ -336,8 +336,8 @@ int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
  * bounds.  A ROUND = at most one matvec per live problem (A x_k + b | A p | A x_{k+1} + b | A dx, by the problem's
  * state), three decision stages (proportioning test :1090-1099; alpha_cg :1106 and the feasible-step search
  * :1112-1118; the expansion half-step's BB dots :1146-1147; the tail :1184-1192) and the elementwise update they
- * ask for.  Slab (>= 56 doubles, zeroed): 0..2 the tail's three scalars, 8 n.g, 10 |x - P(x)|^2, 16..23 feasibility
- * counts, 32..37 {alpha_bb, alpha_cg, p.Ap, alpha_f, half-step alpha, candidates tried}, 38..40 {state, action,
+ * ask for.  Slab (>= 56 doubles, zeroed): 0..2 the tail's three scalars, 8 n.g, 10 |x - P(x)|^2, 16..23 the first
+ * eight feasibility counts of the last pass, 32..37 {alpha_bb, alpha_cg, p.Ap, alpha_f, half-step alpha, candidates tried}, 38..40 {state, action,
  * outer iterations}, 49 {0 running | 1 converged | 2 the feasibility search cannot terminate | 3 a proportioning step
  * (:1165-1182, unreachable on finite data) is due: left to the host-driven loop}, 50 the reference's
  * mv_count, 51 res2, 52 matvecs executed.  A converged problem's solution is X[(outer iterations + 1) % 2]. */
@@ -358,11 +358,12 @@ typedef struct ccqp_pmprgp {
   double* ytmp;      /* A x of the "+ b" matvecs (unused by the loop, written by the matvec kernel) */
   ccqp_seg seg;      /* elementwise kind, offset 0, dim n */
   double* slab;
-  double* partials;  /* 8 * ccqp_bpipe_partials_doubles(n) / 3 doubles */
+  double* partials;  /* ccqp_bmprgp_partial_rows() * ccqp_bpipe_partials_doubles(n) / 3 doubles */
   uint32_t* counter; /* one word, zero on entry */
   double c;
   double tol;
 } ccqp_pmprgp;
+int ccqp_bmprgp_partial_rows(void);
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,
