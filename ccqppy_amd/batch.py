@@ -87,14 +87,15 @@ def solve_batch(make_solver, problems, lanes=4, device=None, quiet=True):
     return solvers
 
 
-def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=None, device=None, fused=True,
+def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=None, device=None, fused="auto",
                         gather=False):
     """One process per GPU: this rank generates and solves problems p = rank, rank+world, ...
     (`make_problem(p)` -> (A, b, x0, op) on this rank's GPU).  Returns {p: solver} for the local
     problems; no collective is issued on the data path.  fused=True uses the lock-step scheduler with batched
     launches (solve_batch_fused, 32 lanes in 2 groups by default), fused=False the one-stream-per-solve scheduler,
-    fused="pipelined" the device-resident lock-step scheduler (solve_batch_pipelined: BBPGD / APGD, equal-size
-    dense problems, elementwise sets).
+    fused="pipelined" the device-resident lock-step scheduler (solve_batch_pipelined: BBPGD / APGD / MPRGP,
+    equal-size dense problems, elementwise sets); the default "auto" takes the lock-step scheduler where it applies
+    and the fused one otherwise (all of them give bitwise the same results).
     gather=True adds ONE exchange after all solves ("host gathers the result vectors at the
     end"): every rank then gets {p: BatchResult} for ALL problems, results as host arrays."""
     world, rank = 1, 0
@@ -103,11 +104,17 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
         rank = torch.distributed.get_rank(group)
     mine = batch_partition(nproblems, world, rank)
     probs = [make_problem(p) for p in mine]
+    solved = None
     if fused == "pipelined":
         solved = solve_batch_pipelined(make_solver, probs, device=device)
-    elif fused:
+    elif fused == "auto":
+        try:                                            # (its argument checks precede any GPU work)
+            solved = solve_batch_pipelined(make_solver, probs, device=device)
+        except (TypeError, ValueError):
+            solved = None
+    if solved is None and fused:
         solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=2, device=device)
-    else:
+    elif solved is None:
         solved = solve_batch(make_solver, probs, lanes=lanes or 4, device=device)
     local = dict(zip(mine, solved))
     if not gather:
