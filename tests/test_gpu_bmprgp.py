@@ -150,6 +150,27 @@ def test_nan_data_take_the_reference_exits():
                 _same(a, c)
 
 
+def test_single_solve_pipeline_option():
+    """CCQPSolverMPRGP(..., pipeline=True) = the lock-step scheduler with a batch of one; where it does not apply
+    (scalar bounds raise as in the reference, spheres, budget reached) the host-driven loop runs."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    for n in (100, 1024, 3000):
+        for p, (A, b, x0, P) in enumerate(_problems(n, 5, 40 + n, 0.1)):
+            for cap in (2000, 9, 21):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    a = solvers.CCQPSolverMPRGP(1e-7, cap).solve(A, b, x0=x0, convex_proj_op=P)
+                    c = solvers.CCQPSolverMPRGP(1e-7, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
+                _same(a, c)
+    op, b, _ = problems.random_problem(256, 3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = solvers.CCQPSolverMPRGP(1e-7, 500).solve(op, b, convex_proj_op=ss.SphereProjOp(256, 2.0))
+        c = solvers.CCQPSolverMPRGP(1e-7, 500, pipeline=True).solve(op, b, convex_proj_op=ss.SphereProjOp(256, 2.0))
+    _same(a, c)
+    with pytest.raises(TypeError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            solvers.CCQPSolverMPRGP(1e-7, 500, pipeline=True).solve(op, b, convex_proj_op=ss.BoxProjOp(256, -0.5, 0.5))
+
+
 def test_rejects_scalar_bounds_and_tiny_problems():
     from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(128, 1)
