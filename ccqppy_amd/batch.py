@@ -333,7 +333,7 @@ _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; ke
 
 
 def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0):
-    """Many dense problems of one size n, solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
+    """Many dense problems (grouped by size n; one lock-step run per size), solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
     (:1002-1224) in lock-step: three launches per iteration (APGD: per matvec; MPRGP: five) for the whole batch, step
     lengths, line search, branch decisions and exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_* /
     ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
@@ -363,8 +363,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD / CCQPSolverMPRGP only, "
                         "got %s" % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
-    items = []
-    n = None
+    by_size = {}                                        # n -> items, in order of first appearance
     for s, (A, b, x0, P) in zip(solvers, problems):
         if type(s) is not kind or getattr(s, "reuse_matvec", False):
             raise TypeError("solve_batch_pipelined: one solver class for the whole batch")
@@ -373,10 +372,9 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         op = as_operator(A)
         if not isinstance(op, DenseOperator) or op.rows != op.n:
             raise TypeError("solve_batch_pipelined needs square dense operators")
-        if n is None:
-            n = op.n
-        if op.n != n or b.shape[0] != n:
-            raise ValueError("solve_batch_pipelined: all problems must have the same size")
+        n = op.n
+        if b.shape[0] != n:
+            raise ValueError("solve_batch_pipelined: b does not match A")
         if op.A.device != eng.device:
             raise ValueError("solve_batch_pipelined: operator on another device")
         P = P if P is not None else ss.IdentityProjOp(n)
@@ -388,15 +386,16 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
             raise TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
                             % _lib.SMALL_SEG_MAX)
         bd = eng.to_device(b).reshape(-1)
-        items.append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
-                      isinstance(b, torch.Tensor), (A, b, x0, P)))
+        by_size.setdefault(n, []).append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
+                                          isinstance(b, torch.Tensor), (A, b, x0, P)))
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
     group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
     with np.errstate(all="ignore"):
-        for lo in range(0, len(items), _BPIPE_MAX):
-            group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
+        for n, items in by_size.items():                # one lock-step run per problem size
+            for lo in range(0, len(items), _BPIPE_MAX):
+                group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
     for s in solvers:
         s._solution_time = dt

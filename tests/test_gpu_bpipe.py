@@ -239,6 +239,17 @@ def test_batch_sharded_driver_with_the_pipelined_scheduler():
             assert np.array_equal(r.solution.view(np.uint64), a.solution.cpu().numpy().view(np.uint64))
 
 
+def test_mixed_sizes_are_grouped():
+    probs = []
+    for i, n in enumerate((96, 200, 96, 333, 200, 96)):
+        probs += _problems(n, 1, 600 + i)
+    for solver in ("BBPGD", "APGD"):
+        ref = _reference(probs, [1e-8] * len(probs), 5000, solver)
+        got = _batch(probs, [1e-8] * len(probs), 5000, solver)
+        for a, c in zip(ref, got):
+            _same(a, c)
+
+
 def test_rejects_what_it_cannot_run():
     from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(64, 1)
@@ -252,5 +263,5 @@ def test_rejects_what_it_cannot_run():
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, ss.ConeProjOp(64))])
     with pytest.raises(ValueError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, None), (op2, b2, None, None)])
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), [(op, b, None, None), (op2, b, None, None)])
     assert batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGD(1e-8), []) == []

@@ -1,0 +1,91 @@
+"""GPU: seeded differential fuzzing of the lock-step schedulers (batch.solve_batch_pipelined) against per-problem
+solve().  Random solver (BBPGD / APGD / MPRGP), batch composition (sizes 65..1300 mixed in one call, so several
+lock-step groups), elementwise sets with array / scalar / integer / default bounds, warm starts, per-problem
+tolerances, matvec budget, run-ahead depth and matvec tuning word.  Every result must be bitwise the one of the
+problem's own solve() (x, residual, converged flag, reported and executed MV counts)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NCASES = int(os.environ.get("CCQP_LOCKSTEP_FUZZ_CASES", "36"))
+
+
+def _set(rng, n, mprgp):
+    from ccqppy_amd import solution_spaces as ss
+    def arr(sign):
+        return sign * rng.uniform(0.05, 0.6, size=n)
+    def bound(sign):
+        mode = rng.integers(4) if not mprgp else 3      # MPRGP: array bounds only (scalar ones raise, as the reference)
+        if mode == 0:
+            return None
+        if mode == 1:
+            return float(sign * rng.uniform(0.1, 0.8))
+        if mode == 2:
+            return int(sign * rng.integers(1, 3))
+        return arr(sign)
+    kind = rng.integers(4)
+    if kind == 0:
+        return ss.IdentityProjOp(n)
+    if kind == 1:
+        lb = bound(-1)
+        return ss.LowerBoundProjOp(n) if lb is None else ss.LowerBoundProjOp(n, lb)
+    if kind == 2:
+        ub = bound(+1)
+        return ss.UpperBoundProjOp(n) if ub is None else ss.UpperBoundProjOp(n, ub)
+    lb, ub = bound(-1), bound(+1)
+    if lb is None and ub is None:
+        return ss.BoxProjOp(n)
+    if lb is None:
+        lb = -np.ones(n)
+    if ub is None:
+        ub = np.ones(n)
+    return ss.BoxProjOp(n, lb, ub)
+
+
+def _bits(x):
+    x = x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    return x.view(np.uint64)
+
+
+@pytest.mark.parametrize("case", range(NCASES))
+def test_lockstep_equals_individual_solves(case):
+    import torch
+    from ccqppy_amd import batch, problems, solvers
+    rng = np.random.default_rng(9000 + case)
+    name = ["BBPGD", "APGD", "MPRGP"][case % 3]
+    cls = getattr(solvers, "CCQPSolver" + name)
+    sizes = rng.choice([65, 96, 130, 257, 512, 777, 1300], size=rng.integers(1, 4), replace=False)
+    probs, tols = [], []
+    for n in sizes:
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(n)
+            op, b, _ = problems.random_problem(n, int(rng.integers(1 << 30)))
+            x0 = None
+            if rng.random() < 0.3:
+                x0 = torch.as_tensor(rng.uniform(-0.5, 0.5, size=n), device=b.device)
+            probs.append((op, b, x0, _set(rng, n, name == "MPRGP")))
+            tols.append(float(10.0 ** rng.uniform(-9, -4)) if name != "MPRGP" else float(10.0 ** rng.uniform(-7, -4)))
+    order = rng.permutation(len(probs))                 # sizes interleaved in the call
+    probs = [probs[i] for i in order]
+    tols = [tols[i] for i in order]
+    max_mv = [np.inf, 5000, 60, 25, 9][rng.integers(5)] if name != "MPRGP" else [3000, 60, 25, 9][rng.integers(4)]
+    ahead = int(rng.choice([1, 2, 4, 9]))
+    tune = int(rng.choice([0, (1 << 1) | (2 << 4), (2 << 1) | (7 << 4) | (8 << 8), (4 << 4) | (3 << 8)]))
+    ref = []
+    for (A, b, x0, P), tol in zip(probs, tols):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.append(cls(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
+    it = iter(tols)
+    got = batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, ahead=ahead, tune=tune)
+    assert len(got) == len(ref)
+    for a, c in zip(ref, got):
+        assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+        assert bool(a.solution_converged) == bool(c.solution_converged)
+        assert float(a.solution_residual) == float(c.solution_residual)
+        assert np.array_equal(_bits(a.solution), _bits(c.solution))
