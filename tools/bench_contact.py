@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Matrix-free contact-type QP: A = D diag(minv) D^T + eps I with D a sparse m x n
-constraint Jacobian, never formed (operators.ComposedOperator), x >= 0, BBPGD tol 1e-8.
+constraint Jacobian, never formed (operators.ComposedOperator), x >= 0, BBPGD (or --solver APGD / MPRGP) tol 1e-8,
+host-driven loop vs pipeline=True (scalars and branch decisions on the device).
 One JSON line per shape m:n; the composed matvec moves 2 CSR matvecs + 4 vector passes."""
 import argparse
 import contextlib
@@ -32,6 +33,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="20000:30000,200000:300000,2000000:3000000,8000000:12000000")
     ap.add_argument("--per-row", type=int, default=6)
+    ap.add_argument("--solver", default="BBPGD", choices=["BBPGD", "APGD", "MPRGP"])
+    ap.add_argument("--tol", type=float, default=1e-8)
     args = ap.parse_args()
     from ccqppy_amd import solvers, solution_spaces as ss
     from ccqppy_amd._engine import get_engine
@@ -47,11 +50,13 @@ def main():
         op = ComposedOperator(D, DiagonalOperator(minv), D.T, shift=0.05)
         xs = torch.rand(m, device=eng.device, dtype=torch.float64, generator=gen) * 2 - 1
         b = -op.dot(xs)
-        P = ss.LowerBoundProjOp(m, 0.0)
+        # (MPRGP indexes the bounds: array bounds, as the reference requires)
+        P = ss.LowerBoundProjOp(m, torch.zeros(m, dtype=torch.float64).numpy() if args.solver == "MPRGP" else 0.0)
+        cls = getattr(solvers, "CCQPSolver" + args.solver)
 
         def solve(pipe=False):
             with contextlib.redirect_stdout(io.StringIO()):
-                return solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=pipe).solve(op, b, convex_proj_op=P)
+                return cls(args.tol, 20000, pipeline=pipe).solve(op, b, convex_proj_op=P)
         walls = {}
         for pipe in (False, True):
             solve(pipe)
@@ -68,7 +73,7 @@ def main():
         mv = int(r.executed_matrix_vector_multiplications)
         nnz = D.nnz
         nbytes = 2 * (12 * nnz + 16 * max(m, n) + 8 * min(m, n)) + 8 * (3 * n + 3 * m)
-        print(json.dumps({"workload": "contact QP: A = D diag D^T + 0.05 I (matrix-free), x >= 0, BBPGD tol 1e-8",
+        print(json.dumps({"workload": "contact QP: A = D diag D^T + 0.05 I (matrix-free), x >= 0, %s tol %g" % (args.solver, args.tol),
                           "constraints_m": m, "coordinates_n": n, "nnz_D": nnz, "wall_s": wall, "executed_mv": mv,
                           "reported_mv": int(r.solution_num_matrix_vector_multiplications),
                           "converged": bool(r.solution_converged), "residual": float(r.solution_residual),
