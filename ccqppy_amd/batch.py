@@ -330,9 +330,11 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
 # Pipelined batch: equal-size dense BBPGD solves in lock-step with every scalar on the device.
 # ---------------------------------------------------------------------------------------------
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
+_BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
 
 
-def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0):
+def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0, single_launch=None,
+                          stats=None):
     """Many dense problems (grouped by size n; one lock-step run per size), solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
     (:1002-1224) in lock-step: three launches per iteration (APGD: per matvec; MPRGP: five) for the whole batch, step
     lengths, line search, branch decisions and exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_* /
@@ -345,8 +347,12 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
     and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
-    the wall-clock of the whole batch.  (APGD / MPRGP problems that would run into the matvec budget are handed to
-    plain solve(), whose exit paths at the budget have quirks of their own.)"""
+    the wall-clock of the whole batch.  BBPGD on small matrices (n <= 512 by default; `single_launch` forces it on,
+    up to n = 2048, or off) runs as ONE launch, one workgroup per problem, instead of lock-step rounds -- the same
+    bits again.  (APGD / MPRGP problems that would run into the matvec budget are handed to
+    plain solve(), whose exit paths at the budget have quirks of their own.)  `stats`, if given, receives the
+    wall-clock split {staging_s: argument checks and per-problem staging on the host, run_s: tables, launches, wait,
+    result objects}."""
     from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
@@ -392,11 +398,14 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         for s in solvers:
             print("solving " + s._label)
     group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
+    t1 = time.time()
     with np.errstate(all="ignore"):
         for n, items in by_size.items():                # one lock-step run per problem size
             for lo in range(0, len(items), _BPIPE_MAX):
-                group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
+                group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
     dt = time.time() - t0
+    if stats is not None:                               # host-side staging of the problem list vs the runs proper
+        stats.update(staging_s=t1 - t0, run_s=time.time() - t1)
     for s in solvers:
         s._solution_time = dt
     return solvers
@@ -430,13 +439,50 @@ def _bpipe_poll_loop(eng, B, launch, last_round, ahead):
     return k
 
 
-def _bpipe_table(eng, items, n, struct, nvec, partial_rows):
+class _Spec:
+    """What a lock-step run needs to know about its B problems of size n, as arrays: matrix / right-hand-side
+    addresses, leading dimensions, set descriptors (struct ccqp_seg records), tolerances, and the start vectors
+    (None: zeros; a (B, n) tensor; or a list of optional n-vectors)."""
+    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep")
+
+    def __len__(self):
+        return self.B
+
+    def stage_x0(self, plane):
+        x0 = self.x0
+        if x0 is None:
+            plane.zero_()                               # x0 = 0 (solvers.py:125-126)
+        elif isinstance(x0, torch.Tensor):
+            plane.copy_(x0)
+        else:
+            plane.zero_()
+            for p, v in enumerate(x0):
+                if v is not None:
+                    plane[p].copy_(v)
+
+
+def _spec_from_items(eng, items, n):
+    """items: tuples (solver, DenseOperator, b on the device, x0 on the device or None, set, ...)"""
+    from . import _lib
+    sp = _Spec()
+    sp.B, sp.n = len(items), n
+    sp.A = np.array([it[1].A.data_ptr() for it in items], dtype=np.uint64)
+    sp.lda = np.array([it[1].A.stride(0) for it in items], dtype=np.int64)
+    sp.b = np.array([it[2].data_ptr() for it in items], dtype=np.uint64)
+    sp.seg = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=np.dtype(_lib.Seg))
+    sp.tol = np.array([it[0].desired_residual_tol for it in items], dtype=np.float64)
+    sp.x0 = None if all(it[3] is None for it in items) else [it[3] for it in items]
+    sp.keep = None
+    return sp
+
+
+def _bpipe_table(eng, spec, n, struct, nvec, partial_rows):
     """Workspace + descriptor table shared by the lock-step drivers: `nvec` (B, n) vector planes, zeroed slabs,
     partial-sum areas, counters; returns (vec, slabs, words, tab, base, plane, rows)."""
     from . import _lib
     from .solvers import _GD
     dev = eng.device
-    B = len(items)
+    B = len(spec)
     nblk = max(int(eng.lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
     vec = torch.empty((nvec, B, n), dtype=torch.float64, device=dev)
     slabs = torch.zeros((B, 64), dtype=torch.float64, device=dev)
@@ -445,15 +491,12 @@ def _bpipe_table(eng, items, n, struct, nvec, partial_rows):
     dt = np.dtype(struct)
     tab = np.zeros(B, dtype=dt)
     idx = np.arange(B, dtype=np.uint64)
-    tab["A"] = [it[1].A.data_ptr() for it in items]
-    tab["lda"] = [it[1].A.stride(0) for it in items]
-    tab["b"] = [it[2].data_ptr() for it in items]
-    tab["seg"] = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=dt["seg"])
+    tab["A"], tab["lda"], tab["b"], tab["seg"] = spec.A, spec.lda, spec.b, spec.seg
     tab["slab"] = np.uint64(slabs.data_ptr()) + idx * np.uint64(8 * 64)
     tab["partials"] = np.uint64(partials.data_ptr()) + idx * np.uint64(8 * partial_rows * nblk)
     tab["counter"] = np.uint64(words.data_ptr()) + idx * np.uint64(4)
     tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
-    tab["tol"] = [it[0].desired_residual_tol for it in items]
+    tab["tol"] = spec.tol
     planes = [np.uint64(vec.data_ptr()) + np.uint64(j) * np.uint64(8 * n * B) + idx * np.uint64(8 * n)
               for j in range(nvec)]
     keep = (partials,)
@@ -465,16 +508,15 @@ def _bpipe_flags(tab, n, tune):
     return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
 
 
-def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
+def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
+    """Lock-step (or single-launch) BBPGD over `spec`; returns (converged mask, index of the final iteration,
+    (B, n) device tensor of final iterates, residuals)."""
     from . import _lib
     from .solvers import _EPS10, _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(items)
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PProb, 7, 3)   # x ring, g ring, y
-    vec[0].zero_()                                                      # x0 = 0 (solvers.py:125-126)
-    for p, it in enumerate(items):
-        if it[3] is not None:
-            vec[0, p].copy_(it[3])
+    B = len(spec)
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 7, 3)    # x ring, g ring, y
+    spec.stage_x0(vec[0])
     for j in range(3):
         tab["x"][:, j] = planes[j]
         tab["g"][:, j] = planes[3 + j]
@@ -483,7 +525,6 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
-    check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
     # iteration k with 1 + k >= max_mv is the last one and has no tail: the reference breaks before the
     # residual (:643-644)
     last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
@@ -491,17 +532,34 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
     def launch(k):
         check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
 
-    k = _bpipe_poll_loop(eng, B, launch, last, ahead)
-    capped = 1 + k >= max_mv
+    if single_launch is None:
+        single_launch = n <= _BSOLVE_MAX_N
+    if single_launch and n <= 2048:
+        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
+        k = int(last) if np.isfinite(last) else 1 << 62
+        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 1, st))
+        capped = np.isfinite(last)
+    else:
+        check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
+        k = _bpipe_poll_loop(eng, B, launch, last, ahead)
+        capped = 1 + k >= max_mv
     h = slabs[:, 48:52].cpu().numpy()                   # blocking: the queue has drained
     done, iters, res2 = h[:, 1] != 0.0, h[:, 2].astype(np.int64), h[:, 3]
     if not capped and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
     final = np.where(done, iters, k)
-    sel = torch.from_numpy(final % 3).to(dev)
-    sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
+    if B == 1:
+        sols = vec[int(final[0] % 3)]
+    else:
+        sel = torch.from_numpy(final % 3).to(dev)
+        sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
+    del keep
+    return done, final, sols, np.sqrt(res2)
+
+
+def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
+    done, final, sols, res = _bpipe_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch)
     host = None
-    res = np.sqrt(res2)
     for p, it in enumerate(items):
         s = it[0]
         mv = 1 + int(final[p])
@@ -515,24 +573,20 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_residual = res[p]
         s._solution_num_matrix_vector_mults = mv
         # start-up: A x0 and -- unless the start already satisfies the tolerance -- A g0 (executed, not counted)
-        s._executed_matrix_vector_mults = 1 if (done[p] and iters[p] == 0) else 2 + int(final[p])
+        s._executed_matrix_vector_mults = 1 if (done[p] and final[p] == 0) else 2 + int(final[p])
         eng.mv_executed += s._executed_matrix_vector_mults
-    del keep
 
 
-def _bapgd_run(eng, items, n, max_mv, ahead, tune=0):
-    """Lock-step APGD over `items`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
+def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0):
+    """Lock-step APGD over `spec`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
     matvec counts) -- rows of problems that did not converge inside the budget are meaningless."""
     from . import _lib
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(items)
+    B = len(spec)
     # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PApgd, 8, 7)
-    vec[0].zero_()
-    for p, it in enumerate(items):
-        if it[3] is not None:
-            vec[0, p].copy_(it[3])
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 8, 7)
+    spec.stage_x0(vec[0])
     vec[2].copy_(vec[0])                                                # yk = x0 (solvers.py:257-258)
     tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
     tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
@@ -563,10 +617,10 @@ def _bapgd_run(eng, items, n, max_mv, ahead, tune=0):
     return done, sols, np.sqrt(res2), mvs
 
 
-def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
+def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     import contextlib
     import io
-    done, sols, res, mvs = _bapgd_run(eng, items, n, max_mv, ahead, tune)
+    done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune)
     host = None
     for p, it in enumerate(items):
         s = it[0]
@@ -588,20 +642,17 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0):
         eng.mv_executed += int(mvs[p])
 
 
-def _bmprgp_run(eng, items, n, max_mv, ahead, tune=0):
-    """Lock-step MPRGP over `items`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
+def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0):
+    """Lock-step MPRGP over `spec`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
     matvecs); status 1 = converged, anything else = not finished here (rows meaningless)."""
     from . import _lib
     from .solvers import _EPS10, _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(items)
+    B = len(spec)
     names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, items, n, _lib.PMprgp, len(names),
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PMprgp, len(names),
                                                          int(lib.ccqp_bmprgp_partial_rows()))
-    vec[1].zero_()                                                      # x0 staged in X[1]
-    for p, it in enumerate(items):
-        if it[3] is not None:
-            vec[1, p].copy_(it[3])
+    spec.stage_x0(vec[1])                                               # x0 staged in X[1]
     tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
     tab["G"][:, 0], tab["G"][:, 1] = planes[2], planes[3]
     for j, name in enumerate(names[4:]):
@@ -633,10 +684,10 @@ def _bmprgp_run(eng, items, n, max_mv, ahead, tune=0):
     return status, sols, np.sqrt(res2), mvs, execd
 
 
-def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0):
+def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     import contextlib
     import io
-    status, sols, res, mvs, execd = _bmprgp_run(eng, items, n, max_mv, ahead, tune)
+    status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune)
     host = None
     for p, it in enumerate(items):
         s = it[0]
@@ -656,3 +707,133 @@ def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_num_matrix_vector_mults = int(mvs[p])
         s._executed_matrix_vector_mults = int(execd[p])
         eng.mv_executed += int(execd[p])
+
+
+# ---------------------------------------------------------------------------------------------
+# Stacked problems: the lock-step runs without any per-problem Python.
+# ---------------------------------------------------------------------------------------------
+class StackedResult:
+    """Results of solve_stacked, one row / entry per problem: `solution` (B, n) device tensor; numpy arrays
+    `residual`, `converged`, `num_matrix_vector_multiplications` (the reference's count), `executed_matrix_vector_
+    multiplications`; `solution_time` the wall-clock of the whole call."""
+    __slots__ = ("solution", "residual", "converged", "num_matrix_vector_multiplications",
+                 "executed_matrix_vector_multiplications", "solution_time")
+
+
+def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_mv=np.inf, device=None, ahead=4,
+                  tune=0, single_launch=None):
+    """B dense problems of one size handed over as STACKED device tensors -- A (B, n, n), b (B, n), optional x0
+    (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
+    (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
+
+    solver        : "BBPGD", "APGD", "MPRGP" or the solver class
+    lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
+                    Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
+                    (scalar ones raise in the reference's normal_vector).
+    tol           : one tolerance or one per problem
+    Problem p gets bit for bit the result of `Solver(tol[p], max_mv).solve(A[p], b[p], x0[p], P_p)` with P_p the
+    corresponding *ProjOp (tests/test_gpu_stacked.py).  Returns a StackedResult."""
+    from . import _lib
+    from . import solution_spaces as ss
+    from . import solvers as sv
+    t0 = time.time()
+    name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
+                                                   sv.CCQPSolverMPRGP: "MPRGP"}.get(solver)
+    if name not in ("BBPGD", "APGD", "MPRGP"):
+        raise TypeError("solve_stacked runs BBPGD, APGD or MPRGP, got %r" % (solver,))
+    eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
+    eng.bind()
+    A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
+    if A.dim() != 3 or A.shape[1] != A.shape[2]:
+        raise ValueError("solve_stacked: A must be (B, n, n)")
+    if A.stride(2) != 1 or A.stride(1) < A.shape[2]:
+        A = A.contiguous()
+    B, n = int(A.shape[0]), int(A.shape[1])
+    b = eng.to_device(b).reshape(B, n)
+    if x0 is not None:
+        x0 = eng.to_device(x0).reshape(B, n)
+
+    def is_scalar(v):
+        return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
+
+    kind = {(False, False): _lib.OP_IDENTITY, (True, False): _lib.OP_LOWER, (False, True): _lib.OP_UPPER,
+            (True, True): _lib.OP_BOX}[(lower is not None, upper is not None)]
+    if name == "MPRGP" and (is_scalar(lower) or is_scalar(upper) or n <= _lib.SMALL_SEG_MAX):
+        raise TypeError("solve_stacked runs MPRGP on sets with array bounds and n > %d" % _lib.SMALL_SEG_MAX)
+    seg = np.zeros(B, dtype=np.dtype(_lib.Seg))
+    seg["kind"], seg["dim"] = kind, n
+    keep = []
+    for field, sfield, flag, v in (("lb", "lb_s", _lib.SEG_LB_INT, lower), ("ub", "ub_s", _lib.SEG_UB_INT, upper)):
+        if v is None:
+            continue
+        if is_scalar(v):
+            seg[sfield] = float(v)
+            if isinstance(v, (int, np.integer)):
+                seg["flags"] |= flag                    # integer bounds multiply integer masks (solution_spaces.py)
+            continue
+        if not isinstance(v, torch.Tensor) and np.asarray(v).dtype.kind in "iu":
+            seg["flags"] |= flag
+        t = eng.to_device(v)
+        keep.append(t)
+        if t.numel() == n:
+            seg[field] = t.data_ptr()
+        elif tuple(t.shape) == (B, n):
+            seg[field] = np.uint64(t.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * n)
+        else:
+            raise ValueError("solve_stacked: bounds must be scalars, (n,) or (B, n)")
+    sp = _Spec()
+    sp.B, sp.n = B, n
+    idx = np.arange(B, dtype=np.uint64)
+    sp.A = np.uint64(A.data_ptr()) + idx * np.uint64(8 * A.stride(0))
+    sp.lda = np.full(B, A.stride(1), dtype=np.int64)
+    sp.b = np.uint64(b.data_ptr()) + idx * np.uint64(8 * n)
+    sp.seg = seg
+    sp.tol = np.broadcast_to(np.asarray(tol, dtype=np.float64), (B,)).copy()
+    sp.x0 = x0
+    sp.keep = keep
+    out = StackedResult()
+    with np.errstate(all="ignore"):
+        if name == "BBPGD":
+            done, final, sols, res = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
+            mv = 1 + final
+            execd = np.where(done & (final == 0), 1, 2 + final)
+            todo = np.zeros(0, dtype=np.int64)
+        elif name == "APGD":
+            done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune)
+            execd = mv
+            todo = np.flatnonzero(~done)
+        else:
+            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune)
+            todo = np.flatnonzero(status != 1.0)
+    mv, execd, res = np.array(mv, dtype=np.int64), np.array(execd, dtype=np.int64), np.array(res, dtype=np.float64)
+    if B == 1:
+        sols = sols.reshape(1, n).clone()
+    eng.mv_executed += int(np.delete(execd, todo).sum())
+    if len(todo):
+        # matvec budget reached (APGD / MPRGP): these problems take the reference's own exit paths in solve()
+        import contextlib
+        import io
+        cls = getattr(sv, "CCQPSolver" + name)
+
+        def bound(v, p):
+            if v is None or is_scalar(v):
+                return v
+            t = v if isinstance(v, torch.Tensor) else np.asarray(v)
+            t = t if t.shape[0] == n and t.ndim == 1 else t[p]
+            return t.cpu().numpy() if isinstance(t, torch.Tensor) else t
+        for p in todo:
+            lo, up = bound(lower, p), bound(upper, p)
+            P = {_lib.OP_IDENTITY: lambda: ss.IdentityProjOp(n), _lib.OP_LOWER: lambda: ss.LowerBoundProjOp(n, lo),
+                 _lib.OP_UPPER: lambda: ss.UpperBoundProjOp(n, up), _lib.OP_BOX: lambda: ss.BoxProjOp(n, lo, up)}[kind]()
+            with contextlib.redirect_stdout(io.StringIO()):
+                s = cls(float(sp.tol[p]), max_mv).solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
+            sols[p].copy_(s.solution)
+            res[p], mv[p] = s.solution_residual, s.solution_num_matrix_vector_multiplications
+            execd[p] = s.executed_matrix_vector_multiplications
+    out.solution = sols
+    out.residual = res
+    out.num_matrix_vector_multiplications = mv
+    out.executed_matrix_vector_multiplications = execd
+    out.converged = mv < max_mv
+    out.solution_time = time.time() - t0
+    return out

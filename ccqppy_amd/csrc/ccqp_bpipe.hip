@@ -461,3 +461,96 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
+
+// =====================================================================================================================
+// One workgroup per problem, the WHOLE BBPGD solve in one launch (n <= CCQP_RED_CHUNK, i.e. every reduction is one
+// block wide).  For matrices of a few hundred rows a lock-step round is bound by its three launches, not by the
+// data (which sits in L2 / MALL); here nothing leaves the workgroup: its four waves stride over the rows of the
+// matvec, the reductions are the single-block form of the same bodies, phases are separated by workgroup barriers,
+// and the scalars live in LDS.  Same bodies, same reduction geometry (one block), same matvec lane map => the same
+// bits as the lock-step run and as solve().  The grid is `count` workgroups; the hardware scheduler keeps as many
+// resident as fit and starts the next problem where one finishes.
+template <bool ALIGNED>
+__global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_pprob* __restrict__ probs, double gd,
+                                                                  double eps10, int64_t last_iter, int64_t n) {
+  __shared__ double lds4[4];
+  __shared__ double sh[4];                    // alpha, res2, flag
+  const ccqp_pprob& q = probs[blockIdx.x];
+  const ccqp_segk sg = bp_segk_of(q);
+  const int64_t wave = threadIdx.x >> 6;
+  const int64_t nwaves = CCQP_BLOCK / 64;
+  const int64_t chunk = CCQP_RED_CHUNK;       // ccqp_red_geometry(n) for n <= CCQP_RED_CHUNK: one block
+  const int64_t ntasks = (n + 3) / 4;         // four rows per wave at a time: loads of four rows in flight
+  double* s = q.slab;
+  // start-up (solvers.py:625-636)
+  gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.x[0], q.b, q.y, q.g[0], n, n, ntasks, wave, nwaves);
+  __syncthreads();
+  {
+    const double r = residual_body(sg, q.x[0], q.g[0], q.c, gd, chunk, 0, lds4);
+    const double gg = dot_body(q.g[0], q.g[0], n, chunk, 0, lds4);
+    if (threadIdx.x == 0) {
+      sh[1] = r;
+      sh[2] = gg;
+      sh[3] = sqrt(r) >= q.tol ? 0.0 : 1.0;   // `if res >= tol:` (a NaN residual skips the loop)
+    }
+  }
+  __syncthreads();
+  int64_t k = 0;
+  bool done = sh[3] != 0.0;
+  if (!done) {
+    gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.g[0], nullptr, q.y, nullptr, n, n, ntasks, wave, nwaves);
+    __syncthreads();
+    const double gAg = dot_body(q.g[0], q.y, n, chunk, 0, lds4);
+    if (threadIdx.x == 0) sh[0] = sh[2] / gAg;
+    __syncthreads();
+    for (;;) {
+      ++k;
+      const int inew = (int)(k % 3), icur = (int)((k - 1) % 3);
+      const double mb = -sh[0];
+      proj_elem_body(sg, 1.0, q.x[icur], mb, q.g[icur], q.x[inew], 0, 1);
+      __syncthreads();
+      gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.x[inew], q.b, q.y, q.g[inew], n, n, ntasks, wave, nwaves);
+      __syncthreads();
+      if (k >= last_iter) break;              // the matvec budget ends before the residual (:643-644)
+      double r, s1, s2;
+      bb_tail_body(sg, q.x[inew], q.x[icur], q.g[inew], q.g[icur], q.c, gd, chunk, 0, lds4, &r, &s1, &s2);
+      if (threadIdx.x == 0) {
+        const double den = s2 + eps10;
+        s[0] = r;
+        s[1] = s1;
+        s[2] = s2;
+        sh[0] = s1 / den;
+        sh[1] = r;
+        sh[3] = sqrt(r) < q.tol ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      if (sh[3] != 0.0) {
+        done = true;
+        break;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    // as the lock-step run leaves them: iterations WITH a tail, the last residual, the converged flag
+    s[BP_ALPHA] = sh[0];
+    s[BP_DONE] = done ? 1.0 : 0.0;
+    s[BP_ITERS] = (double)(done || k == 0 ? k : k - 1);
+    s[BP_RES2] = sh[1];
+  }
+}
+
+extern "C" int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd,
+                                     double eps10, int64_t last_iteration, int flags, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr, "NULL argument");
+  CCQP_REQUIRE(count >= 1 && n >= 1 && n <= CCQP_RED_CHUNK, "one workgroup per problem needs n <= 2048");
+  CCQP_REQUIRE(last_iteration >= 1, "at least one iteration (solvers.py:638-644)");
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & 1)
+    hipLaunchKernelGGL((bsolve_bbpgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
+                       last_iteration, n);
+  else
+    hipLaunchKernelGGL((bsolve_bbpgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
+                       last_iteration, n);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

@@ -119,6 +119,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void pipe_bb_tail_kernel(ccqp_segk sg, 
 
 extern "C" int ccqp_pipe_reset(ccqp_ctx* ctx, double alpha0, void* stream) {
   CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  // The mirror is reset from the HOST side as well: ccqp_pipe_poll may run before the reset kernel does, and must
+  // not see the final state ("converged") of the previous solve.  (That solve has ended with a blocking read, so
+  // none of its kernels is still writing here.)
+  ctx->host_slots[PIPE_MIRROR + 0] = 0.0;
+  ctx->host_slots[PIPE_MIRROR + 1] = 0.0;
+  ctx->host_slots[PIPE_MIRROR + 2] = 0.0;
+  ctx->host_slots[PIPE_MIRROR + 3] = alpha0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   hipLaunchKernelGGL(pipe_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->slots, ctx->host_slots_dev,
                      alpha0);
   CCQP_LAUNCH_CHECK();

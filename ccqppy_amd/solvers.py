@@ -369,13 +369,13 @@ class _APGDCore(CCQPSolverBase):
         """The whole solve as a lock-step batch of one (batch._bapgd_run); None if it does not apply or the matvec
         budget was reached first."""
         from ._record import RecordingEngine
-        from .batch import _bapgd_run
+        from .batch import _bapgd_run, _spec_from_items
         from .operators import DenseOperator
         op, eng = run.op, run.eng
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and hasattr(run.P, "_dev_bb_tail")
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        done, sols, res, mvs = _bapgd_run(eng, [(self, op, run.b, run.x0, run.P)], run.n,
+        done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
                                           self.max_matrix_vector_multiplications, 4)
         if not done[0]:
             return None
@@ -676,15 +676,15 @@ class CCQPSolverMPRGP(CCQPSolverBase):
 
     def _lockstep(self, run):
         from ._record import RecordingEngine
-        from .batch import _bmprgp_run
+        from .batch import _bmprgp_run, _spec_from_items
         from .operators import DenseOperator
         op, eng, P = run.op, run.eng, run.P
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
                 and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names() and run.n > ss._lib.SMALL_SEG_MAX
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        status, sols, res, mvs, execd = _bmprgp_run(eng, [(self, op, run.b, run.x0, P)], run.n,
-                                                    self.max_matrix_vector_multiplications, 4)
+        status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n),
+                                                    run.n, self.max_matrix_vector_multiplications, 4)
         if status[0] != 1.0:
             return None
         eng.mv_executed += int(execd[0])

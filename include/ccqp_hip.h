@@ -302,6 +302,12 @@ int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count
                            double gd, double eps10, int flags, int with_tail, uint32_t* dev_batch, void* stream);
 /* non-blocking: out[0..1] = {problems converged, last iteration every problem has finished (-1: none yet)} */
 int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out);
+/* The WHOLE solve of every problem in ONE launch, one workgroup per problem (n <= 2048: every reduction is one block
+ * wide): for matrices of a few hundred rows, where a lock-step iteration is bound by its launches.  Same descriptors
+ * (partials / counter unused), same slab contents on return, same bits.  `last_iteration` = the iteration at which
+ * the matvec budget ends (max_mv - 1, at least 1; a huge value for "no budget"). */
+int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd, double eps10,
+                          int64_t last_iteration, int flags, void* stream);
 
 /* The same for APGD (solvers.py:220-343), whose iteration is a small state machine (one matvec of y_k, then one
  * matvec per backtracking trial of x_{k+1}).  A ROUND advances every live problem by exactly one matvec: matvec,

@@ -239,6 +239,30 @@ def test_batch_sharded_driver_with_the_pipelined_scheduler():
             assert np.array_equal(r.solution.view(np.uint64), a.solution.cpu().numpy().view(np.uint64))
 
 
+@pytest.mark.parametrize("n,count", [(37, 13), (64, 300), (256, 40), (513, 9), (1000, 12), (2048, 5)])
+def test_one_workgroup_per_problem_equals_lock_step_and_individual_solves(n, count):
+    """BBPGD's single-launch form (whole solve inside one workgroup): forced on and off, against solve(), with warm
+    and trivial starts, mixed tolerances and every matvec budget."""
+    probs = _problems(n, count, 3300 + n)
+    tols = [[1e-8, 1e-5, 1e30][p % 3] for p in range(count)]
+    ref = _reference(probs, tols, 5000)
+    for single in (True, False):
+        got = _batch(probs, tols, 5000, single_launch=single)
+        for a, c in zip(ref, got):
+            _same(a, c)
+    if count > 20:
+        return
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for p in range(0, count, 2):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, ref[p].solution.clone(), P)
+    for cap in (1, 2, 3, 5, longest - 1, longest, longest + 1, np.inf):
+        ref2 = _reference(probs, tols, cap)
+        got = _batch(probs, tols, cap, single_launch=True)
+        for a, c in zip(ref2, got):
+            _same(a, c)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):

@@ -161,3 +161,22 @@ def test_pipelined_bbpgd_randomised(case_id):
     x0 = None if rng.random() < 0.5 else rng.uniform(-0.5, 0.5, size=n)
     a, c = _pair(op, b, P, tol, cap, x0=x0)
     _same(a, c)
+
+
+def test_back_to_back_pipelined_solves_never_see_the_previous_solves_mirror():
+    """ccqp_pipe_poll right after ccqp_pipe_reset used to be able to read the "converged" flag the PREVIOUS solve had
+    left in the pinned mirror (the resetting kernel had not run yet): thousands of short solves in a row, every one
+    must report its own iteration count."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    n = 128
+    ops = [problems.random_problem(n, 500 + p)[:2] for p in range(40)]
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    want = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for op, b in ops:
+            want.append(solvers.CCQPSolverBBPGD(1e-8, 5000).solve(op, b, convex_proj_op=P)
+                        .solution_num_matrix_vector_multiplications)
+        for rep in range(60):
+            for (op, b), mv in zip(ops, want):
+                r = solvers.CCQPSolverBBPGD(1e-8, 5000, pipeline=True).solve(op, b, convex_proj_op=P)
+                assert r.solution_num_matrix_vector_multiplications == mv and r.solution_converged

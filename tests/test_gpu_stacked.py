@@ -1,0 +1,99 @@
+"""GPU: batch.solve_stacked -- B dense problems as stacked tensors A (B, n, n), b (B, n), solved by the lock-step /
+single-launch schedulers with no per-problem host work.  Problem p must get bit for bit the result of
+Solver(tol[p], max_mv).solve(A[p], b[p], x0[p], P_p)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(n, B, seed):
+    import torch
+    from ccqppy_amd import problems
+    A = torch.empty((B, n, n), dtype=torch.float64, device="cuda")
+    b = torch.empty((B, n), dtype=torch.float64, device="cuda")
+    for p in range(B):
+        op, bp, _ = problems.random_problem(n, seed + p)
+        A[p].copy_(op.A)
+        b[p].copy_(bp)
+    return A, b
+
+
+def _check(name, A, b, x0, lower, upper, tol, max_mv, make_P, **kw):
+    import torch
+    from ccqppy_amd import batch, solvers
+    cls = getattr(solvers, "CCQPSolver" + name)
+    B, n = b.shape
+    r = batch.solve_stacked(name, A, b, x0=x0, lower=lower, upper=upper, tol=tol, max_mv=max_mv, **kw)
+    tols = np.broadcast_to(np.asarray(tol, dtype=np.float64), (B,))
+    assert r.solution.shape == (B, n)
+    for p in range(B):
+        with contextlib.redirect_stdout(io.StringIO()):
+            a = cls(float(tols[p]), max_mv).solve(A[p], b[p], x0=None if x0 is None else x0[p],
+                                                  convex_proj_op=make_P(p))
+        assert a.solution_num_matrix_vector_multiplications == r.num_matrix_vector_multiplications[p]
+        assert a.executed_matrix_vector_multiplications == r.executed_matrix_vector_multiplications[p]
+        assert bool(a.solution_converged) == bool(r.converged[p])
+        assert float(a.solution_residual) == float(r.residual[p])
+        assert torch.equal(a.solution, r.solution[p])
+    return r
+
+
+@pytest.mark.parametrize("name", ["BBPGD", "APGD", "MPRGP"])
+def test_stacked_equals_individual_solves_for_every_form_of_bounds(name):
+    import torch
+    from ccqppy_amd import solution_spaces as ss
+    n, B = 200, 7
+    A, b = _stack(n, B, 50)
+    rng = np.random.default_rng(3)
+    lo_n, up_n = -rng.uniform(0.1, 0.5, n), rng.uniform(0.1, 0.5, n)
+    lo_bn = torch.as_tensor(-rng.uniform(0.1, 0.5, (B, n)), device="cuda")
+    up_bn = torch.as_tensor(rng.uniform(0.1, 0.5, (B, n)), device="cuda")
+    tol = 1e-7
+    _check(name, A, b, None, lo_n, up_n, tol, 3000, lambda p: ss.BoxProjOp(n, lo_n, up_n))
+    _check(name, A, b, None, lo_bn, up_bn, tol, 3000,
+           lambda p: ss.BoxProjOp(n, lo_bn[p].cpu().numpy(), up_bn[p].cpu().numpy()))
+    _check(name, A, b, None, lo_n, None, tol, 3000, lambda p: ss.LowerBoundProjOp(n, lo_n))
+    _check(name, A, b, None, None, up_bn, tol, 3000, lambda p: ss.UpperBoundProjOp(n, up_bn[p].cpu().numpy()))
+    _check(name, A, b, None, None, None, tol, 3000, lambda p: ss.IdentityProjOp(n))
+    if name != "MPRGP":                                  # scalar bounds raise in the reference's MPRGP
+        _check(name, A, b, None, -0.25, 0.5, tol, 3000, lambda p: ss.BoxProjOp(n, -0.25, 0.5))
+        _check(name, A, b, None, -1, 2, tol, 3000, lambda p: ss.BoxProjOp(n, -1, 2))
+        _check(name, A, b, None, 0, None, tol, 3000, lambda p: ss.LowerBoundProjOp(n, 0))
+    else:
+        from ccqppy_amd import batch
+        with pytest.raises(TypeError):
+            batch.solve_stacked(name, A, b, lower=-0.25, upper=0.5)
+    # per-problem tolerances, warm starts, budgets (APGD / MPRGP: unfinished problems go through solve())
+    tols = np.array([1e-9, 1e-6, 1e-3, 1e30, 1e-7, 1e-5, 1e-8])
+    x0 = torch.as_tensor(rng.uniform(-0.3, 0.3, (B, n)), device="cuda")
+    first = _check(name, A, b, x0, lo_n, up_n, tols, 3000, lambda p: ss.BoxProjOp(n, lo_n, up_n))
+    for cap in (4, 9, 17, int(first.num_matrix_vector_multiplications.max())):
+        _check(name, A, b, x0, lo_n, up_n, tols, cap, lambda p: ss.BoxProjOp(n, lo_n, up_n))
+
+
+def test_stacked_forms_of_the_inputs():
+    import torch
+    from ccqppy_amd import batch, solution_spaces as ss
+    n, B = 96, 5
+    A, b = _stack(n, B, 9)
+    lo, up = -0.3 * np.ones(n), 0.3 * np.ones(n)
+    # a batch of one; numpy inputs; a non-contiguous stack; both BBPGD execution forms
+    _check("BBPGD", A[:1], b[:1], None, lo, up, 1e-8, 5000, lambda p: ss.BoxProjOp(n, lo, up))
+    r = batch.solve_stacked("BBPGD", A.cpu().numpy(), b.cpu().numpy(), lower=lo, upper=up)
+    big = torch.zeros((B, n + 8, n + 4), dtype=torch.float64, device="cuda")
+    big[:, :n, :n] = A
+    view = big[:, :n, :n]
+    for single in (True, False):
+        r2 = batch.solve_stacked("BBPGD", view, b, lower=lo, upper=up, single_launch=single)
+        assert torch.equal(r.solution, r2.solution)
+    from ccqppy_amd import solvers
+    r3 = batch.solve_stacked(solvers.CCQPSolverBBPGD, A, b, lower=lo, upper=up)
+    assert torch.equal(r.solution, r3.solution) and r3.converged.all()
+    with pytest.raises(TypeError):
+        batch.solve_stacked("SPG", A, b)
+    with pytest.raises(ValueError):
+        batch.solve_stacked("BBPGD", A[0], b)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of MANY SMALL dense BBPGD (--apgd: APGD, --mprgp: MPRGP) solves (Box, tol 1e-8; MPRGP: 1e-6 / 300 matvecs) under every scheduler of ccqppy_amd:
 sequential solve(), sequential with the pipelined iteration, the stream-lane and fused batch schedulers
-(host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device).  One JSON line per size.
+(host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device) and, for BBPGD up to n = 2048, its single-launch form (one workgroup per problem).  One JSON line per size.
    python tools/bench_small_batch.py [--apgd | --mprgp] [n:B ...]"""
 import contextlib
 import io
@@ -44,7 +44,9 @@ def main():
                 ((() if apgd else (("sequential_pipelined", lambda: seq(True)),))) + (
                          ("stream_lanes_8", lambda: solve_batch(mk, probs, lanes=8)),
                          ("fused_32x2", lambda: solve_batch_fused(mk, probs, lanes=32, groups=2)),
-                         ("batch_pipelined", lambda: solve_batch_pipelined(mk, probs))):
+                         ("batch_pipelined", lambda: solve_batch_pipelined(mk, probs, single_launch=False))) + \
+                (() if apgd or n > 2048 else
+                 (("batch_single_launch", lambda: solve_batch_pipelined(mk, probs, single_launch=True)),)):
             fn()
             torch.cuda.synchronize()
             best = 0.0
@@ -58,6 +60,9 @@ def main():
                 res[name] = r
         mvs = [s.solution_num_matrix_vector_multiplications for s in res["batch_pipelined"]]
         same = all(torch.equal(a.solution, c.solution) for a, c in zip(res["fused_32x2"], res["batch_pipelined"]))
+        if "batch_single_launch" in res:
+            same = same and all(torch.equal(a.solution, c.solution)
+                                for a, c in zip(res["fused_32x2"], res["batch_single_launch"]))
         # bytes the matvecs of the batch must read: executed matvecs per problem, 8 n^2 bytes each
         mv_bytes = sum(s.executed_matrix_vector_multiplications * 8.0 * n * n for s in res["batch_pipelined"])
         print(json.dumps({"solver": cls.__name__, "n": n, "problems": B, "problems_per_s": out, "mv_per_problem_mean": float(np.mean(mvs)),
