@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Throughput of batch.solve_stacked: B dense box-QPs of size n as stacked tensors (random SPD matrices from the
+device generator, Box +-0.5, tol 1e-8; MPRGP 1e-6 / 300 matvecs), no per-problem host work.  One JSON line per
+(solver, n): problems/s, matvecs per problem, bytes of matrix the matvecs read per second.
+   python tools/bench_stacked.py [--solvers BBPGD,APGD,MPRGP] [n:B ...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from ccqppy_amd import batch
+    from ccqppy_amd._engine import get_engine
+    args = sys.argv[1:]
+    names = ["BBPGD", "APGD", "MPRGP"]
+    if args and args[0] == "--solvers":
+        names, args = args[1].split(","), args[2:]
+    sizes = [tuple(int(v) for v in a.split(":")) for a in args] or \
+        [(32, 32768), (64, 16384), (128, 8192), (256, 4096), (512, 2048), (1024, 512), (2048, 256)]
+    eng = get_engine(0)
+    eng.bind()
+    for n, B in sizes:
+        A = torch.empty((B, n, n), dtype=torch.float64, device="cuda")
+        xs = torch.empty((B, n), dtype=torch.float64, device="cuda")
+        for p in range(B):                               # problem p = the generator's problem (n, seed 1234 + p)
+            eng.gen_spd_rows(A[p], 0, n, 1234 + p)
+            eng.gen_vec(xs[p], 1234 + p)
+        b = -torch.bmm(A, xs.unsqueeze(2)).squeeze(2)
+        lo, up = -0.5 * np.ones(n), 0.5 * np.ones(n)
+        for name in names:
+            if name == "MPRGP" and n <= 64:
+                continue
+            tol, cap = (1e-6, 300) if name == "MPRGP" else (1e-8, 5000)
+            forms = [None] if name != "BBPGD" else ([False, True] if n <= 2048 else [False])
+            for single in forms:
+                kw = {} if single is None else {"single_launch": single}
+                r = batch.solve_stacked(name, A, b, lower=lo, upper=up, tol=tol, max_mv=cap, **kw)
+                torch.cuda.synchronize()
+                best = 0.0
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    r = batch.solve_stacked(name, A, b, lower=lo, upper=up, tol=tol, max_mv=cap, **kw)
+                    torch.cuda.synchronize()
+                    best = max(best, B / (time.perf_counter() - t0))
+                ex = r.executed_matrix_vector_multiplications
+                print(json.dumps({"solver": name, "form": {None: "lock-step", False: "lock-step", True: "single launch"}[single],
+                                  "n": n, "problems": B, "problems_per_s": round(best, 1),
+                                  "converged": int(r.converged.sum()), "executed_mv_mean": float(ex.mean()),
+                                  "matrix_GBps": round(float(ex.sum()) * 8.0 * n * n / B * best / 1e9, 1)}), flush=True)
+        del A, b, xs
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
