@@ -232,11 +232,9 @@ extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
 #define AP_RES2 BP_RES2   // 51
 
 // d = x0 - ones (solvers.py:262) into the spare x buffer
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_d_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
-  const ccqp_papgd& q = probs[blockIdx.y];
+__device__ __forceinline__ void bapgd_init_d_body(const ccqp_papgd& q, int64_t n, int bx, int nbx) {
   const double* __restrict__ x = q.X[0];
   double* __restrict__ d = q.X[1];
-  const int bx = blockIdx.x, nbx = gridDim.x;
   BODY_LOOP(i, n) {
     const double t1 = 1.0 * x[i];
     const double t2 = -1.0 * 1.0;
@@ -244,12 +242,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_d_kernel(const ccqp_pap
   }
 }
 
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_d_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
+  bapgd_init_d_body(probs[blockIdx.y], n, blockIdx.x, gridDim.x);
+}
+
 template <int U, bool ALIGNED, bool NT>
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd* __restrict__ probs, int init,
-                                                                int64_t n) {
-  const ccqp_papgd& q = probs[blockIdx.y];
-  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+__device__ __forceinline__ void bapgd_gemv_body(const ccqp_papgd& q, int init, int64_t n, int64_t wave,
+                                                int64_t nwaves) {
   if (init) {
     gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
     return;
@@ -262,16 +261,20 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd
     gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, BP_TASKS(U, n), wave, nwaves);
 }
 
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd* __restrict__ probs, int init,
+                                                                int64_t n) {
+  bapgd_gemv_body<U, ALIGNED, NT>(probs[blockIdx.y], init, n, (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6),
+                                  (int64_t)gridDim.x * (CCQP_BLOCK / 64));
+}
+
 // L = |A d| / |d|, t = 1 / L (solvers.py:264-268) and the initial state
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
-                                                                  int64_t chunk, int nblk) {
-  __shared__ double lds4[4];
-  __shared__ int is_last;
-  const ccqp_papgd& q = probs[blockIdx.y];
+__device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n, int64_t chunk, int nblk, int bx,
+                                                  double* lds4, int* is_last_p) {
   double v[2];
-  v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, blockIdx.x, lds4);
-  v[1] = dot_body(q.X[1], q.X[1], n, chunk, blockIdx.x, lds4);
-  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+  v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, bx, lds4);
+  v[1] = dot_body(q.X[1], q.X[1], n, chunk, bx, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {
     double* s = q.slab;
     const double L = sqrt(v[0]) / sqrt(v[1]);
@@ -291,30 +294,31 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
   }
 }
 
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_papgd* __restrict__ probs, double gd,
-                                                                  int64_t chunk, int nblk,
-                                                                  unsigned* __restrict__ batch,
-                                                                  double* __restrict__ host, unsigned count,
-                                                                  double seq) {
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
+                                                                  int64_t chunk, int nblk) {
   __shared__ double lds4[4];
   __shared__ int is_last;
-  const ccqp_papgd& q = probs[blockIdx.y];
+  bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last);
+}
+
+// LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call, converged counter); otherwise the problem
+// of a single-launch solve (bx = 0, nblk = 1)
+template <bool LOCKSTEP>
+__device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, double gd, int64_t chunk, int nblk,
+                                                  unsigned* batch, double* host, unsigned count, double seq,
+                                                  double* lds4, int* is_last_p) {
   double* s = q.slab;
-  if (s[AP_DONE] != 0.0) {                 // converged earlier: only the roll-call
-    if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
-    return;
-  }
   double v[7];
   if (s[AP_PHASE] == 0.0) {
     // the matvec of y_k has run; next: the first trial step.  (All blocks meet so that the state changes only
     // after every block has read it.)
-    if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+    if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, is_last_p)) return;
     if (threadIdx.x == 0) {
       s[AP_PHASE] = 1.0;
       s[AP_ACT] = 1.0;
       s[AP_FIRST] = 1.0;
       s[AP_MV] = s[AP_MV] + 1.0;
-      bp_report(batch, host, count, seq);
+      if (LOCKSTEP) bp_report(batch, host, count, seq);
     }
     return;
   }
@@ -329,7 +333,6 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
   const double* __restrict__ gk = q.gk;
   const double* __restrict__ bv = q.b;
   {
-    const int bx = blockIdx.x;
     CHUNK_RANGE(n)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
@@ -350,9 +353,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
     v[3] = ccqp_block_sum(a3, lds4);
     v[4] = ccqp_block_sum(a4, lds4);
     v[5] = ccqp_block_sum(a5, lds4);
-    v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, blockIdx.x, lds4);
+    v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, bx, lds4);
   }
-  if (!bp_meet(q.partials, q.counter, nblk, 7, v, lds4, &is_last)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, 7, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {
     double r1, r2;
     if (first) {
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
       s[AP_RES2] = v[6];
       if (res < q.tol) {
         s[AP_DONE] = 1.0;
-        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         L = L * 0.9;
         s[AP_L] = L;
@@ -408,23 +411,41 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
       s[AP_ACT] = 1.0;
       s[AP_FIRST] = 0.0;
     }
-    bp_report(batch, host, count, seq);
+    if (LOCKSTEP) bp_report(batch, host, count, seq);
   }
 }
 
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papgd* __restrict__ probs) {
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_papgd* __restrict__ probs, double gd,
+                                                                  int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch,
+                                                                  double* __restrict__ host, unsigned count,
+                                                                  double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
+  if (q.slab[AP_DONE] != 0.0) {            // converged earlier: only the roll-call
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last);
+}
+
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx) {
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0) return;
   const int it = (int)s[AP_IT];
   if (s[AP_ACT] == 1.0) {
     const double mt = -s[AP_T];
-    proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], blockIdx.x, gridDim.x);
+    proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], bx, nbx);
   } else {
     const double beta = s[AP_BETA];
     const double a = 1.0 + beta, b = -beta;
-    axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, blockIdx.x, gridDim.x);
+    axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
   }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papgd* __restrict__ probs) {
+  bapgd_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // Start-up of all solves: d = x0 - 1, A d, L, t.  Expects X[0] = Y[0] = x0, slabs and counters zero.
@@ -551,6 +572,51 @@ extern "C" int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs,
   else
     hipLaunchKernelGGL((bsolve_bbpgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
                        last_iteration, n);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// The same for APGD: the three bodies of a lock-step round (matvec by phase, decide, apply) run one after the other
+// inside the problem's workgroup, separated by barriers; the state stays in the problem's slab, which only this
+// workgroup touches.  `mv_limit`: no round starts once the matvec count has reached it (max_mv - 1: the budget's own
+// exit paths are the host-driven loop's).
+template <bool ALIGNED>
+__global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_kernel(const ccqp_papgd* __restrict__ probs, double gd,
+                                                                 double mv_limit, int64_t n) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_papgd& q = probs[blockIdx.x];
+  const int64_t wave = threadIdx.x >> 6;
+  const int64_t nwaves = CCQP_BLOCK / 64;
+  const int64_t chunk = CCQP_RED_CHUNK;       // ccqp_red_geometry(n) for n <= CCQP_RED_CHUNK: one block
+  double* s = q.slab;
+  bapgd_init_d_body(q, n, 0, 1);
+  __syncthreads();
+  bapgd_gemv_body<4, ALIGNED, false>(q, 1, n, wave, nwaves);
+  __syncthreads();
+  bapgd_init_L_body(q, n, chunk, 1, 0, lds4, &is_last);
+  __syncthreads();
+  for (;;) {
+    if (s[AP_MV] >= mv_limit) break;
+    bapgd_gemv_body<4, ALIGNED, false>(q, 0, n, wave, nwaves);
+    __syncthreads();
+    bapgd_decide_body<false>(q, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last);
+    __syncthreads();
+    if (s[AP_DONE] != 0.0) break;
+    bapgd_apply_body(q, 0, 1);
+    __syncthreads();
+  }
+}
+
+extern "C" int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, double gd,
+                                    double mv_limit, int flags, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr, "NULL argument");
+  CCQP_REQUIRE(count >= 1 && n >= 1 && n <= CCQP_RED_CHUNK, "one workgroup per problem needs n <= 2048");
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & 1)
+    hipLaunchKernelGGL((bsolve_apgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n);
+  else
+    hipLaunchKernelGGL((bsolve_apgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -337,6 +337,11 @@ int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
                          uint32_t* dev_batch, void* stream);
 int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
                          int flags, uint32_t* dev_batch, void* stream);
+/* n <= 2048: the whole solve of every problem in ONE launch, one workgroup per problem (as ccqp_bsolve_bbpgd_f64).
+ * No round starts once a problem's matvec count has reached `mv_limit` (max_mv - 1; a huge value for "no budget"):
+ * such a problem is left unconverged for the host-driven loop. */
+int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, double gd, double mv_limit,
+                         int flags, void* stream);
 
 /* And for MPRGP (solvers.py:1026-1200, README's "MPRGP-BB", BASELINE config 5), elementwise sets with array
  * bounds.  A ROUND = at most one matvec per live problem (A x_k + b | A p | A x_{k+1} + b | A dx, by the problem's

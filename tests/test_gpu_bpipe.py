@@ -263,6 +263,28 @@ def test_one_workgroup_per_problem_equals_lock_step_and_individual_solves(n, cou
             _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(37, 13), (64, 200), (256, 30), (513, 9), (1000, 8), (2048, 4)])
+def test_apgd_one_workgroup_per_problem_equals_lock_step_and_individual_solves(n, count):
+    probs = _problems(n, count, 4300 + n)
+    tols = [[1e-8, 1e-5, 1e30][p % 3] for p in range(count)]
+    ref = _reference(probs, tols, 5000, "APGD")
+    for single in (True, False):
+        got = _batch(probs, tols, 5000, "APGD", single_launch=single)
+        for a, c in zip(ref, got):
+            _same(a, c)
+    if count > 20:
+        return
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for p in range(0, count, 2):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, ref[p].solution.clone(), P)
+    for cap in (3, 4, 5, 9, longest - 1, longest, longest + 1, np.inf):
+        ref2 = _reference(probs, tols, cap, "APGD")
+        got = _batch(probs, tols, cap, "APGD", single_launch=True)
+        for a, c in zip(ref2, got):
+            _same(a, c)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):
