@@ -331,6 +331,7 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
 # ---------------------------------------------------------------------------------------------
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
+_BSOLVE_MAX_N_MPRGP = 128 # MPRGP: likewise
 _BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
 
 
@@ -650,7 +651,7 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
         eng.mv_executed += int(mvs[p])
 
 
-def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0):
+def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     """Lock-step MPRGP over `spec`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
     matvecs); status 1 = converged, anything else = not finished here (rows meaningless)."""
     from . import _lib
@@ -669,7 +670,6 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0):
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
-    check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
     # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where a problem
     # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
     last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
@@ -677,7 +677,15 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0):
     def launch(r):
         check(lib.ccqp_bmprgp_round_f64(ctx, dp, B, n, r, _GD, float(_EPS10), flags, batch, st))
 
-    _bpipe_poll_loop(eng, B, launch, last, ahead)
+    if single_launch is None:
+        single_launch = n <= _BSOLVE_MAX_N_MPRGP
+    if single_launch and n <= 2048:
+        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
+        check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, B, n, _GD, float(_EPS10),
+                                        float(max_mv - 1) if np.isfinite(max_mv) else 1e300, flags & 1, st))
+    else:
+        check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
+        _bpipe_poll_loop(eng, B, launch, last, ahead)
     h = slabs[:, 32:56].cpu().numpy()                   # blocking: the queue has drained
     status, its = h[:, 17], h[:, 8].astype(np.int64)
     mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
@@ -695,7 +703,8 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0):
 def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     import contextlib
     import io
-    status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune)
+    status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune,
+                                                single_launch)
     host = None
     for p, it in enumerate(items):
         s = it[0]
@@ -811,7 +820,7 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             execd = mv
             todo = np.flatnonzero(~done)
         else:
-            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune)
+            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             todo = np.flatnonzero(status != 1.0)
     mv, execd, res = np.array(mv, dtype=np.int64), np.array(execd, dtype=np.int64), np.array(res, dtype=np.float64)
     if B == 1:

@@ -65,10 +65,8 @@ __device__ __forceinline__ double mp_free(const ccqp_segk& sg, double xi, double
 
 // ---------------------------------------------------------------------------------------------------- start-up
 // x_k = P(x0), x_{k+1} = copy (solvers.py:1063-1064)
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_x_kernel(const ccqp_pmprgp* __restrict__ probs) {
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+__device__ __forceinline__ void bmprgp_init_x_body(const ccqp_pmprgp& q, int bx, int nbx) {
   const ccqp_segk sg = bp_segk_of(q);
-  const int bx = blockIdx.x, nbx = gridDim.x;
   const double* __restrict__ x0 = q.X[1];     // staged by the caller
   BODY_LOOP(i, sg.dim) {
     const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
@@ -79,12 +77,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_x_kernel(const ccqp_pm
   }
 }
 
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_x_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  bmprgp_init_x_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
 template <int U, bool ALIGNED, bool NT>
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmprgp* __restrict__ probs, int init,
-                                                                 int64_t n) {
-  const ccqp_pmprgp& q = probs[blockIdx.y];
-  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+__device__ __forceinline__ void bmprgp_gemv_body(const ccqp_pmprgp& q, int init, int64_t n, int64_t wave,
+                                                 int64_t nwaves) {
   if (init == 1) {                            // g_k = A x_k + b
     gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[0], q.b, q.ytmp, q.G[0], n, n, BP_TASKS(U, n), wave, nwaves);
     return;
@@ -114,16 +113,20 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmpr
   }
 }
 
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmprgp* __restrict__ probs, int init,
+                                                                 int64_t n) {
+  bmprgp_gemv_body<U, ALIGNED, NT>(probs[blockIdx.y], init, n, (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6),
+                                   (int64_t)gridDim.x * (CCQP_BLOCK / 64));
+}
+
 // residual of the start (exit test :1070-1073)
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
-                                                                     int64_t chunk, int nblk,
-                                                                     unsigned* __restrict__ batch) {
-  __shared__ double lds4[4];
-  __shared__ int is_last;
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+template <bool LOCKSTEP>
+__device__ __forceinline__ void bmprgp_init_res_body(const ccqp_pmprgp& q, double gd, int64_t chunk, int nblk, int bx,
+                                                     unsigned* batch, double* lds4, int* is_last_p) {
   double v[1];
-  v[0] = residual_body(bp_segk_of(q), q.X[0], q.G[0], q.c, gd, chunk, blockIdx.x, lds4);
-  if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+  v[0] = residual_body(bp_segk_of(q), q.X[0], q.G[0], q.c, gd, chunk, bx, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {
     double* s = q.slab;
     s[MP_S2] = v[0];
@@ -137,22 +140,27 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_
       s[MP_DONE] = 0.0;
     } else {
       s[MP_DONE] = 1.0;
-      __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-// alpha_bb = g.g / g.Ag (:1077), then g_{k+1} = copy(g_k) and p = phi(x_k, g_k) (:1066, :1081)
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_alpha_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n,
-                                                                       int64_t chunk, int nblk) {
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
+                                                                     int64_t chunk, int nblk,
+                                                                     unsigned* __restrict__ batch) {
   __shared__ double lds4[4];
   __shared__ int is_last;
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+  bmprgp_init_res_body<true>(probs[blockIdx.y], gd, chunk, nblk, blockIdx.x, batch, lds4, &is_last);
+}
+
+// alpha_bb = g.g / g.Ag (:1077), then g_{k+1} = copy(g_k) and p = phi(x_k, g_k) (:1066, :1081)
+__device__ __forceinline__ void bmprgp_init_alpha_body(const ccqp_pmprgp& q, int64_t n, int64_t chunk, int nblk, int bx,
+                                                       double* lds4, int* is_last_p) {
   if (q.slab[MP_DONE] != 0.0) return;
   double v[2];
-  v[0] = dot_body(q.G[0], q.G[0], n, chunk, blockIdx.x, lds4);
-  v[1] = dot_body(q.G[0], q.Adx, n, chunk, blockIdx.x, lds4);
-  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+  v[0] = dot_body(q.G[0], q.G[0], n, chunk, bx, lds4);
+  v[1] = dot_body(q.G[0], q.Adx, n, chunk, bx, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {
     double* s = q.slab;
     s[MP_S0] = v[0];
@@ -163,11 +171,16 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_alpha_kernel(const ccq
   }
 }
 
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pmprgp* __restrict__ probs) {
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_alpha_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n,
+                                                                       int64_t chunk, int nblk) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  bmprgp_init_alpha_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last);
+}
+
+__device__ __forceinline__ void bmprgp_init_p_body(const ccqp_pmprgp& q, int bx, int nbx) {
   if (q.slab[MP_DONE] != 0.0) return;
   const ccqp_segk sg = bp_segk_of(q);
-  const int bx = blockIdx.x, nbx = gridDim.x;
   BODY_LOOP(i, sg.dim) {
     const double gi = q.G[0][i];
     q.G[1][i] = gi;
@@ -175,8 +188,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pm
   }
 }
 
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  bmprgp_init_p_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------- the stages
 // tail of an outer iteration (solvers.py:1184-1192): BB step length, exit test, swap of the iterates
+template <bool LOCKSTEP>
 __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double s1, double r2, double eps10,
                                         unsigned* batch) {
   double* s = q.slab;
@@ -186,7 +204,7 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double 
   s[MP_RES2] = r2;
   if (sqrt(r2) < q.tol) {
     s[MP_DONE] = 1.0;
-    __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     s[MP_IT] = s[MP_IT] + 1.0;
     s[MP_STATE] = (double)ST_M1;
@@ -194,18 +212,15 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double 
 }
 
 // stage = 1, 2, 3; grid (nblk, problems)
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmprgp* __restrict__ probs, int stage,
-                                                                  double gd, double eps10, int64_t chunk, int nblk,
-                                                                  unsigned* __restrict__ batch,
-                                                                  double* __restrict__ host, unsigned count,
-                                                                  double seq) {
-  __shared__ double lds4[4];
-  __shared__ int is_last;
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+// LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call in stage 3, converged counter); otherwise
+// the problem of a single-launch solve (bx = 0, nblk = 1)
+template <bool LOCKSTEP>
+__device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stage, int bx, double gd, double eps10,
+                                                  int64_t chunk, int nblk, unsigned* batch, double* host,
+                                                  unsigned count, double seq, double* lds4, int* is_last_p) {
   double* s = q.slab;
-  const bool rollcall = stage == 3;           // every problem reports once per round, in the last stage
   if (s[MP_DONE] != 0.0) {
-    if (rollcall && blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    if (LOCKSTEP && stage == 3 && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
   const ccqp_segk sg = bp_segk_of(q);
@@ -216,13 +231,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
   double* xk1 = q.X[(it + 1) & 1];
   double* gk = q.G[it & 1];
   double* gk1 = q.G[(it + 1) & 1];
-  const int bx = blockIdx.x;
   double v[MP_STEPS];
   if (stage == 1) {
     switch (st) {
       case ST_M1: {                           // :1090-1094
         v[0] = split_body(sg, xk, gk, q.txk, q.psi, q.w, chunk, bx, lds4);
-        if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+        if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
         if (threadIdx.x == 0) {
           s[MP_DIST2] = v[0];
           s[MP_ACT] = (double)ACT_NONE;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
       case ST_AP: {                           // :1100-1106
         v[0] = dot_body(q.psi, q.p, n, chunk, bx, lds4);
         v[1] = dot_body(q.p, q.Ap, n, chunk, bx, lds4);
-        if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+        if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
         if (threadIdx.x == 0) {
           const double acg = v[0] / v[1];
           s[MP_S0] = v[0];
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
       }
       case ST_FEAS_WAIT:
       case ST_G1: {
-        if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+        if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, is_last_p)) return;
         if (threadIdx.x == 0) {
           if (st == ST_G1) {
             s[MP_ACT] = (double)ACT_AFTER_G1;
@@ -272,13 +286,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
         v[0] = dot_body(q.dx, q.dx, n, chunk, bx, lds4);
         v[1] = dot_body(q.dx, q.Adx, n, chunk, bx, lds4);
         v[2] = residual_body(sg, xk1, gk1, q.c, gd, chunk, bx, lds4);
-        if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, &is_last)) return;
+        if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, is_last_p)) return;
         if (threadIdx.x == 0) {
           s[MP_S0] = v[0];
           s[MP_S1] = v[1];
           s[MP_ACT] = (double)ACT_NONE;
           s[MP_EXEC] = s[MP_EXEC] + 1.0;
-          mp_tail(q, v[0], v[1], v[2], eps10, batch);
+          mp_tail<LOCKSTEP>(q, v[0], v[1], v[2], eps10, batch);
         }
         return;
       }
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
   if (stage == 2) {
     if (st == ST_M1_N) {                      // :1095
       v[0] = normal_dot_body(sg, q.txk, gk, q.nv, s[MP_DIST2], chunk, bx, lds4);
-      if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+      if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
       if (threadIdx.x == 0) {
         s[MP_NG] = v[0];
         s[MP_STATE] = (double)ST_M1_P;
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
     } else if (st == ST_FEAS_NOW) {           // :1112-1118, MP_STEPS candidates per pass
       const double a0 = s[MP_AF];
       for (int k = 0; k < MP_STEPS; ++k) v[k] = feasible_body(sg, xk, q.p, a0, k, chunk, bx, lds4);
-      if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, &is_last)) return;
+      if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, is_last_p)) return;
       if (threadIdx.x == 0) {
         double af = a0;
         int found = 0, at = 0;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
         } else if (found || tried + (double)MP_STEPS >= (double)MP_MAX_CANDIDATES) {
           // alpha_f has underflowed without a feasible candidate: the reference never exits, the host loop raises
           s[MP_DONE] = 2.0;
-          __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
           s[MP_TRIED] = tried + (double)MP_STEPS;
           s[MP_STATE] = (double)ST_FEAS_WAIT;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
   // stage 3
   if (st == ST_M1_P) {                        // :1096-1099
     proportion_body(q.w, gk, q.nv, q.psi, s[MP_NG], n, chunk, bx, lds4, &v[0], &v[1]);
-    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
     if (threadIdx.x == 0) {
       s[MP_S0] = v[0];
       s[MP_S1] = v[1];
@@ -347,9 +361,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
         // feasible, so beta.beta = 0 and this needs psi.psi <= 0 or NaN: it does not occur on finite data.  Such a
         // problem leaves the lock-step run and is solved by the host-driven loop.
         s[MP_DONE] = 3.0;
-        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      bp_report(batch, host, count, seq);
+      if (LOCKSTEP) bp_report(batch, host, count, seq);
     }
     return;
   }
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
     }
     v[0] = ccqp_block_sum(a0, lds4);
     v[1] = ccqp_block_sum(a1, lds4);
-    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
     if (threadIdx.x == 0) {
       const double den = v[1] + eps10;
       s[MP_S0] = v[0];
@@ -376,16 +390,26 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
       s[MP_AHALF] = v[0] / den;
       s[MP_ACT] = (double)ACT_HALF;
       s[MP_STATE] = (double)ST_G1;
-      bp_report(batch, host, count, seq);
+      if (LOCKSTEP) bp_report(batch, host, count, seq);
     }
     return;
   }
   // nothing to reduce in this stage: the roll-call only.  (One designated thread: no state is written here.)
-  if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+  if (LOCKSTEP && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
 }
 
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmprgp* __restrict__ probs) {
-  const ccqp_pmprgp& q = probs[blockIdx.y];
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmprgp* __restrict__ probs, int stage,
+                                                                  double gd, double eps10, int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch,
+                                                                  double* __restrict__ host, unsigned count,
+                                                                  double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  bmprgp_stage_body<true>(probs[blockIdx.y], stage, blockIdx.x, gd, eps10, chunk, nblk, batch, host, count, seq, lds4,
+                          &is_last);
+}
+
+__device__ __forceinline__ void bmprgp_apply_body(const ccqp_pmprgp& q, int bx, int nbx) {
   const double* s = q.slab;
   if (s[MP_DONE] != 0.0) return;
   const int act = (int)s[MP_ACT];
@@ -396,7 +420,6 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmp
   double* __restrict__ xk1 = q.X[(it + 1) & 1];
   const double* __restrict__ gk = q.G[it & 1];
   double* __restrict__ gk1 = q.G[(it + 1) & 1];
-  const int bx = blockIdx.x, nbx = gridDim.x;
   if (act == ACT_CGFULL) {             // :1125-1135
     const double macg = -s[MP_ACG];
     const double pAp = s[MP_PAP];
@@ -431,6 +454,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmp
       q.dx[i] = mp_lin(1.0, x1, -1.0, xk[i]);
     }
   }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmprgp* __restrict__ probs) {
+  bmprgp_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------- entry points
@@ -471,6 +498,61 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
     hipLaunchKernelGGL(bmprgp_stage_kernel, rgrid, blk, 0, s, dev_probs, stage, gd, eps10, chunk, nblk, dev_batch,
                        ctx->host_slots_dev, (unsigned)count, (double)round);
   hipLaunchKernelGGL(bmprgp_apply_kernel, dim3(bp_vec_grid(n), count), blk, 0, s, dev_probs);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// n <= CCQP_RED_CHUNK: the whole solve of every problem in ONE launch, one workgroup per problem -- the bodies of a
+// lock-step round run back to back inside the workgroup, separated by barriers (ccqp_bpipe.hip explains the form).
+// No round starts once the matvec count has reached `mv_limit` (max_mv - 1).
+template <bool ALIGNED>
+__global__ __launch_bounds__(CCQP_BLOCK) void bsolve_mprgp_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
+                                                                  double eps10, double mv_limit, int64_t n) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.x];
+  const int64_t wave = threadIdx.x >> 6;
+  const int64_t nwaves = CCQP_BLOCK / 64;
+  const int64_t chunk = CCQP_RED_CHUNK;       // ccqp_red_geometry(n) for n <= CCQP_RED_CHUNK: one block
+  double* s = q.slab;
+  bmprgp_init_x_body(q, 0, 1);
+  __syncthreads();
+  bmprgp_gemv_body<4, ALIGNED, false>(q, 1, n, wave, nwaves);
+  __syncthreads();
+  bmprgp_init_res_body<false>(q, gd, chunk, 1, 0, nullptr, lds4, &is_last);
+  __syncthreads();
+  if (s[MP_DONE] != 0.0) return;
+  bmprgp_gemv_body<4, ALIGNED, false>(q, 2, n, wave, nwaves);
+  __syncthreads();
+  bmprgp_init_alpha_body(q, n, chunk, 1, 0, lds4, &is_last);
+  __syncthreads();
+  bmprgp_init_p_body(q, 0, 1);
+  __syncthreads();
+  for (;;) {
+    if (s[MP_MV] >= mv_limit) break;
+    bmprgp_gemv_body<4, ALIGNED, false>(q, 0, n, wave, nwaves);
+    __syncthreads();
+    for (int stage = 1; stage <= 3; ++stage) {
+      bmprgp_stage_body<false>(q, stage, 0, gd, eps10, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last);
+      __syncthreads();
+    }
+    if (s[MP_DONE] != 0.0) break;
+    bmprgp_apply_body(q, 0, 1);
+    __syncthreads();
+  }
+}
+
+extern "C" int ccqp_bsolve_mprgp_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd,
+                                     double eps10, double mv_limit, int flags, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr, "NULL argument");
+  CCQP_REQUIRE(count >= 1 && n >= 1 && n <= CCQP_RED_CHUNK, "one workgroup per problem needs n <= 2048");
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & 1)
+    hipLaunchKernelGGL((bsolve_mprgp_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10, mv_limit,
+                       n);
+  else
+    hipLaunchKernelGGL((bsolve_mprgp_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
+                       mv_limit, n);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -379,6 +379,9 @@ int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,
                           double eps10, int flags, uint32_t* dev_batch, void* stream);
+/* n <= 2048: the whole solve of every problem in ONE launch, one workgroup per problem (as ccqp_bsolve_apgd_f64). */
+int ccqp_bsolve_mprgp_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, double eps10,
+                          double mv_limit, int flags, void* stream);
 
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional

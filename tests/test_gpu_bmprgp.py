@@ -124,6 +124,30 @@ def test_under_a_matvec_budget():
             _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(70, 150), (100, 15), (257, 12), (1000, 6), (2048, 4)])
+def test_one_workgroup_per_problem_equals_lock_step_and_individual_solves(n, count):
+    """MPRGP's single-launch form, forced on and off, against solve(): tight boxes (multi-pass feasible-step
+    searches), warm starts, mixed tolerances, budgets."""
+    probs = _problems(n, count, 5300 + n, 0.1)
+    tols = [[1e-7, 1e-5, 1e30][p % 3] for p in range(count)]
+    ref = _reference(probs, tols, 3000)
+    for single in (True, False):
+        got = _batch(probs, tols, 3000, single_launch=single)
+        for a, c in zip(ref, got):
+            _same(a, c)
+    if count > 20:
+        return
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for p in range(0, count, 2):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, ref[p].solution.clone(), P)
+    for cap in (2, 3, 4, 5, 9, longest - 1, longest, longest + 1):
+        ref2 = _reference(probs, tols, cap)
+        got = _batch(probs, tols, cap, single_launch=True)
+        for a, c in zip(ref2, got):
+            _same(a, c)
+
+
 def test_nan_data_take_the_reference_exits():
     """A NaN residual at the start fails `res >= tol` and skips the loop (BBPGD, MPRGP); APGD's line search never
     accepts and runs into the budget.  Same exits in lock-step, next to healthy problems of the same batch."""

@@ -37,7 +37,7 @@ def main():
             if name == "MPRGP" and n <= 64:
                 continue
             tol, cap = (1e-6, 300) if name == "MPRGP" else (1e-8, 5000)
-            forms = [None] if name == "MPRGP" else ([False, True] if n <= 2048 else [False])
+            forms = [False, True] if n <= 2048 else [False]
             for single in forms:
                 kw = {} if single is None else {"single_launch": single}
                 r = batch.solve_stacked(name, A, b, lower=lo, upper=up, tol=tol, max_mv=cap, **kw)
