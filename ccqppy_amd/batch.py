@@ -326,531 +326,5 @@ def solve_batch_fused(make_solver, problems, lanes=16, groups=2, device=None, qu
     return solvers
 
 
-# ---------------------------------------------------------------------------------------------
-# Pipelined batch: equal-size dense BBPGD solves in lock-step with every scalar on the device.
-# ---------------------------------------------------------------------------------------------
-_BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
-_BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
-_BSOLVE_MAX_N_MPRGP = 128 # MPRGP: likewise
-_BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
-
-
-def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0, single_launch=None,
-                          stats=None):
-    """Many dense problems (grouped by size n; one lock-step run per size), solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
-    (:1002-1224) in lock-step: three launches per iteration (APGD: per matvec; MPRGP: five) for the whole batch, step
-    lengths, line search, branch decisions and exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_* /
-    ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
-    this one is not.
-
-    make_solver : () -> CCQPSolverBBPGD, CCQPSolverAPGD or CCQPSolverMPRGP (plain: no fallback / anti-relaxation /
-                  matvec reuse), all of one class with the same max_matrix_vector_multiplications
-    problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
-                  elementwise (Identity / Lower / Upper / Box) or None
-    Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
-    and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
-    the wall-clock of the whole batch.  BBPGD on small matrices (n <= 512 by default; `single_launch` forces it on,
-    up to n = 2048, or off) runs as ONE launch, one workgroup per problem, instead of lock-step rounds -- the same
-    bits again.  (APGD / MPRGP problems that would run into the matvec budget are handed to
-    plain solve(), whose exit paths at the budget have quirks of their own.)  `stats`, if given, receives the
-    wall-clock split {staging_s: argument checks and per-problem staging on the host, run_s: tables, launches, wait,
-    result objects}."""
-    from . import _lib
-    from . import solution_spaces as ss
-    from .operators import DenseOperator, as_operator
-    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD, CCQPSolverMPRGP
-    problems = list(problems)
-    solvers = [make_solver() for _ in problems]
-    if not problems:
-        return solvers
-    t0 = time.time()
-    eng = get_engine(device)
-    eng.bind()
-    kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverMPRGP) or getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD / CCQPSolverMPRGP only, "
-                        "got %s" % kind.__name__)
-    max_mv = solvers[0].max_matrix_vector_multiplications
-    by_size = {}                                        # n -> items, in order of first appearance
-    for s, (A, b, x0, P) in zip(solvers, problems):
-        if type(s) is not kind or getattr(s, "reuse_matvec", False):
-            raise TypeError("solve_batch_pipelined: one solver class for the whole batch")
-        if s.max_matrix_vector_multiplications != max_mv:
-            raise ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
-        op = as_operator(A)
-        if not isinstance(op, DenseOperator) or op.rows != op.n:
-            raise TypeError("solve_batch_pipelined needs square dense operators")
-        n = op.n
-        if b.shape[0] != n:
-            raise ValueError("solve_batch_pipelined: b does not match A")
-        if op.A.device != eng.device:
-            raise ValueError("solve_batch_pipelined: operator on another device")
-        P = P if P is not None else ss.IdentityProjOp(n)
-        if not hasattr(P, "_dev_bb_tail"):
-            raise TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
-        if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
-            # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
-            # sequential-sum kernels of the literal path)
-            raise TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
-                            % _lib.SMALL_SEG_MAX)
-        bd = eng.to_device(b).reshape(-1)
-        by_size.setdefault(n, []).append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
-                                          isinstance(b, torch.Tensor), (A, b, x0, P)))
-    if not quiet:
-        for s in solvers:
-            print("solving " + s._label)
-    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
-    t1 = time.time()
-    with np.errstate(all="ignore"):
-        for n, items in by_size.items():                # one lock-step run per problem size
-            for lo in range(0, len(items), _BPIPE_MAX):
-                group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
-    dt = time.time() - t0
-    if stats is not None:                               # host-side staging of the problem list vs the runs proper
-        stats.update(staging_s=t1 - t0, run_s=time.time() - t1)
-    for s in solvers:
-        s._solution_time = dt
-    return solvers
-
-
-def _bpipe_poll_loop(eng, B, launch, last_round, ahead):
-    """Queue rounds 1, 2, ... (`launch(k)`) at most `ahead` beyond the last one the device reported, until every
-    problem has converged or `last_round` has been queued.  Returns the number of rounds queued."""
-    import ctypes
-    lib, ctx = eng.lib, eng.ctx
-    state = (ctypes.c_double * 2)()
-    k = 0
-    while k < last_round:
-        k += 1
-        launch(k)
-        if k >= last_round:                             # (the last round of a budget may report nothing)
-            break
-        lib.ccqp_bpipe_poll(ctx, state)
-        spins = 0
-        while state[0] < B and k - state[1] >= ahead:
-            lib.ccqp_bpipe_poll(ctx, state)
-            spins += 1
-            if spins > 2000000:                         # mirror silent for ~1 s: wait for the queue itself
-                torch.cuda.current_stream(eng.device).synchronize()
-                lib.ccqp_bpipe_poll(ctx, state)
-                if state[1] != k:
-                    raise RuntimeError("solve_batch_pipelined: the device never reported round %d" % k)
-                spins = 0
-        if state[0] >= B:
-            break
-    return k
-
-
-class _Spec:
-    """What a lock-step run needs to know about its B problems of size n, as arrays: matrix / right-hand-side
-    addresses, leading dimensions, set descriptors (struct ccqp_seg records), tolerances, and the start vectors
-    (None: zeros; a (B, n) tensor; or a list of optional n-vectors)."""
-    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep")
-
-    def __len__(self):
-        return self.B
-
-    def stage_x0(self, plane):
-        x0 = self.x0
-        if x0 is None:
-            plane.zero_()                               # x0 = 0 (solvers.py:125-126)
-        elif isinstance(x0, torch.Tensor):
-            plane.copy_(x0)
-        else:
-            plane.zero_()
-            for p, v in enumerate(x0):
-                if v is not None:
-                    plane[p].copy_(v)
-
-
-def _spec_from_items(eng, items, n):
-    """items: tuples (solver, DenseOperator, b on the device, x0 on the device or None, set, ...)"""
-    from . import _lib
-    sp = _Spec()
-    sp.B, sp.n = len(items), n
-    sp.A = np.array([it[1].A.data_ptr() for it in items], dtype=np.uint64)
-    sp.lda = np.array([it[1].A.stride(0) for it in items], dtype=np.int64)
-    sp.b = np.array([it[2].data_ptr() for it in items], dtype=np.uint64)
-    sp.seg = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=np.dtype(_lib.Seg))
-    sp.tol = np.array([it[0].desired_residual_tol for it in items], dtype=np.float64)
-    sp.x0 = None if all(it[3] is None for it in items) else [it[3] for it in items]
-    sp.keep = None
-    return sp
-
-
-def _bpipe_table(eng, spec, n, struct, nvec, partial_rows):
-    """Workspace + descriptor table shared by the lock-step drivers: `nvec` (B, n) vector planes, zeroed slabs,
-    partial-sum areas, counters; returns (vec, slabs, words, tab, base, plane, rows)."""
-    from . import _lib
-    from .solvers import _GD
-    dev = eng.device
-    B = len(spec)
-    nblk = max(int(eng.lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
-    vec = torch.empty((nvec, B, n), dtype=torch.float64, device=dev)
-    slabs = torch.zeros((B, 64), dtype=torch.float64, device=dev)
-    partials = torch.empty((B, partial_rows * nblk), dtype=torch.float64, device=dev)
-    words = torch.zeros(B + 2, dtype=torch.int32, device=dev)           # per-problem counters + 2 batch words
-    dt = np.dtype(struct)
-    tab = np.zeros(B, dtype=dt)
-    idx = np.arange(B, dtype=np.uint64)
-    tab["A"], tab["lda"], tab["b"], tab["seg"] = spec.A, spec.lda, spec.b, spec.seg
-    tab["slab"] = np.uint64(slabs.data_ptr()) + idx * np.uint64(8 * 64)
-    tab["partials"] = np.uint64(partials.data_ptr()) + idx * np.uint64(8 * partial_rows * nblk)
-    tab["counter"] = np.uint64(words.data_ptr()) + idx * np.uint64(4)
-    tab["c"] = 1.0 / (3 * n * _GD)                                      # solvers.py:138
-    tab["tol"] = spec.tol
-    planes = [np.uint64(vec.data_ptr()) + np.uint64(j) * np.uint64(8 * n * B) + idx * np.uint64(8 * n)
-              for j in range(nvec)]
-    keep = (partials,)
-    return vec, slabs, words, tab, planes, keep
-
-
-def _bpipe_flags(tab, n, tune):
-    # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
-    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
-
-
-def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
-    """Lock-step (or single-launch) BBPGD over `spec`; returns (converged mask, index of the final iteration,
-    (B, n) device tensor of final iterates, residuals)."""
-    from . import _lib
-    from .solvers import _EPS10, _GD
-    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(spec)
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 7, 3)    # x ring, g ring, y
-    spec.stage_x0(vec[0])
-    for j in range(3):
-        tab["x"][:, j] = planes[j]
-        tab["g"][:, j] = planes[3 + j]
-    tab["y"] = planes[6]
-    flags = _bpipe_flags(tab, n, tune)
-    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
-    check = _lib.check
-    # iteration k with 1 + k >= max_mv is the last one and has no tail: the reference breaks before the
-    # residual (:643-644)
-    last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
-
-    def launch(k):
-        check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
-
-    if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N
-    if single_launch and n <= 2048:
-        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        k = int(last) if np.isfinite(last) else 1 << 62
-        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 1, st))
-        capped = np.isfinite(last)
-    else:
-        check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
-        k = _bpipe_poll_loop(eng, B, launch, last, ahead)
-        capped = 1 + k >= max_mv
-    h = slabs[:, 48:52].cpu().numpy()                   # blocking: the queue has drained
-    done, iters, res2 = h[:, 1] != 0.0, h[:, 2].astype(np.int64), h[:, 3]
-    if not capped and not done.all():
-        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    final = np.where(done, iters, k)
-    if B == 1:
-        sols = vec[int(final[0] % 3)]
-    else:
-        sel = torch.from_numpy(final % 3).to(dev)
-        sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
-    del keep
-    return done, final, sols, np.sqrt(res2)
-
-
-def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
-    done, final, sols, res = _bpipe_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch)
-    host = None
-    for p, it in enumerate(items):
-        s = it[0]
-        mv = 1 + int(final[p])
-        if it[5]:
-            s._solution = sols[p]
-        else:
-            if host is None:
-                host = sols.cpu().numpy()
-            s._solution = host[p]
-        s._solution_converged = mv < max_mv
-        s._solution_residual = res[p]
-        s._solution_num_matrix_vector_mults = mv
-        # start-up: A x0 and -- unless the start already satisfies the tolerance -- A g0 (executed, not counted)
-        s._executed_matrix_vector_mults = 1 if (done[p] and final[p] == 0) else 2 + int(final[p])
-        eng.mv_executed += s._executed_matrix_vector_mults
-
-
-def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
-    """Lock-step APGD over `spec`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
-    matvec counts) -- rows of problems that did not converge inside the budget are meaningless."""
-    from . import _lib
-    from .solvers import _GD
-    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(spec)
-    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 8, 7)
-    spec.stage_x0(vec[0])
-    vec[2].copy_(vec[0])                                                # yk = x0 (solvers.py:257-258)
-    tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
-    tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
-    tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"] = planes[4], planes[5], planes[6], planes[7]
-    flags = _bpipe_flags(tab, n, tune)
-    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
-    check = _lib.check
-    # round r performs matvec number 1 + r; the rounds stop one short of the budget, where the reference's exit
-    # path takes over (:277-278, :288-289): such problems go to the host-driven loop
-    last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
-
-    def launch(r):
-        check(lib.ccqp_bapgd_round_f64(ctx, dp, B, n, r, _GD, flags, batch, st))
-
-    if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N_APGD
-    if single_launch and n <= 2048:
-        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(max_mv - 1) if np.isfinite(max_mv) else 1e300,
-                                       flags & 1, st))
-    else:
-        check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
-        _bpipe_poll_loop(eng, B, launch, last, ahead)
-    h = slabs[:, 32:52].cpu().numpy()                   # blocking: the queue has drained
-    done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
-    if not np.isfinite(max_mv) and not done.all():
-        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    if B == 1:
-        sols = vec[int((its[0] + 1) % 2)]
-    else:
-        sel = torch.from_numpy((its + 1) % 2).to(dev)
-        sols = vec[0:2][sel, torch.arange(B, device=dev)]
-    del keep
-    return done, sols, np.sqrt(res2), mvs
-
-
-def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
-    import contextlib
-    import io
-    done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch)
-    host = None
-    for p, it in enumerate(items):
-        s = it[0]
-        if not done[p]:                                  # budget reached: the reference's own exit path
-            A, b, x0, P = it[6]
-            with contextlib.redirect_stdout(io.StringIO()):
-                s.solve(A, b, x0=x0, convex_proj_op=P)
-            continue
-        if it[5]:
-            s._solution = sols[p]
-        else:
-            if host is None:
-                host = sols.cpu().numpy()
-            s._solution = host[p]
-        s._solution_converged = int(mvs[p]) < max_mv
-        s._solution_residual = res[p]
-        s._solution_num_matrix_vector_mults = int(mvs[p])
-        s._executed_matrix_vector_mults = int(mvs[p])
-        eng.mv_executed += int(mvs[p])
-
-
-def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
-    """Lock-step MPRGP over `spec`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
-    matvecs); status 1 = converged, anything else = not finished here (rows meaningless)."""
-    from . import _lib
-    from .solvers import _EPS10, _GD
-    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
-    B = len(spec)
-    names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PMprgp, len(names),
-                                                         int(lib.ccqp_bmprgp_partial_rows()))
-    spec.stage_x0(vec[1])                                               # x0 staged in X[1]
-    tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
-    tab["G"][:, 0], tab["G"][:, 1] = planes[2], planes[3]
-    for j, name in enumerate(names[4:]):
-        tab[name] = planes[4 + j]
-    flags = _bpipe_flags(tab, n, tune)
-    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
-    check = _lib.check
-    # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where a problem
-    # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
-    last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
-
-    def launch(r):
-        check(lib.ccqp_bmprgp_round_f64(ctx, dp, B, n, r, _GD, float(_EPS10), flags, batch, st))
-
-    if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N_MPRGP
-    if single_launch and n <= 2048:
-        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, B, n, _GD, float(_EPS10),
-                                        float(max_mv - 1) if np.isfinite(max_mv) else 1e300, flags & 1, st))
-    else:
-        check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
-        _bpipe_poll_loop(eng, B, launch, last, ahead)
-    h = slabs[:, 32:56].cpu().numpy()                   # blocking: the queue has drained
-    status, its = h[:, 17], h[:, 8].astype(np.int64)
-    mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
-    if not np.isfinite(max_mv) and not (status != 0.0).all():
-        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    if B == 1:
-        sols = vec[int((its[0] + 1) % 2)]
-    else:
-        sel = torch.from_numpy((its + 1) % 2).to(dev)
-        sols = vec[0:2][sel, torch.arange(B, device=dev)]
-    del keep
-    return status, sols, np.sqrt(res2), mvs, execd
-
-
-def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
-    import contextlib
-    import io
-    status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune,
-                                                single_launch)
-    host = None
-    for p, it in enumerate(items):
-        s = it[0]
-        if status[p] != 1.0:                             # budget reached (or the search that cannot terminate)
-            A, b, x0, P = it[6]
-            with contextlib.redirect_stdout(io.StringIO()):
-                s.solve(A, b, x0=x0, convex_proj_op=P)
-            continue
-        if it[5]:
-            s._solution = sols[p]
-        else:
-            if host is None:
-                host = sols.cpu().numpy()
-            s._solution = host[p]
-        s._solution_converged = int(mvs[p]) < max_mv
-        s._solution_residual = res[p]
-        s._solution_num_matrix_vector_mults = int(mvs[p])
-        s._executed_matrix_vector_mults = int(execd[p])
-        eng.mv_executed += int(execd[p])
-
-
-# ---------------------------------------------------------------------------------------------
-# Stacked problems: the lock-step runs without any per-problem Python.
-# ---------------------------------------------------------------------------------------------
-class StackedResult:
-    """Results of solve_stacked, one row / entry per problem: `solution` (B, n) device tensor; numpy arrays
-    `residual`, `converged`, `num_matrix_vector_multiplications` (the reference's count), `executed_matrix_vector_
-    multiplications`; `solution_time` the wall-clock of the whole call."""
-    __slots__ = ("solution", "residual", "converged", "num_matrix_vector_multiplications",
-                 "executed_matrix_vector_multiplications", "solution_time")
-
-
-def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_mv=np.inf, device=None, ahead=4,
-                  tune=0, single_launch=None):
-    """B dense problems of one size handed over as STACKED device tensors -- A (B, n, n), b (B, n), optional x0
-    (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
-    (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
-
-    solver        : "BBPGD", "APGD", "MPRGP" or the solver class
-    lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
-                    Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
-                    (scalar ones raise in the reference's normal_vector).
-    tol           : one tolerance or one per problem
-    Problem p gets bit for bit the result of `Solver(tol[p], max_mv).solve(A[p], b[p], x0[p], P_p)` with P_p the
-    corresponding *ProjOp (tests/test_gpu_stacked.py).  Returns a StackedResult."""
-    from . import _lib
-    from . import solution_spaces as ss
-    from . import solvers as sv
-    t0 = time.time()
-    name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
-                                                   sv.CCQPSolverMPRGP: "MPRGP"}.get(solver)
-    if name not in ("BBPGD", "APGD", "MPRGP"):
-        raise TypeError("solve_stacked runs BBPGD, APGD or MPRGP, got %r" % (solver,))
-    eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
-    eng.bind()
-    A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
-    if A.dim() != 3 or A.shape[1] != A.shape[2]:
-        raise ValueError("solve_stacked: A must be (B, n, n)")
-    if A.stride(2) != 1 or A.stride(1) < A.shape[2]:
-        A = A.contiguous()
-    B, n = int(A.shape[0]), int(A.shape[1])
-    b = eng.to_device(b).reshape(B, n)
-    if x0 is not None:
-        x0 = eng.to_device(x0).reshape(B, n)
-
-    def is_scalar(v):
-        return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
-
-    kind = {(False, False): _lib.OP_IDENTITY, (True, False): _lib.OP_LOWER, (False, True): _lib.OP_UPPER,
-            (True, True): _lib.OP_BOX}[(lower is not None, upper is not None)]
-    if name == "MPRGP" and (is_scalar(lower) or is_scalar(upper) or n <= _lib.SMALL_SEG_MAX):
-        raise TypeError("solve_stacked runs MPRGP on sets with array bounds and n > %d" % _lib.SMALL_SEG_MAX)
-    seg = np.zeros(B, dtype=np.dtype(_lib.Seg))
-    seg["kind"], seg["dim"] = kind, n
-    keep = []
-    for field, sfield, flag, v in (("lb", "lb_s", _lib.SEG_LB_INT, lower), ("ub", "ub_s", _lib.SEG_UB_INT, upper)):
-        if v is None:
-            continue
-        if is_scalar(v):
-            seg[sfield] = float(v)
-            if isinstance(v, (int, np.integer)):
-                seg["flags"] |= flag                    # integer bounds multiply integer masks (solution_spaces.py)
-            continue
-        if not isinstance(v, torch.Tensor) and np.asarray(v).dtype.kind in "iu":
-            seg["flags"] |= flag
-        t = eng.to_device(v)
-        keep.append(t)
-        if t.numel() == n:
-            seg[field] = t.data_ptr()
-        elif tuple(t.shape) == (B, n):
-            seg[field] = np.uint64(t.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(8 * n)
-        else:
-            raise ValueError("solve_stacked: bounds must be scalars, (n,) or (B, n)")
-    sp = _Spec()
-    sp.B, sp.n = B, n
-    idx = np.arange(B, dtype=np.uint64)
-    sp.A = np.uint64(A.data_ptr()) + idx * np.uint64(8 * A.stride(0))
-    sp.lda = np.full(B, A.stride(1), dtype=np.int64)
-    sp.b = np.uint64(b.data_ptr()) + idx * np.uint64(8 * n)
-    sp.seg = seg
-    sp.tol = np.broadcast_to(np.asarray(tol, dtype=np.float64), (B,)).copy()
-    sp.x0 = x0
-    sp.keep = keep
-    out = StackedResult()
-    with np.errstate(all="ignore"):
-        if name == "BBPGD":
-            done, final, sols, res = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
-            mv = 1 + final
-            execd = np.where(done & (final == 0), 1, 2 + final)
-            todo = np.zeros(0, dtype=np.int64)
-        elif name == "APGD":
-            done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch)
-            execd = mv
-            todo = np.flatnonzero(~done)
-        else:
-            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune, single_launch)
-            todo = np.flatnonzero(status != 1.0)
-    mv, execd, res = np.array(mv, dtype=np.int64), np.array(execd, dtype=np.int64), np.array(res, dtype=np.float64)
-    if B == 1:
-        sols = sols.reshape(1, n).clone()
-    eng.mv_executed += int(np.delete(execd, todo).sum())
-    if len(todo):
-        # matvec budget reached (APGD / MPRGP): these problems take the reference's own exit paths in solve()
-        import contextlib
-        import io
-        cls = getattr(sv, "CCQPSolver" + name)
-
-        def bound(v, p):
-            if v is None or is_scalar(v):
-                return v
-            t = v if isinstance(v, torch.Tensor) else np.asarray(v)
-            t = t if t.shape[0] == n and t.ndim == 1 else t[p]
-            return t.cpu().numpy() if isinstance(t, torch.Tensor) else t
-        for p in todo:
-            lo, up = bound(lower, p), bound(upper, p)
-            P = {_lib.OP_IDENTITY: lambda: ss.IdentityProjOp(n), _lib.OP_LOWER: lambda: ss.LowerBoundProjOp(n, lo),
-                 _lib.OP_UPPER: lambda: ss.UpperBoundProjOp(n, up), _lib.OP_BOX: lambda: ss.BoxProjOp(n, lo, up)}[kind]()
-            with contextlib.redirect_stdout(io.StringIO()):
-                s = cls(float(sp.tol[p]), max_mv).solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
-            sols[p].copy_(s.solution)
-            res[p], mv[p] = s.solution_residual, s.solution_num_matrix_vector_multiplications
-            execd[p] = s.executed_matrix_vector_multiplications
-    out.solution = sols
-    out.residual = res
-    out.num_matrix_vector_multiplications = mv
-    out.executed_matrix_vector_multiplications = execd
-    out.converged = mv < max_mv
-    out.solution_time = time.time() - t0
-    return out
+# the lock-step schedulers (device-resident scalars and branch decisions) live in lockstep.py
+from .lockstep import StackedResult, solve_batch_pipelined, solve_stacked  # noqa: E402,F401

@@ -369,7 +369,7 @@ class _APGDCore(CCQPSolverBase):
         """The whole solve as a lock-step batch of one (batch._bapgd_run); None if it does not apply or the matvec
         budget was reached first."""
         from ._record import RecordingEngine
-        from .batch import _bapgd_run, _spec_from_items
+        from .lockstep import _bapgd_run, _spec_from_items
         from .operators import DenseOperator
         op, eng = run.op, run.eng
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and hasattr(run.P, "_dev_bb_tail")
@@ -676,7 +676,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
 
     def _lockstep(self, run):
         from ._record import RecordingEngine
-        from .batch import _bmprgp_run, _spec_from_items
+        from .lockstep import _bmprgp_run, _spec_from_items
         from .operators import DenseOperator
         op, eng, P = run.op, run.eng, run.P
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
