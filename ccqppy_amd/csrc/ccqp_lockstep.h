@@ -10,6 +10,12 @@
 #define BP_GG 3                            // g0.g0 between the two start-up reductions
 #define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
 
+// the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
+// tests/test_lockstep_host_cpu.py pins the same numbers)
+static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 176 && sizeof(ccqp_papgd) == 184 &&
+                  sizeof(ccqp_pmprgp) == 224,
+              "descriptor layout changed: update ccqppy_amd/_lib.py and the tests");
+
 #ifdef __HIPCC__
 // Block sums v[0..nred) of this block -> sums over the problem's nblk blocks, in the LAST block to arrive (the
 // pattern of ccqp_reduce_finish with a per-problem area and counter).  Returns true in that block only, with the
