@@ -20,6 +20,16 @@ from ._engine import get_engine
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
 _BSOLVE_MAX_N_MPRGP = 128 # MPRGP: likewise
+
+
+def _device_budget(n):
+    """Matvecs a single-launch kernel may spend on one problem.  A kernel must END whatever the data (a diverging or
+    NaN-poisoned solve never meets its tolerance, and the reference then loops forever -- on the host, where it can be
+    interrupted): about two seconds of one workgroup's time, estimated from the chain of an iteration (~15 us) or the
+    matrix bytes one CU streams (~20 GB/s).  A problem that needs more goes back to the host-driven loop."""
+    return int(min(20000, max(256, 2.0 / max(15e-6, 8.0 * n * n / 20e9))))
+
+
 _BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
 
 
@@ -200,7 +210,7 @@ def _bpipe_flags(tab, n, tune):
 
 def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     """Lock-step (or single-launch) BBPGD over `spec`; returns (converged mask, index of the final iteration,
-    (B, n) device tensor of final iterates, residuals)."""
+    (B, n) device tensor of final iterates, residuals, indices of problems the single-launch kernel gave up on)."""
     from . import _lib
     from .solvers import _EPS10, _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
@@ -224,11 +234,12 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
 
     if single_launch is None:
         single_launch = n <= _BSOLVE_MAX_N
-    if single_launch and n <= 2048:
+    single_launch = bool(single_launch) and n <= 2048
+    if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        k = int(last) if np.isfinite(last) else 1 << 62
+        k = int(min(last, _device_budget(n)))
         check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 1, st))
-        capped = np.isfinite(last)
+        capped = True                                   # (at the caller's budget or at the device's: see `todo`)
     else:
         check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
         k = _bpipe_poll_loop(eng, B, launch, last, ahead)
@@ -238,20 +249,31 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     if not capped and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
     final = np.where(done, iters, k)
+    # stopped by the DEVICE's budget, not the caller's: not a result -- these go to the host-driven loop
+    todo = np.flatnonzero(~done) if k < last else np.zeros(0, dtype=np.int64)
     if B == 1:
         sols = vec[int(final[0] % 3)]
     else:
         sel = torch.from_numpy(final % 3).to(dev)
         sols = vec[0:3][sel, torch.arange(B, device=dev)]   # (B, n) gather of every problem's final iterate
     del keep
-    return done, final, sols, np.sqrt(res2)
+    return done, final, sols, np.sqrt(res2), todo
 
 
 def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
-    done, final, sols, res = _bpipe_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch)
+    import contextlib
+    import io
+    done, final, sols, res, todo = _bpipe_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune,
+                                              single_launch)
     host = None
+    todo = set(todo.tolist())
     for p, it in enumerate(items):
         s = it[0]
+        if p in todo:                                    # beyond the single-launch kernel's own budget
+            A, b, x0, P = it[6]
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            continue
         mv = 1 + int(final[p])
         if it[5]:
             s._solution = sols[p]
@@ -294,16 +316,16 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
 
     if single_launch is None:
         single_launch = n <= _BSOLVE_MAX_N_APGD
-    if single_launch and n <= 2048:
+    single_launch = bool(single_launch) and n <= 2048
+    if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(max_mv - 1) if np.isfinite(max_mv) else 1e300,
-                                       flags & 1, st))
+        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
     else:
         check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
         _bpipe_poll_loop(eng, B, launch, last, ahead)
     h = slabs[:, 32:52].cpu().numpy()                   # blocking: the queue has drained
     done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
-    if not np.isfinite(max_mv) and not done.all():
+    if not single_launch and not np.isfinite(max_mv) and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
     if B == 1:
         sols = vec[int((its[0] + 1) % 2)]
@@ -367,17 +389,18 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
 
     if single_launch is None:
         single_launch = n <= _BSOLVE_MAX_N_MPRGP
-    if single_launch and n <= 2048:
+    single_launch = bool(single_launch) and n <= 2048
+    if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
         check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, B, n, _GD, float(_EPS10),
-                                        float(max_mv - 1) if np.isfinite(max_mv) else 1e300, flags & 1, st))
+                                        float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
     else:
         check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
         _bpipe_poll_loop(eng, B, launch, last, ahead)
     h = slabs[:, 32:56].cpu().numpy()                   # blocking: the queue has drained
     status, its = h[:, 17], h[:, 8].astype(np.int64)
     mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
-    if not np.isfinite(max_mv) and not (status != 0.0).all():
+    if not single_launch and not np.isfinite(max_mv) and not (status != 0.0).all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
     if B == 1:
         sols = vec[int((its[0] + 1) % 2)]
@@ -499,10 +522,9 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     out = StackedResult()
     with np.errstate(all="ignore"):
         if name == "BBPGD":
-            done, final, sols, res = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
+            done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             mv = 1 + final
             execd = np.where(done & (final == 0), 1, 2 + final)
-            todo = np.zeros(0, dtype=np.int64)
         elif name == "APGD":
             done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             execd = mv
@@ -515,7 +537,7 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
         sols = sols.reshape(1, n).clone()
     eng.mv_executed += int(np.delete(execd, todo).sum())
     if len(todo):
-        # matvec budget reached (APGD / MPRGP): these problems take the reference's own exit paths in solve()
+        # matvec budget reached (APGD / MPRGP), or the single-launch kernel's own budget: the host-driven loop
         import contextlib
         import io
         cls = getattr(sv, "CCQPSolver" + name)

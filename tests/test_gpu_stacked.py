@@ -97,3 +97,29 @@ def test_stacked_forms_of_the_inputs():
         batch.solve_stacked("SPG", A, b)
     with pytest.raises(ValueError):
         batch.solve_stacked("BBPGD", A[0], b)
+
+
+@pytest.mark.parametrize("name", ["BBPGD", "APGD", "MPRGP"])
+def test_single_launch_kernels_end_within_their_own_budget(name, monkeypatch):
+    """A single-launch kernel never loops without bound, whatever the data: it stops at a device-side matvec budget
+    and the problems it did not finish go to the host-driven loop -- same results.  (Budget forced tiny here; with the
+    real one a NaN-poisoned or diverging problem ends the kernel after ~2 s instead of hanging the GPU.)"""
+    import torch
+    from ccqppy_amd import batch, lockstep, solution_spaces as ss
+    n, B = 100, 6
+    A, b = _stack(n, B, 321)
+    lo, up = -0.2 * np.ones(n), 0.3 * np.ones(n)
+    for budget in (3, 6, 10):
+        monkeypatch.setattr(lockstep, "_device_budget", lambda n_, v=budget: v)
+        for cap in (np.inf, 5000, 8):
+            if name == "APGD" and cap == 8:
+                continue
+            _check(name, A, b, None, lo, up, 1e-7, cap, lambda p: ss.BoxProjOp(n, lo, up), single_launch=True)
+    monkeypatch.undo()
+    # data that never converge: an indefinite matrix makes BBPGD / APGD iterates blow up to inf / NaN
+    bad = A.clone()
+    bad[2] = -bad[2]
+    r = batch.solve_stacked(name, bad, b, lower=None if name != "MPRGP" else -1e300 * np.ones(n), upper=None, tol=1e-9,
+                            max_mv=400, single_launch=True)
+    assert not r.converged[2] or not np.isfinite(r.residual[2]) or r.residual[2] < 1e-9
+    assert r.converged[[0, 1, 3, 4, 5]].all()
