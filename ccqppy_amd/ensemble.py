@@ -8,7 +8,10 @@ same constructor, same `run()`, same four result tensors of shape
     instead of `scipy.stats.wishart.rvs` + an unseeded `np.random.rand` (:59-63, O(n^3));
   * `process_results()` returns / prints tables (mean and the 95 % band computed with the reference's
     own formula :121-127) instead of opening matplotlib windows; `to_json()` stores everything;
-  * with `lanes > 1` the trials of one (solver, operator) cell run concurrently (batch.solve_batch).
+  * with `lanes > 1` the trials of one (solver, operator) cell run concurrently: in lock-step with every scalar on
+    the device where that applies (batch.solve_batch_pipelined: BBPGD / APGD / MPRGP, elementwise sets; the
+    per-trial time is then the cell's wall-clock / trials), else on `lanes` streams (batch.solve_batch).  Results
+    per trial are bitwise those of sequential solves either way.
 """
 import contextlib
 import copy
@@ -18,19 +21,20 @@ import json
 import numpy as np
 
 from . import problems as _problems
-from .batch import solve_batch
+from .batch import solve_batch, solve_batch_pipelined
 
 
 class BenchmarkRandomCCQP:
     """Benchmark each solver using an ensemble of randomly generated CCQPs."""
 
     def __init__(self, num_random_trials, solvers_to_benchmark, convex_proj_ops_to_benchmark, lanes=1,
-                 device=None):
+                 device=None, lockstep=True):
         self.num_trials = num_random_trials
         self.solvers_to_benchmark = solvers_to_benchmark
         self.convex_proj_ops_to_benchmark = convex_proj_ops_to_benchmark
         self.lanes = lanes
         self.device = device
+        self.lockstep = lockstep
         self.problem_sizes = np.zeros(len(convex_proj_ops_to_benchmark[0]), dtype=int)
         for i, proj_op in enumerate(self.convex_proj_ops_to_benchmark[0]):
             self.problem_sizes[i] = proj_op.embedded_dimension
@@ -61,7 +65,17 @@ class BenchmarkRandomCCQP:
                         cache[(n, trial_id)] = self.generate_random_convex_quadratic_func(n, trial_id)
                 for solver_id, solver in enumerate(self.solvers_to_benchmark):
                     batch = [(cache[(n, t)][0], cache[(n, t)][1], None, proj_op) for t in range(self.num_trials)]
-                    if self.lanes > 1:
+                    results = None
+                    if self.lanes > 1 and self.lockstep:
+                        try:                             # (its argument checks precede any GPU work)
+                            results = solve_batch_pipelined(lambda s=solver: copy.copy(s), batch, device=self.device)
+                            for r in results:
+                                r._solution_time = r.solution_time / max(len(results), 1)
+                        except (TypeError, ValueError):
+                            results = None
+                    if results is not None:
+                        pass
+                    elif self.lanes > 1:
                         results = solve_batch(lambda s=solver: copy.copy(s), batch, lanes=self.lanes,
                                               device=self.device)
                     else:

@@ -39,6 +39,12 @@ def test_ensemble_grid_matches_oracle(lanes):
             [ss.SphereProjOp(d) for d in sizes],
             [ss.DisjointProjOp(*[ss.SphereProjOp(3)] * (d // 3)) for d in sizes]]
     bench = BenchmarkRandomCCQP(trials, slv, fams, lanes=lanes).run()
+    if lanes > 1:
+        # the lock-step scheduler (taken where it applies) and the stream-lane scheduler agree bit for bit
+        other = BenchmarkRandomCCQP(trials, slv, fams, lanes=lanes, lockstep=False).run()
+        assert np.array_equal(bench._problem_num_matrix_vector_mults, other._problem_num_matrix_vector_mults)
+        assert np.array_equal(bench._problem_residual.view(np.uint64), other._problem_residual.view(np.uint64))
+        assert np.array_equal(bench._problem_converged, other._problem_converged)
     shape = (len(slv), len(fams), len(sizes), trials)
     assert bench._problem_num_matrix_vector_mults.shape == shape
     assert bench._problem_time.dtype == np.float32 and bench._problem_converged.dtype == int
