@@ -285,6 +285,20 @@ def test_apgd_one_workgroup_per_problem_equals_lock_step_and_individual_solves(n
             _same(a, c)
 
 
+@pytest.mark.parametrize("solver", ["BBPGD", "APGD"])
+def test_degenerate_sizes(solver):
+    """n = 1, 2, 3, 5 (single rows, odd leading dimensions), both execution forms."""
+    probs = []
+    for i, n in enumerate((1, 2, 3, 5, 1, 2)):
+        probs += _problems(n, 1, 800 + i)
+    tols = [1e-9] * len(probs)
+    ref = _reference(probs, tols, 5000, solver)
+    for single in (True, False):
+        got = _batch(probs, tols, 5000, solver, single_launch=single)
+        for a, c in zip(ref, got):
+            _same(a, c)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):
