@@ -61,7 +61,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_res_kernel(const ccqp_p
                                                                     int64_t chunk, int nblk,
                                                                     unsigned* __restrict__ batch,
                                                                     double* __restrict__ host, unsigned count,
-                                                                    double seq) {
+                                                                    double seq, int const_step) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_res_kernel(const ccqp_p
     q.slab[BP_GG] = v[1];
     q.slab[BP_RES2] = v[0];
     q.slab[BP_ITERS] = 0.0;
-    q.slab[BP_ALPHA] = 0.0;
+    if (!const_step) q.slab[BP_ALPHA] = 0.0;  // (PGD: the caller has put the constant step there)
     if (sqrt(v[0]) >= q.tol) {               // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
       q.slab[BP_DONE] = 0.0;
     } else {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
                                                                 int icur, double gd, double eps10, int64_t chunk,
                                                                 int nblk, unsigned* __restrict__ batch,
                                                                 double* __restrict__ host, unsigned count,
-                                                                double seq) {
+                                                                double seq, int const_step) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
     q.slab[1] = v[1];
     q.slab[2] = v[2];
     q.slab[BP_RES2] = v[0];
-    q.slab[BP_ALPHA] = v[1] / den;
+    if (!const_step) q.slab[BP_ALPHA] = v[1] / den;
     q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
     if (res < q.tol) {
       q.slab[BP_DONE] = 1.0;
@@ -154,10 +154,13 @@ extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   ccqp_lockstep_begin(ctx, dev_batch, s);
   // (DONE is read by the matvec: the caller zeroes the slabs before this call)
   bp_gemv(dev_probs, count, n, 0, 0, flags, s);
+  const int const_step = (flags & BP_FLAG_CONST_STEP) != 0;
   hipLaunchKernelGGL(bpipe_init_res_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
-                     dev_batch, ctx->host_slots_dev, (unsigned)count, 0.0);
-  bp_gemv(dev_probs, count, n, 0, 1, flags, s);
-  hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
+                     dev_batch, ctx->host_slots_dev, (unsigned)count, 0.0, const_step);
+  if (!const_step) {                          // PGD (solvers.py:94-170) has no A.g0 / alpha0
+    bp_gemv(dev_probs, count, n, 0, 1, flags, s);
+    hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
+  }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -178,7 +181,8 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
     int nblk;
     ccqp_red_geometry(n, &chunk, &nblk);
     hipLaunchKernelGGL(bpipe_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd, eps10,
-                       chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration);
+                       chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
+                       (flags & BP_FLAG_CONST_STEP) != 0);
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -493,7 +497,8 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
 // resident as fit and starts the next problem where one finishes.
 template <bool ALIGNED>
 __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_pprob* __restrict__ probs, double gd,
-                                                                  double eps10, int64_t last_iter, int64_t n) {
+                                                                  double eps10, int64_t last_iter, int64_t n,
+                                                                  int const_step) {
   __shared__ double lds4[4];
   __shared__ double sh[4];                    // alpha, res2, flag
   const ccqp_pprob& q = probs[blockIdx.x];
@@ -519,10 +524,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
   int64_t k = 0;
   bool done = sh[3] != 0.0;
   if (!done) {
-    gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.g[0], nullptr, q.y, nullptr, n, n, ntasks, wave, nwaves);
-    __syncthreads();
-    const double gAg = dot_body(q.g[0], q.y, n, chunk, 0, lds4);
-    if (threadIdx.x == 0) sh[0] = sh[2] / gAg;
+    if (const_step) {                         // PGD: the caller has put the constant step into the slab
+      if (threadIdx.x == 0) sh[0] = s[BP_ALPHA];
+    } else {
+      gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.g[0], nullptr, q.y, nullptr, n, n, ntasks, wave, nwaves);
+      __syncthreads();
+      const double gAg = dot_body(q.g[0], q.y, n, chunk, 0, lds4);
+      if (threadIdx.x == 0) sh[0] = sh[2] / gAg;
+    }
     __syncthreads();
     for (;;) {
       ++k;
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
         s[0] = r;
         s[1] = s1;
         s[2] = s2;
-        sh[0] = s1 / den;
+        if (!const_step) sh[0] = s1 / den;
         sh[1] = r;
         sh[3] = sqrt(r) < q.tol ? 1.0 : 0.0;
       }
@@ -568,10 +577,10 @@ extern "C" int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs,
   hipStream_t s = (hipStream_t)stream;
   if (flags & 1)
     hipLaunchKernelGGL((bsolve_bbpgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
-                       last_iteration, n);
+                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0);
   else
     hipLaunchKernelGGL((bsolve_bbpgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
-                       last_iteration, n);
+                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

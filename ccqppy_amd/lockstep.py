@@ -41,8 +41,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
     this one is not.
 
-    make_solver : () -> CCQPSolverBBPGD, CCQPSolverAPGD or CCQPSolverMPRGP (plain: no fallback / anti-relaxation /
-                  matvec reuse), all of one class with the same max_matrix_vector_multiplications
+    make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverAPGD or CCQPSolverMPRGP (plain: no fallback /
+                  anti-relaxation / matvec reuse), all of one class with the same max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
@@ -56,7 +56,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
-    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD, CCQPSolverMPRGP
+    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD, CCQPSolverMPRGP, CCQPSolverPGD
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -65,9 +65,10 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverMPRGP) or getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs plain CCQPSolverBBPGD / CCQPSolverAPGD / CCQPSolverMPRGP only, "
-                        "got %s" % kind.__name__)
+    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverMPRGP, CCQPSolverPGD) or \
+            getattr(solvers[0], "reuse_matvec", False):
+        raise TypeError("solve_batch_pipelined runs plain CCQPSolverPGD / CCQPSolverBBPGD / CCQPSolverAPGD / "
+                        "CCQPSolverMPRGP only, got %s" % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # n -> items, in order of first appearance
     for s, (A, b, x0, P) in zip(solvers, problems):
@@ -97,7 +98,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
-    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
+    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group,
+             CCQPSolverMPRGP: _bmprgp_group}[kind]
     t1 = time.time()
     with np.errstate(all="ignore"):
         for n, items in by_size.items():                # one lock-step run per problem size
@@ -143,7 +145,7 @@ class _Spec:
     """What a lock-step run needs to know about its B problems of size n, as arrays: matrix / right-hand-side
     addresses, leading dimensions, set descriptors (struct ccqp_seg records), tolerances, and the start vectors
     (None: zeros; a (B, n) tensor; or a list of optional n-vectors)."""
-    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep")
+    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep", "step")
 
     def __len__(self):
         return self.B
@@ -173,6 +175,8 @@ def _spec_from_items(eng, items, n):
     sp.tol = np.array([it[0].desired_residual_tol for it in items], dtype=np.float64)
     sp.x0 = None if all(it[3] is None for it in items) else [it[3] for it in items]
     sp.keep = None
+    # PGD (solvers.py:71-194): BBPGD's iteration with a constant step
+    sp.step = np.array([it[0].step_size for it in items], dtype=np.float64) if hasattr(items[0][0], "step_size") else None
     return sp
 
 
@@ -222,6 +226,9 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
         tab["g"][:, j] = planes[3 + j]
     tab["y"] = planes[6]
     flags = _bpipe_flags(tab, n, tune)
+    if getattr(spec, "step", None) is not None:         # PGD: constant steps, in slab slot 48; flag bit 3
+        slabs[:, 48] = torch.from_numpy(np.ascontiguousarray(spec.step)).to(dev)
+        flags |= 8
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
@@ -238,7 +245,7 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
         k = int(min(last, _device_budget(n)))
-        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 1, st))
+        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 9, st))
         capped = True                                   # (at the caller's budget or at the device's: see `todo`)
     else:
         check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
@@ -267,6 +274,7 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
                                               single_launch)
     host = None
     todo = set(todo.tolist())
+    pgd = hasattr(items[0][0], "step_size")
     for p, it in enumerate(items):
         s = it[0]
         if p in todo:                                    # beyond the single-launch kernel's own budget
@@ -284,8 +292,8 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
         s._solution_converged = mv < max_mv
         s._solution_residual = res[p]
         s._solution_num_matrix_vector_mults = mv
-        # start-up: A x0 and -- unless the start already satisfies the tolerance -- A g0 (executed, not counted)
-        s._executed_matrix_vector_mults = 1 if (done[p] and final[p] == 0) else 2 + int(final[p])
+        # start-up: A x0 and -- BBPGD, unless the start already satisfies the tolerance -- A g0 (executed, not counted)
+        s._executed_matrix_vector_mults = mv if (pgd or (done[p] and final[p] == 0)) else 2 + int(final[p])
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
@@ -449,12 +457,12 @@ class StackedResult:
 
 
 def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_mv=np.inf, device=None, ahead=4,
-                  tune=0, single_launch=None):
+                  tune=0, single_launch=None, step_size=0.01):
     """B dense problems of one size handed over as STACKED device tensors -- A (B, n, n), b (B, n), optional x0
     (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
     (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
 
-    solver        : "BBPGD", "APGD", "MPRGP" or the solver class
+    solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "APGD", "MPRGP" or the solver class
     lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
                     Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
                     (scalar ones raise in the reference's normal_vector).
@@ -466,9 +474,9 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     from . import solvers as sv
     t0 = time.time()
     name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
-                                                   sv.CCQPSolverMPRGP: "MPRGP"}.get(solver)
-    if name not in ("BBPGD", "APGD", "MPRGP"):
-        raise TypeError("solve_stacked runs BBPGD, APGD or MPRGP, got %r" % (solver,))
+                                                   sv.CCQPSolverMPRGP: "MPRGP", sv.CCQPSolverPGD: "PGD"}.get(solver)
+    if name not in ("PGD", "BBPGD", "APGD", "MPRGP"):
+        raise TypeError("solve_stacked runs PGD, BBPGD, APGD or MPRGP, got %r" % (solver,))
     eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
     eng.bind()
     A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
@@ -519,12 +527,13 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     sp.tol = np.broadcast_to(np.asarray(tol, dtype=np.float64), (B,)).copy()
     sp.x0 = x0
     sp.keep = keep
+    sp.step = np.broadcast_to(np.asarray(step_size, dtype=np.float64), (B,)).copy() if name == "PGD" else None
     out = StackedResult()
     with np.errstate(all="ignore"):
-        if name == "BBPGD":
+        if name in ("BBPGD", "PGD"):
             done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             mv = 1 + final
-            execd = np.where(done & (final == 0), 1, 2 + final)
+            execd = mv if name == "PGD" else np.where(done & (final == 0), 1, 2 + final)
         elif name == "APGD":
             done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             execd = mv
@@ -553,7 +562,8 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             P = {_lib.OP_IDENTITY: lambda: ss.IdentityProjOp(n), _lib.OP_LOWER: lambda: ss.LowerBoundProjOp(n, lo),
                  _lib.OP_UPPER: lambda: ss.UpperBoundProjOp(n, up), _lib.OP_BOX: lambda: ss.BoxProjOp(n, lo, up)}[kind]()
             with contextlib.redirect_stdout(io.StringIO()):
-                s = cls(float(sp.tol[p]), max_mv).solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
+                args = (float(sp.tol[p]), max_mv) + ((float(sp.step[p]),) if name == "PGD" else ())
+                s = cls(*args).solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
             sols[p].copy_(s.solution)
             res[p], mv[p] = s.solution_residual, s.solution_num_matrix_vector_multiplications
             execd[p] = s.executed_matrix_vector_multiplications

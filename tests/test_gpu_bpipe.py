@@ -299,6 +299,25 @@ def test_degenerate_sizes(solver):
             _same(a, c)
 
 
+def test_pgd_constant_step_in_both_forms():
+    """PGD = BBPGD's iteration with a constant step (per solver object), no A.g0 at the start."""
+    from ccqppy_amd import batch, solvers
+    for n, count in ((50, 9), (300, 7), (1500, 4)):
+        probs = _problems(n, count, 6100 + n)
+        steps = [0.3, 0.25, 0.35][:count] + [0.3] * max(0, count - 3)
+        for cap in (5000, 1, 2, 7, 40):
+            ref = []
+            for (A, b, x0, P), st in zip(probs, steps):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ref.append(solvers.CCQPSolverPGD(1e-7, cap, st).solve(A, b, x0=x0, convex_proj_op=P))
+            for single in (True, False):
+                it = iter(steps)
+                got = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverPGD(1e-7, cap, next(it)), probs,
+                                                  single_launch=single)
+                for a, c in zip(ref, got):
+                    _same(a, c)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):

@@ -75,6 +75,25 @@ def test_stacked_equals_individual_solves_for_every_form_of_bounds(name):
         _check(name, A, b, x0, lo_n, up_n, tols, cap, lambda p: ss.BoxProjOp(n, lo_n, up_n))
 
 
+def test_stacked_pgd():
+    import torch
+    from ccqppy_amd import batch, solvers, solution_spaces as ss
+    n, B = 120, 6
+    A, b = _stack(n, B, 77)
+    lo, up = -0.2 * np.ones(n), 0.3 * np.ones(n)
+    steps = np.array([0.3, 0.2, 0.35, 0.3, 0.25, 0.3])
+    for cap in (5000, 12):
+        r = batch.solve_stacked("PGD", A, b, lower=lo, upper=up, tol=1e-7, max_mv=cap, step_size=steps)
+        for p in range(B):
+            with contextlib.redirect_stdout(io.StringIO()):
+                a = solvers.CCQPSolverPGD(1e-7, cap, float(steps[p])).solve(A[p], b[p], convex_proj_op=ss.BoxProjOp(n, lo, up))
+            assert a.solution_num_matrix_vector_multiplications == r.num_matrix_vector_multiplications[p]
+            assert a.executed_matrix_vector_multiplications == r.executed_matrix_vector_multiplications[p]
+            assert bool(a.solution_converged) == bool(r.converged[p])
+            assert float(a.solution_residual) == float(r.residual[p])
+            assert torch.equal(a.solution, r.solution[p])
+
+
 def test_stacked_forms_of_the_inputs():
     import torch
     from ccqppy_amd import batch, solution_spaces as ss
