@@ -59,7 +59,7 @@ class PApgd(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
                 ("X", ctypes.c_void_p * 2), ("Y", ctypes.c_void_p * 2), ("gk", ctypes.c_void_p),
                 ("g1", ctypes.c_void_p), ("Ayk", ctypes.c_void_p), ("Ax1", ctypes.c_void_p),
-                ("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
+                ("xhat", ctypes.c_void_p), ("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
                 ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
 
 

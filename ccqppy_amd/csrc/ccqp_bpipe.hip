@@ -230,6 +230,9 @@ extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
 #define AP_PHASE 38
 #define AP_ACT 39
 #define AP_IT 40
+#define AP_RESMIN 41      // anti-relaxation (solvers.py:370-557): smallest residual so far ...
+#define AP_COPYHAT 42     // ... "apply: xhat = x_{k+1}" ...
+#define AP_SOLHAT 43      // ... and, at convergence, whether the solution is xhat (1) or x_{k+1} itself (0)
 #define AP_FIRST 44
 #define AP_DONE BP_DONE   // 49
 #define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
@@ -295,6 +298,9 @@ __device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n
     s[AP_DONE] = 0.0;
     s[AP_MV] = 1.0;
     s[AP_RES2] = 0.0;
+    s[AP_RESMIN] = INFINITY;
+    s[AP_COPYHAT] = 0.0;
+    s[AP_SOLHAT] = 1.0;
   }
 }
 
@@ -310,9 +316,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
 template <bool LOCKSTEP>
 __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, double gd, int64_t chunk, int nblk,
                                                   unsigned* batch, double* host, unsigned count, double seq,
-                                                  double* lds4, int* is_last_p) {
+                                                  double* lds4, int* is_last_p, int ar) {
   double* s = q.slab;
-  double v[7];
+  double v[8];
   if (s[AP_PHASE] == 0.0) {
     // the matvec of y_k has run; next: the first trial step.  (All blocks meet so that the state changes only
     // after every block has read it.)
@@ -336,11 +342,16 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
   const double* __restrict__ Ax1 = q.Ax1;
   const double* __restrict__ gk = q.gk;
   const double* __restrict__ bv = q.b;
+  const double* __restrict__ xk = q.X[it & 1];
   {
     CHUNK_RANGE(n)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
       const double xi = x1[i], yi = yk[i], bi = bv[i];
+      if (ar) {                                          // gk.(x_{k+1} - x_k), solvers.py:510
+        const double dk = xi - xk[i];
+        a6 = fma(gk[i], dk, a6);
+      }
       if (first) {
         a0 = fma(yi, Ayk[i], a0);
         a1 = fma(yi, bi, a1);
@@ -358,8 +369,9 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
     v[4] = ccqp_block_sum(a4, lds4);
     v[5] = ccqp_block_sum(a5, lds4);
     v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, bx, lds4);
+    v[7] = ar ? ccqp_block_sum(a6, lds4) : 0.0;
   }
-  if (!bp_meet(q.partials, q.counter, nblk, 7, v, lds4, is_last_p)) return;
+  if (!bp_meet(q.partials, q.counter, nblk, ar ? 8 : 7, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {
     double r1, r2;
     if (first) {
@@ -373,7 +385,8 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       r1 = s[AP_R1];
       r2 = s[AP_R2];
     }
-    for (int k = 2; k < 7; ++k) s[k] = v[k];
+    for (int k = 2; k < 6; ++k) s[k] = v[k];
+    s[6] = v[7];
     s[7] = v[6];
     double L = s[AP_L];
     const double l1 = v[2] * 0.5;
@@ -395,18 +408,26 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       const double beta = num / (tt + thk1);             // :313
       const double res = sqrt(v[6]);
       s[AP_RES2] = v[6];
+      bool improved = false;
+      if (ar && res < s[AP_RESMIN]) {                    // :501-503  xhat = copy(x_{k+1})
+        s[AP_RESMIN] = res;
+        improved = true;
+      }
       if (res < q.tol) {
         s[AP_DONE] = 1.0;
+        if (improved) s[AP_SOLHAT] = 0.0;                // the solution is x_{k+1} itself; else the xhat kept so far
         if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
+        const bool restart = ar && v[7] > 0.0;           // :510-512  y_{k+1} = copy(x_{k+1}), theta = 1
         L = L * 0.9;
         s[AP_L] = L;
         s[AP_T] = 1.0 / L;
-        s[AP_THK] = thk1;
+        s[AP_THK] = restart ? 1.0 : thk1;
         s[AP_BETA] = beta;
         s[AP_IT] = (double)(it + 1);
         s[AP_PHASE] = 0.0;
-        s[AP_ACT] = 2.0;
+        s[AP_ACT] = restart ? 3.0 : 2.0;
+        s[AP_COPYHAT] = improved ? 1.0 : 0.0;
       }
     } else {
       L = L * 2.0;
@@ -423,7 +444,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
                                                                   int64_t chunk, int nblk,
                                                                   unsigned* __restrict__ batch,
                                                                   double* __restrict__ host, unsigned count,
-                                                                  double seq) {
+                                                                  double seq, int ar) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
-  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last);
+  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar);
 }
 
 __device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx) {
@@ -442,9 +463,14 @@ __device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, in
     const double mt = -s[AP_T];
     proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], bx, nbx);
   } else {
-    const double beta = s[AP_BETA];
-    const double a = 1.0 + beta, b = -beta;
-    axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
+    if (s[AP_ACT] == 3.0) {                   // anti-relaxation restart: y_{k+1} = copy(x_{k+1})
+      copy_body(q.X[it & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
+    } else {
+      const double beta = s[AP_BETA];
+      const double a = 1.0 + beta, b = -beta;
+      axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
+    }
+    if (s[AP_COPYHAT] != 0.0) copy_body(q.X[it & 1], q.xhat, q.seg.dim, bx, nbx);   // xhat = copy(x_{k+1})
   }
 }
 
@@ -481,7 +507,7 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 0, n);
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
-                     dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round);
+                     dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, (flags & BP_FLAG_CONST_STEP) != 0);
   hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -591,7 +617,7 @@ extern "C" int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs,
 // exit paths are the host-driven loop's).
 template <bool ALIGNED>
 __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_kernel(const ccqp_papgd* __restrict__ probs, double gd,
-                                                                 double mv_limit, int64_t n) {
+                                                                 double mv_limit, int64_t n, int ar) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.x];
@@ -609,7 +635,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_kernel(const ccqp_papg
     if (s[AP_MV] >= mv_limit) break;
     bapgd_gemv_body<4, ALIGNED, false>(q, 0, n, wave, nwaves);
     __syncthreads();
-    bapgd_decide_body<false>(q, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last);
+    bapgd_decide_body<false>(q, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar);
     __syncthreads();
     if (s[AP_DONE] != 0.0) break;
     bapgd_apply_body(q, 0, 1);
@@ -623,9 +649,11 @@ extern "C" int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   CCQP_REQUIRE(count >= 1 && n >= 1 && n <= CCQP_RED_CHUNK, "one workgroup per problem needs n <= 2048");
   hipStream_t s = (hipStream_t)stream;
   if (flags & 1)
-    hipLaunchKernelGGL((bsolve_apgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n);
+    hipLaunchKernelGGL((bsolve_apgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n,
+                       (flags & BP_FLAG_CONST_STEP) != 0);
   else
-    hipLaunchKernelGGL((bsolve_apgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n);
+    hipLaunchKernelGGL((bsolve_apgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n,
+                       (flags & BP_FLAG_CONST_STEP) != 0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

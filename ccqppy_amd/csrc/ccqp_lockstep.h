@@ -8,12 +8,13 @@
 #define BP_ITERS 50
 #define BP_RES2 51
 #define BP_GG 3                            // g0.g0 between the two start-up reductions
-#define BP_FLAG_CONST_STEP 8                // `flags` bit 3 of the BBPGD entry points: PGD, constant step from the slab
+#define BP_FLAG_CONST_STEP 8                // `flags` bit 3: BBPGD entry points -> PGD (constant step from the slab);
+                                            // APGD entry points -> the anti-relaxation variant
 #define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
 
 // the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
 // tests/test_lockstep_host_cpu.py pins the same numbers)
-static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 176 && sizeof(ccqp_papgd) == 184 &&
+static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 176 && sizeof(ccqp_papgd) == 192 &&
                   sizeof(ccqp_pmprgp) == 224,
               "descriptor layout changed: update ccqppy_amd/_lib.py and the tests");
 

@@ -41,8 +41,9 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
     this one is not.
 
-    make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverAPGD or CCQPSolverMPRGP (plain: no fallback /
-                  anti-relaxation / matvec reuse), all of one class with the same max_matrix_vector_multiplications
+    make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation or CCQPSolverMPRGP
+                  (no fallback variant, no matvec reuse), all of one class with the same
+                  max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
@@ -56,7 +57,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
-    from .solvers import CCQPSolverAPGD, CCQPSolverBBPGD, CCQPSolverMPRGP, CCQPSolverPGD
+    from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverMPRGP,
+                          CCQPSolverPGD)
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -65,10 +67,10 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverMPRGP, CCQPSolverPGD) or \
+    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP, CCQPSolverPGD) or \
             getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs plain CCQPSolverPGD / CCQPSolverBBPGD / CCQPSolverAPGD / "
-                        "CCQPSolverMPRGP only, got %s" % kind.__name__)
+        raise TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / APGD / APGDAntiRelaxation / MPRGP "
+                        "(no fallback variant, no matvec reuse), got %s" % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # n -> items, in order of first appearance
     for s, (A, b, x0, P) in zip(solvers, problems):
@@ -99,7 +101,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         for s in solvers:
             print("solving " + s._label)
     group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group,
-             CCQPSolverMPRGP: _bmprgp_group}[kind]
+             CCQPSolverAPGDAntiRelaxation: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
     t1 = time.time()
     with np.errstate(all="ignore"):
         for n, items in by_size.items():                # one lock-step run per problem size
@@ -297,21 +299,22 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
-def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
+def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False):
     """Lock-step APGD over `spec`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
     matvec counts) -- rows of problems that did not converge inside the budget are meaningless."""
     from . import _lib
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(spec)
-    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 8, 7)
+    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 9, 8)
     spec.stage_x0(vec[0])
+    vec[8].fill_(1.0)                                                   # xhat = ones (solvers.py:432)
     vec[2].copy_(vec[0])                                                # yk = x0 (solvers.py:257-258)
     tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
     tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
-    tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"] = planes[4], planes[5], planes[6], planes[7]
-    flags = _bpipe_flags(tab, n, tune)
+    tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"], tab["xhat"] = planes[4], planes[5], planes[6], planes[7], planes[8]
+    flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0)  # bit 3: the anti-relaxation variant
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
@@ -327,7 +330,7 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     single_launch = bool(single_launch) and n <= 2048
     if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
+        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 9, st))
     else:
         check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
         _bpipe_poll_loop(eng, B, launch, last, ahead)
@@ -335,11 +338,15 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
     if not single_launch and not np.isfinite(max_mv) and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+    # the solution: x_{k+1} = X[(accepted iterations + 1) % 2]; anti-relaxation: xhat (plane 8) unless the converging
+    # iterate was itself the best one so far (slot 43)
+    pick = (its + 1) % 2
+    if ar:
+        pick = np.where(h[:, 11] != 0.0, 8, pick)
     if B == 1:
-        sols = vec[int((its[0] + 1) % 2)]
+        sols = vec[int(pick[0])]
     else:
-        sel = torch.from_numpy((its + 1) % 2).to(dev)
-        sols = vec[0:2][sel, torch.arange(B, device=dev)]
+        sols = vec[torch.from_numpy(pick).to(dev), torch.arange(B, device=dev)]
     del keep
     return done, sols, np.sqrt(res2), mvs
 
@@ -347,7 +354,8 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
 def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     import contextlib
     import io
-    done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch)
+    done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch,
+                                      ar=items[0][0]._anti_relaxation)
     host = None
     for p, it in enumerate(items):
         s = it[0]
@@ -462,7 +470,8 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
     (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
 
-    solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "APGD", "MPRGP" or the solver class
+    solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "APGD", "APGDAntiRelaxation",
+                    "MPRGP", or the solver class
     lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
                     Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
                     (scalar ones raise in the reference's normal_vector).
@@ -474,9 +483,10 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     from . import solvers as sv
     t0 = time.time()
     name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
-                                                   sv.CCQPSolverMPRGP: "MPRGP", sv.CCQPSolverPGD: "PGD"}.get(solver)
-    if name not in ("PGD", "BBPGD", "APGD", "MPRGP"):
-        raise TypeError("solve_stacked runs PGD, BBPGD, APGD or MPRGP, got %r" % (solver,))
+                                                   sv.CCQPSolverMPRGP: "MPRGP", sv.CCQPSolverPGD: "PGD",
+                                                   sv.CCQPSolverAPGDAntiRelaxation: "APGDAntiRelaxation"}.get(solver)
+    if name not in ("PGD", "BBPGD", "APGD", "APGDAntiRelaxation", "MPRGP"):
+        raise TypeError("solve_stacked runs PGD, BBPGD, APGD, APGDAntiRelaxation or MPRGP, got %r" % (solver,))
     eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
     eng.bind()
     A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
@@ -534,8 +544,9 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             mv = 1 + final
             execd = mv if name == "PGD" else np.where(done & (final == 0), 1, 2 + final)
-        elif name == "APGD":
-            done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch)
+        elif name in ("APGD", "APGDAntiRelaxation"):
+            done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch,
+                                             ar=name == "APGDAntiRelaxation")
             execd = mv
             todo = np.flatnonzero(~done)
         else:

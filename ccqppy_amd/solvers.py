@@ -261,7 +261,7 @@ class _APGDCore(CCQPSolverBase):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, b, AR = run.eng, run.b, self._anti_relaxation
         reuse = self.reuse_matvec
-        if self.pipeline and not AR and not reuse:
+        if self.pipeline and not reuse:
             out = self._lockstep(run)
             if out is not None:
                 return out
@@ -376,7 +376,7 @@ class _APGDCore(CCQPSolverBase):
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
         done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
-                                          self.max_matrix_vector_multiplications, 4)
+                                          self.max_matrix_vector_multiplications, 4, ar=self._anti_relaxation)
         if not done[0]:
             return None
         eng.mv_executed += int(mvs[0])

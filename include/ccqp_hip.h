@@ -317,7 +317,10 @@ int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count,
  * :312-313, exit test, L update), apply (trial step x_{k+1} = P(y_k - t g_k)  or  y_{k+1} = (1+beta) x_{k+1} -
  * beta x_k).  Slab (>= 52 doubles, zeroed): 0..7 the host loop's eight scalars, 32..37 {L, t, theta_k, beta, r1,
  * r2}, 38..40 {phase, action, accepted iterations}, 49..51 {converged, matvecs so far, res2}.  A converged
- * problem's solution is X[(accepted iterations + 1) % 2].  ccqp_bpipe_poll reports {converged, round}. */
+ * problem's solution is X[(accepted iterations + 1) % 2].  ccqp_bpipe_poll reports {converged, round}.
+ * `flags` bit 3 (8) selects the anti-relaxation variant (solvers.py:370-557; slots 41..43 {smallest residual,
+ * copy pending, solution is xhat}): restart of the momentum where gk.(x_{k+1} - x_k) > 0, best iterate kept in xhat;
+ * its solution is xhat if slot 43 is set, X[...] otherwise. */
 typedef struct ccqp_papgd {
   const double* A;
   int64_t lda;
@@ -328,9 +331,10 @@ typedef struct ccqp_papgd {
   double* g1;        /* A x_{k+1} + b */
   double* Ayk;
   double* Ax1;
+  double* xhat;      /* anti-relaxation only (flags bit 3): best iterate so far, ones on entry (solvers.py:432) */
   ccqp_seg seg;      /* elementwise kind, offset 0, dim n */
   double* slab;
-  double* partials;  /* 7 * ccqp_bpipe_partials_doubles(n) / 3 doubles */
+  double* partials;  /* 8 * ccqp_bpipe_partials_doubles(n) / 3 doubles */
   uint32_t* counter; /* one word, zero on entry */
   double c;
   double tol;

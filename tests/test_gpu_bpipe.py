@@ -318,6 +318,32 @@ def test_pgd_constant_step_in_both_forms():
                     _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(37, 13), (64, 120), (256, 20), (1000, 8), (2049, 5)])
+def test_anti_relaxation_apgd_in_both_forms(n, count):
+    """CCQPSolverAPGDAntiRelaxation: momentum restarts where gk.(x_{k+1} - x_k) > 0, best iterate returned."""
+    probs = _problems(n, count, 7300 + n)
+    tols = [[1e-8, 1e-5, 1e30][p % 3] for p in range(count)]
+    ref = _reference(probs, tols, 5000, "APGDAntiRelaxation")
+    for single in (True, False):
+        got = _batch(probs, tols, 5000, "APGDAntiRelaxation", single_launch=single)
+        for a, c in zip(ref, got):
+            _same(a, c)
+    if count > 20:
+        return
+    plain = _reference(probs, tols, 5000, "APGD")
+    assert any(a.solution_num_matrix_vector_multiplications != c.solution_num_matrix_vector_multiplications
+               for a, c in zip(ref, plain))              # the restarts do change the iteration
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for p in range(0, count, 2):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, ref[p].solution.clone(), P)
+    for cap in (3, 4, 5, 9, longest - 1, longest, longest + 1):
+        ref2 = _reference(probs, tols, cap, "APGDAntiRelaxation")
+        got = _batch(probs, tols, cap, "APGDAntiRelaxation", single_launch=(cap % 2 == 0))
+        for a, c in zip(ref2, got):
+            _same(a, c)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):
@@ -335,8 +361,6 @@ def test_rejects_what_it_cannot_run():
     op2, b2, _ = problems.random_problem(96, 2)
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGDf(1e-8), [(op, b, None, None)])
-    with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGDAntiRelaxation(1e-8), [(op, b, None, None)])
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(1e-8, reuse_matvec=True), [(op, b, None, None)])
     with pytest.raises(TypeError):

@@ -59,14 +59,14 @@ def test_poll_loop_stops_at_the_budget_without_waiting_for_a_report():
 
 def test_descriptor_dtypes_match_the_c_structs():
     from ccqppy_amd import _lib
-    for struct, size in ((_lib.Seg, 56), (_lib.PProb, 176), (_lib.PApgd, 184), (_lib.PMprgp, 224)):
+    for struct, size in ((_lib.Seg, 56), (_lib.PProb, 176), (_lib.PApgd, 192), (_lib.PMprgp, 224)):
         dt = np.dtype(struct)
         assert dt.itemsize == ctypes.sizeof(struct) == size
         for name, _ in struct._fields_:
             assert dt.fields[name][1] == getattr(struct, name).offset
     # the records embed struct ccqp_seg at the same offset the C header gives it (after the vector pointers)
     assert np.dtype(_lib.PProb).fields["seg"][1] == 80
-    assert np.dtype(_lib.PApgd).fields["seg"][1] == 88
+    assert np.dtype(_lib.PApgd).fields["seg"][1] == 96
     assert np.dtype(_lib.PMprgp).fields["seg"][1] == 128
 
 
