@@ -25,6 +25,11 @@ static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 176 && sizeof(ccqp
 // at the start of a launch may be changed by the block this returns true in.
 __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int nblk, int nred, double* v,
                                         double* lds4, int* is_last) {
+  // Every wave of this block has read the state words of the launch (phase / state / done) before anybody may change
+  // them: the block that turns out to be the last changes them right after this function, and a path without a
+  // reduction (nred == 0) has no barrier of its own.  (Without this barrier a late wave read the NEW state once per
+  // ~10^4 decisions under a saturated memory system and took another branch: an APGD solve that never converged.)
+  __syncthreads();
   if (nblk == 1) return true;
   if (threadIdx.x == 0) {
     for (int k = 0; k < nred; ++k) partials[(int64_t)k * nblk + blockIdx.x] = v[k];
@@ -92,7 +97,7 @@ static inline int bp_vec_grid(int64_t n) {
 
 // `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
 // result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
-// per wave step in units of 128 (1, 2, 4; 7 = two rows per wave, one step), bits 8.. workgroups per problem.
+// per wave step in units of 128 (1, 2, 4; 7 / 6 = two / four rows per wave, one step), bits 8.. workgroups per problem.
 struct bp_mv_tuning {
   bool aligned;
   int nt, U;
@@ -113,15 +118,16 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   if (per > (n + rows_per_wg - 1) / rows_per_wg) per = (n + rows_per_wg - 1) / rows_per_wg;
   if (per < 1) per = 1;
   // few waves in flight (a batch of one, or few problems): more loads per lane; large matrices: two rows per wave
-  if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : 1);
+  // (short rows: several rows per wave amortise the per-row reduction, profiles/r01g_bpipe_sweep.txt)
+  if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : n <= 256 ? 6 : n <= 512 ? 7 : 1);
   t.grid = dim3((unsigned)per, count);
   return t;
 }
 
 // The matvec kernels' first template argument is a CODE: 1, 2, 4 = one row per wave and that many 128-column
-// steps in flight; 8 = two rows per wave, one step (the large-matrix form of ccqp_gemv.hip).
-#define BP_R(C) ((C) == 8 ? 2 : 1)
-#define BP_U(C) ((C) == 8 ? 1 : (C))
+// steps in flight; 8 / 9 = two / four rows per wave, one step (8: the large-matrix form of ccqp_gemv.hip).
+#define BP_R(C) ((C) == 8 ? 2 : (C) == 9 ? 4 : 1)
+#define BP_U(C) ((C) >= 8 ? 1 : (C))
 #define BP_TASKS(C, n) (((n) + BP_R(C) - 1) / BP_R(C))
 
 // launches KERNEL<code, ALIGNED, NT>(args...) for the tuning `t`
@@ -130,6 +136,7 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 #define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
   do {                                                                \
     if (t.U == 7) BP_MV_LAUNCH1(KERNEL, 8, AL, NTT, __VA_ARGS__);     \
+    else if (t.U == 6) BP_MV_LAUNCH1(KERNEL, 9, AL, NTT, __VA_ARGS__); \
     else if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__); \
     else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
     else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
