@@ -378,6 +378,8 @@ class _APGDCore(CCQPSolverBase):
         done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
                                           self.max_matrix_vector_multiplications, 4, ar=self._anti_relaxation)
         if not done[0]:
+            from . import lockstep
+            lockstep.stats["fallback_solves"] += 1
             return None
         eng.mv_executed += int(mvs[0])
         return sols[0], res[0], int(mvs[0])
@@ -686,6 +688,8 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n),
                                                     run.n, self.max_matrix_vector_multiplications, 4)
         if status[0] != 1.0:
+            from . import lockstep
+            lockstep.stats["fallback_solves"] += 1
             return None
         eng.mv_executed += int(execd[0])
         return sols[0], res[0], int(mvs[0])

@@ -51,9 +51,14 @@ def _reference(probs, tols, max_mv):
 
 
 def _batch(probs, tols, max_mv, **kw):
-    from ccqppy_amd import batch, solvers
+    from ccqppy_amd import batch, lockstep, solvers
     it = iter(tols)
-    return batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(next(it), max_mv), probs, **kw)
+    before = lockstep.stats["fallback_solves"]
+    out = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(next(it), max_mv), probs, **kw)
+    # far from the matvec budget only a solve that does not converge at all may go back to the host loop
+    assert max_mv < 2000 or lockstep.stats["fallback_solves"] - before <= sum(not c.solution_converged for c in out), \
+        "a device-resident solve fell back to the host loop"
+    return out
 
 
 @pytest.mark.parametrize("n,count", [(100, 15), (257, 20), (1000, 10), (2049, 10), (4500, 5)])

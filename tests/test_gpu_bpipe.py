@@ -52,10 +52,15 @@ def _reference(probs, tols, max_mv, solver="BBPGD"):
 
 
 def _batch(probs, tols, max_mv, solver="BBPGD", **kw):
-    from ccqppy_amd import batch, solvers
+    from ccqppy_amd import batch, lockstep, solvers
     cls = getattr(solvers, "CCQPSolver" + solver)
     it = iter(tols)
-    return batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, **kw)
+    before = lockstep.stats["fallback_solves"]
+    out = batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, **kw)
+    # far from the matvec budget only a solve that does not converge at all may go back to the host loop
+    assert max_mv < 5000 or lockstep.stats["fallback_solves"] - before <= sum(not c.solution_converged for c in out), \
+        "a device-resident solve fell back to the host loop"
+    return out
 
 
 @pytest.mark.parametrize("n,count", [(37, 13), (256, 40), (1000, 12), (2049, 7), (4500, 5)])

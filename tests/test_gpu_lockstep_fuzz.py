@@ -82,7 +82,12 @@ def test_lockstep_equals_individual_solves(case):
         with contextlib.redirect_stdout(io.StringIO()):
             ref.append(cls(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
     it = iter(tols)
+    from ccqppy_amd import lockstep
+    before = lockstep.stats["fallback_solves"]
     got = batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, ahead=ahead, tune=tune)
+    # far from the matvec budget only a solve that does not converge at all may go back to the host loop
+    assert max_mv < 3000 or lockstep.stats["fallback_solves"] - before <= sum(not c.solution_converged for c in got), \
+        "a device-resident solve fell back to the host loop"
     assert len(got) == len(ref)
     for a, c in zip(ref, got):
         assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications

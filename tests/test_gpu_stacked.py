@@ -27,7 +27,12 @@ def _check(name, A, b, x0, lower, upper, tol, max_mv, make_P, **kw):
     from ccqppy_amd import batch, solvers
     cls = getattr(solvers, "CCQPSolver" + name)
     B, n = b.shape
+    from ccqppy_amd import lockstep
+    before = lockstep.stats["fallback_solves"]
     r = batch.solve_stacked(name, A, b, x0=x0, lower=lower, upper=upper, tol=tol, max_mv=max_mv, **kw)
+    if max_mv >= 3000 and lockstep._device_budget(b.shape[1]) >= 256:   # (one test forces a tiny device budget)
+        assert lockstep.stats["fallback_solves"] - before <= int((~r.converged).sum()), \
+            "a device-resident solve fell back to the host loop"
     tols = np.broadcast_to(np.asarray(tol, dtype=np.float64), (B,))
     assert r.solution.shape == (B, n)
     for p in range(B):
