@@ -186,10 +186,13 @@ def test_single_solve_pipeline_option():
     for n in (100, 1024, 3000):
         for p, (A, b, x0, P) in enumerate(_problems(n, 5, 40 + n, 0.1)):
             for cap in (2000, 9, 21):
+                from ccqppy_amd import lockstep
+                before = lockstep.stats["fallback_solves"]
                 with contextlib.redirect_stdout(io.StringIO()):
                     a = solvers.CCQPSolverMPRGP(1e-7, cap).solve(A, b, x0=x0, convex_proj_op=P)
                     c = solvers.CCQPSolverMPRGP(1e-7, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
                 _same(a, c)
+                assert cap < 2000 or lockstep.stats["fallback_solves"] == before   # really solved on the device
     op, b, _ = problems.random_problem(256, 3)
     with contextlib.redirect_stdout(io.StringIO()):
         a = solvers.CCQPSolverMPRGP(1e-7, 500).solve(op, b, convex_proj_op=ss.SphereProjOp(256, 2.0))

@@ -210,10 +210,13 @@ def test_single_solve_apgd_pipeline_option():
     for n in (100, 1024, 3000):
         for p, (A, b, x0, P) in enumerate(_problems(n, 6, 40 + n)):
             for cap in (5000, 9, 30):
+                from ccqppy_amd import lockstep
+                before = lockstep.stats["fallback_solves"]
                 with contextlib.redirect_stdout(io.StringIO()):
                     a = solvers.CCQPSolverAPGD(1e-8, cap).solve(A, b, x0=x0, convex_proj_op=P)
                     c = solvers.CCQPSolverAPGD(1e-8, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
                 _same(a, c)
+                assert cap < 5000 or lockstep.stats["fallback_solves"] == before   # really solved on the device
     op, b, _ = problems.random_problem(256, 3)
     with contextlib.redirect_stdout(io.StringIO()):
         a = solvers.CCQPSolverAPGDAntiRelaxation(1e-8, 5000).solve(op, b, convex_proj_op=ss.BoxProjOp(256, -0.5, 0.5))
