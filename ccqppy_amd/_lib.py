@@ -51,7 +51,8 @@ class PProb(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
                 ("x", ctypes.c_void_p * 3), ("g", ctypes.c_void_p * 3), ("y", ctypes.c_void_p),
                 ("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
-                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
+                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double),
+                ("xmin", ctypes.c_void_p), ("gmin", ctypes.c_void_p)]
 
 
 class PApgd(ctypes.Structure):

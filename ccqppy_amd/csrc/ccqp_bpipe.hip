@@ -75,6 +75,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_res_kernel(const ccqp_p
     q.slab[BP_GG] = v[1];
     q.slab[BP_RES2] = v[0];
     q.slab[BP_ITERS] = 0.0;
+    q.slab[BP_RESMIN] = INFINITY;             // (BBPGDf, :767)
     if (!const_step) q.slab[BP_ALPHA] = 0.0;  // (PGD: the caller has put the constant step there)
     if (sqrt(v[0]) >= q.tol) {               // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
       q.slab[BP_DONE] = 0.0;
@@ -99,6 +100,105 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_alpha_kernel(const ccqp
   if (threadIdx.x == 0) {
     q.slab[1] = v[0];
     q.slab[BP_ALPHA] = q.slab[BP_GG] / v[0];
+  }
+}
+
+// ---- BBPGDf (solvers.py:696-843): between the residual and the BB dots the reference keeps the best iterate so far
+// and, when the step length has collapsed, restarts from it -- so the tail is two reductions with an elementwise
+// update folded into the second.  Slab: 4 smallest residual so far, 5 "this iterate is the best", 6 "fall back".
+// part B, elementwise + reduction: xmin / gmin = x_new / g_new where improved; x_new = P(xmin - gd gmin) where the
+// fallback is due (:799-800, g_new is NOT recomputed); then dx.dx, dx.dg with the possibly replaced x_new
+__device__ __forceinline__ void bbf_tail_b_body(const ccqp_pprob& q, const ccqp_segk& sg, int inew, int icur,
+                                                bool improved, bool fallback, double gd, int64_t chunk, int bx,
+                                                double* lds4, double* dxdx, double* dxdg) {
+  double* __restrict__ xn = q.x[inew];
+  const double* __restrict__ gn = q.g[inew];
+  const double* __restrict__ xo = q.x[icur];
+  const double* __restrict__ go = q.g[icur];
+  const double mgd = -gd;
+  CHUNK_RANGE(sg.dim)
+  double a1 = 0.0, a2 = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    double xi = xn[i];
+    const double gi = gn[i];
+    if (improved) {
+      q.xmin[i] = xi;
+      q.gmin[i] = gi;
+    }
+    if (fallback) {
+      const double t1 = 1.0 * q.xmin[i];
+      const double t2 = mgd * q.gmin[i];
+      const double u = t1 + t2;
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      xi = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+      xn[i] = xi;
+    }
+    const double dx = xi - xo[i];
+    const double dg = gi - go[i];
+    a1 = fma(dx, dx, a1);
+    a2 = fma(dx, dg, a2);
+  }
+  *dxdx = ccqp_block_sum(a1, lds4);
+  *dxdg = ccqp_block_sum(a2, lds4);
+}
+
+// part A: the residual, the exit test, "best so far", "fall back" (thread 0 of the problem's last block)
+__device__ __forceinline__ bool bbf_decide_a(double* s, double r, double tol, double eps10) {
+  const double res = sqrt(r);
+  s[0] = r;
+  s[BP_RES2] = r;
+  if (res < tol) return true;
+  if (res < s[BP_RESMIN]) {                   // :793-796
+    s[BP_RESMIN] = res;
+    s[BP_IMPROVED] = 1.0;
+  } else {
+    s[BP_IMPROVED] = 0.0;
+  }
+  s[BP_FALLBACK] = s[BP_ALPHA] < eps10 ? 1.0 : 0.0;   // :799
+  return false;
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_a_kernel(const ccqp_pprob* __restrict__ probs, int inew,
+                                                                   double gd, double eps10, int64_t chunk, int nblk,
+                                                                   unsigned* __restrict__ batch) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pprob& q = probs[blockIdx.y];
+  if (q.slab[BP_DONE] != 0.0) return;
+  double v[1];
+  v[0] = residual_body(bp_segk_of(q), q.x[inew], q.g[inew], q.c, gd, chunk, blockIdx.x, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0 && bbf_decide_a(q.slab, v[0], q.tol, eps10)) {
+    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    q.slab[BP_DONE] = 1.0;
+    __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pprob* __restrict__ probs, int inew,
+                                                                   int icur, double gd, double eps10, int64_t chunk,
+                                                                   int nblk, unsigned* __restrict__ batch,
+                                                                   double* __restrict__ host, unsigned count,
+                                                                   double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pprob& q = probs[blockIdx.y];
+  if (q.slab[BP_DONE] != 0.0) {             // converged (now or earlier): only the roll-call
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  double v[2];
+  bbf_tail_b_body(q, bp_segk_of(q), inew, icur, q.slab[BP_IMPROVED] != 0.0, q.slab[BP_FALLBACK] != 0.0, gd, chunk,
+                  blockIdx.x, lds4, &v[0], &v[1]);
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    const double den = v[1] + eps10;
+    q.slab[1] = v[0];
+    q.slab[2] = v[1];
+    q.slab[BP_ALPHA] = v[0] / den;
+    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    bp_report(batch, host, count, seq);
   }
 }
 
@@ -180,9 +280,16 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
     int64_t chunk;
     int nblk;
     ccqp_red_geometry(n, &chunk, &nblk);
-    hipLaunchKernelGGL(bpipe_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd, eps10,
-                       chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
-                       (flags & BP_FLAG_CONST_STEP) != 0);
+    if (flags & BP_FLAG_FALLBACK) {
+      hipLaunchKernelGGL(bpipe_tailf_a_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, gd, eps10,
+                         chunk, nblk, dev_batch);
+      hipLaunchKernelGGL(bpipe_tailf_b_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd,
+                         eps10, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration);
+    } else {
+      hipLaunchKernelGGL(bpipe_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd, eps10,
+                         chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
+                         (flags & BP_FLAG_CONST_STEP) != 0);
+    }
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -524,7 +631,7 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
 template <bool ALIGNED>
 __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_pprob* __restrict__ probs, double gd,
                                                                   double eps10, int64_t last_iter, int64_t n,
-                                                                  int const_step) {
+                                                                  int const_step, int fallback) {
   __shared__ double lds4[4];
   __shared__ double sh[4];                    // alpha, res2, flag
   const ccqp_pprob& q = probs[blockIdx.x];
@@ -544,6 +651,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
       sh[1] = r;
       sh[2] = gg;
       sh[3] = sqrt(r) >= q.tol ? 0.0 : 1.0;   // `if res >= tol:` (a NaN residual skips the loop)
+      s[BP_RESMIN] = INFINITY;                // (BBPGDf, :767)
     }
   }
   __syncthreads();
@@ -568,6 +676,29 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
       gemv_body<4, 1, ALIGNED, false>(q.A, q.lda, q.x[inew], q.b, q.y, q.g[inew], n, n, ntasks, wave, nwaves);
       __syncthreads();
       if (k >= last_iter) break;              // the matvec budget ends before the residual (:643-644)
+      if (fallback) {                         // BBPGDf: residual -> best iterate / fall-back -> BB dots
+        const double r = residual_body(sg, q.x[inew], q.g[inew], q.c, gd, chunk, 0, lds4);
+        if (threadIdx.x == 0) {
+          s[BP_ALPHA] = sh[0];
+          sh[3] = bbf_decide_a(s, r, q.tol, eps10) ? 1.0 : 0.0;
+          sh[1] = r;
+        }
+        __syncthreads();
+        if (sh[3] != 0.0) {
+          done = true;
+          break;
+        }
+        double s1, s2;
+        bbf_tail_b_body(q, sg, inew, icur, s[BP_IMPROVED] != 0.0, s[BP_FALLBACK] != 0.0, gd, chunk, 0, lds4, &s1, &s2);
+        if (threadIdx.x == 0) {
+          const double den = s2 + eps10;
+          s[1] = s1;
+          s[2] = s2;
+          sh[0] = s1 / den;
+        }
+        __syncthreads();
+        continue;
+      }
       double r, s1, s2;
       bb_tail_body(sg, q.x[inew], q.x[icur], q.g[inew], q.g[icur], q.c, gd, chunk, 0, lds4, &r, &s1, &s2);
       if (threadIdx.x == 0) {
@@ -603,10 +734,10 @@ extern "C" int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs,
   hipStream_t s = (hipStream_t)stream;
   if (flags & 1)
     hipLaunchKernelGGL((bsolve_bbpgd_kernel<true>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
-                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0);
+                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0, (flags & BP_FLAG_FALLBACK) != 0);
   else
     hipLaunchKernelGGL((bsolve_bbpgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
-                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0);
+                       last_iteration, n, (flags & BP_FLAG_CONST_STEP) != 0, (flags & BP_FLAG_FALLBACK) != 0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -8,13 +8,18 @@
 #define BP_ITERS 50
 #define BP_RES2 51
 #define BP_GG 3                            // g0.g0 between the two start-up reductions
+#define BP_RESMIN 4                        // BBPGDf: smallest residual so far, "this iterate is the best", "fall back"
+#define BP_IMPROVED 5
+#define BP_FALLBACK 6
 #define BP_FLAG_CONST_STEP 8                // `flags` bit 3: BBPGD entry points -> PGD (constant step from the slab);
                                             // APGD entry points -> the anti-relaxation variant
+#define BP_FLAG_FALLBACK 128                // `flags` bit 7 of the BBPGD entry points: BBPGDf (needs xmin / gmin)
+                                            // (bits 1-2, 4-6 and 8.. belong to the matvec's tuning word)
 #define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
 
 // the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
 // tests/test_lockstep_host_cpu.py pins the same numbers)
-static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 176 && sizeof(ccqp_papgd) == 192 &&
+static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 192 && sizeof(ccqp_papgd) == 192 &&
                   sizeof(ccqp_pmprgp) == 224,
               "descriptor layout changed: update ccqppy_amd/_lib.py and the tests");
 

@@ -46,8 +46,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
     this one is not.
 
-    make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation or CCQPSolverMPRGP
-                  (no fallback variant, no matvec reuse), all of one class with the same
+    make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD,
+                  CCQPSolverAPGDAntiRelaxation or CCQPSolverMPRGP (no matvec reuse), all of one class with the same
                   max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
@@ -62,8 +62,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
-    from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverMPRGP,
-                          CCQPSolverPGD)
+    from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
+                          CCQPSolverMPRGP, CCQPSolverPGD)
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -72,10 +72,10 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP, CCQPSolverPGD) or \
-            getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / APGD / APGDAntiRelaxation / MPRGP "
-                        "(no fallback variant, no matvec reuse), got %s" % kind.__name__)
+    if kind not in (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
+                    CCQPSolverPGD) or getattr(solvers[0], "reuse_matvec", False):
+        raise TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
+                        "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # n -> items, in order of first appearance
     for s, (A, b, x0, P) in zip(solvers, problems):
@@ -105,7 +105,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
-    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverPGD: _bpipe_group, CCQPSolverAPGD: _bapgd_group,
+    group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverBBPGDf: _bpipe_group, CCQPSolverPGD: _bpipe_group,
+             CCQPSolverAPGD: _bapgd_group,
              CCQPSolverAPGDAntiRelaxation: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
     t1 = time.time()
     with np.errstate(all="ignore"):
@@ -152,7 +153,7 @@ class _Spec:
     """What a lock-step run needs to know about its B problems of size n, as arrays: matrix / right-hand-side
     addresses, leading dimensions, set descriptors (struct ccqp_seg records), tolerances, and the start vectors
     (None: zeros; a (B, n) tensor; or a list of optional n-vectors)."""
-    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep", "step")
+    __slots__ = ("B", "n", "A", "lda", "b", "seg", "tol", "x0", "keep", "step", "fallback")
 
     def __len__(self):
         return self.B
@@ -184,6 +185,7 @@ def _spec_from_items(eng, items, n):
     sp.keep = None
     # PGD (solvers.py:71-194): BBPGD's iteration with a constant step
     sp.step = np.array([it[0].step_size for it in items], dtype=np.float64) if hasattr(items[0][0], "step_size") else None
+    sp.fallback = bool(getattr(items[0][0], "_fallback", False))       # BBPGDf
     return sp
 
 
@@ -216,7 +218,8 @@ def _bpipe_table(eng, spec, n, struct, nvec, partial_rows):
 
 def _bpipe_flags(tab, n, tune):
     # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
-    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~1)
+    # (bits 3 and 7 select solver variants -- PGD / anti-relaxation, BBPGDf -- and are not the caller's to set)
+    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~(1 | 8 | 128))
 
 
 def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
@@ -226,8 +229,9 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     from .solvers import _EPS10, _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(spec)
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 7, 3)    # x ring, g ring, y
-    spec.stage_x0(vec[0])
+    fallback = bool(getattr(spec, "fallback", False))
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 9 if fallback else 7, 3)
+    spec.stage_x0(vec[0])                                               # planes: x ring, g ring, y (, xmin, gmin)
     for j in range(3):
         tab["x"][:, j] = planes[j]
         tab["g"][:, j] = planes[3 + j]
@@ -236,6 +240,11 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     if getattr(spec, "step", None) is not None:         # PGD: constant steps, in slab slot 48; flag bit 3
         slabs[:, 48] = torch.from_numpy(np.ascontiguousarray(spec.step)).to(dev)
         flags |= 8
+    if fallback:                                        # BBPGDf: xmin = gmin = copy(x0) (solvers.py:762-763), bit 7
+        vec[7].copy_(vec[0])
+        vec[8].copy_(vec[0])
+        tab["xmin"], tab["gmin"] = planes[7], planes[8]
+        flags |= 128
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
@@ -252,7 +261,7 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
         k = int(min(last, _device_budget(n)))
-        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 9, st))
+        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, B, n, _GD, float(_EPS10), k, flags & 137, st))
         capped = True                                   # (at the caller's budget or at the device's: see `todo`)
     else:
         check(lib.ccqp_bpipe_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
@@ -478,8 +487,8 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
     (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
 
-    solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "APGD", "APGDAntiRelaxation",
-                    "MPRGP", or the solver class
+    solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "BBPGDf", "APGD",
+                    "APGDAntiRelaxation", "MPRGP", or the solver class
     lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
                     Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
                     (scalar ones raise in the reference's normal_vector).
@@ -492,9 +501,10 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     t0 = time.time()
     name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
                                                    sv.CCQPSolverMPRGP: "MPRGP", sv.CCQPSolverPGD: "PGD",
+                                                   sv.CCQPSolverBBPGDf: "BBPGDf",
                                                    sv.CCQPSolverAPGDAntiRelaxation: "APGDAntiRelaxation"}.get(solver)
-    if name not in ("PGD", "BBPGD", "APGD", "APGDAntiRelaxation", "MPRGP"):
-        raise TypeError("solve_stacked runs PGD, BBPGD, APGD, APGDAntiRelaxation or MPRGP, got %r" % (solver,))
+    if name not in ("PGD", "BBPGD", "BBPGDf", "APGD", "APGDAntiRelaxation", "MPRGP"):
+        raise TypeError("solve_stacked runs PGD, BBPGD, BBPGDf, APGD, APGDAntiRelaxation or MPRGP, got %r" % (solver,))
     eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
     eng.bind()
     A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
@@ -546,9 +556,10 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     sp.x0 = x0
     sp.keep = keep
     sp.step = np.broadcast_to(np.asarray(step_size, dtype=np.float64), (B,)).copy() if name == "PGD" else None
+    sp.fallback = name == "BBPGDf"
     out = StackedResult()
     with np.errstate(all="ignore"):
-        if name in ("BBPGD", "PGD"):
+        if name in ("BBPGD", "BBPGDf", "PGD"):
             done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             mv = 1 + final
             execd = mv if name == "PGD" else np.where(done & (final == 0), 1, 2 + final)

@@ -289,13 +289,17 @@ typedef struct ccqp_pprob {
   uint32_t* counter; /* one word, zero on entry */
   double c;          /* residual scale 1/(3 n gd), solvers.py:138 */
   double tol;
+  double* xmin;      /* BBPGDf only (flags bit 7): best iterate so far and its gradient, both = x0 on entry */
+  double* gmin;      /* (solvers.py:762-763 -- sic, gmin starts as a copy of x0); NULL otherwise */
 } ccqp_pprob;
 int64_t ccqp_bpipe_partials_doubles(int64_t n);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
  * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_lockstep.h).  Bit 3 (8)
  * turns the run into PGD (solvers.py:94-170): the caller stores each problem's constant step in slab slot 48, the
- * start-up has no A g0 / alpha0 and the tail leaves the step alone (same flag for iterate and bsolve). */
+ * start-up has no A g0 / alpha0 and the tail leaves the step alone (same flag for iterate and bsolve).  Bit 7 (128)
+ * selects BBPGDf (solvers.py:696-843): slab slots 4..6 {smallest residual, best-so-far, fall back}, the best iterate
+ * kept in xmin / gmin, the restart from it when the step length drops below 10 eps. */
 int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, double gd, int flags,
                          uint32_t* dev_batch, void* stream);
 /* iteration >= 1: x[it%3] = P(x[(it-1)%3] - alpha g[..]); g[it%3] = A x[it%3] + b; with_tail != 0: residual, BB

@@ -164,6 +164,8 @@ int main(void) {
       hp3[q].counter = words + q;
       hp3[q].c = 1.0 / (3 * n * gd);
       hp3[q].tol = tol;
+      hp3[q].xmin = NULL;                                  /* (BBPGDf only) */
+      hp3[q].gmin = NULL;
     }
     hipMemcpy(dp3, hp3, sizeof(hp3), hipMemcpyHostToDevice);
     const int flags = 1;                                   /* hipMalloc + even n: 16-byte aligned rows */

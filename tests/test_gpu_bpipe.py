@@ -352,6 +352,30 @@ def test_anti_relaxation_apgd_in_both_forms(n, count):
             _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(37, 9), (120, 40), (700, 8), (2049, 4)])
+def test_bbpgdf_fallback_variant_in_both_forms(n, count):
+    """CCQPSolverBBPGDf: best iterate kept, restart from it when the step length collapses.  On convex problems the
+    restart never fires; INDEFINITE matrices (A - shift I inside a box) make the BB step negative in most iterations,
+    so the fall-back branch runs hundreds of times -- still bit for bit the host loop, at every budget."""
+    import torch
+    from ccqppy_amd.operators import DenseOperator
+    probs = _problems(n, count, 8300 + n)
+    for shift in (0.0, 1.8, 2.2):
+        ps = []
+        for p, (op, b, x0, P) in enumerate(probs):
+            A = op.A - shift * torch.eye(n, dtype=torch.float64, device=op.A.device)
+            ps.append((DenseOperator(A), b, x0, P if (shift == 0.0 or P is not None) else _sets(n, 0)))
+        tols = [1e-8] * count
+        for cap in ((5000,) if shift == 0.0 else (60, 7, 150)):
+            ref = _reference(ps, tols, cap, "BBPGDf")
+            for single in (True, False):
+                got = _batch(ps, tols, cap, "BBPGDf", single_launch=single)
+                for a, c in zip(ref, got):
+                    _same(a, c)
+            if shift == 2.2 and cap == 150:
+                assert any(not r.solution_converged for r in ref)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):
@@ -368,7 +392,7 @@ def test_rejects_what_it_cannot_run():
     op, b, _ = problems.random_problem(64, 1)
     op2, b2, _ = problems.random_problem(96, 2)
     with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGDf(1e-8), [(op, b, None, None)])
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverSPG(1e-8), [(op, b, None, None)])
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(1e-8, reuse_matvec=True), [(op, b, None, None)])
     with pytest.raises(TypeError):

@@ -1,5 +1,5 @@
 """GPU: seeded differential fuzzing of the lock-step schedulers (batch.solve_batch_pipelined) against per-problem
-solve().  Random solver (PGD / BBPGD / APGD / anti-relaxation APGD / MPRGP), batch composition (sizes 65..1300 mixed in one call, so several
+solve().  Random solver (PGD / BBPGD / BBPGDf / APGD / anti-relaxation APGD / MPRGP), batch composition (sizes 65..1300 mixed in one call, so several
 lock-step groups), elementwise sets with array / scalar / integer / default bounds, warm starts, per-problem
 tolerances, matvec budget, run-ahead depth and matvec tuning word.  Every result must be bitwise the one of the
 problem's own solve() (x, residual, converged flag, reported and executed MV counts)."""
@@ -57,7 +57,7 @@ def test_lockstep_equals_individual_solves(case):
     import torch
     from ccqppy_amd import batch, problems, solvers
     rng = np.random.default_rng(9000 + case)
-    name = ["BBPGD", "APGD", "MPRGP", "APGDAntiRelaxation", "PGD"][case % 5]
+    name = ["BBPGD", "APGD", "MPRGP", "APGDAntiRelaxation", "PGD", "BBPGDf"][case % 6]
     base = getattr(solvers, "CCQPSolver" + name)
     cls = base if name != "PGD" else (lambda tol, cap: base(tol, cap, 0.3))
     sizes = rng.choice([65, 96, 130, 257, 512, 777, 1300], size=rng.integers(1, 4), replace=False)
