@@ -47,7 +47,7 @@ enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 // Candidate steps alpha_f * 0.5^k per feasibility pass.  The host-driven loop tries 8 per launch; the values visited
 // and the first feasible one are the same whatever the pass size, and a larger pass saves whole rounds (the search
 // typically needs ~20 halvings).  The host loop gives up after 151 passes of 8 = candidates 0..1207.
-#define MP_STEPS 24
+#define MP_STEPS 24     // a multiple of 8
 #define MP_MAX_CANDIDATES 1208
 
 __device__ __forceinline__ double mp_lin(double a, double x, double b, double y) {   // axpby_body, one element
@@ -283,9 +283,32 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
       }
       case ST_ADXC:
       case ST_ADXH: {                         // :1129 / :1163, and the tail's residual
-        v[0] = dot_body(q.dx, q.dx, n, chunk, bx, lds4);
-        v[1] = dot_body(q.dx, q.Adx, n, chunk, bx, lds4);
-        v[2] = residual_body(sg, xk1, gk1, q.c, gd, chunk, bx, lds4);
+        {
+          // dot_body twice and residual_body in one pass, one set of barriers
+          const double* __restrict__ dxv = q.dx;
+          const double* __restrict__ Adxv = q.Adx;
+          const double c = q.c;
+          CHUNK_RANGE(n)
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+          for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+            const double di = dxv[i];
+            a0 = fma(di, di, a0);
+            a1 = fma(di, Adxv[i], a1);
+            const double xi = xk1[i];
+            const double t = gd * gk1[i];
+            const double u = xi - t;
+            const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+            const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+            const double pr = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+            const double dd = xi - pr;
+            const double w = c * dd;
+            a2 = fma(w, w, a2);
+          }
+          v[0] = a0;
+          v[1] = a1;
+          v[2] = a2;
+          ccqp_block_sum_multi<3>(v);
+        }
         if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, is_last_p)) return;
         if (threadIdx.x == 0) {
           s[MP_S0] = v[0];
@@ -310,7 +333,21 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
       }
     } else if (st == ST_FEAS_NOW) {           // :1112-1118, MP_STEPS candidates per pass
       const double a0 = s[MP_AF];
-      for (int k = 0; k < MP_STEPS; ++k) v[k] = feasible_body(sg, xk, q.p, a0, k, chunk, bx, lds4);
+      {
+        // feasible_body for the MP_STEPS candidates with ONE pair of barriers instead of one per candidate: the wave
+        // sums go to LDS as they come, the four of each candidate are added (wave 0..3, as ccqp_block_sum) at the end
+        __shared__ double wsum[4 * MP_STEPS];
+        const int wv = threadIdx.x >> 6;
+        for (int k = 0; k < MP_STEPS; ++k) {
+          const double acc = ccqp_wave_sum(feasible_thread_count(sg, xk, q.p, a0, k, chunk, bx));
+          if ((threadIdx.x & 63) == 0) wsum[4 * k + wv] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+          for (int k = 0; k < MP_STEPS; ++k)
+            v[k] = ((wsum[4 * k] + wsum[4 * k + 1]) + wsum[4 * k + 2]) + wsum[4 * k + 3];
+        __syncthreads();
+      }
       if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, is_last_p)) return;
       if (threadIdx.x == 0) {
         double af = a0;

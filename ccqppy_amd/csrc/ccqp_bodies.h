@@ -137,14 +137,16 @@ __device__ __forceinline__ void bb_tail_body(const ccqp_segk& sg, const double* 
     a1 = fma(dx, dx, a1);
     a2 = fma(dx, dg, a2);
   }
-  *res2 = ccqp_block_sum(a0, lds4);
-  *dxdx = ccqp_block_sum(a1, lds4);
-  *dxdg = ccqp_block_sum(a2, lds4);
+  double v[3] = {a0, a1, a2};
+  ccqp_block_sum_multi<3>(v);                 // (same bits as three ccqp_block_sum calls, a third of the barriers)
+  *res2 = v[0];
+  *dxdx = v[1];
+  *dxdg = v[2];
 }
 
-// count of i with not isclose(yf_i, P(yf)_i), yf = x - (alpha0 * 0.5^k)*p
-__device__ __forceinline__ double feasible_body(const ccqp_segk& sg, const double* x, const double* p,
-                                                double alpha0, int k, int64_t chunk, int bx, double* lds4) {
+// count of i with not isclose(yf_i, P(yf)_i), yf = x - (alpha0 * 0.5^k)*p: this thread's share of block bx
+__device__ __forceinline__ double feasible_thread_count(const ccqp_segk& sg, const double* x, const double* p,
+                                                        double alpha0, int k, int64_t chunk, int bx) {
   double alpha = alpha0;
   for (int j = 0; j < k; ++j) alpha *= 0.5;  // the reference's `alpha_f *= 0.5`, k times
   CHUNK_RANGE(sg.dim)
@@ -157,7 +159,12 @@ __device__ __forceinline__ double feasible_body(const ccqp_segk& sg, const doubl
     const double pr = ccqp_proj_elem(sg.kind, sg.flags, yf, lb, ub);
     acc += ccqp_isclose(yf, pr) ? 0.0 : 1.0;
   }
-  return ccqp_block_sum(acc, lds4);
+  return acc;
+}
+
+__device__ __forceinline__ double feasible_body(const ccqp_segk& sg, const double* x, const double* p,
+                                                double alpha0, int k, int64_t chunk, int bx, double* lds4) {
+  return ccqp_block_sum(feasible_thread_count(sg, x, p, alpha0, k, chunk, bx), lds4);
 }
 
 // xp = P(x); psi = isclose(x,xp)*g; w = 1 - isclose; returns sum (x-xp)^2

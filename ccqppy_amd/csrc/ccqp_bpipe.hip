@@ -451,8 +451,11 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
   const double* __restrict__ bv = q.b;
   const double* __restrict__ xk = q.X[it & 1];
   {
+    // one pass: the dot products and the residual (residual_body's arithmetic, element for element)
+    const double* __restrict__ g1 = q.g1;
+    const double c = q.c;
     CHUNK_RANGE(n)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
       const double xi = x1[i], yi = yk[i], bi = bv[i];
       if (ar) {                                          // gk.(x_{k+1} - x_k), solvers.py:510
@@ -468,15 +471,26 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       const double d = xi - yi;
       a4 = fma(gk[i], d, a4);
       a5 = fma(d, d, a5);
+      {
+        const double t = gd * g1[i];
+        const double u = xi - t;
+        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+        const double pr = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+        const double dd = xi - pr;
+        const double w = c * dd;
+        a7 = fma(w, w, a7);
+      }
     }
-    v[0] = ccqp_block_sum(a0, lds4);
-    v[1] = ccqp_block_sum(a1, lds4);
-    v[2] = ccqp_block_sum(a2, lds4);
-    v[3] = ccqp_block_sum(a3, lds4);
-    v[4] = ccqp_block_sum(a4, lds4);
-    v[5] = ccqp_block_sum(a5, lds4);
-    v[6] = residual_body(sg, x1, q.g1, q.c, gd, chunk, bx, lds4);
-    v[7] = ar ? ccqp_block_sum(a6, lds4) : 0.0;
+    v[0] = a0;
+    v[1] = a1;
+    v[2] = a2;
+    v[3] = a3;
+    v[4] = a4;
+    v[5] = a5;
+    v[6] = a7;
+    v[7] = a6;
+    ccqp_block_sum_multi<8>(v);
   }
   if (!bp_meet(q.partials, q.counter, nblk, ar ? 8 : 7, v, lds4, is_last_p)) return;
   if (threadIdx.x == 0) {

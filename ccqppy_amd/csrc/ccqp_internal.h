@@ -99,6 +99,26 @@ __device__ __forceinline__ double ccqp_block_sum(double v, double* lds4) {
   return s;
 }
 
+// K sums at once: the same wave butterflies and the same (wave 0..3) order per value as K calls of ccqp_block_sum,
+// hence the same bits, but two workgroup barriers instead of 2 K (results valid in thread 0).
+template <int K>
+__device__ __forceinline__ void ccqp_block_sum_multi(double* v) {
+  __shared__ double lds[4 * K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = ccqp_wave_sum(v[k]);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[4 * k + wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = ((lds[4 * k] + lds[4 * k + 1]) + lds[4 * k + 2]) + lds[4 * k + 3];
+  }
+  __syncthreads();
+}
+
 // Arrival counters of a reduction workspace (`partials` of a context): they sit behind the partial sums.
 __device__ __forceinline__ unsigned* ccqp_red_counters(double* partials) {
   return reinterpret_cast<unsigned*>(partials + (size_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK);
