@@ -513,6 +513,15 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     if A.stride(2) != 1 or A.stride(1) < A.shape[2]:
         A = A.contiguous()
     B, n = int(A.shape[0]), int(A.shape[1])
+    if B == 0:                                          # an empty batch
+        out = StackedResult()
+        out.solution = torch.empty((0, n), dtype=torch.float64, device=eng.device)
+        out.residual = np.zeros(0)
+        out.converged = np.zeros(0, dtype=bool)
+        out.num_matrix_vector_multiplications = np.zeros(0, dtype=np.int64)
+        out.executed_matrix_vector_multiplications = np.zeros(0, dtype=np.int64)
+        out.solution_time = time.time() - t0
+        return out
     b = eng.to_device(b).reshape(B, n)
     if x0 is not None:
         x0 = eng.to_device(x0).reshape(B, n)

@@ -117,6 +117,8 @@ def test_stacked_forms_of_the_inputs():
     from ccqppy_amd import solvers
     r3 = batch.solve_stacked(solvers.CCQPSolverBBPGD, A, b, lower=lo, upper=up)
     assert torch.equal(r.solution, r3.solution) and r3.converged.all()
+    empty = batch.solve_stacked("APGD", A[:0], b[:0], lower=lo, upper=up)
+    assert empty.solution.shape == (0, n) and len(empty.converged) == 0
     with pytest.raises(TypeError):
         batch.solve_stacked("SPG", A, b)
     with pytest.raises(ValueError):
