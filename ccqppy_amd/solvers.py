@@ -521,9 +521,33 @@ class _BBPGDCore(CCQPSolverBase):
         eng.mv_executed += k
         return X[k % 3], (np.sqrt(res2) if kf >= 1 else res), 1 + k
 
+    def _lockstep_fallback_variant(self, run):
+        """BBPGDf with pipeline=True: the whole solve on the device as a lock-step batch of one (dense operator,
+        n <= 2048, elementwise set); None where that does not apply or the device budget was reached."""
+        from ._record import RecordingEngine
+        from .lockstep import _bpipe_run, _spec_from_items, stats
+        from .operators import DenseOperator
+        op, eng = run.op, run.eng
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and hasattr(run.P, "_dev_bb_tail")
+                and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
+            return None
+        max_mv = self.max_matrix_vector_multiplications
+        done, final, sols, res, todo = _bpipe_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n),
+                                                  run.n, max_mv, 4)
+        if len(todo):
+            stats["fallback_solves"] += 1
+            return None
+        k = int(final[0])
+        eng.mv_executed += 1 if (done[0] and k == 0) else 2 + k
+        return sols[0], res[0], 1 + k
+
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
+        if self.pipeline and self._fallback:
+            out = self._lockstep_fallback_variant(run)
+            if out is not None:
+                return out
         mv_count = 0
         xk = run.copy(run.x0)
         xkm1 = run.copy(run.x0)

@@ -376,6 +376,25 @@ def test_bbpgdf_fallback_variant_in_both_forms(n, count):
                 assert any(not r.solution_converged for r in ref)
 
 
+def test_single_solve_bbpgdf_pipeline_option():
+    """CCQPSolverBBPGDf(..., pipeline=True) = the lock-step scheduler with a batch of one (n <= 2048)."""
+    import torch
+    from ccqppy_amd import lockstep, solvers
+    from ccqppy_amd.operators import DenseOperator
+    for n in (90, 700, 3000):
+        for p, (op, b, x0, P) in enumerate(_problems(n, 4, 90 + n)):
+            for shift in (0.0, 2.2):
+                A = DenseOperator(op.A - shift * torch.eye(n, dtype=torch.float64, device=op.A.device))
+                P2 = P if P is not None else _sets(n, 0)
+                for cap in ((5000, 9) if shift == 0.0 else (80, 9)):
+                    before = lockstep.stats["fallback_solves"]
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        a = solvers.CCQPSolverBBPGDf(1e-8, cap).solve(A, b, x0=x0, convex_proj_op=P2)
+                        c = solvers.CCQPSolverBBPGDf(1e-8, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P2)
+                    _same(a, c)
+                    assert lockstep.stats["fallback_solves"] == before       # (n = 3000: the host loop, by the gate)
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):
