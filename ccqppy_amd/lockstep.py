@@ -1,5 +1,6 @@
 """Lock-step batch schedulers: many dense problems of one size advance together, with every scalar and every branch
-decision of the solver on the device (csrc/ccqp_bpipe.hip: BBPGD and APGD; csrc/ccqp_bmprgp.hip: MPRGP).
+decision of the solver on the device (csrc/ccqp_bpipe.hip: PGD / BBPGD / BBPGDf and APGD / anti-relaxation APGD;
+csrc/ccqp_bmprgp.hip: MPRGP).
 
   solve_batch_pipelined   a list of (A, b, x0, set) problems -> solver objects (grouped by size)
   solve_stacked           stacked tensors A (B, n, n), b (B, n) -> stacked results, no per-problem host work
@@ -25,6 +26,7 @@ stats = {"fallback_solves": 0}
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
 _BSOLVE_MAX_N_MPRGP = 128 # MPRGP: likewise
+_BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
 
 
 def _device_budget(n):
@@ -35,16 +37,14 @@ def _device_budget(n):
     return int(min(20000, max(256, 2.0 / max(15e-6, 8.0 * n * n / 20e9))))
 
 
-_BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
-
-
 def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0, single_launch=None,
-                          stats=None):
-    """Many dense problems (grouped by size n; one lock-step run per size), solved by BBPGD (solvers.py:560-693), APGD (:197-367) or MPRGP
-    (:1002-1224) in lock-step: three launches per iteration (APGD: per matvec; MPRGP: five) for the whole batch, step
-    lengths, line search, branch decisions and exit tests computed on the device (ccqp_bpipe_* / ccqp_bapgd_* /
-    ccqp_bmprgp_*), the host only polls a progress word.  The schedulers above are bound by ~20 us of Python per problem and scalar read at n <= 4096;
-    this one is not.
+                          timing=None):
+    """Many dense problems (grouped by size n: one run per size), each solved by PGD, BBPGD, BBPGDf, APGD, anti-relaxation
+    APGD or MPRGP with every scalar and branch decision on the device (ccqp_bpipe_* / ccqp_bapgd_* / ccqp_bmprgp_*):
+    lock-step rounds of 3-5 launches per matvec for the whole batch while the host only polls a progress word, or --
+    small matrices (BBPGD-type n <= 512, APGD / MPRGP n <= 128 by default; `single_launch` forces it on, up to
+    n = 2048, or off) -- ONE launch in which every problem is solved inside its own workgroup.  The host-driven
+    schedulers of batch.py are bound by ~20 us of Python per problem and scalar read at n <= 4096; this one is not.
 
     make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD,
                   CCQPSolverAPGDAntiRelaxation or CCQPSolverMPRGP (no matvec reuse), all of one class with the same
@@ -53,12 +53,10 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
     and MV count are bit for bit those of `make_solver().solve(A, b, x0, convex_proj_op)`.  `solution_time` is
-    the wall-clock of the whole batch.  BBPGD on small matrices (n <= 512 by default; `single_launch` forces it on,
-    up to n = 2048, or off) runs as ONE launch, one workgroup per problem, instead of lock-step rounds -- the same
-    bits again.  (APGD / MPRGP problems that would run into the matvec budget are handed to
-    plain solve(), whose exit paths at the budget have quirks of their own.)  `stats`, if given, receives the
-    wall-clock split {staging_s: argument checks and per-problem staging on the host, run_s: tables, launches, wait,
-    result objects}."""
+    the wall-clock of the whole batch.  Problems that would run into the matvec budget (APGD / MPRGP, whose exit paths
+    at the budget have quirks of their own) or into a single-launch kernel's own budget are handed to plain solve()
+    and counted in `lockstep.stats`.  `timing`, if given, receives the wall-clock split {staging_s: argument checks
+    and per-problem staging on the host, run_s: tables, launches, wait, result objects}."""
     from . import _lib
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
@@ -114,8 +112,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
             for lo in range(0, len(items), _BPIPE_MAX):
                 group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
     dt = time.time() - t0
-    if stats is not None:                               # host-side staging of the problem list vs the runs proper
-        stats.update(staging_s=t1 - t0, run_s=time.time() - t1)
+    if timing is not None:                              # host-side staging of the problem list vs the runs proper
+        timing.update(staging_s=t1 - t0, run_s=time.time() - t1)
     for s in solvers:
         s._solution_time = dt
     return solvers
