@@ -271,7 +271,8 @@ int ccqp_pipe_graph_launch(ccqp_ctx* ctx, void* graph_exec, void* stream);
 int ccqp_pipe_graph_destroy(void* graph_exec);
 
 /* ---- opt-in: MANY equal-size dense BBPGD solves (solvers.py:560-693) in lock-step, scalars on the device ---
- * The pipelined iteration above, batched: blockIdx.y = problem, three launches per iteration for the whole batch,
+ * The pipelined iteration above, batched: blockIdx.y = problem, three launches per iteration for the whole batch
+ * (four for the BBPGDf variant),
  * a converged problem's blocks leave at once.  `dev_probs` is a DEVICE array of `count` descriptors; `dev_batch`
  * two device words owned by the caller.  Per-problem slab (>= 52 doubles, zeroed before start): slots 0..2 as
  * ccqp_bb_tail_elementwise_f64, 48..51 = {alpha, converged, iterations finished, res2}.  Each problem's results are
@@ -358,8 +359,8 @@ int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
  * state), three decision stages (proportioning test :1090-1099; alpha_cg :1106 and the feasible-step search
  * :1112-1118; the expansion half-step's BB dots :1146-1147; the tail :1184-1192) and the elementwise update they
  * ask for.  Slab (>= 56 doubles, zeroed): 0..2 the tail's three scalars, 8 n.g, 10 |x - P(x)|^2, 16..23 the first
- * eight feasibility counts of the last pass, 32..37 {alpha_bb, alpha_cg, p.Ap, alpha_f, half-step alpha, candidates tried}, 38..40 {state, action,
- * outer iterations}, 49 {0 running | 1 converged | 2 the feasibility search cannot terminate | 3 a proportioning step
+ * eight feasibility counts of the last pass, 32..37 {alpha_bb, alpha_cg, p.Ap, alpha_f, half-step alpha, candidates
+ * tried}, 38..40 {state, action, outer iterations}, 49 {0 running | 1 converged | 2 the feasibility search cannot terminate | 3 a proportioning step
  * (:1165-1182, unreachable on finite data) is due: left to the host-driven loop}, 50 the reference's
  * mv_count, 51 res2, 52 matvecs executed.  A converged problem's solution is X[(outer iterations + 1) % 2]. */
 typedef struct ccqp_pmprgp {
