@@ -17,8 +17,11 @@ Extra objects on the JSON line:
                   duration measured with HIP events on the launch stream inside the timed region,
                   against the 8 TB/s HBM3E peak.
   cpu_baseline -- the numpy oracle (oracle/cpu_ref.py, a port of the reference; OpenBLAS threads =
-                  host cores) solving a bounded sample (n = 32768, same generator / solver settings)
-                  on the GPU box's host, N = 1 only; reported in n=131072-equivalent matvecs/s.
+                  host cores) solving THE SAME problem (the device matrix copied to the host, n = 131072,
+                  ~60 s of host work) on the GPU box's host, N = 1 only; if the host has less than ~160 GiB
+                  of free RAM the sample is n = 65536 and the figure is scaled by bytes (stated in `sample`).
+For N > 1 the roofline object also carries `exchange_ms_per_mv` (HIP events around the per-matvec vector
+exchange), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange time) and `rccl_ranks`.
 """
 import argparse
 import contextlib
@@ -43,26 +46,62 @@ def mv_bytes(rows, n):
     return 8.0 * (rows * n + n + rows)
 
 
-def pmc_traffic(bytes_per_launch):
-    """HBM bytes per GEMV launch from the committed rocprofv3 PMC summary of this same workload
+def pmc_traffic(bytes_per_launch, kernel_prefix="gemv_stream_kernel"):
+    """HBM bytes per GEMV launch from a committed rocprofv3 PMC summary of this same launch
     (profiles/*_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes).
-    PMC counters cannot be read from inside the timed run, so this is the tracked measurement of
-    the identical launch (same kernel, same n, same rows); None if no matching profile exists."""
+    PMC counters cannot be read from inside the timed run, so this is a LOOK-UP, reported as
+    `traffic_from_profile`, and only if the profile was taken of the same kernel source: the summary records
+    the sha1 of the matvec sources (tools/summarize_prof.py) and a mismatch -- the kernel changed after the
+    profile was taken -- yields None."""
     import glob
+    cur = gemv_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
         for k, e in d.items():
-            if "gemv" in k and e.get("algorithmic_bytes_per_launch") == bytes_per_launch \
+            if not isinstance(e, dict):
+                continue
+            if kernel_prefix in k and e.get("algorithmic_bytes_per_launch") == bytes_per_launch \
                     and "hbm_traffic_bytes_per_launch" in e:
-                return e["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                if e.get("kernel_source_sha1") not in (None, cur):
+                    continue                                   # stale: the kernel was edited since
+                return e["hbm_traffic_bytes_per_launch"], {
+                    "file": os.path.relpath(f, ROOT), "kernel": k,
+                    "kernel_source_sha1": e.get("kernel_source_sha1"), "current_source_sha1": cur,
+                    "verified_same_source": e.get("kernel_source_sha1") == cur}
     return None, None
 
 
-def cpu_baseline(n_cpu, seed, tol, max_mv, n_metric):
-    """Time the oracle on the host cores on a bounded sample of the same workload."""
+def gemv_source_hash():
+    """sha1 over the sources the dense matvec kernel is built from."""
+    import hashlib
+    h = hashlib.sha1()
+    for rel in ("ccqppy_amd/csrc/ccqp_gemv.hip", "ccqppy_amd/csrc/ccqp_bodies.h", "ccqppy_amd/csrc/ccqp_internal.h"):
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def host_available_gib():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2.0 ** 30
+    except Exception:  # noqa: BLE001
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 2.0 ** 20
+        except Exception:  # noqa: BLE001
+            pass
+    return 0.0
+
+
+def cpu_baseline(op, b, x_gpu, mv_gpu, n_cpu, seed, tol, max_mv, n_metric):
+    """Time the oracle on the host cores.  n_cpu == n_metric: the SAME problem as the GPU solved (the device matrix
+    is copied to the host in row chunks; copy time reported separately, never part of the rate); otherwise a
+    smaller sample of the same generator / settings, scaled by bytes."""
     from ccqppy_amd import problems
     from oracle import cpu_ref
     try:
@@ -70,27 +109,51 @@ def cpu_baseline(n_cpu, seed, tol, max_mv, n_metric):
         cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] + [1])
     except Exception:  # noqa: BLE001
         cores = os.cpu_count()
-    op, b, _ = problems.random_problem(n_cpu, seed)
-    A = op.A.cpu().numpy()
+    same = n_cpu == n_metric and op is not None
+    if not same:
+        del op
+        torch.cuda.empty_cache()
+        op, b, _ = problems.random_problem(n_cpu, seed)
+    t0 = time.perf_counter()
+    A = np.empty((n_cpu, n_cpu), dtype=np.float64)
+    step = 8192
+    for r0 in range(0, n_cpu, step):
+        A[r0:r0 + step] = op.A[r0:r0 + step].cpu().numpy()
+        if (r0 // step) % 4 == 3:
+            print("[bench] cpu_baseline: copied rows %d / %d to the host" % (r0 + step, n_cpu), file=sys.stderr, flush=True)
+    t_copy = time.perf_counter() - t0
     bb = b.cpu().numpy()
     del op
     torch.cuda.empty_cache()
     lb, ub = -0.5 * np.ones(n_cpu), 0.5 * np.ones(n_cpu)
-    A.dot(bb)                                             # warm the BLAS thread pool / page in A
+    A[:min(n_cpu, 16384)].dot(bb)                          # warm the BLAS thread pool
+    print("[bench] cpu_baseline: oracle solve at n=%d on %d BLAS threads ..." % (n_cpu, cores), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     r = cpu_ref.solve_apgd(A, bb, tol, max_mv, P=cpu_ref.Box(n_cpu, lb, ub))
     dt = time.perf_counter() - t0
     gbs = r.executed_mv * mv_bytes(n_cpu, n_cpu) / dt / 1e9
-    return {
+    out = {
         "value": gbs * 1e9 / mv_bytes(n_metric, n_metric),
-        "unit": "matvecs/s (n=%d-equivalent: measured solve bytes/s / bytes per n=%d matvec)" % (n_metric, n_metric),
+        "unit": "matvecs/s" if same else
+                "matvecs/s (n=%d-equivalent: measured solve bytes/s / bytes per n=%d matvec)" % (n_metric, n_metric),
         "cores": int(cores),
         "kind": "port",
-        "sample": "oracle/cpu_ref.solve_apgd (numpy+OpenBLAS), n=%d box-QP, tol=%g: %d matvecs in %.2f s = "
-                  "%.1f matvecs/s at n=%d (%.1f GB/s)" % (n_cpu, tol, r.executed_mv, dt, r.executed_mv / dt,
-                                                         n_cpu, gbs),
+        "sample": "oracle/cpu_ref.solve_apgd (numpy+OpenBLAS), %s n=%d box-QP, tol=%g: %d matvecs in %.2f s = "
+                  "%.2f matvecs/s at n=%d (%.1f GB/s)" % ("the metric's own problem," if same else "smaller sample,",
+                                                         n_cpu, tol, r.executed_mv, dt, r.executed_mv / dt, n_cpu, gbs),
+        "n": n_cpu,
+        "reported_mv": int(r.solution_num_matrix_vector_multiplications),
+        "solve_s": dt,
+        "matrix_copy_to_host_s": t_copy,
         "host_cpus": os.cpu_count(),
     }
+    if same and x_gpu is not None:
+        # free parity evidence: the GPU solve of the timed region against the oracle on the same matrix
+        out["gpu_vs_oracle"] = {
+            "mv_equal": int(r.solution_num_matrix_vector_multiplications) == int(mv_gpu),
+            "rel_diff_x": float(np.linalg.norm(x_gpu - r.solution) / np.linalg.norm(r.solution)),
+        }
+    return out
 
 
 def main():
@@ -104,7 +167,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
-    ap.add_argument("--cpu-n", type=int, default=65536, help="size of the CPU-baseline sample (0 = skip); 65536: ~20 s of host work")
+    ap.add_argument("--cpu-n", type=int, default=-1,
+                    help="size of the CPU-baseline problem (0 = skip); default: the metric's own n when the host has "
+                         ">= 160 GiB of free RAM (~30 s copy + ~60 s oracle solve), else 65536")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +222,10 @@ def main():
         step()
     barrier()
     eng.gemv_events = []
+    exch = getattr(op, "exchange", None)
+    if exch is not None:
+        exch.events = []
+        exch.calls = 0
     mv0 = eng.mv_executed
     t0 = time.perf_counter()
     last = None
@@ -168,10 +237,25 @@ def main():
     events = eng.gemv_events
     eng.gemv_events = None
     gemv_ms = [a.elapsed_time(b_) for a, b_ in events]
+    exch_ms = []
+    if exch is not None:
+        exch_ms = [a.elapsed_time(b_) for a, b_ in exch.events]
+        exch.events = None
+    rccl_ranks = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # ranks that actually took part in a device collective (one all_gather_into_tensor of the rank ids)
+        ids = torch.full((world,), -1, dtype=torch.int64, device="cuda")
+        me = torch.tensor([rank], dtype=torch.int64, device="cuda")
+        if backend == "nccl":
+            torch.distributed.all_gather_into_tensor(ids, me)
+        else:
+            parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            torch.distributed.all_gather(parts, me.cpu())
+            ids = torch.cat(parts)
+        rccl_ranks = int((ids.cpu() == torch.arange(world)).sum()) if backend == "nccl" else 0
 
     # outside the timed region, informational: the opt-in NON-parity APGD mode that obtains A.y_{k+1} from
     # A.x_{k+1} and A.x_k (one matvec per iteration instead of two) -- never part of `value`
@@ -207,6 +291,7 @@ def main():
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
         achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(mv_bytes(rows_local, n))
+        steps = max(args.steps, 1)
         line = {
             "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
             "value": mv_exec / elapsed,
@@ -248,18 +333,32 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic if (traffic_src or {}).get("verified_same_source") else None,
+                "traffic_from_profile": traffic,
                 "traffic_source": traffic_src,
                 "bytes_per_launch": mv_bytes(rows_local, n),
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(gemv_ms),
                 "solve_level_frac": mv_exec * mv_bytes(rows_local, n) / elapsed / 1e9 / HBM_PEAK_GBS,
+                "gemv_ms_per_step": float(np.sum(gemv_ms)) / steps if gemv_ms else None,
+                # N > 1: where the rest of a step goes (rank 0's own clock; the exchange includes waiting for the
+                # slowest rank's slab)
+                "exchange_ms_per_mv": float(np.mean(exch_ms)) if exch_ms else None,
+                "exchange_ms_per_step": float(np.sum(exch_ms)) / steps if exch_ms else None,
+                "vector_work_ms_per_step": (1e3 * elapsed - float(np.sum(gemv_ms)) - float(np.sum(exch_ms))) / steps
+                                           if gemv_ms else None,
+                "rccl_ranks": rccl_ranks,
+                "exchange_backend": None if exch is None else exch.backend,
             },
         }
-        if world == 1 and args.cpu_n > 0:
-            del op
-            torch.cuda.empty_cache()
-            line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.seed, args.tol, args.max_mv, n)
+        cpu_n = args.cpu_n
+        if cpu_n < 0:
+            need = 8.0 * n * n / 2.0 ** 30 + 24.0
+            cpu_n = n if host_available_gib() >= need else min(n, 65536)
+        if world == 1 and cpu_n > 0:
+            x_gpu = last.solution.cpu().numpy() if isinstance(last.solution, torch.Tensor) else np.asarray(last.solution)
+            line["cpu_baseline"] = cpu_baseline(op, b, x_gpu, last.solution_num_matrix_vector_multiplications, cpu_n,
+                                                args.seed, args.tol, args.max_mv, n)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

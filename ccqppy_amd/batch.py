@@ -107,11 +107,15 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
     solved = None
     if fused == "pipelined":
         solved = solve_batch_pipelined(make_solver, probs, device=device)
-    elif fused == "auto":
-        try:                                            # (its argument checks precede any GPU work)
+    elif fused == "auto" and probs:
+        # decided on the argument check alone; whatever the lock-step run itself raises propagates
+        from . import lockstep
+        made = [make_solver() for _ in probs]           # made ONCE: make_solver may be stateful
+        make_solver = iter(made).__next__
+        if lockstep.why_not_pipelined(made, probs, get_engine(device).device) is None:
             solved = solve_batch_pipelined(make_solver, probs, device=device)
-        except (TypeError, ValueError):
-            solved = None
+        else:
+            lockstep.stats["auto_declined"] += 1
     if solved is None and fused:
         solved = solve_batch_fused(make_solver, probs, lanes=lanes or 32, groups=2, device=device)
     elif solved is None:

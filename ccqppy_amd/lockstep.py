@@ -21,7 +21,7 @@ from ._engine import get_engine
 # Problems the device-resident runs handed back to the host-driven loop (matvec budget reached, device budget of a
 # single-launch kernel, MPRGP's unreachable branches).  The fall-back keeps every result right, so a device-side bug
 # can hide behind it: the tests assert that this counter does not move where no fall-back is expected.
-stats = {"fallback_solves": 0}
+stats = {"fallback_solves": 0, "auto_declined": 0}
 
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
@@ -35,6 +35,53 @@ def _device_budget(n):
     interrupted): about two seconds of one workgroup's time, estimated from the chain of an iteration (~15 us) or the
     matrix bytes one CU streams (~20 GB/s).  A problem that needs more goes back to the host-driven loop."""
     return int(min(20000, max(256, 2.0 / max(15e-6, 8.0 * n * n / 20e9))))
+
+
+def why_not_pipelined(solvers, problems, device):
+    """Argument check of solve_batch_pipelined WITHOUT any staging or GPU work: None if the lock-step scheduler can take
+    the batch, else the TypeError / ValueError it would raise (returned, not raised).  `solve_batch_sharded(fused="auto")`
+    decides on this alone, so that nothing raised while a batch is being staged or run can be mistaken for "does not
+    apply" and silently re-solved by another scheduler."""
+    from . import _lib
+    from . import solution_spaces as ss
+    from .operators import DenseOperator, as_operator
+    from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
+                          CCQPSolverMPRGP, CCQPSolverPGD)
+    kind = type(solvers[0])
+    if kind not in (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
+                    CCQPSolverPGD) or getattr(solvers[0], "reuse_matvec", False):
+        return TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
+                         "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
+    max_mv = solvers[0].max_matrix_vector_multiplications
+    for s, (A, b, x0, P) in zip(solvers, problems):
+        if type(s) is not kind or getattr(s, "reuse_matvec", False):
+            return TypeError("solve_batch_pipelined: one solver class for the whole batch")
+        if s.max_matrix_vector_multiplications != max_mv:
+            return ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
+        if hasattr(A, "matvec") and hasattr(A, "engine"):
+            op_ok = isinstance(A, DenseOperator) and A.rows == A.n
+            n = getattr(A, "n", None)
+            dev = A.A.device if op_ok else None
+        else:
+            op_ok = getattr(A, "ndim", None) == 2 and A.shape[0] == A.shape[1] and \
+                getattr(A, "layout", torch.strided) == torch.strided and not hasattr(A, "tocsr")
+            n = A.shape[1] if op_ok else None
+            dev = A.device if isinstance(A, torch.Tensor) and A.is_cuda else None
+        if not op_ok:
+            return TypeError("solve_batch_pipelined needs square dense operators")
+        if b.shape[0] != n:
+            return ValueError("solve_batch_pipelined: b does not match A")
+        if dev is not None and dev != device:
+            return ValueError("solve_batch_pipelined: operator on another device")
+        P = P if P is not None else ss.IdentityProjOp(n)
+        if not hasattr(P, "_dev_bb_tail"):
+            return TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
+        if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
+            # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
+            # sequential-sum kernels of the literal path)
+            return TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
+                             % _lib.SMALL_SEG_MAX)
+    return None
 
 
 def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=4, tune=0, single_launch=None,
@@ -70,33 +117,16 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
-                    CCQPSolverPGD) or getattr(solvers[0], "reuse_matvec", False):
-        raise TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
-                        "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
+    reason = why_not_pipelined(solvers, problems, eng.device)
+    if reason is not None:
+        raise reason
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # n -> items, in order of first appearance
     for s, (A, b, x0, P) in zip(solvers, problems):
-        if type(s) is not kind or getattr(s, "reuse_matvec", False):
-            raise TypeError("solve_batch_pipelined: one solver class for the whole batch")
-        if s.max_matrix_vector_multiplications != max_mv:
-            raise ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
         op = as_operator(A)
-        if not isinstance(op, DenseOperator) or op.rows != op.n:
-            raise TypeError("solve_batch_pipelined needs square dense operators")
         n = op.n
-        if b.shape[0] != n:
-            raise ValueError("solve_batch_pipelined: b does not match A")
-        if op.A.device != eng.device:
-            raise ValueError("solve_batch_pipelined: operator on another device")
         P = P if P is not None else ss.IdentityProjOp(n)
-        if not hasattr(P, "_dev_bb_tail"):
-            raise TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
-        if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
-            # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
-            # sequential-sum kernels of the literal path)
-            raise TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
-                            % _lib.SMALL_SEG_MAX)
+        P._refresh()
         bd = eng.to_device(b).reshape(-1)
         by_size.setdefault(n, []).append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
                                           isinstance(b, torch.Tensor), (A, b, x0, P)))

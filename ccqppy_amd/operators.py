@@ -63,7 +63,12 @@ class DenseOperator:
 
 class VectorExchange:
     """Reassembles the replicated n-vector from per-rank row slabs.  Backend-agnostic on purpose:
-    the same code runs over RCCL (device tensors) and, in the CPU test-suite, over gloo."""
+    the same code runs over RCCL (device tensors) and, in the CPU test-suite, over gloo.
+
+    Per matvec the device side issues ONE copy of the own slab into a persistent staging buffer (n/G doubles;
+    send and receive buffers then never alias, whatever the backend's rules about in-place all-gather are) and
+    ONE collective; `events`, when set to a list, receives a (start, end) pair of HIP events per call, recorded
+    on the stream the engine launches on (bench.py: exchange time per matvec)."""
 
     def __init__(self, n, group=None, mode="allgather"):
         import torch.distributed as dist
@@ -77,8 +82,12 @@ class VectorExchange:
         self.mode = mode
         self.even = (n % self.world) == 0
         self._pad = None
+        self._send = None
         backend = dist.get_backend(group)
+        self.backend = backend
         self.stage_cpu = backend != "nccl"   # gloo: stage device tensors through the host (tests only)
+        self.events = None
+        self.calls = 0
 
     def _run(self, fn, t):
         """Run collective `fn` on tensor t, staging through the host when the backend cannot
@@ -90,41 +99,70 @@ class VectorExchange:
         else:
             fn(t)
 
-    def _gather_into(self, full, mine):
-        # the slab is staged in its own small buffer (n/G doubles) so that send and receive buffers
-        # never alias, whatever the backend's rules about in-place all-gather are
-        src = mine.clone()
+    def _staged(self, mine, eng):
+        """The own slab in the persistent send buffer (engine copy kernel; plain torch for CPU tensors)."""
+        if eng is None or not mine.is_cuda:
+            return mine.clone()
+        if self._send is None or self._send.numel() != mine.numel() or self._send.device != mine.device:
+            self._send = torch.empty(mine.numel(), dtype=mine.dtype, device=mine.device)
+        eng.copy(mine, self._send)
+        return self._send
+
+    def _gather_into(self, full, mine, eng):
+        src = self._staged(mine, eng) if mine.device == full.device else mine.clone()
         chunks = list(full.chunk(self.world))
         try:
             self.dist.all_gather_into_tensor(full, src, group=self.group)
         except (RuntimeError, NotImplementedError):
             self.dist.all_gather(chunks, src, group=self.group)
 
-    def __call__(self, y):
+    def __call__(self, y, eng=None):
         """y holds this rank's slab at [row0, row0+rows); on return every rank holds all of y."""
         if self.world == 1:
             return
+        ev = None
+        if self.events is not None and y.is_cuda:
+            st = eng.torch_stream if eng is not None else torch.cuda.current_stream(y.device)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(st)
+        self._exchange(y, eng)
+        self.calls += 1
+        if ev is not None:
+            ev[1].record(st)
+            self.events.append(ev)
+
+    def _exchange(self, y, eng):
         dist = self.dist
         if self.mode == "allreduce":
             # zero everything but the own slab, then sum: adding zeros is exact
-            if self.row0 > 0:
-                y[:self.row0].zero_()
-            if self.row0 + self.rows < self.n:
-                y[self.row0 + self.rows:].zero_()
+            for lo, hi in ((0, self.row0), (self.row0 + self.rows, self.n)):
+                if hi > lo:
+                    if eng is not None and y.is_cuda:
+                        eng.fill(0.0, y[lo:hi])
+                    else:
+                        y[lo:hi].zero_()
             self._run(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group), y)
             return
         if self.even:
-            self._run(lambda t: self._gather_into(t, t[self.row0:self.row0 + self.rows]), y)
+            self._run(lambda t: self._gather_into(t, t[self.row0:self.row0 + self.rows],
+                                                  eng if t.is_cuda else None), y)
             return
         # ragged: gather fixed-size (padded) slabs, then drop the padding
         if self._pad is None or self._pad.device != y.device:
             self._pad = torch.zeros(self.per * self.world, dtype=y.dtype, device=y.device)
         full = self._pad
         lo = self.rank * self.per
-        full[lo:lo + self.rows].copy_(y[self.row0:self.row0 + self.rows])
-        self._run(lambda t: self._gather_into(t, t[lo:lo + self.per]), full)
+        if self.rows:
+            if eng is not None and y.is_cuda:
+                eng.copy(y[self.row0:self.row0 + self.rows], full[lo:lo + self.rows])
+            else:
+                full[lo:lo + self.rows].copy_(y[self.row0:self.row0 + self.rows])
+        self._run(lambda t: self._gather_into(t, t[lo:lo + self.per], eng if t.is_cuda else None), full)
         # rank r's rows sit at [r*per, r*per + rows_r); only the last non-empty rank is short
-        y.copy_(full[:self.n])
+        if eng is not None and y.is_cuda:
+            eng.copy(full[:self.n], y)
+        else:
+            y.copy_(full[:self.n])
 
 
 def _is_sparse_input(A):
@@ -362,7 +400,7 @@ class RowShardedOperator:
             self.A.apply(eng, x, y[sl])
         else:
             eng.gemv(self.A, x, y[sl])
-        self.exchange(y)
+        self.exchange(y, eng)
         if g is not None:
             eng.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
 

@@ -24,7 +24,7 @@ from . import _lib
 from ._engine import get_engine
 
 __all__ = ["ProjOpBase", "IdentityProjOp", "LowerBoundProjOp", "UpperBoundProjOp", "BoxProjOp",
-           "SphereProjOp", "ConeProjOp", "DisjointProjOp"]
+           "SphereProjOp", "ConeProjOp", "DisjointProjOp", "HostCallableProjOp"]
 
 # scalar-slab slots reserved for operator internals (solvers use 0..31)
 _SLOT_NORM2 = 40   # |x_block|^2 of a Sphere/Cone block
@@ -47,6 +47,7 @@ def _is_int(b):
 class ProjOpBase(ABC):
     """Mirror of the reference ABC (solution_spaces.py:9-74)."""
     _kind = None            # CCQP_OP_* for leaf operators
+    _version = 0            # bumped by _refresh() whenever a public parameter was found changed
     _fixed_dim = True       # False: the reference never uses `dim` inside __call__ (Identity/Sphere/Cone)
 
     def __init__(self, embedded_dimension):
@@ -90,7 +91,16 @@ class ProjOpBase(ABC):
             ax.scatter(p[0], p[1] if dim > 1 else 0.0, p[2] if dim > 2 else 0.0)
         plt.show()
 
+    def _refresh(self):
+        """Re-read the operator's public parameters (the reference reads `self.lower_bound`, `self.radius`, ... on
+        every call, solution_spaces.py:200-201,276-277,363-366,430-433,484-492): if they were reassigned or edited
+        IN PLACE since the device copies / descriptors were built, drop those caches.  Called at every public entry
+        point (`op(x)`, `normal_vector`, `projected_gradient`, the start of a solve or of a batch); returns True if
+        something changed.  Nothing can change in between -- one Python thread drives a solve."""
+        return False
+
     def _stage_in(self, x):
+        self._refresh()
         if isinstance(x, torch.Tensor):
             eng = get_engine(x.device if x.is_cuda else None)
         else:
@@ -161,7 +171,46 @@ class _ElementwiseOp(ProjOpBase):
     def _bounds(self):
         return None, None
 
+    @staticmethod
+    def _snapshot(b):
+        """Private copy of a bound for change detection (None / scalars are kept as they are)."""
+        if b is None or _is_scalar(b):
+            return b
+        return np.array(b, copy=True)
+
+    @staticmethod
+    def _unchanged(b, snap):
+        if b is None or _is_scalar(b):
+            if snap is None or _is_scalar(snap):
+                if b is None or snap is None:
+                    return b is snap
+                return type(b) is type(snap) and (b == snap or (b != b and snap != snap)) \
+                    and np.signbit(b) == np.signbit(snap)
+            return False
+        if snap is None or _is_scalar(snap):
+            return False
+        a = np.asarray(b)
+        return a.dtype == snap.dtype and a.shape == snap.shape and \
+            np.ascontiguousarray(a).view(np.uint8).reshape(-1).tobytes() == snap.view(np.uint8).reshape(-1).tobytes()
+
+    def _refresh(self):
+        lb, ub = self._bounds()
+        st = self.__dict__.get("_bounds_state")
+        # the state holds references to the bound objects themselves, so the ids the caches are keyed on cannot be
+        # recycled while the caches live; contents are compared bit for bit against the snapshot taken at upload
+        if st is not None and st[0] is lb and st[1] is ub and self._unchanged(lb, st[2]) \
+                and self._unchanged(ub, st[3]):
+            return False
+        self.__dict__["_bounds_state"] = (lb, ub, self._snapshot(lb), self._snapshot(ub))
+        for k in ("_seg_cache", "_dev_bounds", "_single_tables"):
+            self.__dict__.pop(k, None)
+        if st is not None:
+            self._version = self._version + 1
+        return st is not None
+
     def _seg(self, eng, offset, n):
+        if "_bounds_state" not in self.__dict__:
+            self._refresh()
         lb, ub = self._bounds()
         segs = self.__dict__.setdefault("_seg_cache", {})
         skey = (eng.index, offset, n, id(lb), id(ub))
@@ -349,6 +398,23 @@ class BoxProjOp(_ElementwiseOp):
 class _NormOp(ProjOpBase):
     _fixed_dim = False
 
+    def _param(self):
+        raise NotImplementedError
+
+    def _refresh(self):
+        cur = self._param()
+        st = self.__dict__.get("_param_state")
+        if st is not None and st[0] is cur:
+            return False
+        if st is not None and type(st[0]) is type(cur) and _is_scalar(cur) and st[0] == cur:
+            self.__dict__["_param_state"] = (cur,)
+            return False
+        self.__dict__["_param_state"] = (cur,)
+        self.__dict__.pop("_single_tables", None)
+        if st is not None:
+            self._version = self._version + 1
+        return st is not None
+
     def _seg(self, eng, offset, n):
         raise NotImplementedError
 
@@ -388,6 +454,9 @@ class SphereProjOp(_NormOp):
     @property
     def name(self):
         return "Sphere"
+
+    def _param(self):
+        return self.radius
 
     def _seg(self, eng, offset, n):
         seg = _lib.Seg()
@@ -436,6 +505,9 @@ class ConeProjOp(_NormOp):
     @property
     def name(self):
         return "Cone"
+
+    def _param(self):
+        return self.aspect_ratio
 
     def _seg(self, eng, offset, n):
         mu = self.aspect_ratio
@@ -491,6 +563,21 @@ class DisjointProjOp(ProjOpBase):
             out.extend(op._leaves(offset))
             offset += op.embedded_dimension
         return out
+
+    def _refresh(self):
+        ops = self.proj_ops
+        for op in ops:
+            if isinstance(op, ProjOpBase):
+                op._refresh()
+        # a child may have been refreshed on its own in the meantime (it was called directly): compare versions
+        cur = (ops, tuple(getattr(op, "_version", 0) for op in ops))
+        st = self.__dict__.get("_ops_state")
+        self.__dict__["_ops_state"] = cur
+        if st is None or (st[0] is cur[0] and st[1] == cur[1]):
+            return False
+        self.__dict__.pop("_plans", None)
+        self._version = self._version + 1
+        return True
 
     def _plan(self, eng, for_normal):
         cache = self.__dict__.setdefault("_plans", {})
@@ -561,3 +648,68 @@ class DisjointProjOp(ProjOpBase):
 
     def _block_project(self, eng, x, out, offset, n, want_alias=False):
         raise AssertionError("DisjointProjOp is flattened by _leaves()")
+
+
+# ------------------------------------------------------------------ arbitrary host callables
+class HostCallableProjOp(ProjOpBase):
+    """Any Python callable `x_proj = fn(x)` on numpy arrays as the feasible set of a solve.
+
+    The reference accepts whatever is callable as `convex_proj_op` (solvers.py:115-116 and the same lines of every
+    solver: the object is only ever called, plus `.normal_vector(x)` under MPRGP).  `CCQPSolver*.solve` wraps such an
+    object in this class: every projection copies the vector to the host, calls `fn` there and copies the result
+    back -- two PCIe transfers and a stream synchronisation per projection, i.e. SLOW, and documented as such.  It is
+    what makes a user-defined set run at all; it is not a fallback of any of the seven built-in operators, which
+    never take this route."""
+    _fixed_dim = False
+
+    def __init__(self, embedded_dimension, fn):
+        if not callable(fn):
+            raise TypeError("'%s' object is not callable" % type(fn).__name__)
+        self.dim = embedded_dimension
+        self.fn = fn
+
+    @property
+    def name(self):
+        return str(getattr(self.fn, "name", getattr(self.fn, "__name__", type(self.fn).__name__)))
+
+    def __call__(self, x):
+        if isinstance(x, torch.Tensor):
+            out = self._host_call(self.fn, x)
+            return torch.from_numpy(out).to(x.device)
+        return self.fn(x)
+
+    def normal_vector(self, x):
+        nv = self._normal_fn()
+        if isinstance(x, torch.Tensor):
+            return torch.from_numpy(self._host_call(nv, x)).to(x.device)
+        return nv(x)
+
+    def _normal_fn(self):
+        nv = getattr(self.fn, "normal_vector", None)
+        if nv is None:          # what the reference's MPRGP raises on `convex_proj_op.normal_vector(xk)` (:1095)
+            raise AttributeError("'%s' object has no attribute 'normal_vector'" % type(self.fn).__name__)
+        return nv
+
+    @staticmethod
+    def _host_call(fn, x):
+        xh = x.detach().cpu().numpy()          # (synchronises the stream x was produced on)
+        out = np.ascontiguousarray(np.asarray(fn(xh), dtype=np.float64)).reshape(-1)
+        if out.shape[0] != xh.shape[0]:
+            raise ValueError("operands could not be broadcast together with shapes (%d,) (%d,)"
+                             % (xh.shape[0], out.shape[0]))
+        return out
+
+    def _round_trip(self, fn, eng, x, out):
+        flush = getattr(eng, "flush_self", None)
+        if flush is not None:
+            flush()                            # recording engines: queued work first, in program order
+        with torch.cuda.stream(eng.torch_stream):
+            res = self._host_call(fn, x)
+            out.copy_(torch.from_numpy(res), non_blocking=False)
+
+    def _dev_project(self, eng, x, out, want_alias=False):
+        self._round_trip(self.fn, eng, x, out)
+        return False
+
+    def _dev_normal_vector(self, eng, x, out):
+        self._round_trip(self._normal_fn(), eng, x, out)

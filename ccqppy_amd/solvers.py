@@ -40,9 +40,11 @@ class _Run:
         self.n = n = b.shape[0]
         self.P = convex_proj_op if convex_proj_op is not None else ss.IdentityProjOp(n)   # :115-116
         if not isinstance(self.P, ss.ProjOpBase):
-            raise TypeError("convex_proj_op must be one of ccqppy_amd.solution_spaces.*ProjOp (the projection "
-                            "runs on the GPU; arbitrary host callables are not supported), got %r"
-                            % type(self.P).__name__)
+            # anything callable is a legal feasible set for the reference (:115-116): run it on the host, slowly
+            # (two PCIe copies per projection, solution_spaces.HostCallableProjOp); a non-callable raises the
+            # TypeError the reference's first `convex_proj_op(x)` would
+            self.P = ss.HostCallableProjOp(n, self.P)
+        self.P._refresh()                      # public parameters edited since the last solve are picked up here
         self.op = as_operator(A)
         # `engine` = a lane engine of the batch scheduler (own stream + scalar slab); default: the
         # operator's engine, bound to torch's current stream

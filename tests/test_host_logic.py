@@ -73,3 +73,52 @@ def test_batch_partition_covers_problems_once():
             got = sorted(p for r in range(world) for p in operators.batch_partition(nprob, world, r))
             assert got == list(range(nprob))
     assert len(operators.batch_partition(1024, 8, 3)) == 128     # BASELINE config 5
+
+
+def test_parameter_refresh_detects_in_place_edits_and_reassignment():
+    """solution_spaces._refresh (host logic of the stale-bounds fix): the reference re-reads the public bound /
+    radius attributes on every call (solution_spaces.py:200-201,276-277,363-366,430-433); the device copies are
+    rebuilt when those were edited in place or reassigned -- and only then."""
+    lb, ub = -np.ones(6), np.ones(6)
+    P = ss.BoxProjOp(6, lb, ub)
+    assert P._refresh() is False and P._refresh() is False        # first sight, then unchanged
+    v0 = P._version
+    lb[2] = -0.5                                                   # in place
+    assert P._refresh() is True and P._version == v0 + 1
+    assert P._refresh() is False
+    P.upper_bound = np.ones(6)                                     # reassigned to an equal array: a new object
+    assert P._refresh() is True
+    P.upper_bound[0] = -0.0
+    P._refresh()
+    P.upper_bound[0] = 0.0                                         # sign of zero matters to the mask arithmetic
+    assert P._refresh() is True
+    Q = ss.LowerBoundProjOp(3, 2)                                  # scalar (int) bound
+    assert Q._refresh() is False
+    Q.lower_bound = 2.0                                            # int -> float changes `bound * mask`
+    assert Q._refresh() is True
+    S = ss.SphereProjOp(3, 1.0)
+    assert S._refresh() is False
+    S.radius = 1.0
+    assert S._refresh() is False
+    S.radius = 2.0
+    assert S._refresh() is True
+    D = ss.DisjointProjOp(P, S)
+    assert D._refresh() is False and D._refresh() is False
+    S.radius = 3.0
+    S._refresh()                                                   # the child noticed on its own ...
+    assert D._refresh() is True                                    # ... the parent still does (version counters)
+    lb[0] = 0.25
+    assert D._refresh() is True and D._refresh() is False
+
+
+def test_host_callable_wrapper_surface():
+    import pytest
+    f = lambda x: np.clip(x, -1, 1)  # noqa: E731
+    P = ss.HostCallableProjOp(4, f)
+    assert P.embedded_dimension == 4 and isinstance(P, ss.ProjOpBase) and P.name == "<lambda>"
+    x = np.array([-3.0, 0.5, 2.0, 1.0])
+    assert np.array_equal(P(x), f(x))                              # numpy in: the callable itself, on the host
+    with pytest.raises(AttributeError):
+        P.normal_vector(x)
+    with pytest.raises(TypeError):
+        ss.HostCallableProjOp(4, 42)

@@ -14,6 +14,17 @@ import shutil
 import sys
 
 
+def source_hash():
+    """sha1 over the sources the dense matvec kernel is built from (the same function as bench.gemv_source_hash)."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for rel in ("ccqppy_amd/csrc/ccqp_gemv.hip", "ccqppy_amd/csrc/ccqp_bodies.h", "ccqppy_amd/csrc/ccqp_internal.h"):
+        with open(os.path.join(root, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def main(tag, trace_dir, pmc_dirs, kernel_filter="gemv"):
     os.makedirs("profiles", exist_ok=True)
     for f in glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True):
@@ -37,6 +48,7 @@ def main(tag, trace_dir, pmc_dirs, kernel_filter="gemv"):
         e = {"launches_profiled_per_counter": len(c["_ms"]) // ncounters,
              "avg_ms_under_pmc": sum(c["_ms"]) / len(c["_ms"])}
         e.update(json.loads(os.environ.get("PROF_META", "{}")))
+        e["kernel_source_sha1"] = source_hash()      # bench.py reports this traffic only for the same sources
         e.update(meta[k])
         for name, vals in c.items():
             if name != "_ms":
