@@ -288,6 +288,31 @@ class Engine:
         if rc:
             _lib.check(rc)
 
+    # segmented engine (ccqp_segs.hip): any feasible set in <= 2 launches; `plan` is a solution_spaces._SegPlan
+    def segs_project(self, plan, a, x, b, y, z, out):
+        """out = P(a*x + b*y) - z   (y None: P(x); z None: no subtraction)."""
+        rc = self.lib.ccqp_segs_project_f64(self.ctx, plan.table_ptr, plan.work_ptr, plan.nwork, plan.normwork_ptr,
+                                            plan.nnorm, plan.npartials, plan.workspace(self).data_ptr(), a,
+                                            x.data_ptr(), b, None if y is None else y.data_ptr(),
+                                            None if z is None else z.data_ptr(), out.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def segs_residual_sq(self, plan, x, g, c, gd, slot):
+        rc = self.lib.ccqp_segs_residual_sq_f64(self.ctx, plan.table_ptr, plan.work_ptr, plan.nwork,
+                                                plan.normwork_ptr, plan.nnorm, plan.npartials,
+                                                plan.workspace(self).data_ptr(), x.data_ptr(), g.data_ptr(), c, gd,
+                                                slot, self.stream)
+        if rc:
+            _lib.check(rc)
+
+    def segs_normal(self, plan, x, out):
+        rc = self.lib.ccqp_segs_normal_f64(self.ctx, plan.table_ptr, plan.work_ptr, plan.nwork, plan.normwork_ptr,
+                                           plan.nnorm, plan.npartials, plan.workspace(self).data_ptr(), x.data_ptr(),
+                                           out.data_ptr(), self.stream)
+        if rc:
+            _lib.check(rc)
+
     def residual_sq_elementwise(self, seg, x, g, c, gd, slot):
         rc = self.lib.ccqp_residual_sq_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), c, gd, slot,
                                                        self.stream)

@@ -37,6 +37,12 @@ class Seg(ctypes.Structure):
                 ("lb_s", ctypes.c_double), ("ub_s", ctypes.c_double)]
 
 
+class SegWork(ctypes.Structure):
+    """struct ccqp_segwork (include/ccqp_hip.h): one workgroup's share of a segmented projection."""
+    _fields_ = [("type", ctypes.c_int32), ("seg", ctypes.c_int32), ("chunk", ctypes.c_int32),
+                ("pbase", ctypes.c_int32)]
+
+
 class Bop(ctypes.Structure):
     """struct ccqp_bop (include/ccqp_hip.h): one (problem, operation) descriptor of a batched launch."""
     _fields_ = [("p", ctypes.c_void_p * 16), ("s", ctypes.c_double * 4),
@@ -109,6 +115,11 @@ SIGNATURES = {
     "ccqp_proj_elementwise_sub_f64": [_P, _c.POINTER(Seg), _D, _P, _D, _P, _P, _P, _P],
     "ccqp_proj_normscale_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
     "ccqp_proj_small_segments_f64": [_P, _P, _I64, _P, _P, _I, _P],
+    "ccqp_segs_plan": [_P, _I64, _P, _I64, _c.POINTER(_I64), _P, _I64, _c.POINTER(_I64), _c.POINTER(_I64)],
+    "ccqp_segs_workspace_doubles": [_I64, _I64],
+    "ccqp_segs_project_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _D, _P, _D, _P, _P, _P, _P],
+    "ccqp_segs_residual_sq_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P, _D, _D, _I, _P],
+    "ccqp_segs_normal_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
     "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
     "ccqp_fused_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _I64, _I,
                             _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
@@ -189,7 +200,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "ccqp_last_error" else
                       ctypes.c_int64 if name in ("ccqp_symv_workspace_doubles", "ccqp_spmv_plan_words",
-                                                 "ccqp_bpipe_partials_doubles") else ctypes.c_int)
+                                                 "ccqp_bpipe_partials_doubles", "ccqp_segs_workspace_doubles")
+                      else ctypes.c_int)
     if lib.ccqp_abi_version() != 1:
         raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib

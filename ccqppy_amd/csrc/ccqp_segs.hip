@@ -1,0 +1,537 @@
+// Segmented projection engine: P, P(a*x + b*y) (- z), the Eq. 25 residual and normal_vector of ANY feasible set
+// -- Sphere, Cone, DisjointUnion with blocks of every size -- in at most 2 (normal_vector: 3) launches, whatever
+// the number of blocks.
+//
+// Reference: DisjointProjOp.__call__ (solution_spaces.py:540-560) loops over its blocks in Python; with 1365
+// Sphere(3) blocks that loop is 85 % of a reference solve.  Round 1 put the blocks of dimension
+// <= 64 into one launch and gave every larger Sphere / Cone block two launches of its own, i.e. 2000 launches for
+// DisjointProjOp(*[SphereProjOp(100)] * 1000).  Here the set is flattened to a device table of `ccqp_seg` and a
+// WORK list whose items are one workgroup each:
+//   type 0  a run of up to 256 consecutive SMALL blocks (dim <= CCQP_SMALL_SEG_MAX), one thread per block, norms by
+//           the sequential chain s = fma(x_i, x_i, s) (= OpenBLAS ddot for n <= 15: bit-exact against numpy);
+//   type 1  one 2048-element chunk of a LARGE block (the stage-1 geometry of every reduction, ccqp_red_geometry).
+// Launch 1 (norm items only) leaves the chunk sums of |u|^2 in the workspace; launch 2 (all items) finishes each
+// block's sum -- every workgroup of a block adds that block's chunk sums itself, in index order, so no atomics and
+// no third launch -- and applies the set's branches.  The arithmetic per element and the order of every sum are
+// those of the round-1 kernels (dots_stage1 + last-block finish + normscale_kernel, small_segments_kernel,
+// proj_elem_kernel), hence the same bits: the 408 operator goldens are unchanged.
+// Built with -ffp-contract=off: one rounding per operation, like numpy.
+#include "ccqp_bodies.h"
+
+__host__ __device__ static inline void segs_geometry(int64_t n, int64_t* chunk, int* nblk) {
+  int64_t c = CCQP_RED_CHUNK;
+  if ((n + c - 1) / c > CCQP_RED_MAXBLK) {
+    c = (n + CCQP_RED_MAXBLK - 1) / CCQP_RED_MAXBLK;
+    c = (c + CCQP_BLOCK - 1) / CCQP_BLOCK * CCQP_BLOCK;
+  }
+  int64_t nb = n > 0 ? (n + c - 1) / c : 1;
+  *chunk = c;
+  *nblk = (int)nb;
+}
+
+static inline bool seg_is_norm(int kind) { return kind == CCQP_OP_SPHERE || kind == CCQP_OP_CONE; }
+
+// ------------------------------------------------------------------ plan (host only, no GPU involved)
+extern "C" int ccqp_segs_plan(const ccqp_seg* segs, int64_t nseg, ccqp_segwork* work, int64_t work_cap,
+                              int64_t* nwork_out, ccqp_segwork* normwork, int64_t norm_cap, int64_t* nnorm_out,
+                              int64_t* npartials_out) {
+  CCQP_REQUIRE(nseg >= 0, "negative nseg");
+  CCQP_REQUIRE(nseg == 0 || segs != nullptr, "segs is NULL");
+  CCQP_REQUIRE(nwork_out && nnorm_out && npartials_out, "NULL output");
+  int64_t nwork = 0, nnorm = 0, npart = 0;
+  int64_t run0 = -1, runlen = 0;
+  auto close_run = [&]() {
+    if (runlen > 0) {
+      if (work && nwork < work_cap) {
+        work[nwork].type = 0;
+        work[nwork].seg = (int32_t)run0;
+        work[nwork].chunk = (int32_t)runlen;
+        work[nwork].pbase = 0;
+      }
+      ++nwork;
+    }
+    run0 = -1;
+    runlen = 0;
+  };
+  for (int64_t s = 0; s < nseg; ++s) {
+    const ccqp_seg& sg = segs[s];
+    CCQP_REQUIRE(sg.dim >= 0 && sg.offset >= 0, "negative offset/dim");
+    CCQP_REQUIRE(sg.kind >= CCQP_OP_IDENTITY && sg.kind <= CCQP_OP_CONE, "unknown kind");
+    CCQP_REQUIRE(s < INT32_MAX, "too many segments");
+    if (sg.dim <= CCQP_SMALL_SEG_MAX) {
+      // a run = up to 256 CONSECUTIVE table entries, all small (the kernel skips the empty ones)
+      if (runlen == 0) run0 = s;
+      if (++runlen == CCQP_BLOCK) close_run();
+      continue;
+    }
+    close_run();
+    int64_t chunk;
+    int nblk;
+    segs_geometry(sg.dim, &chunk, &nblk);
+    CCQP_REQUIRE(npart + nblk < INT32_MAX, "too many chunks");
+    for (int c = 0; c < nblk; ++c) {
+      if (work && nwork < work_cap) {
+        work[nwork].type = 1;
+        work[nwork].seg = (int32_t)s;
+        work[nwork].chunk = c;
+        work[nwork].pbase = (int32_t)npart;
+      }
+      ++nwork;
+      if (seg_is_norm(sg.kind)) {
+        if (normwork && nnorm < norm_cap) {
+          normwork[nnorm].type = 1;
+          normwork[nnorm].seg = (int32_t)s;
+          normwork[nnorm].chunk = c;
+          normwork[nnorm].pbase = (int32_t)npart;
+        }
+        ++nnorm;
+      }
+    }
+    npart += nblk;
+  }
+  close_run();
+  *nwork_out = nwork;
+  *nnorm_out = nnorm;
+  *npartials_out = npart;
+  if (work) CCQP_REQUIRE(nwork <= work_cap, "work_cap too small");
+  if (normwork) CCQP_REQUIRE(nnorm <= norm_cap, "norm_cap too small");
+  return CCQP_OK;
+}
+
+// workspace (doubles): 3 arrays of npartials chunk sums (|u|^2 | |x - xp|^2 | |xp|^2), nwork residual partials,
+// 8 doubles of arrival counters (zero on entry, left at zero)
+extern "C" int64_t ccqp_segs_workspace_doubles(int64_t npartials, int64_t nwork) {
+  if (npartials < 0 || nwork < 0) return -1;
+  return 3 * npartials + nwork + 8;
+}
+
+// ------------------------------------------------------------------ device side
+struct segs_in {          // u_i = a*x_i + b*y_i (y == NULL: u = x), block-local pointers
+  const double* x;
+  const double* y;
+  double a, b;
+  __device__ __forceinline__ double operator()(int64_t i) const {
+    double u = x[i];
+    if (y) {
+      const double t1 = a * u;
+      const double t2 = b * y[i];
+      u = t1 + t2;
+    }
+    return u;
+  }
+};
+
+// launch 1: chunk sums of |u|^2 for the Sphere / Cone blocks (same thread -> element map and fma chain as dot_body)
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_norm_kernel(const ccqp_seg* __restrict__ table,
+                                                               const ccqp_segwork* __restrict__ normwork,
+                                                               double* __restrict__ part, double a, const double* x,
+                                                               double b, const double* y) {
+  __shared__ double lds4[4];
+  const ccqp_segwork w = normwork[blockIdx.x];
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double v = u(i);
+    acc = fma(v, v, acc);
+  }
+  const double s = ccqp_block_sum(acc, lds4);
+  if (threadIdx.x == 0) part[w.pbase + w.chunk] = s;
+}
+
+// a block's |.|^2 from its chunk sums: the single partial, or the index-order sum ccqp_reduce_finish performs
+__device__ __forceinline__ double segs_finish(const double* part, int nblk, double* lds4, double* bcast) {
+  double s;
+  if (nblk == 1) {
+    s = part[0];
+  } else {
+    const double t = partial_sum_body(part, nblk, lds4);
+    if (threadIdx.x == 0) *bcast = t;
+    __syncthreads();
+    s = *bcast;
+    __syncthreads();
+  }
+  return s;
+}
+
+// P of one element of a LARGE Sphere / Cone block, r = |u| known (normscale_kernel, solution_spaces.py:430-435,
+// 484-492)
+struct segs_norm_rule {
+  int kind, branch;     // branch: 0 copy, 1 zeros, 2 scale
+  double r, radius, mu, s;
+  __device__ __forceinline__ void setup(const ccqp_seg& sg, double norm2, double zlast) {
+    kind = sg.kind;
+    r = sqrt(norm2);
+    if (kind == CCQP_OP_SPHERE) {
+      radius = sg.lb_s;
+      branch = (r > radius) ? 2 : 0;
+    } else {
+      mu = sg.lb_s;
+      if (mu * zlast >= r) branch = 0;
+      else if ((-zlast) / mu >= r) branch = 1;
+      else {
+        branch = 2;
+        const double num = zlast + mu * r;
+        s = num / sg.ub_s;
+      }
+    }
+  }
+  __device__ __forceinline__ double operator()(double u, bool is_last) const {
+    if (branch == 0) return u;
+    if (branch == 1) return 0.0;
+    if (kind == CCQP_OP_SPHERE) {
+      const double t = radius * u;
+      return t / r;
+    }
+    const double e = is_last ? -mu : u / r;
+    return s * e;
+  }
+};
+
+// one SMALL block, sequentially by one thread; emit(i, u_i, p_i) receives every element's input and projection
+template <class Emit>
+__device__ __forceinline__ void segs_small(const ccqp_seg& sg, const segs_in& u, Emit& emit) {
+  const int64_t d = sg.dim;
+  if (sg.kind <= CCQP_OP_BOX) {
+    for (int64_t i = 0; i < d; ++i) {
+      const double v = u(i);
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      emit(i, v, ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub));
+    }
+    return;
+  }
+  double n2 = 0.0;
+  for (int64_t i = 0; i < d; ++i) {
+    const double v = u(i);
+    n2 = fma(v, v, n2);
+  }
+  segs_norm_rule rule;
+  rule.setup(sg, n2, u(d - 1));
+  for (int64_t i = 0; i < d; ++i) {
+    const double v = u(i);
+    emit(i, v, rule(v, i == d - 1));
+  }
+}
+
+struct emit_store {       // out = P(u)  |  out = P(u) - z
+  double* out;
+  const double* z;
+  __device__ __forceinline__ void operator()(int64_t i, double, double p) { out[i] = z ? p - z[i] : p; }
+};
+
+struct emit_residual {    // acc += (c*(x - P(u)))^2, u = x - gd*g
+  const double* x;
+  double c, acc;
+  __device__ __forceinline__ void operator()(int64_t i, double, double p) {
+    const double d = x[i] - p;
+    const double v = c * d;
+    acc = fma(v, v, acc);
+  }
+};
+
+// launch 2.  EPI 0: out = P(u) (- z);  EPI 1: residual^2 of (x, g) = sum (c*(x - P(x - gd*g)))^2 -> slab slot
+template <int EPI>
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_apply_kernel(const ccqp_seg* __restrict__ table,
+                                                                const ccqp_segwork* __restrict__ work,
+                                                                const double* __restrict__ part, double a,
+                                                                const double* x, double b, const double* y,
+                                                                const double* z, double* out, double c,
+                                                                double* respart, int nwork, unsigned* counter,
+                                                                double* slot) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_segwork w = work[blockIdx.x];
+  double racc = 0.0;
+  if (w.type == 0) {
+    if ((int)threadIdx.x < w.chunk) {
+      const ccqp_seg sg = table[w.seg + threadIdx.x];
+      if (sg.dim > 0 && sg.dim <= CCQP_SMALL_SEG_MAX) {
+        const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
+        if constexpr (EPI == 0) {
+          emit_store e = {out + sg.offset, z ? z + sg.offset : nullptr};
+          segs_small(sg, u, e);
+        } else {
+          emit_residual e = {x + sg.offset, c, 0.0};
+          segs_small(sg, u, e);
+          racc = e.acc;
+        }
+      }
+    }
+  } else {
+    const ccqp_seg sg = table[w.seg];
+    int64_t chunk;
+    int nblk;
+    segs_geometry(sg.dim, &chunk, &nblk);
+    const int64_t lo = (int64_t)w.chunk * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > sg.dim) hi = sg.dim;
+    const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
+    const double* xs = x + sg.offset;
+    const double* zs = z ? z + sg.offset : nullptr;
+    double* os = out ? out + sg.offset : nullptr;
+    if (sg.kind <= CCQP_OP_BOX) {
+      for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+        const double v = u(i);
+        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+        const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
+        if constexpr (EPI == 0) {
+          os[i] = zs ? p - zs[i] : p;
+        } else {
+          const double d = xs[i] - p;
+          const double t = c * d;
+          racc = fma(t, t, racc);
+        }
+      }
+    } else {
+      const double n2 = segs_finish(part + w.pbase, nblk, lds4, &bcast);
+      segs_norm_rule rule;
+      rule.setup(sg, n2, u(sg.dim - 1));
+      for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+        const double v = u(i);
+        const double p = rule(v, i == sg.dim - 1);
+        if constexpr (EPI == 0) {
+          os[i] = zs ? p - zs[i] : p;
+        } else {
+          const double d = xs[i] - p;
+          const double t = c * d;
+          racc = fma(t, t, racc);
+        }
+      }
+    }
+  }
+  if constexpr (EPI == 1) {
+    const double s = ccqp_block_sum(racc, lds4);
+    if (nwork == 1) {
+      if (threadIdx.x == 0) *slot = s;
+      return;
+    }
+    if (threadIdx.x == 0) respart[blockIdx.x] = s;
+    ccqp_reduce_finish(respart, nwork, 1, counter, slot, lds4);
+  }
+}
+
+// normal_vector, launch 2 of 3: xp = P(x) into `out`; chunk sums of |x - xp|^2 (and |xp|^2 for Spheres).  Small blocks
+// finish here (small_segments_kernel mode 1: solution_spaces.py:146-160,222-236,306-322,389-403,92-98).
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_normal_project_kernel(const ccqp_seg* __restrict__ table,
+                                                                         const ccqp_segwork* __restrict__ work,
+                                                                         const double* __restrict__ part,
+                                                                         double* __restrict__ dpart,
+                                                                         double* __restrict__ lpart, const double* x,
+                                                                         double* out) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_segwork w = work[blockIdx.x];
+  if (w.type == 0) {
+    if ((int)threadIdx.x >= w.chunk) return;
+    const ccqp_seg sg = table[w.seg + threadIdx.x];
+    const int64_t d = sg.dim;
+    if (d <= 0 || d > CCQP_SMALL_SEG_MAX) return;
+    const double* xs = x + sg.offset;
+    double* os = out + sg.offset;
+    if (sg.kind == CCQP_OP_IDENTITY) {
+      for (int64_t i = 0; i < d; ++i) os[i] = 0.0;
+      return;
+    }
+    const segs_in u = {xs, nullptr, 1.0, 0.0};
+    emit_store e = {os, nullptr};
+    segs_small(sg, u, e);
+    double dist2 = 0.0;
+    for (int64_t i = 0; i < d; ++i) {
+      const double df = xs[i] - os[i];
+      dist2 = fma(df, df, dist2);
+    }
+    const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
+    if (sg.kind == CCQP_OP_SPHERE) {
+      double l2 = 0.0;
+      for (int64_t i = 0; i < d; ++i) l2 = fma(os[i], os[i], l2);
+      const double len = sqrt(l2);
+      const bool on = !outside && ccqp_isclose(len, sg.lb_s);
+      for (int64_t i = 0; i < d; ++i) os[i] = on ? os[i] / len : 0.0;
+      return;
+    }
+    const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+    const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+    for (int64_t i = 0; i < d; ++i) {
+      double nv = 0.0;
+      if (!outside) {
+        const double xp = os[i];
+        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+        if (has_ub && ccqp_isclose(xp, ub)) nv = 1.0;
+        else if (has_lb && ccqp_isclose(xp, lb)) nv = -1.0;
+      }
+      os[i] = nv;
+    }
+    return;
+  }
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  const double* xs = x + sg.offset;
+  double* os = out + sg.offset;
+  double dacc = 0.0, lacc = 0.0;
+  if (sg.kind <= CCQP_OP_BOX) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = xs[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
+      os[i] = p;
+      const double df = v - p;
+      dacc = fma(df, df, dacc);
+    }
+  } else {
+    const double n2 = segs_finish(part + w.pbase, nblk, lds4, &bcast);
+    segs_norm_rule rule;
+    rule.setup(sg, n2, xs[sg.dim - 1]);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = xs[i];
+      const double p = rule(v, i == sg.dim - 1);
+      os[i] = p;
+      const double df = v - p;
+      dacc = fma(df, df, dacc);
+      lacc = fma(p, p, lacc);
+    }
+  }
+  const double ds = ccqp_block_sum(dacc, lds4);
+  const double ls = ccqp_block_sum(lacc, lds4);
+  if (threadIdx.x == 0) {
+    dpart[w.pbase + w.chunk] = ds;
+    lpart[w.pbase + w.chunk] = ls;
+  }
+}
+
+// normal_vector, launch 3 of 3: large blocks only, in place on `out` (which holds xp)
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_normal_finish_kernel(const ccqp_seg* __restrict__ table,
+                                                                        const ccqp_segwork* __restrict__ work,
+                                                                        const double* __restrict__ dpart,
+                                                                        const double* __restrict__ lpart,
+                                                                        double* out) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_segwork w = work[blockIdx.x];
+  if (w.type == 0) return;
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  double* os = out + sg.offset;
+  if (sg.kind == CCQP_OP_IDENTITY) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = 0.0;
+    return;
+  }
+  const double dist2 = segs_finish(dpart + w.pbase, nblk, lds4, &bcast);
+  const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
+  if (sg.kind == CCQP_OP_SPHERE) {
+    const double len = sqrt(segs_finish(lpart + w.pbase, nblk, lds4, &bcast));
+    const bool on = !outside && ccqp_isclose(len, sg.lb_s);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = on ? os[i] / len : 0.0;
+    return;
+  }
+  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    double nv = 0.0;
+    if (!outside) {
+      const double v = os[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
+      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
+    }
+    os[i] = nv;
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+static int segs_check(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                      const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, const double* ws) {
+  CCQP_REQUIRE(ctx != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(nwork >= 0 && nnorm >= 0 && npartials >= 0, "negative count");
+  CCQP_REQUIRE(nwork < INT32_MAX, "too many work items");
+  CCQP_REQUIRE(nwork == 0 || (table && work && ws), "NULL table / work list / workspace");
+  CCQP_REQUIRE(nnorm == 0 || normwork, "NULL norm work list");
+  return CCQP_OK;
+}
+
+static inline unsigned* segs_counter(double* ws, int64_t npartials, int64_t nwork) {
+  return reinterpret_cast<unsigned*>(ws + 3 * npartials + nwork);
+}
+
+extern "C" int ccqp_segs_project_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                                     const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* ws,
+                                     double a, const double* x, double b, const double* y, const double* z,
+                                     double* out, void* stream) {
+  int rc = segs_check(ctx, table, work, nwork, normwork, nnorm, npartials, ws);
+  if (rc) return rc;
+  if (nwork == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && out, "NULL vector");
+  CCQP_REQUIRE(x != out && y != out, "the segmented projection cannot run in place");
+  hipStream_t s = (hipStream_t)stream;
+  if (nnorm > 0)
+    hipLaunchKernelGGL(segs_norm_kernel, dim3((unsigned)nnorm), dim3(CCQP_BLOCK), 0, s, table, normwork, ws, a, x, b, y);
+  hipLaunchKernelGGL((segs_apply_kernel<0>), dim3((unsigned)nwork), dim3(CCQP_BLOCK), 0, s, table, work, ws, a, x, b, y,
+                     z, out, 0.0, (double*)nullptr, (int)nwork, (unsigned*)nullptr, (double*)nullptr);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_segs_residual_sq_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work,
+                                         int64_t nwork, const ccqp_segwork* normwork, int64_t nnorm,
+                                         int64_t npartials, double* ws, const double* x, const double* g, double c,
+                                         double gd, int slot, void* stream) {
+  int rc = segs_check(ctx, table, work, nwork, normwork, nnorm, npartials, ws);
+  if (rc) return rc;
+  CCQP_REQUIRE(ccqp_slot_ok(slot, 1), "slot outside the slab");
+  hipStream_t s = (hipStream_t)stream;
+  if (nwork == 0) {
+    CCQP_HIP(hipMemsetAsync(ctx->slots + slot, 0, sizeof(double), s));
+    return CCQP_OK;
+  }
+  CCQP_REQUIRE(x && g, "NULL vector");
+  // u = x - gd*g  ==  1.0*x + (-gd)*g, rounded like the axpby it replaces
+  if (nnorm > 0)
+    hipLaunchKernelGGL(segs_norm_kernel, dim3((unsigned)nnorm), dim3(CCQP_BLOCK), 0, s, table, normwork, ws, 1.0, x, -gd,
+                       g);
+  hipLaunchKernelGGL((segs_apply_kernel<1>), dim3((unsigned)nwork), dim3(CCQP_BLOCK), 0, s, table, work, ws, 1.0, x,
+                     -gd, g, (const double*)nullptr, (double*)nullptr, c, ws + 3 * npartials, (int)nwork,
+                     segs_counter(ws, npartials, nwork), ctx->slots + slot);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_segs_normal_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                                    const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* ws,
+                                    const double* x, double* out, void* stream) {
+  int rc = segs_check(ctx, table, work, nwork, normwork, nnorm, npartials, ws);
+  if (rc) return rc;
+  if (nwork == 0) return CCQP_OK;
+  CCQP_REQUIRE(x && out, "NULL vector");
+  CCQP_REQUIRE(x != out, "the segmented normal_vector cannot run in place");
+  hipStream_t s = (hipStream_t)stream;
+  if (nnorm > 0)
+    hipLaunchKernelGGL(segs_norm_kernel, dim3((unsigned)nnorm), dim3(CCQP_BLOCK), 0, s, table, normwork, ws, 1.0, x, 0.0,
+                       (const double*)nullptr);
+  hipLaunchKernelGGL(segs_normal_project_kernel, dim3((unsigned)nwork), dim3(CCQP_BLOCK), 0, s, table, work, ws,
+                     ws + npartials, ws + 2 * npartials, x, out);
+  if (npartials > 0)
+    hipLaunchKernelGGL(segs_normal_finish_kernel, dim3((unsigned)nwork), dim3(CCQP_BLOCK), 0, s, table, work,
+                       ws + npartials, ws + 2 * npartials, out);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

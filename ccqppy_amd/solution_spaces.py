@@ -44,6 +44,47 @@ def _is_int(b):
     return isinstance(b, np.ndarray) and np.issubdtype(b.dtype, np.integer)
 
 
+class _SegPlan:
+    """A feasible set flattened for the segmented engine (csrc/ccqp_segs.hip): device table of block descriptors,
+    work lists (one workgroup per item), and one zero-initialised workspace per engine that uses it."""
+
+    def __init__(self, eng, segs):
+        lib = eng.lib
+        n = len(segs)
+        host = (_lib.Seg * max(n, 1))()
+        self._keep = []
+        for i, sg in enumerate(segs):
+            ctypes.memmove(ctypes.byref(host[i]), ctypes.byref(sg), ctypes.sizeof(_lib.Seg))
+            self._keep.append(getattr(sg, "_keep", None))      # device copies of bounds stay alive with the plan
+        nwork, nnorm, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.ccqp_segs_plan(host, n, None, 0, ctypes.byref(nwork), None, 0, ctypes.byref(nnorm),
+                                      ctypes.byref(npart)))
+        work = (_lib.SegWork * max(nwork.value, 1))()
+        normwork = (_lib.SegWork * max(nnorm.value, 1))()
+        _lib.check(lib.ccqp_segs_plan(host, n, work, nwork.value, ctypes.byref(nwork), normwork, nnorm.value,
+                                      ctypes.byref(nnorm), ctypes.byref(npart)))
+        self.nseg, self.nwork, self.nnorm, self.npartials = n, nwork.value, nnorm.value, npart.value
+
+        def up(buf):
+            return torch.from_numpy(np.frombuffer(bytes(buf), dtype=np.uint8).copy()).to(eng.device)
+        self.table, self.work, self.normwork = up(host), up(work), up(normwork)
+        self.table_ptr, self.work_ptr, self.normwork_ptr = (self.table.data_ptr(), self.work.data_ptr(),
+                                                            self.normwork.data_ptr())
+        self.ws_doubles = int(lib.ccqp_segs_workspace_doubles(self.npartials, self.nwork))
+        self._ws = {}
+
+    def workspace(self, eng):
+        # per ENGINE (= per stream): lane engines of one device share the read-only tables, never a workspace
+        ws = self._ws.get(id(eng))
+        if ws is None or ws[0]() is not eng:
+            import weakref
+            ws = (weakref.ref(eng), torch.zeros(self.ws_doubles, dtype=torch.float64, device=eng.device))
+            if len(self._ws) > 128:
+                self._ws = {k: v for k, v in self._ws.items() if v[0]() is not None}
+            self._ws[id(eng)] = ws
+        return ws[1]
+
+
 class ProjOpBase(ABC):
     """Mirror of the reference ABC (solution_spaces.py:9-74)."""
     _kind = None            # CCQP_OP_* for leaf operators
@@ -121,15 +162,59 @@ class ProjOpBase(ABC):
     def _leaves(self, offset=0):
         return [(self, offset)]
 
+    def _segplan(self, eng, n):
+        """The set as a segment plan for vectors of length n (None: some block has no device descriptor, e.g. a host
+        callable inside a DisjointProjOp -- the per-block path is taken)."""
+        cache = self.__dict__.setdefault("_segplans", {})
+        key = (eng.index, n)
+        if key not in cache:
+            segs = []
+            for op, off in self._leaves():
+                d = op.embedded_dimension if op is not self else n
+                if getattr(op, "_kind", None) is None:
+                    segs = None
+                    break
+                if d > 0:
+                    segs.append(op._seg(eng, off, d))
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = None if segs is None else _SegPlan(eng, segs)
+        return cache[key]
+
     def _dev_project(self, eng, x, out, want_alias=False):
+        if not want_alias:
+            plan = self._segplan(eng, x.numel())
+            if plan is not None:
+                if x.data_ptr() == out.data_ptr():
+                    raise ValueError("%s cannot project in place" % type(self).__name__)
+                eng.segs_project(plan, 1.0, x, 0.0, None, None, out)
+                return False
         return self._block_project(eng, x, out, 0, x.numel(), want_alias)
 
     def _dev_step_project(self, eng, a, x, b, y, out):
+        plan = self._segplan(eng, x.numel())
+        if plan is not None:
+            eng.segs_project(plan, a, x, b, y, None, out)      # a*x + b*y formed on the fly, rounded like axpby
+            return
         t = eng.scratch(x.numel(), "op.step")
         eng.axpby(a, x, b, y, t)
         self._dev_project(eng, t, out)
 
+    def _dev_step_project_minus(self, eng, x, b, y, out):
+        """out = P(x + b*y) - x  (SPG's direction, solvers.py:937)."""
+        plan = self._segplan(eng, x.numel())
+        if plan is not None:
+            eng.segs_project(plan, 1.0, x, b, y, x, out)
+            return
+        t = eng.scratch(x.numel(), "op.stepm")
+        self._dev_step_project(eng, 1.0, x, b, y, t)
+        eng.axpby(1.0, t, -1.0, x, out)
+
     def _dev_residual_sq(self, eng, x, g, c, gd, slot):
+        plan = self._segplan(eng, x.numel())
+        if plan is not None:
+            eng.segs_residual_sq(plan, x, g, c, gd, slot)
+            return
         n = x.numel()
         t1 = eng.scratch(n, "op.res1")
         t2 = eng.scratch(n, "op.res2")
@@ -139,7 +224,20 @@ class ProjOpBase(ABC):
         eng.scale(c, t1, t1)               # c * (...)
         eng.dots([(t1, t1)], slot)
 
+    def _normal_on_device(self):
+        """False where normal_vector needs the host per block: a Cone block raises (solution_spaces.py:465), scalar
+        bounds raise TypeError depending on the data (:318), a host callable is called."""
+        return self._kind is not None
+
     def _dev_normal_vector(self, eng, x, out):
+        if all(op._normal_on_device() for op, _ in self._leaves()):
+            plan = self._segplan(eng, x.numel())
+            if plan is not None:
+                eng.segs_normal(plan, x, out)
+                return
+        self._legacy_normal_vector(eng, x, out)
+
+    def _legacy_normal_vector(self, eng, x, out):
         self._block_normal(eng, x, out, 0, x.numel())
 
     def _block_project(self, eng, x, out, offset, n, want_alias=False):
@@ -202,7 +300,7 @@ class _ElementwiseOp(ProjOpBase):
                 and self._unchanged(ub, st[3]):
             return False
         self.__dict__["_bounds_state"] = (lb, ub, self._snapshot(lb), self._snapshot(ub))
-        for k in ("_seg_cache", "_dev_bounds", "_single_tables"):
+        for k in ("_seg_cache", "_dev_bounds", "_single_tables", "_segplans"):
             self.__dict__.pop(k, None)
         if st is not None:
             self._version = self._version + 1
@@ -251,6 +349,15 @@ class _ElementwiseOp(ProjOpBase):
     def _block_project(self, eng, x, out, offset, n, want_alias=False):
         eng.proj_elementwise(self._seg(eng, offset, n), x, out)
         return False
+
+    def _dev_project(self, eng, x, out, want_alias=False):
+        return self._block_project(eng, x, out, 0, x.numel(), want_alias)
+
+    def _normal_on_device(self):
+        return not self._scalar_bound_names()
+
+    def _dev_normal_vector(self, eng, x, out):
+        self._block_normal(eng, x, out, 0, x.numel())
 
     def _dev_step_project(self, eng, a, x, b, y, out):
         eng.proj_elementwise(self._seg(eng, 0, x.numel()), x, out, a, b, y)
@@ -411,6 +518,7 @@ class _NormOp(ProjOpBase):
             return False
         self.__dict__["_param_state"] = (cur,)
         self.__dict__.pop("_single_tables", None)
+        self.__dict__.pop("_segplans", None)
         if st is not None:
             self._version = self._version + 1
         return st is not None
@@ -530,6 +638,9 @@ class ConeProjOp(_NormOp):
     def proximal_gradient(self, x, g):
         raise NotImplementedError("Cone proximal gradient not implemented, yet.")   # :468
 
+    def _normal_on_device(self):
+        return False
+
     def _block_normal(self, eng, x, out, offset, n):
         raise NotImplementedError("Cone normal not implemented, yet.")
 
@@ -543,9 +654,11 @@ class ConeProjOp(_NormOp):
 class DisjointProjOp(ProjOpBase):
     """Cartesian product of sub-operators on consecutive slices.  solution_spaces.py:495-560.
 
-    Device plan: every leaf block of dimension <= CCQP_SMALL_SEG_MAX goes into ONE segment-table
-    launch (one thread per block; the reference spends ~85 % of a solve in the Python loop over
-    such blocks); larger blocks get their own kernels."""
+    Device plan: the union is flattened (recursively) to a table of block descriptors and runs through the
+    segmented engine (csrc/ccqp_segs.hip) -- projection, fused step, residual in at most 2 launches, normal_vector in
+    3, for any number of blocks of any size (the reference spends ~85 % of a solve in its Python loop over the
+    blocks).  Only a union that holds a block without a device form (a user callable; a Cone or a
+    scalar-bounded block under normal_vector, whose errors depend on the data) takes the per-block path."""
 
     def __init__(self, *convex_proj_ops):
         self.proj_ops = convex_proj_ops
@@ -557,10 +670,20 @@ class DisjointProjOp(ProjOpBase):
     def name(self):
         return "DisjointUnion"
 
+    def _wrapped(self, op):
+        """Blocks may be anything callable with an `embedded_dimension` (solution_spaces.py:555-558 only calls them)."""
+        if isinstance(op, ProjOpBase):
+            return op
+        cache = self.__dict__.setdefault("_foreign", {})
+        w = cache.get(id(op))
+        if w is None or w.fn is not op:
+            w = cache[id(op)] = HostCallableProjOp(op.embedded_dimension, op)
+        return w
+
     def _leaves(self, offset=0):
         out = []
         for op in self.proj_ops:
-            out.extend(op._leaves(offset))
+            out.extend(self._wrapped(op)._leaves(offset))
             offset += op.embedded_dimension
         return out
 
@@ -576,6 +699,7 @@ class DisjointProjOp(ProjOpBase):
         if st is None or (st[0] is cur[0] and st[1] == cur[1]):
             return False
         self.__dict__.pop("_plans", None)
+        self.__dict__.pop("_segplans", None)
         self._version = self._version + 1
         return True
 
@@ -617,7 +741,8 @@ class DisjointProjOp(ProjOpBase):
         self._dev_project(eng, xd, out)
         return self._stage_out(x, out)
 
-    def _dev_project(self, eng, x, out, want_alias=False):
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        # per-block path (a block without a device descriptor is present)
         if x.data_ptr() == out.data_ptr():
             raise ValueError("DisjointProjOp cannot project in place")
         table, nsmall, large, _ = self._plan(eng, False)
@@ -627,7 +752,7 @@ class DisjointProjOp(ProjOpBase):
             op._block_project(eng, x, out, off, op.embedded_dimension)
         return False
 
-    def _dev_normal_vector(self, eng, x, out):
+    def _legacy_normal_vector(self, eng, x, out):
         table, nsmall, large, _ = self._plan(eng, True)
         if nsmall:
             eng.proj_small(table, nsmall, x, out, 1)
@@ -645,9 +770,6 @@ class DisjointProjOp(ProjOpBase):
                 raise AttributeError("'%s' object has no attribute 'projected_gradient'" % type(op).__name__)
             op._block_projected_gradient(eng, xd, gd, free_g, chopped_g, off, op.embedded_dimension)
         return (self._stage_out(x, free_g), self._stage_out(x, chopped_g))
-
-    def _block_project(self, eng, x, out, offset, n, want_alias=False):
-        raise AssertionError("DisjointProjOp is flattened by _leaves()")
 
 
 # ------------------------------------------------------------------ arbitrary host callables
@@ -713,3 +835,11 @@ class HostCallableProjOp(ProjOpBase):
 
     def _dev_normal_vector(self, eng, x, out):
         self._round_trip(self._normal_fn(), eng, x, out)
+
+    # as a block of a DisjointProjOp
+    def _block_project(self, eng, x, out, offset, n, want_alias=False):
+        self._round_trip(self.fn, eng, x[offset:offset + n], out[offset:offset + n])
+        return False
+
+    def _block_normal(self, eng, x, out, offset, n):
+        self._round_trip(self._normal_fn(), eng, x[offset:offset + n], out[offset:offset + n])

@@ -161,6 +161,46 @@ int ccqp_proj_normscale_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
 int ccqp_proj_small_segments_f64(ccqp_ctx* ctx, const ccqp_seg* table, int64_t nseg, const double* x,
                                  double* out, int mode, void* stream);
 
+/* ---- a5-a8 for ANY feasible set in <= 2 launches: the segmented engine (ccqp_segs.hip) -----------------------
+ * Replaces the Python loop of DisjointProjOp.__call__ / normal_vector (solution_spaces.py:540-560, 512-525) and
+ * the dot + scale pairs of Sphere / Cone (:417-435, 470-492) for tables with blocks of EVERY size; the residual
+ * form replaces `np.linalg.norm(c*(x - P(x - gd*g)))` (solvers.py:137-139,321-323,629-631,647-648,1070-1072).
+ * A set is a DEVICE table of ccqp_seg plus a work list (ccqp_segs_plan, host side): one workgroup per item --
+ *   type 0: `chunk` consecutive table entries starting at `seg`, all of dim <= CCQP_SMALL_SEG_MAX, one thread each;
+ *   type 1: chunk number `chunk` (stage-1 geometry of the reductions: 2048 elements) of the large block `seg`,
+ *           whose chunk sums live at workspace[pbase ...].
+ * Per element the arithmetic, and per block the order of every sum, are those of ccqp_proj_small_segments_f64,
+ * ccqp_dots_f64 + ccqp_proj_normscale_f64 and ccqp_proj_elementwise_f64: the same bits. */
+typedef struct ccqp_segwork {
+  int32_t type;
+  int32_t seg;
+  int32_t chunk;
+  int32_t pbase;
+} ccqp_segwork;
+/* Host-side planning (no GPU work): fills `work` (all items, table order) and `normwork` (the type-1 items of Sphere
+ * / Cone blocks) up to their capacities and ALWAYS returns the needed counts; call once with NULL lists to size
+ * them.  `segs` is the HOST copy of the table. */
+int ccqp_segs_plan(const ccqp_seg* segs, int64_t nseg, ccqp_segwork* work, int64_t work_cap, int64_t* nwork,
+                   ccqp_segwork* normwork, int64_t norm_cap, int64_t* nnorm, int64_t* npartials);
+/* doubles of device workspace for a plan; must be ZERO when first used (arrival counter), is left so. */
+int64_t ccqp_segs_workspace_doubles(int64_t npartials, int64_t nwork);
+/* out = P(a*x + b*y) - z over the whole table; y == NULL: P(x); z == NULL: no subtraction (SPG's direction
+ * solvers.py:937 otherwise).  x, y must not alias out. */
+int ccqp_segs_project_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                          const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* workspace,
+                          double a, const double* x, double b, const double* y, const double* z, double* out,
+                          void* stream);
+/* slab[slot] = sum_i (c*(x_i - P(x - gd*g)_i))^2: per work item a block sum (chunk: thread t takes elements
+ * t, t+256, ...; small blocks: one fma chain per block), the items added in index order by the last block. */
+int ccqp_segs_residual_sq_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                              const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* workspace,
+                              const double* x, const double* g, double c, double gd, int slot, void* stream);
+/* out = normal_vector(x) over the whole table (Identity / Lower / Upper / Box / Sphere blocks; a Cone block has no
+ * normal in the reference, solution_spaces.py:465 -- the caller raises before coming here). 3 launches. */
+int ccqp_segs_normal_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                         const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* workspace,
+                         const double* x, double* out, void* stream);
+
 /* ---- a4: residual (Mazhar 2015 Eq. 25 as coded, solvers.py:138-139 etc.) --------------------
  * slab[slot] = sum_i v_i^2, v = c*(x - P(x - gd*g)) for an ELEMENTWISE kind over the block;
  * the caller takes the square root (np.linalg.norm = sqrt(v.v)). */

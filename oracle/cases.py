@@ -207,6 +207,48 @@ def op_cases():
             add("disjoint.%s.s%d" % (name, si), spec, rng.normal(size=dd) * scale)
     xb = np.clip(rng.normal(size=spec_dim(nvmix)), -1, 1)
     add("disjoint.nvmix.onbound", nvmix, xb)
+
+    # round 2: unions with MANY blocks beyond the thread-per-block size and blocks spanning several 2048-element
+    # reduction chunks (the segmented engine, csrc/ccqp_segs.hip; reference loop solution_spaces.py:540-560, Sphere
+    # :417-435, Cone :470-492).  Own generator so that the cases above keep their inputs.
+    rng2 = np.random.default_rng(20260202)
+    arrays["l2lb"] = -np.abs(rng2.normal(size=2500)) - 0.05
+    arrays["l2ub"] = np.abs(rng2.normal(size=2500)) + 0.05
+    sph100 = {"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 100}, "count": 40}}
+    largemix = {"kind": "Disjoint", "ops": [
+        {"kind": "Box", "dim": 5}, {"kind": "Cone", "dim": 3}, {"kind": "Sphere", "dim": 300, "radius": 2.0},
+        {"kind": "Identity", "dim": 70}, {"kind": "Box", "dim": 2500, "lb": {"arr": "l2lb"}, "ub": {"arr": "l2ub"}},
+        {"kind": "Cone", "dim": 2100, "aspect_ratio": 0.5}, {"kind": "Sphere", "dim": 64}, {"kind": "Upper", "dim": 65},
+        {"kind": "Disjoint", "ops": [{"kind": "Sphere", "dim": 65, "radius": 0.25}, {"kind": "Lower", "dim": 130}]},
+        {"kind": "Sphere", "dim": 4100, "radius": 30.0}]}
+    largenv = {"kind": "Disjoint", "ops": [
+        {"kind": "Sphere", "dim": 300, "radius": 1.3}, {"kind": "Box", "dim": 2500, "lb": {"arr": "l2lb"},
+                                                         "ub": {"arr": "l2ub"}},
+        {"kind": "Lower", "dim": 70}, {"kind": "Sphere", "dim": 100}, {"kind": "Identity", "dim": 66},
+        {"kind": "Sphere", "dim": 2200, "radius": 2.0}, {"kind": "Upper", "dim": 3}]}
+    for name, spec in (("sph100x40", sph100), ("largemix", largemix)):
+        dd = spec_dim(spec)
+        for si, scale in enumerate((0.05, 1.0)):
+            add("disjoint.%s.s%d" % (name, si), spec, rng2.normal(size=dd) * scale, nv=(name == "sph100x40"))
+    # normal_vector of large blocks: on / inside / outside each set
+    dd = spec_dim(largenv)
+    on = rng2.uniform(-0.04, 0.04, size=dd)
+    v = rng2.normal(size=300); on[:300] = 1.3 * v / np.linalg.norm(v)                 # on the first sphere
+    xb = rng2.uniform(arrays["l2lb"], arrays["l2ub"])
+    xb[::3] = arrays["l2lb"][::3]; xb[1::3] = arrays["l2ub"][1::3]
+    on[300:2800] = xb                                                                  # on the box's faces
+    on[2800:2870] = -1.0                                                               # on the default lower bound
+    v = rng2.normal(size=2200); on[3036:5236] = 2.0 * v / np.linalg.norm(v)            # on the large sphere
+    on[5236:] = 1.0
+    add("disjoint.largenv.on", largenv, on)
+    add("disjoint.largenv.in", largenv, 0.01 * rng2.normal(size=dd))
+    out = on.copy(); out[:300] *= 1.5; out[400] += 3.0; out[3036:5236] *= 1.01
+    add("disjoint.largenv.out", largenv, out)
+    for d, r in ((65, 1.0), (100, 0.5), (2049, 3.0), (5000, 1.0)):
+        for si, scale in enumerate((0.01, 1.0)):
+            add("large.sphere.d%d.s%d" % (d, si), {"kind": "Sphere", "dim": d, "radius": r}, rng2.normal(size=d) * scale)
+            add("large.cone.d%d.s%d" % (d, si), {"kind": "Cone", "dim": d, "aspect_ratio": r},
+                rng2.normal(size=d) * scale)
     return cases, arrays
 
 
@@ -376,6 +418,34 @@ def solver_cases():
     cases.append(dict(id="warm.MPRGP.identity", problem="gen:64:7", solver="MPRGP", tol=1e-8, max_mv=500,
                       kwargs={}, op=None, rng_seed=1234, x0="ramp"))
     return cases
+
+
+# ------------------------------------------------------------------ per-iteration host-scalar traces
+# One row per completed iteration ("the trace is what localises a control-flow divergence"): the
+# scalars that steer the reference's branches -- the sufficient-decrease test solvers.py:302, the exit tests
+# :324,649,949,1186, the BB steps :655-656, MPRGP's three-way branch :1098,1121 and its halving loop :1113-1118.
+TRACE_ROWS = 32
+TRACE_COLUMNS = {
+    "PGD": ("mv", "res"),
+    "APGD": ("mv", "res", "L", "nback"),
+    "APGDAntiRelaxation": ("mv", "res", "L", "nback"),
+    "BBPGD": ("mv", "res", "alpha"),
+    "BBPGDf": ("mv", "res", "alpha"),
+    "SPG": ("mv", "dd", "alpha", "betak"),
+    "MPRGP": ("mv", "res", "branch", "nhalve", "alpha_bb"),
+}
+TRACE_EXACT = ("mv", "nback", "branch", "nhalve")          # integer-valued columns: compared exactly
+MPRGP_BRANCH = {"cg": 0.0, "expand": 1.0, "prop": 2.0}
+
+
+def trace_array(solver, trace):
+    """First TRACE_ROWS entries of a trace (list of dicts, oracle/cpu_ref.py `trace=` or the product's
+    `solver.trace`) as a float array with TRACE_COLUMNS[solver] columns."""
+    cols = TRACE_COLUMNS[solver]
+    rows = []
+    for e in trace[:TRACE_ROWS]:
+        rows.append([MPRGP_BRANCH[e[c]] if c == "branch" else float(e[c]) for c in cols])
+    return np.array(rows, dtype=np.float64).reshape(len(rows), len(cols))
 
 
 def case_x0(case, n):

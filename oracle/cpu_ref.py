@@ -585,7 +585,7 @@ def solve_mprgp(A, b, tol, max_mv=np.inf, x0=None, P=None, trace=None):
                 p = np.copy(np.isclose(xkp1, P(xkp1)) * gkp1)           # STALE gkp1 (:1180-1182)
             res = _residual(P, n, xkp1, gkp1)
             if trace is not None:
-                trace.append(dict(mv=mv, res=float(res), branch=branch, nhalve=nhalve))
+                trace.append(dict(mv=mv, res=float(res), branch=branch, nhalve=nhalve, alpha_bb=float(alpha_bb)))
             if res < tol:
                 break
             xk, xkp1 = xkp1, xk

@@ -228,6 +228,18 @@ def gen_solvers(sparse=False, contact=False):
             entry["converged"] = bool(r.solution_converged)
             entry["res"] = float(r.solution_residual)
             entry["executed_mv"] = int(o.executed_mv)
+            if not sparse:
+                # per-iteration host scalars (first C.TRACE_ROWS iterations) from the oracle's `trace=` hook, taken from
+                # a re-run that must reproduce the pinned result bit for bit
+                def run_traced():
+                    np.random.seed(c["rng_seed"])
+                    return cpu_ref.SOLVERS[c["solver"]](A, b, c["tol"], max_mv, x0=None if x0 is None else x0.copy(),
+                                                        P=oop, trace=[], **c["kwargs"])
+                t, terr = call_or_error(run_traced)
+                assert terr is None and same_bits(t.solution, r.solution) and \
+                    t.solution_num_matrix_vector_multiplications == entry["mv"], ("traced re-run differs", c["id"])
+                out[c["id"] + ".trace"] = C.trace_array(c["solver"], t.trace)
+                entry["trace_len"] = len(t.trace)
             # Control-flow stability probe (SURVEY.md hard part 1): re-run the oracle on inputs
             # perturbed by <= 1 ulp.  Where the REFERENCE algorithm's own MV count moves under such
             # a perturbation, "identical MV count" is not a meaningful bar for any implementation

@@ -101,7 +101,7 @@ def _rccl_worker(port, q):
         # the RCCL calls of the N>1 path, issued on torch's current stream right behind a HIP kernel of ours
         op.engine.bind()
         op.engine.scale(1.0, want, y)
-        ex._gather_into(y, y[ex.row0:ex.row0 + ex.rows])
+        ex._gather_into(y, y[ex.row0:ex.row0 + ex.rows], op.engine)
         dist.all_reduce(y, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         same = bool(torch.equal(y, want))
