@@ -165,7 +165,9 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-mv", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce"])
+    ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce", "direct"],
+                    help="N > 1: torch.distributed all_gather_into_tensor (default) | zero-padded all_reduce | 'direct' = the "
+                         "in-place RCCL all-gather of the C ABI on the compute stream (ccqp_comm_allgather_f64)")
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
     ap.add_argument("--cpu-n", type=int, default=-1,
                     help="size of the CPU-baseline problem (0 = skip); default: the metric's own n when the host has "
@@ -309,7 +311,8 @@ def main():
                 "workload": "BASELINE metric: n=%d dense random-SPD fp64 + BoxProjOp(+-0.5), CCQPSolverAPGD(tol=%g, "
                             "max_mv=%d); 1 step = 1 full solve from x0=0" % (n, args.tol, args.max_mv),
                 "n": n, "solver": "APGD", "projection": "Box", "tol": args.tol,
-                "sharding": "none" if world == 1 else "row-block x%d, RCCL %s of the n-vector per matvec" % (world, args.mode),
+                "sharding": "none" if world == 1 else "row-block x%d, %s %s of the n-vector per matvec" % (
+                    world, "RCCL" if backend == "nccl" else backend, args.mode),
                 "matrix_bytes_per_gpu": 8 * rows_local * n,
             },
             "solve": {

@@ -164,11 +164,11 @@ class Engine:
 
     def spmv_plan(self, rowptr, col, nnz, local_x=True):
         """One-time analysis of a CSR matrix -> (plan tensor, host summary {rows on the wave-per-row path,
-        windows in transposed gather order, local-x windows} as a ctypes int64[3])."""
+        windows in transposed gather order, local-x windows, diagonal windows} as a ctypes int64[4])."""
         rows = rowptr.numel() - 1
         words = self.lib.ccqp_spmv_plan_words(rows, nnz)
         plan = torch.empty(words, dtype=torch.int64, device=self.device)
-        summary = (ctypes.c_int64 * 3)()
+        summary = (ctypes.c_int64 * 4)()
         rc = self.lib.ccqp_spmv_plan_csr(self.ctx, rowptr.data_ptr(), col.data_ptr() if (nnz and local_x) else None, rows, nnz,
                                          plan.data_ptr(), summary, self.stream)
         if rc:

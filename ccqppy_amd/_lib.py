@@ -61,6 +61,13 @@ class PProb(ctypes.Structure):
                 ("xmin", ctypes.c_void_p), ("gmin", ctypes.c_void_p)]
 
 
+class PSegs(ctypes.Structure):
+    """struct ccqp_psegs (include/ccqp_hip.h): the feasible set of one problem of a segmented lock-step run."""
+    _fields_ = [("table", ctypes.c_void_p), ("work", ctypes.c_void_p), ("normwork", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("npartials", ctypes.c_int64), ("nwork", ctypes.c_int32),
+                ("nnorm", ctypes.c_int32)]
+
+
 class PApgd(ctypes.Structure):
     """struct ccqp_papgd (include/ccqp_hip.h): one problem of a lock-step APGD run."""
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
@@ -115,6 +122,14 @@ SIGNATURES = {
     "ccqp_proj_elementwise_sub_f64": [_P, _c.POINTER(Seg), _D, _P, _D, _P, _P, _P, _P],
     "ccqp_proj_normscale_f64": [_P, _c.POINTER(Seg), _P, _P, _I, _P],
     "ccqp_proj_small_segments_f64": [_P, _P, _I64, _P, _P, _I, _P],
+    "ccqp_comm_rccl_version": [],
+    "ccqp_comm_unique_id": [_P],
+    "ccqp_comm_create": [_P, _I, _I, _P, _c.POINTER(_P)],
+    "ccqp_comm_destroy": [_P],
+    "ccqp_comm_info": [_P, _c.POINTER(_I), _c.POINTER(_I)],
+    "ccqp_comm_allgather_f64": [_P, _P, _I64, _P],
+    "ccqp_comm_allreduce_sum_f64": [_P, _P, _I64, _P],
+    "ccqp_shard_gemv_allgather_f64": [_P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _I, _P],
     "ccqp_segs_plan": [_P, _I64, _P, _I64, _c.POINTER(_I64), _P, _I64, _c.POINTER(_I64), _c.POINTER(_I64)],
     "ccqp_segs_workspace_doubles": [_I64, _I64],
     "ccqp_segs_project_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _D, _P, _D, _P, _P, _P, _P],
@@ -139,6 +154,8 @@ SIGNATURES = {
     "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
+    "ccqp_bsegs_start_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _D, _I, _P, _P],
+    "ccqp_bsegs_iterate_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bsolve_bbpgd_f64": [_P, _P, _I, _I64, _D, _D, _I64, _I, _P],
     "ccqp_bsolve_apgd_f64": [_P, _P, _I, _I64, _D, _D, _I, _P],
     "ccqp_bsolve_mprgp_f64": [_P, _P, _I, _I64, _D, _D, _D, _I, _P],

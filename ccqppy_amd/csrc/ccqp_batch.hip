@@ -9,10 +9,16 @@
 
 #define BATCH_RING 16384  // descriptors in the device ring (one flush uses a few hundred)
 
+#define BATCH_QUARTERS 4
 struct ccqp_batch {
   ccqp_bop* dev;     // device ring
   ccqp_bop* host;    // pinned staging ring
   int64_t cursor;
+  // one event per ring quarter, recorded behind the last flush that used descriptors of that quarter: before a later
+  // flush overwrites a quarter (the ring has wrapped) the host waits for that event, so descriptors still unread by a
+  // queued copy or kernel are never overwritten -- however many flushes a caller queues without synchronising
+  hipEvent_t ev[BATCH_QUARTERS];
+  bool ev_set[BATCH_QUARTERS];
 };
 
 static ccqp_batch* batch_of(ccqp_ctx* ctx) {
@@ -21,9 +27,19 @@ static ccqp_batch* batch_of(ccqp_ctx* ctx) {
   b->dev = nullptr;
   b->host = nullptr;
   b->cursor = 0;
-  if (hipMalloc(&b->dev, sizeof(ccqp_bop) * BATCH_RING) != hipSuccess ||
-      hipHostMalloc(&b->host, sizeof(ccqp_bop) * BATCH_RING, hipHostMallocDefault) != hipSuccess) {
+  for (int q = 0; q < BATCH_QUARTERS; ++q) {
+    b->ev[q] = nullptr;
+    b->ev_set[q] = false;
+  }
+  bool ok = hipMalloc(&b->dev, sizeof(ccqp_bop) * BATCH_RING) == hipSuccess &&
+            hipHostMalloc(&b->host, sizeof(ccqp_bop) * BATCH_RING, hipHostMallocDefault) == hipSuccess;
+  for (int q = 0; ok && q < BATCH_QUARTERS; ++q)
+    ok = hipEventCreateWithFlags(&b->ev[q], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     if (b->dev) (void)hipFree(b->dev);
+    if (b->host) (void)hipHostFree(b->host);
+    for (int q = 0; q < BATCH_QUARTERS; ++q)
+      if (b->ev[q]) (void)hipEventDestroy(b->ev[q]);
     delete b;
     return nullptr;
   }
@@ -35,6 +51,8 @@ void ccqp_batch_free(ccqp_ctx* ctx) {
   if (!ctx->batch) return;
   (void)hipFree(ctx->batch->dev);
   (void)hipHostFree(ctx->batch->host);
+  for (int q = 0; q < BATCH_QUARTERS; ++q)
+    if (ctx->batch->ev[q]) (void)hipEventDestroy(ctx->batch->ev[q]);
   delete ctx->batch;
   ctx->batch = nullptr;
 }
@@ -274,6 +292,10 @@ extern "C" int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes
     return CCQP_ERR_HIP;
   }
   if (b->cursor + total > BATCH_RING) b->cursor = 0;
+  const int64_t qlen = BATCH_RING / BATCH_QUARTERS;
+  const int q0 = (int)(b->cursor / qlen), q1 = (int)((b->cursor + total - 1) / qlen);
+  for (int q = q0; q <= q1; ++q)
+    if (b->ev_set[q]) CCQP_HIP(hipEventSynchronize(b->ev[q]));   // (returns at once unless the ring has lapped the GPU)
   ccqp_bop* hst = b->host + b->cursor;
   ccqp_bop* dev = b->dev + b->cursor;
   b->cursor += total;
@@ -287,6 +309,10 @@ extern "C" int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes
     at += counts[gidx];
   }
   CCQP_LAUNCH_CHECK();
+  for (int q = q0; q <= q1; ++q) {
+    CCQP_HIP(hipEventRecord(b->ev[q], s));
+    b->ev_set[q] = true;
+  }
   return CCQP_OK;
 }
 

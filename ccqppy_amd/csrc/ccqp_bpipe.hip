@@ -237,9 +237,18 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
   }
 }
 
-static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+// (also used by the segmented lock-step form, ccqp_bsegs.hip)
+void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   BP_MV_LAUNCH(bpipe_gemv_kernel, probs, i, mode, n);
+}
+
+void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, probs, n, chunk, nblk);
+}
+
+static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+  ccqp_bp_gemv(probs, count, n, i, mode, flags, s);
 }
 
 // Start-up of all solves (solvers.py:626-636): g0 = A x0 + b, residual, A g0, alpha0.  Expects x[0] staged, the
@@ -665,6 +674,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
       sh[1] = r;
       sh[2] = gg;
       sh[3] = sqrt(r) >= q.tol ? 0.0 : 1.0;   // `if res >= tol:` (a NaN residual skips the loop)
+      sh[0] = s[BP_ALPHA];                    // (x0 already meets tol: the step in the slab is stored back as it is)
       s[BP_RESMIN] = INFINITY;                // (BBPGDf, :767)
     }
   }

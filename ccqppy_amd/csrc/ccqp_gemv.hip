@@ -61,8 +61,97 @@ static int launch_r(int U, bool aligned, bool nt, hipStream_t s, int grid, const
   }
 }
 
+// ------------------------------------------------------------------ MFMA form (A/B variant, bit 9 of the variant word)
+// BASELINE config 3 words the matvec as "MFMA GEMV"; this is that kernel, kept selectable so the question is answered
+// by a measurement (profiles/r02_gemv_mfma_ab.md) rather than by an argument.  One wave owns 16 consecutive rows.
+// v_mfma_f64_16x16x4_f64 computes D(16x16) += Aop(16x4) . Bop(4x16); the matrix tile is the B operand,
+//   Bop[k][j] = A[row0 + j][c(k)]      (lane l holds j = l & 15, k = l >> 4 -- one fp64 per lane),
+// and x enters through ROW 0 of the A operand only (Aop[0][k] = x[c(k)], Aop[i > 0][k] = 0), so row 0 of D collects
+// the 16 row sums: lanes 0..15, accumulator register 0 (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg).
+// A single right-hand side uses 1/16 of the instruction's multiply-adds; that still sustains ~19 TB/s of matrix bytes
+// (64 cycles per 512-byte tile and SIMD), i.e. the kernel stays HBM-bound like the VALU form.
+// Loads: per 16-column step a lane issues two 16-byte non-temporal loads, columns c0 + 2k + {0,1} and c0 + 8 + 2k +
+// {0,1}, so one wave instruction reads 64 contiguous bytes of each of its 16 rows (the VALU form reads 1 KiB of ONE
+// row).  Summation order per row: columns in groups of four per MFMA (hardware order inside), groups in increasing
+// column order -- NOT the lane-strided chain of the VALU form, so the last bits of y differ between the two forms
+// (both within the fp64 bound 4*eps*sqrt(n)*sum|a_ij x_j| the tests state).  Needs cols % 16 == 0 and 16-byte
+// aligned A / x / lda; other shapes take the VALU form.
+typedef double ccqp_d4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+__global__ __launch_bounds__(CCQP_BLOCK) void gemv_mfma_kernel(const double* __restrict__ A, int64_t lda,
+                                                               const double* __restrict__ x,
+                                                               const double* __restrict__ b, double* __restrict__ y,
+                                                               double* __restrict__ g, int64_t rows, int64_t cols,
+                                                               int64_t ntasks, const double* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0.0) return;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  const bool xlane = j == 0;
+  constexpr int64_t SPAN = 16 * U;
+  for (int64_t task = wave; task < ntasks; task += nwaves) {
+    int64_t row = task * 16 + j;
+    if (row > rows - 1) row = rows - 1;           // clamp: tail rows re-read a valid row, never stored
+    const double* rp = A + row * lda + 2 * kq;
+    const double* xp = x + 2 * kq;
+    ccqp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c0 = 0; c0 < cols; c0 += SPAN) {
+      ccqp_d2 av[U][2], xv[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        av[u][0] = ccqp_ld2<true, true>(rp + c0 + 16 * u);
+        av[u][1] = ccqp_ld2<true, true>(rp + c0 + 16 * u + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xv[u][0] = ccqp_ld2<true, false>(xp + c0 + 16 * u);
+        xv[u][1] = ccqp_ld2<true, false>(xp + c0 + 16 * u + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xlane ? xv[u][h].x : 0.0, av[u][h].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xlane ? xv[u][h].y : 0.0, av[u][h].y, acc, 0, 0, 0);
+        }
+    }
+    // row 0 of D: lanes 0..15 hold y[task*16 + lane] in accumulator register 0
+    const int64_t orow = task * 16 + lane;
+    if (lane < 16 && orow < rows) {
+      y[orow] = acc.x;
+      if (g) g[orow] = acc.x + b[orow];
+    }
+  }
+}
+
+static bool gemv_mfma_applicable(const double* A, int64_t lda, const double* x, int64_t cols) {
+  return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (lda % 2) == 0 &&
+         cols > 0 && (cols % 64) == 0;
+}
+
+static void launch_mfma(ccqp_ctx* ctx, int U, int bpc, hipStream_t s, const double* A, int64_t lda, const double* x,
+                        const double* b, double* y, double* g, int64_t rows, int64_t cols, const double* skip) {
+  const int64_t ntasks = (rows + 15) / 16;
+  int64_t blocks = (ntasks + (CCQP_BLOCK / 64) - 1) / (CCQP_BLOCK / 64);
+  const int64_t cap = (int64_t)ctx->num_cu * (bpc > 0 ? bpc : 4);
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  if (U == 4)
+    hipLaunchKernelGGL((gemv_mfma_kernel<4>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y, g, rows,
+                       cols, ntasks, skip);
+  else if (U == 2)
+    hipLaunchKernelGGL((gemv_mfma_kernel<2>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y, g, rows,
+                       cols, ntasks, skip);
+  else
+    hipLaunchKernelGGL((gemv_mfma_kernel<1>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y, g, rows,
+                       cols, ntasks, skip);
+}
+
 // variant word: bits 0-3 R (rows per wave: 1,2,4,8), bits 4-7 U (unroll: 1,2,4), bit 8 = 1 disables
-// the non-temporal A loads, bits 12-19 workgroups per CU (0 = default).  0 = tuned default
+// the non-temporal A loads, bit 9 = 1 selects the MFMA form (16 rows per wave; U = columns/16 per step: 1, 2, 4;
+// shapes it does not cover fall through to the VALU form), bits 12-19 workgroups per CU (0 = default).  0 = tuned default
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
 // yields the same bits, so this is speed only.
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
@@ -71,6 +160,10 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
   int R = variant & 0xF, U = (variant >> 4) & 0xF;
   const bool nt = !((variant >> 8) & 1);
   int bpc = (variant >> 12) & 0xFF;
+  if (((variant >> 9) & 1) && gemv_mfma_applicable(A, lda, x, cols)) {
+    launch_mfma(ctx, U == 0 ? 4 : U, bpc, s, A, lda, x, b, y, g, rows, cols, skip);
+    return CCQP_OK;
+  }
   ccqp_gemv_defaults(rows, cols, &R, &U, &bpc);
   const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
                        (lda % 2) == 0;

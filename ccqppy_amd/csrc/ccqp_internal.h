@@ -132,6 +132,11 @@ __device__ __forceinline__ unsigned* ccqp_red_counters(double* partials) {
 __device__ __forceinline__ void ccqp_reduce_finish(const double* partials, int nblk, int nred, unsigned* counter,
                                                    double* out, double* lds4) {
   __shared__ int is_last;
+  // Structural form of the invariant the lock-step kernels rely on (ccqp_lockstep.h:bp_meet): every wave of this
+  // block has finished reading whatever the launch reads at its start (skip / state words, operands) before the
+  // block takes its ticket -- the last block to arrive may overwrite such words right after this function.  The
+  // callers' bodies happen to contain a barrier already; this one makes it independent of them.
+  __syncthreads();
   if (threadIdx.x == 0) {
     // the guide's counter hand-off (cdna_hip_programming.md, in-launch reduction / Guideline 16), to the letter:
     // drain the store, agent-scope release, drain again (ROCm 7.2 can drop the fence's own wait), relaxed

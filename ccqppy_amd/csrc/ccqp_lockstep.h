@@ -164,3 +164,7 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 
 // zeroes the two batch words and resets the host mirror (ccqp_bpipe.hip)
 void ccqp_lockstep_begin(ccqp_ctx* ctx, uint32_t* dev_batch, hipStream_t s);
+// the batched matvec (mode 0: y = A x[i], g[i] = y + b; mode 1: y = A g[i]) and the alpha0 reduction of the BBPGD
+// start-up, as launched by ccqp_bpipe_*: shared with the segmented form (ccqp_bsegs.hip)
+void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s);
+void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s);

@@ -16,18 +16,7 @@
 // those of the round-1 kernels (dots_stage1 + last-block finish + normscale_kernel, small_segments_kernel,
 // proj_elem_kernel), hence the same bits: the 408 operator goldens are unchanged.
 // Built with -ffp-contract=off: one rounding per operation, like numpy.
-#include "ccqp_bodies.h"
-
-__host__ __device__ static inline void segs_geometry(int64_t n, int64_t* chunk, int* nblk) {
-  int64_t c = CCQP_RED_CHUNK;
-  if ((n + c - 1) / c > CCQP_RED_MAXBLK) {
-    c = (n + CCQP_RED_MAXBLK - 1) / CCQP_RED_MAXBLK;
-    c = (c + CCQP_BLOCK - 1) / CCQP_BLOCK * CCQP_BLOCK;
-  }
-  int64_t nb = n > 0 ? (n + c - 1) / c : 1;
-  *chunk = c;
-  *nblk = (int)nb;
-}
+#include "ccqp_segs.h"
 
 static inline bool seg_is_norm(int kind) { return kind == CCQP_OP_SPHERE || kind == CCQP_OP_CONE; }
 
@@ -105,136 +94,17 @@ extern "C" int64_t ccqp_segs_workspace_doubles(int64_t npartials, int64_t nwork)
   return 3 * npartials + nwork + 8;
 }
 
-// ------------------------------------------------------------------ device side
-struct segs_in {          // u_i = a*x_i + b*y_i (y == NULL: u = x), block-local pointers
-  const double* x;
-  const double* y;
-  double a, b;
-  __device__ __forceinline__ double operator()(int64_t i) const {
-    double u = x[i];
-    if (y) {
-      const double t1 = a * u;
-      const double t2 = b * y[i];
-      u = t1 + t2;
-    }
-    return u;
-  }
-};
-
-// launch 1: chunk sums of |u|^2 for the Sphere / Cone blocks (same thread -> element map and fma chain as dot_body)
+// ------------------------------------------------------------------ device side (helpers: ccqp_segs.h)
+// launch 1: chunk sums of |u|^2 for the Sphere / Cone blocks
 __global__ __launch_bounds__(CCQP_BLOCK) void segs_norm_kernel(const ccqp_seg* __restrict__ table,
                                                                const ccqp_segwork* __restrict__ normwork,
                                                                double* __restrict__ part, double a, const double* x,
                                                                double b, const double* y) {
   __shared__ double lds4[4];
   const ccqp_segwork w = normwork[blockIdx.x];
-  const ccqp_seg sg = table[w.seg];
-  int64_t chunk;
-  int nblk;
-  segs_geometry(sg.dim, &chunk, &nblk);
-  const int64_t lo = (int64_t)w.chunk * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
-  double acc = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    const double v = u(i);
-    acc = fma(v, v, acc);
-  }
-  const double s = ccqp_block_sum(acc, lds4);
+  const double s = segs_norm_item(table, w, a, x, b, y, lds4);
   if (threadIdx.x == 0) part[w.pbase + w.chunk] = s;
 }
-
-// a block's |.|^2 from its chunk sums: the single partial, or the index-order sum ccqp_reduce_finish performs
-__device__ __forceinline__ double segs_finish(const double* part, int nblk, double* lds4, double* bcast) {
-  double s;
-  if (nblk == 1) {
-    s = part[0];
-  } else {
-    const double t = partial_sum_body(part, nblk, lds4);
-    if (threadIdx.x == 0) *bcast = t;
-    __syncthreads();
-    s = *bcast;
-    __syncthreads();
-  }
-  return s;
-}
-
-// P of one element of a LARGE Sphere / Cone block, r = |u| known (normscale_kernel, solution_spaces.py:430-435,
-// 484-492)
-struct segs_norm_rule {
-  int kind, branch;     // branch: 0 copy, 1 zeros, 2 scale
-  double r, radius, mu, s;
-  __device__ __forceinline__ void setup(const ccqp_seg& sg, double norm2, double zlast) {
-    kind = sg.kind;
-    r = sqrt(norm2);
-    if (kind == CCQP_OP_SPHERE) {
-      radius = sg.lb_s;
-      branch = (r > radius) ? 2 : 0;
-    } else {
-      mu = sg.lb_s;
-      if (mu * zlast >= r) branch = 0;
-      else if ((-zlast) / mu >= r) branch = 1;
-      else {
-        branch = 2;
-        const double num = zlast + mu * r;
-        s = num / sg.ub_s;
-      }
-    }
-  }
-  __device__ __forceinline__ double operator()(double u, bool is_last) const {
-    if (branch == 0) return u;
-    if (branch == 1) return 0.0;
-    if (kind == CCQP_OP_SPHERE) {
-      const double t = radius * u;
-      return t / r;
-    }
-    const double e = is_last ? -mu : u / r;
-    return s * e;
-  }
-};
-
-// one SMALL block, sequentially by one thread; emit(i, u_i, p_i) receives every element's input and projection
-template <class Emit>
-__device__ __forceinline__ void segs_small(const ccqp_seg& sg, const segs_in& u, Emit& emit) {
-  const int64_t d = sg.dim;
-  if (sg.kind <= CCQP_OP_BOX) {
-    for (int64_t i = 0; i < d; ++i) {
-      const double v = u(i);
-      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-      emit(i, v, ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub));
-    }
-    return;
-  }
-  double n2 = 0.0;
-  for (int64_t i = 0; i < d; ++i) {
-    const double v = u(i);
-    n2 = fma(v, v, n2);
-  }
-  segs_norm_rule rule;
-  rule.setup(sg, n2, u(d - 1));
-  for (int64_t i = 0; i < d; ++i) {
-    const double v = u(i);
-    emit(i, v, rule(v, i == d - 1));
-  }
-}
-
-struct emit_store {       // out = P(u)  |  out = P(u) - z
-  double* out;
-  const double* z;
-  __device__ __forceinline__ void operator()(int64_t i, double, double p) { out[i] = z ? p - z[i] : p; }
-};
-
-struct emit_residual {    // acc += (c*(x - P(u)))^2, u = x - gd*g
-  const double* x;
-  double c, acc;
-  __device__ __forceinline__ void operator()(int64_t i, double, double p) {
-    const double d = x[i] - p;
-    const double v = c * d;
-    acc = fma(v, v, acc);
-  }
-};
 
 // launch 2.  EPI 0: out = P(u) (- z);  EPI 1: residual^2 of (x, g) = sum (c*(x - P(x - gd*g)))^2 -> slab slot
 template <int EPI>
@@ -248,65 +118,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void segs_apply_kernel(const ccqp_seg* 
   __shared__ double lds4[4];
   __shared__ double bcast;
   const ccqp_segwork w = work[blockIdx.x];
-  double racc = 0.0;
-  if (w.type == 0) {
-    if ((int)threadIdx.x < w.chunk) {
-      const ccqp_seg sg = table[w.seg + threadIdx.x];
-      if (sg.dim > 0 && sg.dim <= CCQP_SMALL_SEG_MAX) {
-        const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
-        if constexpr (EPI == 0) {
-          emit_store e = {out + sg.offset, z ? z + sg.offset : nullptr};
-          segs_small(sg, u, e);
-        } else {
-          emit_residual e = {x + sg.offset, c, 0.0};
-          segs_small(sg, u, e);
-          racc = e.acc;
-        }
-      }
-    }
-  } else {
-    const ccqp_seg sg = table[w.seg];
-    int64_t chunk;
-    int nblk;
-    segs_geometry(sg.dim, &chunk, &nblk);
-    const int64_t lo = (int64_t)w.chunk * chunk;
-    int64_t hi = lo + chunk;
-    if (hi > sg.dim) hi = sg.dim;
-    const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
-    const double* xs = x + sg.offset;
-    const double* zs = z ? z + sg.offset : nullptr;
-    double* os = out ? out + sg.offset : nullptr;
-    if (sg.kind <= CCQP_OP_BOX) {
-      for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-        const double v = u(i);
-        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-        const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
-        if constexpr (EPI == 0) {
-          os[i] = zs ? p - zs[i] : p;
-        } else {
-          const double d = xs[i] - p;
-          const double t = c * d;
-          racc = fma(t, t, racc);
-        }
-      }
-    } else {
-      const double n2 = segs_finish(part + w.pbase, nblk, lds4, &bcast);
-      segs_norm_rule rule;
-      rule.setup(sg, n2, u(sg.dim - 1));
-      for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-        const double v = u(i);
-        const double p = rule(v, i == sg.dim - 1);
-        if constexpr (EPI == 0) {
-          os[i] = zs ? p - zs[i] : p;
-        } else {
-          const double d = xs[i] - p;
-          const double t = c * d;
-          racc = fma(t, t, racc);
-        }
-      }
-    }
-  }
+  const double racc = segs_apply_item<EPI>(table, w, part, a, x, b, y, z, out, c, lds4, &bcast);
   if constexpr (EPI == 1) {
     const double s = ccqp_block_sum(racc, lds4);
     if (nwork == 1) {

@@ -50,6 +50,11 @@
 #define SPMV_UNIFORM (1ll << 32)   // flag in plan word 4: all rows of the window have the same length
 #define SPMV_LOCALX (1ll << 33)    // flag in plan word 4: the window gathers x through LDS ("local x" mode); the
                                    // number of distinct columns sits in bits 40-55
+#define SPMV_DIAG (1ll << 34)      // flag in plan word 4: "diagonal" window -- every row has the same length L (bits
+                                   // 40-55) and the same column OFFSETS col - row, stored once (L int32) where a
+                                   // local-x window keeps its distinct columns; the matvec then reads no column
+                                   // index at all for the window
+#define SPMV_DIAG_MAXLEN 256       // longest row of a diagonal window (its offsets live in 1 KiB of LDS)
 #define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
                                    // products: 8 KB)
 #define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order: measured
@@ -110,10 +115,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_kernel(const int64_t* __
 }
 
 static inline int64_t spmv_windows(int64_t nnz) { return nnz / SPMV_CAP + 1; }
-// plan layout (int64 words): [5 per window][3 counters: long rows, transposed windows, local-x windows]
+// plan layout (int64 words): [5 per window][4 counters: long rows, transposed windows, local-x windows, diagonal windows]
 // [long-row list, one slot per window][distinct columns, SPMV_XS int32 per window][16-bit local column per entry]
 static inline int64_t spmv_off_counts(int64_t nwin) { return SPMV_PLAN_WORDS * nwin; }
-static inline int64_t spmv_off_long(int64_t nwin) { return spmv_off_counts(nwin) + 3; }
+static inline int64_t spmv_off_long(int64_t nwin) { return spmv_off_counts(nwin) + 4; }
 static inline int64_t spmv_off_ucol(int64_t nwin) { return spmv_off_long(nwin) + nwin; }
 static inline int64_t spmv_off_lcol(int64_t nwin) { return spmv_off_ucol(nwin) + nwin * (SPMV_XS / 2); }
 
@@ -127,13 +132,15 @@ extern "C" int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz) {
 // distinct ones, and -- if they fit SPMV_XS and every x value is used 1.5 times or more -- store them
 // (sorted) plus, for every entry, the 16-bit position of its column in that list.  The matvec then loads
 // each distinct x ONCE with coalesced gathers, parks it in LDS, and reads 2 bytes instead of 4 per entry.
-__global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int32_t* __restrict__ col,
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int64_t* __restrict__ rowptr,
+                                                                      const int32_t* __restrict__ col,
                                                                       int64_t* __restrict__ plan,
                                                                       int32_t* __restrict__ ucol,
                                                                       uint16_t* __restrict__ lcol,
                                                                       unsigned long long* __restrict__ nlocal) {
   __shared__ int32_t key[SPMV_LDS];
   __shared__ int ndistinct;
+  __shared__ int notdiag;
   const int64_t w = blockIdx.x;
   const int64_t nzb = plan[SPMV_PLAN_WORDS * w + 2];
   const int E = (int)(plan[SPMV_PLAN_WORDS * w + 3] - nzb);
@@ -165,8 +172,34 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int3
   }
   __syncthreads();
   const int cnt = ndistinct;
-  if (cnt > SPMV_XS || 2 * E < 3 * cnt) return;                   // too many columns, or too little reuse
   int32_t* uc = ucol + w * SPMV_XS;
+  if (cnt > SPMV_XS || 2 * E < 3 * cnt) {                         // too many columns, or too little reuse
+    // ---- "diagonal" window?  All rows of the same length L <= SPMV_DIAG_MAXLEN and, position by position, the same
+    // offset col - row (banded / circulant / regular-grid matrices): keep the L offsets once; the matvec rebuilds
+    // every column index as row + offset and streams 8 instead of 12 bytes per entry.
+    const int64_t rb = plan[SPMV_PLAN_WORDS * w + 0];
+    const int64_t nr = plan[SPMV_PLAN_WORDS * w + 1] - rb;
+    if (nr < 1 || E % nr != 0) return;
+    const int L = (int)(E / nr);
+    if (L < 1 || L > SPMV_DIAG_MAXLEN) return;
+    if (t == 0) notdiag = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int64_t r = t; r < nr; r += CCQP_BLOCK) bad |= (rowptr[rb + r + 1] - rowptr[rb + r]) != L;
+    for (int i = t; i < E; i += CCQP_BLOCK) {
+      const int r = i / L, pos = i - r * L;
+      bad |= ((int64_t)col[nzb + i] - (rb + r)) != ((int64_t)col[nzb + pos] - rb);
+    }
+    if (bad) notdiag = 1;                                         // (benign race: every writer stores 1)
+    __syncthreads();
+    if (notdiag) return;
+    for (int i = t; i < L; i += CCQP_BLOCK) uc[i] = (int32_t)((int64_t)col[nzb + i] - rb);
+    if (t == 0) {
+      plan[SPMV_PLAN_WORDS * w + 4] |= SPMV_DIAG | ((int64_t)L << 40);
+      atomicAdd(nlocal + 1, 1ull);
+    }
+    return;
+  }
   for (int i = t; i < cnt; i += CCQP_BLOCK) uc[i] = key[i];
   for (int i = t; i < E; i += CCQP_BLOCK) {
     const int32_t c = col[nzb + i];
@@ -191,19 +224,19 @@ extern "C" int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, const in
   hipStream_t s = (hipStream_t)stream;
   const int64_t nwin = spmv_windows(nnz);
   int64_t* count = plan + spmv_off_counts(nwin);
-  CCQP_HIP(hipMemsetAsync(count, 0, 3 * sizeof(int64_t), s));
+  CCQP_HIP(hipMemsetAsync(count, 0, 4 * sizeof(int64_t), s));
   const int64_t grid = (nwin + CCQP_BLOCK - 1) / CCQP_BLOCK;
   CCQP_REQUIRE(grid <= (int64_t)INT32_MAX, "matrix too large for one plan launch");
   hipLaunchKernelGGL(spmv_plan_kernel, dim3((unsigned)grid), dim3(CCQP_BLOCK), 0, s, rowptr, rows, nwin, plan,
                      (unsigned long long*)count, (unsigned long long*)count + 1, plan + spmv_off_long(nwin));
   CCQP_REQUIRE(nwin <= (int64_t)INT32_MAX, "matrix too large for one plan launch");
   if (col != nullptr && nnz > 0)             // local-x analysis (optional: without col the windows keep their mode)
-    hipLaunchKernelGGL(spmv_plan_localx_kernel, dim3((unsigned)nwin), dim3(CCQP_BLOCK), 0, s, col, plan,
+    hipLaunchKernelGGL(spmv_plan_localx_kernel, dim3((unsigned)nwin), dim3(CCQP_BLOCK), 0, s, rowptr, col, plan,
                        reinterpret_cast<int32_t*>(plan + spmv_off_ucol(nwin)),
                        reinterpret_cast<uint16_t*>(plan + spmv_off_lcol(nwin)), (unsigned long long*)count + 2);
   CCQP_LAUNCH_CHECK();
   if (summary) {                             // blocking: lets the matvec skip the wave-per-row launch
-    CCQP_HIP(hipMemcpyAsync(summary, count, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    CCQP_HIP(hipMemcpyAsync(summary, count, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CCQP_HIP(hipStreamSynchronize(s));
   }
   return CCQP_OK;
@@ -248,6 +281,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   if (skip != nullptr && *skip != 0.0) return;      // pipelined solves: queued behind a converged iteration
   __shared__ double prod[SPMV_LDS];
   __shared__ uint16_t rstart[SPMV_ROWS_LDS + 2];      // row starts relative to the window
+  __shared__ int32_t offs[SPMV_DIAG_MAXLEN];          // column offsets of a diagonal window
   // transposed windows pass the column indices through the first half of `prod` before any product exists
   int32_t* const colv = reinterpret_cast<int32_t*>(prod);
   const int64_t* pw = plan + (int64_t)SPMV_PLAN_WORDS * blockIdx.x;
@@ -256,6 +290,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   const int longest = (int)(pw[4] & 0xffffffff);
   const bool uniform = (pw[4] & SPMV_UNIFORM) != 0;
   const bool localx = (pw[4] & SPMV_LOCALX) != 0;
+  const bool diag = (pw[4] & SPMV_DIAG) != 0;
   const int t = threadIdx.x;
   const int l = t % W;
   const int64_t nrows = re - rb;
@@ -315,6 +350,76 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
     for (int j = 0; j < SPMV_SLOTS; ++j) {
       const int e = t + j * CCQP_BLOCK;
       if (e < E) prod[e] = pr[j];
+    }
+  } else if (diag) {
+    // ---- "diagonal" window: col = row + offset[position], the offsets (L int32, from the plan) parked in LDS.  No
+    // column stream (8 instead of 12 bytes per entry) and, in transposed order, no pass of the columns through LDS.
+    const int L = (int)((pw[4] >> 40) & 0xffff);
+    const int32_t* __restrict__ uc = ucol + (int64_t)blockIdx.x * SPMV_XS;
+    const int32_t myoff = uc[t < L ? t : L - 1];
+    double v[SPMV_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      const int64_t e = nzb + t + j * CCQP_BLOCK;
+      const int64_t es = e < elast ? e : elast;
+      v[j] = __builtin_nontemporal_load(val + es);
+    }
+    if (rows_in_lds) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (t + j * CCQP_BLOCK <= nrows) rstart[t + j * CCQP_BLOCK] = (uint16_t)(rp[j] - nzb);
+      for (int i = t + 2 * CCQP_BLOCK; i <= (int)nrows; i += CCQP_BLOCK)
+        rstart[i] = (uint16_t)(rowptr[rb + i] - nzb);
+    }
+    if (t < L) offs[t] = myoff;
+    __syncthreads();
+    if (longest > 0) {
+      // transposed order: thread p of the (position, row) grid takes position p / nr of row p % nr -- consecutive
+      // lanes gather consecutive x
+      const int nr = (int)nrows;
+      const int q = CCQP_BLOCK / nr, m = CCQP_BLOCK % nr;
+      int row = t % nr, pos = t / nr;
+      int e[SPMV_SLOTS];
+      bool ok[SPMV_SLOTS];
+      int64_t cc[SPMV_SLOTS];
+      double xv[SPMV_SLOTS];
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j) {
+        ok[j] = pos < L;
+        e[j] = ok[j] ? row * L + pos : 0;
+        cc[j] = rb + (ok[j] ? row : 0) + offs[ok[j] ? pos : 0];
+        row += m;
+        pos += q;
+        if (row >= nr) {
+          row -= nr;
+          pos += 1;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j) xv[j] = x[cc[j]];
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j)
+        if (ok[j]) prod[e[j]] = xv[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j) {
+        const int eo = t + j * CCQP_BLOCK;
+        if (eo < E) prod[eo] = v[j] * prod[eo];
+      }
+    } else {
+      double xv[SPMV_SLOTS];
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j) {
+        int e = t + j * CCQP_BLOCK;
+        e = e < E ? e : E - 1;
+        const int r = e / L, pos = e - r * L;
+        xv[j] = x[rb + r + offs[pos]];
+      }
+#pragma unroll
+      for (int j = 0; j < SPMV_SLOTS; ++j) {
+        const int e = t + j * CCQP_BLOCK;
+        if (e < E) prod[e] = v[j] * xv[j];
+      }
     }
   } else {
   // phase 1: ALL (value, column) loads of the window and its row pointers back to back, then all

@@ -9,9 +9,10 @@ same constructor, same `run()`, same four result tensors of shape
   * `process_results()` returns / prints tables (mean and the 95 % band computed with the reference's
     own formula :121-127) instead of opening matplotlib windows; `to_json()` stores everything;
   * with `lanes > 1` the trials of one (solver, operator) cell run concurrently: in lock-step with every scalar on
-    the device where that applies (batch.solve_batch_pipelined: BBPGD / APGD / MPRGP, elementwise sets; the
-    per-trial time is then the cell's wall-clock / trials), else on `lanes` streams (batch.solve_batch).  Results
-    per trial are bitwise those of sequential solves either way.
+    the device where that applies (batch.solve_batch_pipelined: PGD / BBPGD / BBPGDf / APGD / AR / MPRGP on elementwise
+    sets, PGD / BBPGD on Sphere / Cone / DisjointUnion sets too; the per-trial time is then the cell's wall-clock /
+    trials), else on `lanes` streams (batch.solve_batch).  Results per trial are bitwise those of sequential solves
+    either way; `cell_scheduler` records which one ran.
 """
 import contextlib
 import copy
@@ -22,6 +23,7 @@ import numpy as np
 
 from . import problems as _problems
 from .batch import solve_batch, solve_batch_pipelined
+from .lockstep import why_not_pipelined
 
 
 class BenchmarkRandomCCQP:
@@ -43,6 +45,7 @@ class BenchmarkRandomCCQP:
         self._problem_converged = None
         self._problem_time = None
         self._problem_num_matrix_vector_mults = None
+        self.cell_scheduler = {}        # (solver, family, size) -> "lock-step" | "stream lanes" | "sequential"
 
     def generate_random_convex_quadratic_func(self, problem_size, seed=1234):
         """(A, b) on the device: A = counter-hashed SPD matrix (kappa ~ 3.7), b = -A x*, x* = 1 - 2u."""
@@ -66,16 +69,20 @@ class BenchmarkRandomCCQP:
                 for solver_id, solver in enumerate(self.solvers_to_benchmark):
                     batch = [(cache[(n, t)][0], cache[(n, t)][1], None, proj_op) for t in range(self.num_trials)]
                     results = None
+                    how = "sequential"
                     if self.lanes > 1 and self.lockstep:
-                        try:                             # (its argument checks precede any GPU work)
-                            results = solve_batch_pipelined(lambda s=solver: copy.copy(s), batch, device=self.device)
+                        # decided on the argument check alone: whatever a lock-step run itself raises propagates
+                        made = [copy.copy(solver) for _ in batch]
+                        from ._engine import get_engine
+                        if why_not_pipelined(made, batch, get_engine(self.device).device) is None:
+                            results = solve_batch_pipelined(iter(made).__next__, batch, device=self.device)
                             for r in results:
                                 r._solution_time = r.solution_time / max(len(results), 1)
-                        except (TypeError, ValueError):
-                            results = None
+                            how = "lock-step"
                     if results is not None:
                         pass
                     elif self.lanes > 1:
+                        how = "stream lanes"
                         results = solve_batch(lambda s=solver: copy.copy(s), batch, lanes=self.lanes,
                                               device=self.device)
                     else:
@@ -83,6 +90,7 @@ class BenchmarkRandomCCQP:
                         for A, b, x0, op in batch:
                             with contextlib.redirect_stdout(io.StringIO()):
                                 results.append(copy.copy(solver).solve(A, b, convex_proj_op=op))
+                    self.cell_scheduler[(solver_id, proj_type_id, proj_id)] = how
                     for trial_id, r in enumerate(results):
                         idx = (solver_id, proj_type_id, proj_id, trial_id)
                         self._problem_residual[idx] = r.solution_residual
@@ -126,7 +134,10 @@ class BenchmarkRandomCCQP:
                "projection_families": [ops[0].name for ops in self.convex_proj_ops_to_benchmark],
                "residual": self._problem_residual.tolist(), "converged": self._problem_converged.tolist(),
                "time_s": self._problem_time.astype(float).tolist(),
-               "matrix_vector_mults": self._problem_num_matrix_vector_mults.tolist()}
+               "matrix_vector_mults": self._problem_num_matrix_vector_mults.tolist(),
+               "scheduler": [[[self.cell_scheduler.get((s, p, i), "?") for i in range(len(self.problem_sizes))]
+                              for p in range(len(self.convex_proj_ops_to_benchmark))]
+                             for s in range(len(self.solvers_to_benchmark))]}
         with open(path, "w") as f:
             json.dump(doc, f)
         return doc

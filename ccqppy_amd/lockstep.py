@@ -75,7 +75,14 @@ def why_not_pipelined(solvers, problems, device):
             return ValueError("solve_batch_pipelined: operator on another device")
         P = P if P is not None else ss.IdentityProjOp(n)
         if not hasattr(P, "_dev_bb_tail"):
-            return TypeError("solve_batch_pipelined needs elementwise feasible sets, got %r" % type(P).__name__)
+            # Sphere / Cone / DisjointUnion: the segmented lock-step form (ccqp_bsegs.hip), BBPGD and PGD only
+            if kind not in (CCQPSolverBBPGD, CCQPSolverPGD) or not isinstance(P, ss.ProjOpBase) or \
+                    any(getattr(op, "_kind", None) is None for op, _ in P._leaves()):
+                return TypeError("solve_batch_pipelined needs elementwise feasible sets (BBPGD / PGD: any set built "
+                                 "from the seven operators), got %r" % type(P).__name__)
+            if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
+                return ValueError("solve_batch_pipelined: the feasible set does not match b")
+            continue
         if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
             # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
             # sequential-sum kernels of the literal path)
@@ -128,8 +135,9 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         P = P if P is not None else ss.IdentityProjOp(n)
         P._refresh()
         bd = eng.to_device(b).reshape(-1)
-        by_size.setdefault(n, []).append((s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P,
-                                          isinstance(b, torch.Tensor), (A, b, x0, P)))
+        by_size.setdefault((n, hasattr(P, "_dev_bb_tail")), []).append(
+            (s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P, isinstance(b, torch.Tensor),
+             (A, b, x0, P)))
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
@@ -138,9 +146,12 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
              CCQPSolverAPGDAntiRelaxation: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
     t1 = time.time()
     with np.errstate(all="ignore"):
-        for n, items in by_size.items():                # one lock-step run per problem size
+        for (n, elementwise), items in by_size.items():     # one lock-step run per problem size (and kind of set)
             for lo in range(0, len(items), _BPIPE_MAX):
-                group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
+                if elementwise:
+                    group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
+                else:
+                    _bsegs_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
     if timing is not None:                              # host-side staging of the problem list vs the runs proper
         timing.update(staging_s=t1 - t0, run_s=time.time() - t1)
@@ -207,7 +218,10 @@ def _spec_from_items(eng, items, n):
     sp.A = np.array([it[1].A.data_ptr() for it in items], dtype=np.uint64)
     sp.lda = np.array([it[1].A.stride(0) for it in items], dtype=np.int64)
     sp.b = np.array([it[2].data_ptr() for it in items], dtype=np.uint64)
-    sp.seg = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=np.dtype(_lib.Seg))
+    if all(hasattr(it[4], "_dev_bb_tail") for it in items):
+        sp.seg = np.frombuffer(b"".join(bytes(it[4]._seg(eng, 0, n)) for it in items), dtype=np.dtype(_lib.Seg))
+    else:                                               # segmented form: the sets travel as plans (_bsegs_run)
+        sp.seg = np.zeros(len(items), dtype=np.dtype(_lib.Seg))
     sp.tol = np.array([it[0].desired_residual_tol for it in items], dtype=np.float64)
     sp.x0 = None if all(it[3] is None for it in items) else [it[3] for it in items]
     sp.keep = None
@@ -338,6 +352,85 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
         s._solution_residual = res[p]
         s._solution_num_matrix_vector_mults = mv
         # start-up: A x0 and -- BBPGD, unless the start already satisfies the tolerance -- A g0 (executed, not counted)
+        s._executed_matrix_vector_mults = mv if (pgd or (done[p] and final[p] == 0)) else 2 + int(final[p])
+        eng.mv_executed += s._executed_matrix_vector_mults
+
+
+def _bsegs_run(eng, spec, plans, n, max_mv, ahead, tune=0):
+    """Lock-step BBPGD / PGD over `spec` with the feasible sets given as segment plans (one per problem, shared objects
+    allowed): the segmented form of _bpipe_run (ccqp_bsegs.hip).  Returns (converged mask, index of the final
+    iteration, (B, n) device tensor of final iterates, residuals)."""
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(spec)
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 7, 3)
+    spec.stage_x0(vec[0])
+    for j in range(3):
+        tab["x"][:, j] = planes[j]
+        tab["g"][:, j] = planes[3 + j]
+    tab["y"] = planes[6]
+    flags = _bpipe_flags(tab, n, tune)
+    if getattr(spec, "step", None) is not None:         # PGD: constant steps, in slab slot 48; flag bit 3
+        slabs[:, 48] = torch.from_numpy(np.ascontiguousarray(spec.step)).to(dev)
+        flags |= 8
+    # one zeroed workspace slice per problem; tables and work lists are read-only and may be shared
+    wsd = np.array([pl.ws_doubles for pl in plans], dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(wsd)[:-1]))
+    ws = torch.zeros(int(wsd.sum()), dtype=torch.float64, device=dev)
+    stab = np.zeros(B, dtype=np.dtype(_lib.PSegs))
+    stab["table"] = [pl.table_ptr for pl in plans]
+    stab["work"] = [pl.work_ptr for pl in plans]
+    stab["normwork"] = [pl.normwork_ptr for pl in plans]
+    stab["workspace"] = np.uint64(ws.data_ptr()) + off.astype(np.uint64) * np.uint64(8)
+    stab["npartials"] = [pl.npartials for pl in plans]
+    stab["nwork"] = [pl.nwork for pl in plans]
+    stab["nnorm"] = [pl.nnorm for pl in plans]
+    max_nwork, max_nnorm = max(int(stab["nwork"].max()), 1), int(stab["nnorm"].max())
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    dsegs = torch.from_numpy(stab.view(np.uint8).reshape(-1)).to(dev)
+    dp, dsp, batch = dprobs.data_ptr(), dsegs.data_ptr(), words.data_ptr() + 4 * B
+    check = _lib.check
+    last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
+
+    def launch(k):
+        check(lib.ccqp_bsegs_iterate_f64(ctx, dp, dsp, B, n, k, max_nwork, max_nnorm, _GD, float(_EPS10), flags,
+                                         int(1 + k < max_mv), batch, st))
+
+    check(lib.ccqp_bsegs_start_f64(ctx, dp, dsp, B, n, max_nwork, max_nnorm, _GD, flags, batch, st))
+    k = _bpipe_poll_loop(eng, B, launch, last, ahead)
+    capped = 1 + k >= max_mv
+    h = slabs[:, 48:52].cpu().numpy()                   # blocking: the queue has drained
+    done, iters, res2 = h[:, 1] != 0.0, h[:, 2].astype(np.int64), h[:, 3]
+    if not capped and not done.all():
+        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+    final = np.where(done, iters, k)
+    if B == 1:
+        sols = vec[int(final[0] % 3)]
+    else:
+        sel = torch.from_numpy(final % 3).to(dev)
+        sols = vec[0:3][sel, torch.arange(B, device=dev)]
+    del keep, ws, dsegs
+    return done, final, sols, np.sqrt(res2)
+
+
+def _bsegs_group(eng, items, n, max_mv, ahead, tune=0):
+    plans = [it[4]._segplan(eng, n) for it in items]
+    done, final, sols, res = _bsegs_run(eng, _spec_from_items(eng, items, n), plans, n, max_mv, ahead, tune)
+    host = None
+    pgd = hasattr(items[0][0], "step_size")
+    for p, it in enumerate(items):
+        s = it[0]
+        mv = 1 + int(final[p])
+        if it[5]:
+            s._solution = sols[p]
+        else:
+            if host is None:
+                host = sols.cpu().numpy()
+            s._solution = host[p]
+        s._solution_converged = mv < max_mv
+        s._solution_residual = res[p]
+        s._solution_num_matrix_vector_mults = mv
         s._executed_matrix_vector_mults = mv if (pgd or (done[p] and final[p] == 0)) else 2 + int(final[p])
         eng.mv_executed += s._executed_matrix_vector_mults
 

@@ -78,14 +78,20 @@ class VectorExchange:
         self.rank = dist.get_rank(group)
         self.n = n
         self.row0, self.rows, self.per = row_partition(n, self.world, self.rank)
-        assert mode in ("allgather", "allreduce")
-        self.mode = mode
+        assert mode in ("allgather", "allreduce", "direct")
+        # "direct": the all-gather is issued by RCCL itself through the C ABI (ccqp_comm_allgather_f64) on the engine's
+        # own stream, in place -- no staging copy, no second stream, no event hand-off; opt-in (default: torch's binding)
+        self.direct = mode == "direct"
+        self._comm = None
+        self.mode = "allgather" if self.direct else mode
         self.even = (n % self.world) == 0
         self._pad = None
         self._send = None
         backend = dist.get_backend(group)
         self.backend = backend
         self.stage_cpu = backend != "nccl"   # gloo: stage device tensors through the host (tests only)
+        if self.direct and backend != "nccl":
+            raise ValueError("VectorExchange(mode='direct') needs the nccl (RCCL) backend, got %r" % backend)
         self.events = None
         self.calls = 0
 
@@ -131,8 +137,44 @@ class VectorExchange:
             ev[1].record(st)
             self.events.append(ev)
 
+    def _direct_comm(self, eng):
+        """The C-ABI communicator of this exchange (created once: rank 0's unique id travels over the process group)."""
+        if self._comm is None:
+            import ctypes
+            from . import _lib
+            lib = eng.lib
+            idbuf = (ctypes.c_ubyte * 128)()
+            if self.rank == 0:
+                _lib.check(lib.ccqp_comm_unique_id(idbuf))
+            box = [bytes(idbuf)]
+            src = 0 if self.group is None else self.dist.get_global_rank(self.group, 0)
+            self.dist.broadcast_object_list(box, src=src, group=self.group)
+            idbuf = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+            comm = ctypes.c_void_p()
+            _lib.check(lib.ccqp_comm_create(eng.ctx, self.world, self.rank, idbuf, ctypes.byref(comm)))
+            self._comm = comm
+        return self._comm
+
+    def _exchange_direct(self, y, eng):
+        from . import _lib
+        comm = self._direct_comm(eng)
+        if self.even:
+            _lib.check(eng.lib.ccqp_comm_allgather_f64(comm, y.data_ptr(), self.rows, eng.stream))
+            return
+        if self._pad is None or self._pad.device != y.device:
+            self._pad = torch.zeros(self.per * self.world, dtype=y.dtype, device=y.device)
+        full, lo = self._pad, self.rank * self.per
+        if self.rows:
+            eng.copy(y[self.row0:self.row0 + self.rows], full[lo:lo + self.rows])
+        _lib.check(eng.lib.ccqp_comm_allgather_f64(comm, full.data_ptr(), self.per, eng.stream))
+        eng.copy(full[:self.n], y)
+
     def _exchange(self, y, eng):
         dist = self.dist
+        if self.direct:
+            if eng is None or not y.is_cuda:
+                raise ValueError("VectorExchange(mode='direct') works on device vectors through an engine")
+            return self._exchange_direct(y, eng)
         if self.mode == "allreduce":
             # zero everything but the own slab, then sum: adding zeros is exact
             for lo, hi in ((0, self.row0), (self.row0 + self.rows, self.n)):
@@ -181,7 +223,7 @@ class SparseOperator:
     (include/ccqp_hip.h), so row-sharded and single-GPU runs agree bitwise.
     `check=True` validates the index arrays on the device once (the matvec does not bounds-check)."""
 
-    def __init__(self, A, shape=None, engine=None, check=True, width=0, local_x=True):
+    def __init__(self, A, shape=None, engine=None, check=True, width=0, local_x=True, diagonal_windows=True):
         if isinstance(A, torch.Tensor) and A.is_cuda:
             self.engine = engine or get_engine(A.device)
         elif isinstance(A, (tuple, list)) and isinstance(A[2], torch.Tensor) and A[2].is_cuda:
@@ -230,8 +272,14 @@ class SparseOperator:
                                  "not ending at nnz, or column index outside [0, %d))" % (bad, self.n))
         # one-time analysis: which rows each workgroup streams, which rows are too long for the LDS path
         # (local_x=False keeps every window on the global-gather paths: a tuning / testing switch, same bits)
+        # (diagonal_windows=False likewise keeps windows with one repeated column-offset pattern on the generic paths)
         self.local_x = local_x
+        self.diagonal_windows = diagonal_windows
         self.plan, self.summary = self.engine.spmv_plan(self.rowptr, self.col, self.nnz, local_x)
+        if not diagonal_windows and self.summary[3]:
+            nwin = self.nnz // 1792 + 1                # (SPMV_CAP; plan word 4 of every window: clear SPMV_DIAG, bit 34)
+            self.plan[4:5 * nwin:5] &= ~(1 << 34)
+            self.summary[3] = 0
 
     @property
     def shape(self):
@@ -244,7 +292,8 @@ class SparseOperator:
         hi = int(self.rowptr[row0 + rows].item())
         rp = (self.rowptr[row0:row0 + rows + 1] - lo).contiguous()
         return SparseOperator((rp, self.col[lo:hi], self.val[lo:hi]), shape=(rows, self.n), engine=self.engine,
-                              check=False, width=self.width, local_x=self.local_x)
+                              check=False, width=self.width, local_x=self.local_x,
+                              diagonal_windows=self.diagonal_windows)
 
     def apply(self, eng, x, y, b=None, g=None):
         eng.spmv_csr(self.rowptr, self.col, self.val, self.plan, self.summary, self.n, x, y, b, g, self.width)
@@ -269,7 +318,8 @@ class SparseOperator:
             rp[1:] = torch.cumsum(torch.bincount(self.col.long(), minlength=self.n), 0)
             self._transposed = SparseOperator((rp, row_of[order].to(torch.int32), self.val[order]),
                                               shape=(self.n, self.rows), engine=self.engine, check=False,
-                                              width=self.width, local_x=self.local_x)
+                                              width=self.width, local_x=self.local_x,
+                                              diagonal_windows=self.diagonal_windows)
         return self._transposed
 
     def matvec(self, x, y, b=None, g=None, engine=None):

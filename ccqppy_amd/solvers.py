@@ -133,6 +133,11 @@ class CCQPSolverBase(ABC):
         self._solution_time = None
         self._solution_num_matrix_vector_mults = None
         self._executed_matrix_vector_mults = None
+        # diagnostics, OFF by default: set `solver.trace = []` before solve() and the host loop appends one dict of
+        # its steering scalars per completed iteration (the keys of oracle/cases.py:TRACE_COLUMNS) -- what the
+        # parity tests compare with the per-iteration traces stored in tests/golden/solvers.npz.  Host-driven loops
+        # only: a device-resident form (pipeline=True, the lock-step schedulers) keeps its scalars on the GPU.
+        self.trace = None
 
     def solve(self, A, b, x0=None, convex_proj_op=None):
         """Solve; returns self.  A: (n, n); b: (n,); x0: (n,) or None (zeros); convex_proj_op:
@@ -233,6 +238,8 @@ class CCQPSolverPGD(CCQPSolverBase):
                 if mv_count >= max_mv:
                     break
                 res = yield from run.residual_now(xk, gk)
+                if self.trace is not None:
+                    self.trace.append(dict(mv=mv_count, res=float(res)))
                 if res < tol:
                     break
                 xk, xkm1 = xkm1, xk
@@ -263,7 +270,7 @@ class _APGDCore(CCQPSolverBase):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, b, AR = run.eng, run.b, self._anti_relaxation
         reuse = self.reuse_matvec
-        if self.pipeline and not reuse:
+        if self.pipeline and not reuse and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
                 return out
@@ -299,6 +306,7 @@ class _APGDCore(CCQPSolverBase):
                     Axk = Ayk                           # first iteration: xk == yk == x0
             xkp1 = run.step_project(yk, t, gk)
             first = True
+            nback = 0
             while True:
                 Ax1, g1 = run.mv(xkp1, True)
                 mv_count += 1
@@ -340,12 +348,15 @@ class _APGDCore(CCQPSolverBase):
                 L *= 2
                 t = 1.0 / L
                 xkp1 = run.step_project(yk, t, gk)
+                nback += 1
             thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
             beta = thk * (1 - thk) / (thk * thk + thk1)
             ykp1 = run.lin(1 + beta, xkp1, -beta, xk)   # (1+beta)*xkp1 - beta*xk
             if reuse:
                 Ay_next = run.lin(1 + beta, Ax1, -beta, Axk)
             res = np.sqrt(res2[1])
+            if self.trace is not None:
+                self.trace.append(dict(mv=mv_count, res=float(res), L=float(L), nback=nback))
             if AR and res < resmin:                     # :501-503
                 resmin = res
                 xhat = run.copy(xkp1)
@@ -425,7 +436,7 @@ class _BBPGDCore(CCQPSolverBase):
         op = run.op
         ok_op = isinstance(op, (DenseOperator, SparseOperator)) or \
             (isinstance(op, ComposedOperator) and op.can_pipeline())
-        return (self.pipeline and not self._fallback and ok_op
+        return (self.pipeline and self.trace is None and not self._fallback and ok_op
                 and hasattr(run.P, "_dev_bb_tail") and not isinstance(run.eng, RecordingEngine)
                 and run.eng.gemv_events is None)
 
@@ -546,7 +557,7 @@ class _BBPGDCore(CCQPSolverBase):
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
-        if self.pipeline and self._fallback:
+        if self.pipeline and self._fallback and self.trace is None:
             out = self._lockstep_fallback_variant(run)
             if out is not None:
                 return out
@@ -585,11 +596,15 @@ class _BBPGDCore(CCQPSolverBase):
                         eng.dots([(dx, dx), (dx, dg)], 1)
                     sc = yield from run.read(0, 3)
                     res = np.sqrt(sc[0])
+                    if self.trace is not None:
+                        self.trace.append(dict(mv=mv_count, res=float(res), alpha=float(alpha)))
                     if res < tol:
                         break
                 else:
                     run.residual_sq(xk, gk, 0)
                     res = np.sqrt((yield from run.read(0, 1))[0])
+                    if self.trace is not None:
+                        self.trace.append(dict(mv=mv_count, res=float(res), alpha=float(alpha)))
                     if res < tol:
                         break
                     if res < resmin:                    # :793-796
@@ -676,6 +691,8 @@ class CCQPSolverSPG(CCQPSolverBase):
             beta = -dkdotgk / dkdotAdk
             betahat = tau * beta + np.sqrt((tau ** 2) * (beta ** 2) + 2 * xi)
             betak = (self.rng or np.random).uniform(low=sig1, high=min(betahat, sig2))
+            if self.trace is not None:
+                self.trace.append(dict(mv=mv_count, dd=float(dkdotdk), alpha=float(alpha), betak=float(betak)))
             eng.axpby2(1.0, xk, betak, dk, xk, 1.0, gk, betak, Adk, gk)   # xk += betak*dk; gk += betak*Adk
             fk += betak * betak * dkdotgk + 0.5 * (betak ** 2) * dkdotAdk   # sic, :963
             fk_queue.append(fk)
@@ -736,7 +753,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         eng, P = run.eng, run.P
         # elementwise feasible set with array bounds: the proportioning test, the free gradient and
         # the CG direction run as fused kernels (ccqp_mprgp.hip); anything else takes the literal path
-        if self.pipeline and self.FUSED:
+        if self.pipeline and self.FUSED and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
                 return out
@@ -782,6 +799,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                     beta_x = run.new()
                     eng.chopped_gradient(w, gk, nv, 8, beta_x)           # :1096-1097
                     bb, pp = yield from run.dots_now([(beta_x, beta_x), (psi, psi)])
+                self._nhalve = 0
                 if bb < pp:
                     Ap = run.mv(p)
                     mv_count += 1
@@ -791,6 +809,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                     alpha_cg = psip / pAp
                     y = run.lin(1.0, xk, -alpha_cg, p)
                     alpha_f = yield from self._feasible_step(run, xk, p, alpha_cg + _EPS10)
+                    branch = "cg" if alpha_cg <= alpha_f else "expand"
                     if alpha_cg <= alpha_f:
                         xkp1 = y                                         # np.copy(y): nothing writes in place
                         gkp1 = run.lin(1.0, gk, -alpha_cg, Ap)
@@ -818,6 +837,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                         Adx = run.mv(dx)                                 # executed, not counted (:1163)
                         eng.dots([(dx, dx), (dx, Adx)], 0)
                 else:
+                    branch = "prop"
                     xkp1 = run.step_project(xk, alpha_bb, gk)
                     dx = run.lin(1.0, xkp1, -1.0, xk)
                     Adx = run.mv(dx)                                     # executed, not counted (:1172)
@@ -832,6 +852,9 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 sc = yield from run.read(0, 3)
                 alpha_bb = sc[0] / (sc[1] + _EPS10)
                 res = np.sqrt(sc[2])
+                if self.trace is not None:
+                    self.trace.append(dict(mv=mv_count, res=float(res), branch=branch, nhalve=self._nhalve,
+                                           alpha_bb=float(alpha_bb)))
                 if res < tol:
                     break
                 xk, xkp1 = xkp1, xk
@@ -855,6 +878,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                     if c == 0:
                         return alpha_f
                     alpha_f *= 0.5
+                    self._nhalve += 1
                 tried += self._STEPS
                 if tried > 1200:   # alpha_f has underflowed to 0: the reference never exits either
                     raise RuntimeError("MPRGP feasibility bisection cannot terminate "
@@ -865,6 +889,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
             if (yield from run.read(9, 1))[0] == 0:
                 return alpha_f
             alpha_f *= 0.5
+            self._nhalve += 1
             tried += 1
             if tried > 1200:
                 raise RuntimeError("MPRGP feasibility bisection cannot terminate "

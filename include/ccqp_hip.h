@@ -161,6 +161,31 @@ int ccqp_proj_normscale_f64(ccqp_ctx* ctx, const ccqp_seg* seg, const double* x,
 int ccqp_proj_small_segments_f64(ccqp_ctx* ctx, const ccqp_seg* table, int64_t nseg, const double* x,
                                  double* out, int mode, void* stream);
 
+/* ---- (e1) row-sharded multi-GPU matvec, one process per GPU, RCCL over xGMI (ccqp_comm.hip) -------------------
+ * The exchange step of SURVEY.md 8(e)1 behind the C ABI (the Python shells default to torch.distributed's RCCL
+ * binding; this is the same step without torch, and their opt-in VectorExchange(direct=True)).  RCCL is bound at run
+ * time: without a loadable librccl the calls fail with CCQP_ERR_UNSUPPORTED.  Bootstrap: rank 0 obtains a unique id
+ * and ships its 128 bytes to the other ranks by any means (MPI, a file, torch.distributed); every rank then
+ * creates its communicator on its context's device.  All calls are asynchronous on `stream`. */
+#define CCQP_COMM_ID_BYTES 128
+typedef struct ccqp_comm ccqp_comm;
+int ccqp_comm_rccl_version(void);                      /* 0: no RCCL available */
+int ccqp_comm_unique_id(unsigned char* id128);
+int ccqp_comm_create(ccqp_ctx* ctx, int nranks, int rank, const unsigned char* id128, ccqp_comm** out);
+int ccqp_comm_destroy(ccqp_comm* comm);
+int ccqp_comm_info(const ccqp_comm* comm, int* nranks, int* rank);
+/* y holds `count` doubles per rank, rank r's at y[r*count ...): in-place all-gather / in-place sum. */
+int ccqp_comm_allgather_f64(ccqp_comm* comm, double* y, int64_t count, void* stream);
+int ccqp_comm_allreduce_sum_f64(ccqp_comm* comm, double* buf, int64_t count, void* stream);
+/* One row-sharded `A.dot(v)` (solvers.py:133,...): y[rank*per + i] = A_local[i,:] . x for i < rows_local
+ * (per = ceil(n / nranks) >= rows_local), then ONE exchange on the same stream -- mode 0: in-place all-gather of `per`
+ * doubles per rank; mode 1: the other slabs zeroed + all-reduce (adds exact zeros).  y must hold per * nranks doubles;
+ * its first n entries are the assembled vector.  Each row sum comes from one wave in an order that depends on the row
+ * only, so the result is bitwise the single-GPU ccqp_gemv_f64 for every rank count. */
+int ccqp_shard_gemv_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda, const double* x,
+                                  double* y, int64_t rows_local, int64_t per, int64_t cols, int variant, int mode,
+                                  void* stream);
+
 /* ---- a5-a8 for ANY feasible set in <= 2 launches: the segmented engine (ccqp_segs.hip) -----------------------
  * Replaces the Python loop of DisjointProjOp.__call__ / normal_vector (solution_spaces.py:540-560, 512-525) and
  * the dot + scale pairs of Sphere / Cone (:417-435, 470-492) for tables with blocks of EVERY size; the residual
@@ -347,6 +372,29 @@ int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, 
  * dots, alpha, exit test (with_tail == 0 where the matvec budget ends before the residual, solvers.py:643-644). */
 int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count, int64_t n, int64_t iteration,
                            double gd, double eps10, int flags, int with_tail, uint32_t* dev_batch, void* stream);
+/* ---- lock-step BBPGD / PGD for NON-elementwise feasible sets (Sphere, Cone, DisjointUnion; ccqp_bsegs.hip) ----------
+ * The same scheduler with the projection, the fused step and the Eq. 25 residual taken from the segmented engine:
+ * problem p brings its block table and work lists (ccqp_segs_plan) in dev_segs[p]; its `seg` in dev_probs[p] is
+ * unused.  4-6 launches per iteration for the whole batch (grids of max_nwork / max_nnorm work items per problem;
+ * a problem with fewer items idles the rest).  Replaces the Python loops solvers.py:583-669 / 94-170 around
+ * solution_spaces.py:540-560, 417-435, 470-492 as run by benchmarks/benchmark_random_ccqp.py:67-102.  Per problem
+ * the bits of its own solve() (ccqp_segs_project_f64 + ccqp_segs_residual_sq_f64 + ccqp_dots_f64 + the host loop's
+ * scalar arithmetic).  `workspace` must be zero on entry.  Polling, slab slots, flags bit 0 / bit 3 (PGD) and the
+ * matvec tuning word: as ccqp_bpipe_*; BBPGDf (bit 7) is not available here. */
+typedef struct ccqp_psegs {
+  const ccqp_seg* table;
+  const ccqp_segwork* work;
+  const ccqp_segwork* normwork;
+  double* workspace;   /* ccqp_segs_workspace_doubles(npartials, nwork) doubles */
+  int64_t npartials;
+  int32_t nwork, nnorm;
+} ccqp_psegs;
+int ccqp_bsegs_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, const ccqp_psegs* dev_segs, int count, int64_t n,
+                         int64_t max_nwork, int64_t max_nnorm, double gd, int flags, uint32_t* dev_batch,
+                         void* stream);
+int ccqp_bsegs_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, const ccqp_psegs* dev_segs, int count,
+                           int64_t n, int64_t iteration, int64_t max_nwork, int64_t max_nnorm, double gd,
+                           double eps10, int flags, int with_tail, uint32_t* dev_batch, void* stream);
 /* non-blocking: out[0..1] = {problems converged, last iteration every problem has finished (-1: none yet)} */
 int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out);
 /* The WHOLE solve of every problem in ONE launch, one workgroup per problem (n <= 2048: every reduction is one block
@@ -454,10 +502,14 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  *         when `col` is given -- for every window whose entries reuse their columns (each distinct column
  *         1.5 times or more, at most 1024 of them) the sorted distinct columns plus a 16-bit local column
  *         per entry: such "local-x" windows load each x value once into LDS and stream 10 instead of 12
- *         bytes per entry.  The plan takes ~2.3 + 2 bytes per stored entry.
- *   summary (optional, 3 host words): {rows on the wave-per-row path, windows in transposed order,
- *         local-x windows}.  Asking for it makes the plan call blocking; handing it to the matvec lets it
- *         skip the second launch when no row needs it (NULL = unknown: launched, the kernel reads the count).
+ *         bytes per entry; for the other windows, whether all rows have one length L <= 256 and, position by
+ *         position, the same offset col - row (banded / circulant / regular-grid matrices): such "diagonal"
+ *         windows keep the L offsets once and the matvec reads NO column index for them (8 instead of 12 bytes per
+ *         entry).  The plan takes ~2.3 + 2 bytes per stored entry.
+ *   summary (optional, 4 host words): {rows on the wave-per-row path, windows in transposed order,
+ *         local-x windows, diagonal windows}.  Asking for it makes the plan call blocking; handing it to the
+ *         matvec (which reads word 0 only) lets it skip the second launch when no row needs it (NULL = unknown:
+ *         launched, the kernel reads the count).
  * Bits of y[i]: a function of row i's stored entries (in storage order) and x only -- not of the plan,
  * not of `width` (lanes that reduce one row: 0 = from the mean row length; 4, 8, 16, 32, 64 to force),
  * not of how the rows are sharded over GPUs: p_e = fl(val_e * x[col_e]); canonical lane e mod 64 adds its
@@ -512,7 +564,11 @@ int ccqp_batch_serialize_matvecs(ccqp_ctx* ctx, int on);
 /* Device addresses of a context's scalar slab and reduction workspace (to fill ccqp_bop). */
 int ccqp_ctx_workspace(ccqp_ctx* ctx, double** slab, double** partials);
 /* Upload all descriptors once, then launch group after group on `stream`:
- * group i = opcodes[i] applied to the next counts[i] descriptors of `ops` (host array). */
+ * group i = opcodes[i] applied to the next counts[i] descriptors of `ops` (host array).
+ * Contract: ONE stream per context (a context's descriptor ring, scalar slab and reduction workspace are ordered by
+ * that stream only).  Any number of calls may be queued without synchronising: the ring (16384 descriptors, at most
+ * 4096 per call) keeps an event per quarter and the call waits on the host before it reuses a quarter whose
+ * descriptors a queued copy or kernel may still read. */
 int ccqp_batch_run_f64(ccqp_ctx* ctx, int ngroups, const int* opcodes, const int* counts,
                        const ccqp_bop* ops, void* stream);
 

@@ -105,7 +105,7 @@ int main(void) {
     CHECK(ccqp_csr_validate(ctx, rp, cidx, rows, cols, nnz, 5, NULL));
     CHECK(ccqp_scalars_read(ctx, 5, 1, &viol, NULL));
     if (viol != 0.0) bad++;
-    int64_t summary[3] = {-1, -1, -1};
+    int64_t summary[4] = {-1, -1, -1, -1};
     CHECK(ccqp_spmv_plan_csr(ctx, rp, cidx, rows, nnz, plan, summary, NULL));
     if (summary[0] != 1) bad++;                              /* exactly the 2500-entry row */
     CHECK(ccqp_spmv_csr_f64(ctx, rp, cidx, vals, plan, summary, x, b, y, g, rows, cols, nnz, 0, NULL));

@@ -1,0 +1,203 @@
+"""GPU: the segmented lock-step scheduler (ccqp_bsegs_* in ccqp_bsegs.hip; batch.solve_batch_pipelined with BBPGD / PGD
+on Sphere, Cone and DisjointUnion sets).  An execution strategy only: per problem x, the residual, the converged
+flag, the reported and the executed MV counts must be those of that problem's own solve(), bit for bit -- for sets
+with small blocks only (no norm launch), with large blocks (norm launches), whole-vector Sphere / Cone, several
+reduction blocks, different sets inside one batch, warm and trivial starts, mixed tolerances, every MV cap.
+Reference loops: solvers.py:583-669, 94-170 around solution_spaces.py:540-560, 417-435, 470-492."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref, gen_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, c):
+    assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+    assert bool(a.solution_converged) == bool(c.solution_converged)
+    assert float(a.solution_residual) == float(c.solution_residual) or \
+        (np.isnan(a.solution_residual) and np.isnan(c.solution_residual))
+    xa, xc = a.solution, c.solution
+    xa = xa.cpu().numpy() if hasattr(xa, "cpu") else xa
+    xc = xc.cpu().numpy() if hasattr(xc, "cpu") else xc
+    assert np.array_equal(xa.view(np.uint64), xc.view(np.uint64))
+
+
+def _set(n, p, family):
+    """Feasible set number p of a family for vectors of length n."""
+    from ccqppy_amd import solution_spaces as ss
+    if family == "sphere":
+        return ss.SphereProjOp(n, [0.5, 2.0, 40.0][p % 3])
+    if family == "cone":
+        return ss.ConeProjOp(n, [1, 0.5, 3.0][p % 3])
+    if family == "spheres3":                      # the ensemble's friction-like family: many tiny blocks
+        k = n // 3
+        ops = [ss.SphereProjOp(3, 0.2 + 0.1 * (p % 4))] * k
+        if n - 3 * k:
+            ops.append(ss.IdentityProjOp(n - 3 * k))
+        return ss.DisjointProjOp(*ops)
+    if family == "mixed":                         # small and large blocks, elementwise and norm-based, nested
+        half = n // 2
+        q = (n - half) // 3
+        lo, hi = -0.3 * np.ones(half) - 0.01 * p, 0.4 * np.ones(half)
+        return ss.DisjointProjOp(ss.BoxProjOp(half, lo, hi),
+                                 ss.DisjointProjOp(ss.SphereProjOp(q, 0.7), ss.ConeProjOp(q, 2.0)),
+                                 ss.SphereProjOp(n - half - 2 * q, 0.3 + 0.05 * p))
+    raise KeyError(family)
+
+
+def _problems(n, count, seed, family):
+    from ccqppy_amd import problems
+    out = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, seed + p)
+        fam = family if isinstance(family, str) else family[p % len(family)]
+        out.append((op, b, None, _set(n, p, fam)))
+    return out
+
+
+def _reference(probs, tols, max_mv, solver="BBPGD"):
+    from ccqppy_amd import solvers
+    cls = getattr(solvers, "CCQPSolver" + solver)
+    ref = []
+    for (A, b, x0, P), tol in zip(probs, tols):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.append(cls(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
+    return ref
+
+
+def _batch(probs, tols, max_mv, solver="BBPGD", **kw):
+    from ccqppy_amd import batch, lockstep, solvers
+    cls = getattr(solvers, "CCQPSolver" + solver)
+    it = iter(tols)
+    before = dict(lockstep.stats)
+    out = batch.solve_batch_pipelined(lambda: cls(next(it), max_mv), probs, **kw)
+    assert lockstep.stats == before, "a device-resident solve fell back to the host loop"
+    return out
+
+
+@pytest.mark.parametrize("family", ["sphere", "spheres3", "mixed"])
+@pytest.mark.parametrize("n,count", [(36, 11), (256, 24), (1000, 9), (2049, 6), (4500, 4)])
+def test_segmented_lockstep_equals_individual_solves(family, n, count):
+    probs = _problems(n, count, 900 + n, family)
+    tols = [1e-8] * count
+    # "mixed" holds a Cone block, which is not a projection in the reference (:439): such solves run to their budget
+    budget = 90 if family == "mixed" else 4000
+    ref = _reference(probs, tols, budget)
+    got = _batch(probs, tols, budget)
+    assert len(got) == count
+    for a, c in zip(ref, got):
+        assert c.solution_converged or family == "mixed"
+        _same(a, c)
+    assert max(r.solution_num_matrix_vector_multiplications for r in ref) > 5
+
+
+def test_cone_runs_to_its_budget_like_the_reference():
+    """The reference's Cone is not a projection (solution_spaces.py:439,484): no solve converges; the budget exit path
+    (solvers.py:641-644) and every iterate must still be those of solve()."""
+    n, count = 300, 6
+    probs = _problems(n, count, 17, "cone")
+    for cap in (1, 2, 3, 7, 40):
+        ref = _reference(probs, [1e-8] * count, cap)
+        got = _batch(probs, [1e-8] * count, cap)
+        for a, c in zip(ref, got):
+            assert not c.solution_converged or cap > 40
+            _same(a, c)
+
+
+def test_different_sets_in_one_batch_and_sharded_entry():
+    """Problems of one size with DIFFERENT sets (different work-list lengths; some without any norm block) advance in
+    one lock-step run; `solve_batch_sharded` picks this scheduler by itself."""
+    from ccqppy_amd import batch, lockstep, solvers
+    n, count = 600, 12
+    probs = _problems(n, count, 3, ["sphere", "spheres3", "mixed", "cone"])
+    tols = [1e-7] * count
+    ref = _reference(probs, tols, 60)
+    got = _batch(probs, tols, 60)
+    for a, c in zip(ref, got):
+        _same(a, c)
+    before = dict(lockstep.stats)
+    sharded = batch.solve_batch_sharded(lambda: solvers.CCQPSolverBBPGD(1e-7, 60), lambda p: probs[p], count)
+    assert lockstep.stats == before                       # neither declined nor fell back
+    for p in range(count):
+        _same(ref[p], sharded[p])
+
+
+def test_mixed_tolerances_warm_and_trivial_starts_numpy_inputs_and_oracle():
+    import torch
+    n, count = 384, 15
+    probs = _problems(n, count, 7, ["spheres3", "mixed", "sphere"])
+    first = _reference(probs, [1e-9] * count, 300)
+    for p in range(0, count, 3):                          # warm start every third problem at (nearly) its solution
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, first[p].solution.clone(), P)
+    tols = [[1e-10, 1e-6, 1e-3, 1e30][p % 4] for p in range(count)]       # 1e30: satisfied by x0 already
+    ref = _reference(probs, tols, 300)
+    got = _batch(probs, tols, 300, ahead=1)
+    for a, c in zip(ref, got):
+        _same(a, c)
+    assert any(r.solution_num_matrix_vector_multiplications == 1 for r in ref)
+    # numpy inputs, and the ORACLE as the yardstick: same MV count, x within 1e-10
+    from ccqppy_amd import solution_spaces as ss
+    A = gen_ref.spd_rows(192, 8)
+    b = -A.dot(gen_ref.xstar(192, 8))
+    P = ss.DisjointProjOp(*([ss.SphereProjOp(3, 0.25)] * 40 + [ss.SphereProjOp(72, 1.5)]))
+    Po = cpu_ref.Disjoint(*([cpu_ref.Sphere(3, 0.25)] * 40 + [cpu_ref.Sphere(72, 1.5)]))
+    got = _batch([(A, b, None, P)], [1e-8], 4000)
+    assert isinstance(got[0].solution, np.ndarray) and not isinstance(got[0].solution, torch.Tensor)
+    o = cpu_ref.solve_bbpgd(A, b, 1e-8, 4000, P=Po)
+    assert o.solution_num_matrix_vector_multiplications == got[0].solution_num_matrix_vector_multiplications
+    assert o.executed_mv == got[0].executed_matrix_vector_multiplications
+    assert np.linalg.norm(got[0].solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+
+
+def test_every_mv_cap():
+    n, count = 300, 8
+    probs = _problems(n, count, 5, ["spheres3", "sphere"])
+    tols = [1e-9] * count
+    full = _reference(probs, tols, 4000)
+    longest = max(r.solution_num_matrix_vector_multiplications for r in full)
+    shortest = min(r.solution_num_matrix_vector_multiplications for r in full)
+    assert longest >= shortest >= 3
+    for cap in range(1, longest + 3):
+        ref = _reference(probs, tols, cap)
+        got = _batch(probs, tols, cap)
+        for a, c in zip(ref, got):
+            _same(a, c)
+
+
+def test_pgd_constant_step_on_general_sets():
+    from ccqppy_amd import batch, lockstep, solvers
+    n, count = 200, 10
+    probs = _problems(n, count, 23, ["sphere", "spheres3"])
+    ref, it = [], iter(range(count))
+    for (A, b, x0, P) in probs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.append(solvers.CCQPSolverPGD(1e-7, 600, 0.2 + 0.01 * next(it)).solve(A, b, convex_proj_op=P))
+    it = iter(range(count))
+    before = dict(lockstep.stats)
+    got = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverPGD(1e-7, 600, 0.2 + 0.01 * next(it)), probs)
+    assert lockstep.stats == before
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
+
+
+def test_solvers_without_a_segmented_form_are_declined_not_mis_solved():
+    """APGD / MPRGP / BBPGDf on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
+    host-driven scheduler, counted in lockstep.stats)."""
+    from ccqppy_amd import batch, lockstep, solvers
+    probs = _problems(128, 3, 1, "spheres3")
+    for cls in (solvers.CCQPSolverAPGD, solvers.CCQPSolverBBPGDf, solvers.CCQPSolverMPRGP):
+        with pytest.raises(TypeError):
+            batch.solve_batch_pipelined(lambda: cls(1e-6, 300), probs)
+    before = lockstep.stats["auto_declined"]
+    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverAPGD(1e-6, 300), lambda p: probs[p], 3)
+    assert lockstep.stats["auto_declined"] == before + 1
+    ref = _reference(probs, [1e-6] * 3, 300, "APGD")
+    for p in range(3):
+        _same(ref[p], out[p])

@@ -177,3 +177,72 @@ def test_batch_sharded_two_ranks_with_final_gather():
         for p, (x, mv, conv, name) in res.items():
             assert mv == want[p][1] and conv and name == "MPRGP"
             assert np.array_equal(x.view(np.uint64), want[p][0].view(np.uint64)), (rank, p)
+
+
+def _rccl_direct_worker(port, q):
+    """RCCL through the C ABI (ccqp_comm_*, ccqp_shard_gemv_allgather_f64) with the one rank a 1-GPU box allows: the
+    bootstrap (unique id -> communicator on the context's device), the in-place all-gather and the padded all-reduce
+    on our own stream behind our own kernels, the sharded matvec entry, and VectorExchange(mode="direct")."""
+    import ctypes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    out = {}
+    try:
+        from ccqppy_amd import _lib, problems
+        from ccqppy_amd._engine import get_engine
+        from ccqppy_amd.operators import VectorExchange
+        eng = get_engine(0)
+        lib = eng.lib
+        out["version"] = int(lib.ccqp_comm_rccl_version())
+        idbuf = (ctypes.c_ubyte * 128)()
+        _lib.check(lib.ccqp_comm_unique_id(idbuf))
+        comm = ctypes.c_void_p()
+        _lib.check(lib.ccqp_comm_create(eng.ctx, 1, 0, idbuf, ctypes.byref(comm)))
+        nr, rk = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.ccqp_comm_info(comm, ctypes.byref(nr), ctypes.byref(rk)))
+        out["info"] = (nr.value, rk.value)
+        n = 4096
+        A = problems.spd_rows(n, 5)
+        x = problems.xstar(n, 5)
+        want = eng.empty(n)
+        eng.gemv(A, x, want)
+        for mode in (0, 1):
+            y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            _lib.check(lib.ccqp_shard_gemv_allgather_f64(eng.ctx, comm, A.data_ptr(), A.stride(0), x.data_ptr(),
+                                                         y.data_ptr(), n, n, n, 0, mode, eng.stream))
+            torch.cuda.synchronize()
+            out["shard_mode%d" % mode] = bool(torch.equal(y.view(torch.int64), want.view(torch.int64)))
+        # the collectives themselves, on our stream right behind one of our kernels (1 rank: identity / x1 sum)
+        z = eng.empty(n)
+        eng.scale(2.0, want, z)
+        _lib.check(lib.ccqp_comm_allgather_f64(comm, z.data_ptr(), n, eng.stream))
+        _lib.check(lib.ccqp_comm_allreduce_sum_f64(comm, z.data_ptr(), n, eng.stream))
+        torch.cuda.synchronize()
+        out["collectives"] = bool(torch.equal(z, 2.0 * want))
+        rc = lib.ccqp_comm_create(eng.ctx, 2, 5, idbuf, ctypes.byref(ctypes.c_void_p()))
+        out["bad_rank_rejected"] = rc != 0
+        _lib.check(lib.ccqp_comm_destroy(comm))
+        ex = VectorExchange(n, dist.group.WORLD, "direct")
+        out["exchange_mode"] = (ex.direct, ex.mode)
+        ex(z, eng)                                  # world == 1: nothing to exchange, must not touch RCCL
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_through_the_c_abi_single_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_direct_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=180)
+    p.join(60)
+    assert p.exitcode == 0
+    assert out["version"] > 0 and out["info"] == (1, 0)
+    assert out["shard_mode0"] and out["shard_mode1"] and out["collectives"] and out["bad_rank_rejected"]
+    assert out["exchange_mode"] == (True, "allgather")

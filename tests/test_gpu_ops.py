@@ -237,6 +237,45 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
     assert H.same_bits(y.cpu().numpy(), base)
 
 
+@pytest.mark.parametrize("rows,cols", [(16, 64), (17, 128), (100, 1024), (777, 4096), (5, 64), (4096, 8192)])
+def test_gemv_mfma_variant_against_fp64_reference(rows, cols, eng):
+    """The `v_mfma_f64_16x16x4_f64` form of the matvec (variant bit 9; BASELINE config 3's "MFMA GEMV", kept as an
+    A/B variant -- profiles/r02_gemv_mfma_ab.md).  Asymmetric data: a swapped row / column map cannot pass.  Same
+    fp64 bound as the VALU form; the two forms sum a row's columns in different orders, so their last bits may
+    differ -- by no more than twice that bound.  Row blocks of the MFMA form are bitwise invariant too."""
+    import math
+    rng = np.random.default_rng(rows * 7 + cols)
+    A = rng.normal(size=(rows, cols)) + np.arange(rows)[:, None] * 0.01 - np.arange(cols)[None, :] * 0.003
+    x = rng.normal(size=cols)
+    b = rng.normal(size=rows)
+    dA, dx, db = eng.to_device(A), eng.to_device(x), eng.to_device(b)
+    exact = np.array([math.fsum(A[i] * x) for i in range(rows)])
+    bound = _gemv_ref_bound(A, x)
+    base = eng.empty(rows)
+    eng.gemv(dA, dx, base)
+    for U in (0, 1, 2, 4):
+        y, g = eng.empty(rows), eng.empty(rows)
+        eng.gemv(dA, dx, y, db, g, variant=0x200 | (U << 4))
+        yy = y.cpu().numpy()
+        assert np.all(np.abs(yy - exact) <= bound), U
+        assert H.same_bits(g.cpu().numpy(), yy + b)
+        assert np.all(np.abs(yy - base.cpu().numpy()) <= 2 * bound)
+        if U == 0:
+            first = yy
+        else:
+            assert H.same_bits(yy, first)                      # the unroll does not change the order
+    if rows > 40:
+        yb = eng.empty(rows - 32)
+        eng.gemv(dA[32:], dx, yb, variant=0x200)
+        assert H.same_bits(yb.cpu().numpy(), first[32:])
+    # a shape the MFMA form does not cover (cols % 64 != 0) falls through to the VALU form: its bits
+    y2 = eng.empty(rows)
+    eng.gemv(dA[:, :cols - 2], dx, y2, variant=0x200)
+    y3 = eng.empty(rows)
+    eng.gemv(dA[:, :cols - 2], dx, y3)
+    assert H.same_bits(y2.cpu().numpy(), y3.cpu().numpy())
+
+
 def test_abi_error_reporting(eng):
     import ctypes
     from ccqppy_amd import _lib

@@ -127,6 +127,60 @@ def test_local_x_windows_are_used_where_columns_repeat_and_change_no_bit():
     assert H.same_bits(on.row_block(5000, 3000).dot(x).cpu().numpy(), y_on[5000:8000])
 
 
+@pytest.mark.parametrize("k", [8, 32, 100])
+def test_diagonal_windows_are_used_for_repeated_offset_patterns_and_change_no_bit(k):
+    """Windows whose rows all have one length and, position by position, one offset col - row (banded / circulant /
+    regular-grid matrices without column reuse inside a window) keep their L offsets in the plan; the matvec then reads
+    no column index for them.  Same products in the same order: the bits of the generic paths and of the canonical
+    order.  Rows whose wrapped columns sort differently (near the ends of a circulant matrix) break the pattern: their
+    windows stay generic."""
+    from ccqppy_amd import problems
+    from ccqppy_amd.operators import SparseOperator
+    n = 65536
+    csr = problems.sparse_spd_csr(n, k, 1234)
+    on = SparseOperator(csr, shape=(n, n))
+    off = SparseOperator(csr, shape=(n, n), diagonal_windows=False)
+    nwin = on.nnz // 1792 + 1
+    assert on.summary[2] == 0 and 0.8 * nwin < on.summary[3] < nwin      # most windows, not the wrapped ones
+    assert off.summary[3] == 0
+    rng = np.random.default_rng(k)
+    x = rng.normal(size=n)
+    y_on, y_off = on.dot(x).cpu().numpy(), off.dot(x).cpu().numpy()
+    assert H.same_bits(y_on, y_off)
+    rowptr, col, val = (t.cpu().numpy() for t in csr)
+    for rows in (slice(0, 70), slice(30000, 30100), slice(n - 70, n)):
+        want = H.spmv_canonical(rowptr[rows.start:rows.stop + 1] - rowptr[rows.start],
+                                col[rowptr[rows.start]:rowptr[rows.stop]], val[rowptr[rows.start]:rowptr[rows.stop]], x)
+        assert H.same_bits(y_on[rows], want)
+    for width in (4, 8, 16, 32, 64):
+        assert H.same_bits(SparseOperator(csr, shape=(n, n), width=width).dot(x).cpu().numpy(), y_on)
+    # with the epilogue, through row blocks and the transpose (each re-plans for itself)
+    b = rng.normal(size=n)
+    eng = on.engine
+    yd, gd = eng.empty(n), eng.empty(n)
+    on.apply(eng, eng.to_device(x), yd, eng.to_device(b), gd)
+    assert H.same_bits(gd.cpu().numpy(), y_on + b)
+    assert H.same_bits(on.row_block(777, 5000).dot(x).cpu().numpy(), y_on[777:5777])
+    assert H.same_bits(on.T.dot(x).cpu().numpy(), off.T.dot(x).cpu().numpy())
+    # a banded matrix with an irregular row in the middle: that window must not be taken for a diagonal one
+    m = 20000
+    offs = np.array([-7, -3, -1, 0, 2, 5, 11])
+    rws = np.arange(20, m - 20)
+    cols = (rws[:, None] + offs[None, :]).astype(np.int32)
+    data = rng.normal(size=cols.shape)
+    cols[9000, 3] = 8990                                   # one entry off its diagonal (row stays sorted: 8990 < 8999 ...)
+    cols[9000] = np.sort(cols[9000])
+    ip = np.arange(len(rws) + 1, dtype=np.int64) * len(offs)
+    band = SparseOperator((ip, cols.reshape(-1), data.reshape(-1)), shape=(len(rws), m))
+    ref = SparseOperator((ip, cols.reshape(-1), data.reshape(-1)), shape=(len(rws), m), diagonal_windows=False,
+                         local_x=False)
+    xb = rng.normal(size=m)
+    assert band.summary[3] + band.summary[2] > 0
+    assert H.same_bits(band.dot(xb).cpu().numpy(), ref.dot(xb).cpu().numpy())
+    want = H.spmv_canonical(ip[8990:9011] - ip[8990], cols[8990:9010].reshape(-1), data[8990:9010].reshape(-1), xb)
+    assert H.same_bits(band.dot(xb).cpu().numpy()[8990:9010], want)
+
+
 def test_duplicate_and_unsorted_columns_inside_rows():
     """CSR does not forbid repeated or unsorted columns within a row: every stored entry contributes, in storage
     order, on every path (entry order, transposed, local-x)."""

@@ -80,7 +80,7 @@ def test_solver_case(case):
 
     def run():
         np.random.seed(case["rng_seed"])
-        return cpu_ref.SOLVERS[case["solver"]](A, b, case["tol"], max_mv, x0=x0, P=P, **case["kwargs"])
+        return cpu_ref.SOLVERS[case["solver"]](A, b, case["tol"], max_mv, x0=x0, P=P, trace=[], **case["kwargs"])
 
     r, err = _call(run)
     assert err == case["err"]
@@ -95,6 +95,14 @@ def test_solver_case(case):
         assert float(r.solution_residual) == case["res"] or (np.isnan(r.solution_residual) and np.isnan(case["res"]))
     else:
         np.testing.assert_allclose(r.solution, want, rtol=1e-10, atol=1e-12, equal_nan=True)
+    # per-iteration host scalars of the first C.TRACE_ROWS iterations
+    assert len(r.trace) == case["trace_len"]
+    got, stored = C.trace_array(case["solver"], r.trace), SOLV_ARR[case["id"] + ".trace"]
+    assert got.shape == stored.shape
+    if SAME_HOST:
+        assert H.same_bits(got, stored)
+    else:
+        np.testing.assert_allclose(got, stored, rtol=1e-6, equal_nan=True)
 
 
 def test_generator_known_answers():

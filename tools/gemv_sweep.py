@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--U", default="1,2,4")
     ap.add_argument("--nt", default="0,1")
     ap.add_argument("--bpc", default="4,8,16")
+    ap.add_argument("--variants", default="", help="explicit variant words (hex, comma separated) instead of the R/U/nt/bpc "
+                                                  "product; bit 9 (0x200) = the MFMA form")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -41,7 +43,9 @@ def main():
         x = torch.randn(cols, dtype=torch.float64, device="cuda")
         y = torch.empty(rows, dtype=torch.float64, device="cuda")
         variants = [0]
-        for R in args.R.split(","):
+        if args.variants:
+            variants = [int(v, 0) for v in args.variants.split(",")]
+        for R in ([] if args.variants else args.R.split(",")):
             for U in args.U.split(","):
                 for nt in args.nt.split(","):
                     for bpc in args.bpc.split(","):
@@ -56,7 +60,7 @@ def main():
         res = []
         for v in variants:
             t = np.array(times[v])
-            res.append(dict(shape=shape, variant=hex(v), R=v & 0xF, U=(v >> 4) & 0xF, nt=1 - ((v >> 8) & 1),
+            res.append(dict(shape=shape, variant=hex(v), mfma=(v >> 9) & 1, R=v & 0xF, U=(v >> 4) & 0xF, nt=1 - ((v >> 8) & 1),
                             bpc=(v >> 12) & 0xFF, med_ms=float(np.median(t)), min_ms=float(t.min()),
                             gbs_med=nbytes / float(np.median(t)) / 1e6, gbs_best=nbytes / float(t.min()) / 1e6))
         res.sort(key=lambda r: r["med_ms"])

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--scramble", action="store_true", help="also time a column-scrambled copy (random gathers)")
     ap.add_argument("--stencil", action="store_true", help="with k = 26: also a 27-point-stencil pattern (column reuse)")
+    ap.add_argument("--ab", action="store_true", help="also time the generic paths (diagonal windows off), width auto: "
+                                                      "key w0_generic")
     args = ap.parse_args()
     from ccqppy_amd import problems
     from ccqppy_amd.operators import SparseOperator
@@ -43,8 +45,9 @@ def main():
         nbytes = 12 * nnz + 16 * n + 8 * n
         for pname, c in variants:
             row = {"n": n, "k": k, "nnz": nnz, "pattern": pname, "GB": nbytes / 1e9}
-            for width, r in [(w, 0) for w in (0, 4, 8, 16, 32, 64)]:
-                op = SparseOperator((rowptr, c, val), shape=(n, n), width=width, check=False)
+            todo = [(w, True) for w in (0, 4, 8, 16, 32, 64)] + ([(0, False)] if args.ab else [])
+            for width, diag in todo:
+                op = SparseOperator((rowptr, c, val), shape=(n, n), width=width, check=False, diagonal_windows=diag)
                 row.setdefault("plan_summary", [int(v) for v in op.summary])
                 for _ in range(3):
                     op.matvec(x, y)
@@ -55,7 +58,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.reps
-                row["w%d" % width] = [round(ms, 4), round(nbytes / ms / 1e6)]
+                row["w%d" % width if diag else "w0_generic"] = [round(ms, 4), round(nbytes / ms / 1e6)]
             print(json.dumps(row), flush=True)
         del rowptr, col, val
 
