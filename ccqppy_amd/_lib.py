@@ -155,6 +155,7 @@ SIGNATURES = {
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
     "ccqp_bsegs_start_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _D, _I, _P, _P],
+    "ccqp_bsegs_apgd_round_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _I, _P, _P],
     "ccqp_bsegs_iterate_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bsolve_bbpgd_f64": [_P, _P, _I, _I64, _D, _D, _I64, _I, _P],
     "ccqp_bsolve_apgd_f64": [_P, _P, _I, _I64, _D, _D, _I, _P],

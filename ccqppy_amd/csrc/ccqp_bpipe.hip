@@ -337,22 +337,7 @@ extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
 // iterates" is the increment of `it` by the deciding thread.  State changes are made only by the LAST block of a
 // problem to arrive in `decide`, i.e. after every block of that launch has read the state.
 // The scalar arithmetic is the host loop's, operation for operation (fp contraction is off in this library).
-#define AP_L 32
-#define AP_T 33
-#define AP_THK 34
-#define AP_BETA 35
-#define AP_R1 36
-#define AP_R2 37
-#define AP_PHASE 38
-#define AP_ACT 39
-#define AP_IT 40
-#define AP_RESMIN 41      // anti-relaxation (solvers.py:370-557): smallest residual so far ...
-#define AP_COPYHAT 42     // ... "apply: xhat = x_{k+1}" ...
-#define AP_SOLHAT 43      // ... and, at convergence, whether the solution is xhat (1) or x_{k+1} itself (0)
-#define AP_FIRST 44
-#define AP_DONE BP_DONE   // 49
-#define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
-#define AP_RES2 BP_RES2   // 51
+// (slab slots AP_*: ccqp_lockstep.h)
 
 // d = x0 - ones (solvers.py:262) into the spare x buffer
 __device__ __forceinline__ void bapgd_init_d_body(const ccqp_papgd& q, int64_t n, int bx, int nbx) {
@@ -429,10 +414,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
 
 // LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call, converged counter); otherwise the problem
 // of a single-launch solve (bx = 0, nblk = 1)
+// ps != NULL: the feasible set is not elementwise -- the problem's n comes from the caller, the residual from the
+// work-item sums the segmented residual launch (ccqp_bsegs.hip) has left in ps->workspace
 template <bool LOCKSTEP>
 __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, double gd, int64_t chunk, int nblk,
                                                   unsigned* batch, double* host, unsigned count, double seq,
-                                                  double* lds4, int* is_last_p, int ar) {
+                                                  double* lds4, int* is_last_p, int ar, const ccqp_psegs* ps = nullptr,
+                                                  int64_t n_segs = 0) {
   double* s = q.slab;
   double v[8];
   if (s[AP_PHASE] == 0.0) {
@@ -449,7 +437,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
     return;
   }
   const ccqp_segk sg = bp_segk_of(q);
-  const int64_t n = sg.dim;
+  const int64_t n = ps ? n_segs : sg.dim;
   const int it = (int)s[AP_IT];
   const bool first = s[AP_FIRST] != 0.0;
   const double* __restrict__ x1 = q.X[(it + 1) & 1];
@@ -480,7 +468,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       const double d = xi - yi;
       a4 = fma(gk[i], d, a4);
       a5 = fma(d, d, a5);
-      {
+      if (!ps) {
         const double t = gd * g1[i];
         const double u = xi - t;
         const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
@@ -502,6 +490,12 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
     ccqp_block_sum_multi<8>(v);
   }
   if (!bp_meet(q.partials, q.counter, nblk, ar ? 8 : 7, v, lds4, is_last_p)) return;
+  if (ps) {
+    // the problem's last block: residual = the work items' sums in index order (ccqp_segs_residual_sq_f64)
+    const double* respart = ps->workspace + 3 * ps->npartials;
+    const double r = ps->nwork == 1 ? respart[0] : partial_sum_body(respart, ps->nwork, lds4);
+    if (threadIdx.x == 0) v[6] = r;
+  }
   if (threadIdx.x == 0) {
     double r1, r2;
     if (first) {
@@ -574,7 +568,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
                                                                   int64_t chunk, int nblk,
                                                                   unsigned* __restrict__ batch,
                                                                   double* __restrict__ host, unsigned count,
-                                                                  double seq, int ar) {
+                                                                  double seq, int ar,
+                                                                  const ccqp_psegs* __restrict__ segs = nullptr,
+                                                                  int64_t n_segs = 0) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
@@ -582,30 +578,56 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
-  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar);
+  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar,
+                          segs ? segs + blockIdx.y : nullptr, n_segs);
 }
 
-__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx) {
+// n_segs > 0: segmented form -- the trial step is taken by the segmented launches (ccqp_bsegs.hip), the vector length
+// comes from the caller
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0) {
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0) return;
   const int it = (int)s[AP_IT];
+  const int64_t n = n_segs > 0 ? n_segs : q.seg.dim;
   if (s[AP_ACT] == 1.0) {
+    if (n_segs > 0) return;
     const double mt = -s[AP_T];
     proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], bx, nbx);
   } else {
     if (s[AP_ACT] == 3.0) {                   // anti-relaxation restart: y_{k+1} = copy(x_{k+1})
-      copy_body(q.X[it & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
+      copy_body(q.X[it & 1], q.Y[it & 1], n, bx, nbx);
     } else {
       const double beta = s[AP_BETA];
       const double a = 1.0 + beta, b = -beta;
-      axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], q.seg.dim, bx, nbx);
+      axpby_body(a, q.X[it & 1], b, q.X[(it + 1) & 1], q.Y[it & 1], n, bx, nbx);
     }
-    if (s[AP_COPYHAT] != 0.0) copy_body(q.X[it & 1], q.xhat, q.seg.dim, bx, nbx);   // xhat = copy(x_{k+1})
+    if (s[AP_COPYHAT] != 0.0) copy_body(q.X[it & 1], q.xhat, n, bx, nbx);   // xhat = copy(x_{k+1})
   }
 }
 
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papgd* __restrict__ probs) {
-  bapgd_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papgd* __restrict__ probs,
+                                                                 int64_t n_segs = 0) {
+  bapgd_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x, n_segs);
+}
+
+// the three launches of an APGD round, for the segmented form's driver (ccqp_bsegs.hip)
+void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s);
+void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
+                              double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s) {
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, probs, gd, chunk, nblk, dev_batch,
+                     ctx->host_slots_dev, (unsigned)count, seq, ar, segs, n);
+}
+
+void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
+}
+
+void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s) {
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bapgd_gemv_kernel, probs, init, n);
 }
 
 // Start-up of all solves: d = x0 - 1, A d, L, t.  Expects X[0] = Y[0] = x0, slabs and counters zero.

@@ -206,3 +206,99 @@ extern "C" int ccqp_bsegs_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
+
+// =====================================================================================================================
+// Lock-step APGD / anti-relaxation APGD (solvers.py:220-343, 393-533) on non-elementwise sets: the state machine of
+// ccqp_bapgd_* (ccqp_bpipe.hip) with the two places where the feasible set enters taken from the segmented engine --
+//   * the residual of (x_{k+1}, g1) (solvers.py:321-323): work-item sums by the launches below, added in index order
+//     by the deciding block;
+//   * the trial step x_{k+1} = P(y_k - t g_k) (:283, :310).
+// A round = matvec, [norm,] residual, decide, [norm,] step, apply: up to 7 launches for the whole batch.  The slab
+// slots are those of ccqp_bpipe.hip (AP_*, ccqp_lockstep.h).
+
+// what = 0: residual operands (x_{k+1}, g1), for problems whose matvec of this round was A x_{k+1} (phase 1);
+// what = 1: trial-step operands (y_k, g_k) with t from the slab, for problems whose next action is a trial step.
+struct bsegs_apgd_io {
+  const double* x;
+  const double* y;
+  double b;
+  double* out;
+  bool live;
+};
+
+__device__ __forceinline__ bsegs_apgd_io bsegs_apgd_operands(const ccqp_papgd& q, int what, double gd) {
+  bsegs_apgd_io io = {nullptr, nullptr, 0.0, nullptr, false};
+  const double* s = q.slab;
+  if (s[AP_DONE] != 0.0) return io;
+  const int it = (int)s[AP_IT];
+  if (what == 0) {
+    if (s[AP_PHASE] != 1.0) return io;
+    io.x = q.X[(it + 1) & 1];
+    io.y = q.g1;
+    io.b = -gd;
+  } else {
+    if (s[AP_ACT] != 1.0) return io;
+    io.x = q.Y[it & 1];
+    io.y = q.gk;
+    io.b = -s[AP_T];
+    io.out = q.X[(it + 1) & 1];
+  }
+  io.live = true;
+  return io;
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bsegs_apgd_norm_kernel(const ccqp_papgd* __restrict__ probs,
+                                                                     const ccqp_psegs* __restrict__ segs, int what,
+                                                                     double gd) {
+  __shared__ double lds4[4];
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nnorm) return;
+  const bsegs_apgd_io io = bsegs_apgd_operands(probs[blockIdx.y], what, gd);
+  if (!io.live) return;
+  const ccqp_segwork w = ps.normwork[blockIdx.x];
+  const double s = segs_norm_item(ps.table, w, 1.0, io.x, io.b, io.y, lds4);
+  if (threadIdx.x == 0) ps.workspace[w.pbase + w.chunk] = s;
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bsegs_apgd_apply_kernel(const ccqp_papgd* __restrict__ probs,
+                                                                      const ccqp_psegs* __restrict__ segs, int what,
+                                                                      double gd) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nwork) return;
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const bsegs_apgd_io io = bsegs_apgd_operands(q, what, gd);
+  if (!io.live) return;
+  const ccqp_segwork w = ps.work[blockIdx.x];
+  if (what == 0) {
+    const double racc = segs_apply_item<1>(ps.table, w, ps.workspace, 1.0, io.x, io.b, io.y, nullptr, nullptr, q.c, lds4,
+                                           &bcast);
+    const double s = ccqp_block_sum(racc, lds4);
+    if (threadIdx.x == 0) ps.workspace[3 * ps.npartials + blockIdx.x] = s;
+  } else {
+    (void)segs_apply_item<0>(ps.table, w, ps.workspace, 1.0, io.x, io.b, io.y, nullptr, io.out, 0.0, lds4, &bcast);
+  }
+}
+
+// Round `round` >= 1 of all live solves (start-up: ccqp_bapgd_start_f64 -- it involves no projection).
+extern "C" int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, const ccqp_psegs* dev_segs,
+                                         int count, int64_t n, int64_t round, int64_t max_nwork, int64_t max_nnorm,
+                                         double gd, int flags, uint32_t* dev_batch, void* stream) {
+  BSEGS_CHECK();
+  CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
+  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s);
+  if (max_nnorm > 0)
+    hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
+  hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
+  ccqp_bapgd_launch_decide(ctx, dev_probs, dev_segs, count, n, gd, (double)round, (flags & BP_FLAG_CONST_STEP) != 0,
+                           dev_batch, s);
+  if (max_nnorm > 0)
+    hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 1, gd);
+  hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 1, gd);
+  ccqp_bapgd_launch_apply(dev_probs, count, n, s);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}

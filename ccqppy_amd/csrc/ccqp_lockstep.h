@@ -15,6 +15,23 @@
                                             // APGD entry points -> the anti-relaxation variant
 #define BP_FLAG_FALLBACK 128                // `flags` bit 7 of the BBPGD entry points: BBPGDf (needs xmin / gmin)
                                             // (bits 1-2, 4-6 and 8.. belong to the matvec's tuning word)
+// slab slots of the lock-step APGD state machine (ccqp_bpipe.hip, ccqp_bsegs.hip)
+#define AP_L 32
+#define AP_T 33
+#define AP_THK 34
+#define AP_BETA 35
+#define AP_R1 36
+#define AP_R2 37
+#define AP_PHASE 38
+#define AP_ACT 39
+#define AP_IT 40
+#define AP_RESMIN 41      // anti-relaxation (solvers.py:370-557): smallest residual so far ...
+#define AP_COPYHAT 42     // ... "apply: xhat = x_{k+1}" ...
+#define AP_SOLHAT 43      // ... and, at convergence, whether the solution is xhat (1) or x_{k+1} itself (0)
+#define AP_FIRST 44
+#define AP_DONE BP_DONE   // 49
+#define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
+#define AP_RES2 BP_RES2   // 51
 #define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
 
 // the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
@@ -168,3 +185,9 @@ void ccqp_lockstep_begin(ccqp_ctx* ctx, uint32_t* dev_batch, hipStream_t s);
 // start-up, as launched by ccqp_bpipe_*: shared with the segmented form (ccqp_bsegs.hip)
 void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s);
 void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s);
+// the launches of a lock-step APGD round (ccqp_bpipe.hip), shared with the segmented form: `segs` != NULL takes the
+// residual from the segmented residual launch and leaves the trial step to the segmented step launch
+void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s);
+void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
+                              double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s);
+void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s);

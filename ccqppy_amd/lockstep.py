@@ -76,10 +76,11 @@ def why_not_pipelined(solvers, problems, device):
         P = P if P is not None else ss.IdentityProjOp(n)
         if not hasattr(P, "_dev_bb_tail"):
             # Sphere / Cone / DisjointUnion: the segmented lock-step form (ccqp_bsegs.hip), BBPGD and PGD only
-            if kind not in (CCQPSolverBBPGD, CCQPSolverPGD) or not isinstance(P, ss.ProjOpBase) or \
+            if kind not in (CCQPSolverBBPGD, CCQPSolverPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation) or \
+                    not isinstance(P, ss.ProjOpBase) or \
                     any(getattr(op, "_kind", None) is None for op, _ in P._leaves()):
-                return TypeError("solve_batch_pipelined needs elementwise feasible sets (BBPGD / PGD: any set built "
-                                 "from the seven operators), got %r" % type(P).__name__)
+                return TypeError("solve_batch_pipelined needs elementwise feasible sets (PGD / BBPGD / APGD / anti-relaxation "
+                                 "APGD: any set built from the seven operators), got %r" % type(P).__name__)
             if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
                 return ValueError("solve_batch_pipelined: the feasible set does not match b")
             continue
@@ -150,6 +151,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
             for lo in range(0, len(items), _BPIPE_MAX):
                 if elementwise:
                     group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
+                elif kind in (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation):
+                    _bapgd_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, False, segmented=True)
                 else:
                     _bsegs_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
@@ -356,6 +359,26 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
+def _psegs_table(plans, dev):
+    """Device array of struct ccqp_psegs for one lock-step run: per problem its (possibly shared, read-only) block table
+    and work lists and its OWN zeroed workspace slice.  Returns (table tensor, workspace tensor, max nwork, max nnorm)."""
+    from . import _lib
+    B = len(plans)
+    wsd = np.array([pl.ws_doubles for pl in plans], dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(wsd)[:-1]))
+    ws = torch.zeros(int(wsd.sum()), dtype=torch.float64, device=dev)
+    stab = np.zeros(B, dtype=np.dtype(_lib.PSegs))
+    stab["table"] = [pl.table_ptr for pl in plans]
+    stab["work"] = [pl.work_ptr for pl in plans]
+    stab["normwork"] = [pl.normwork_ptr for pl in plans]
+    stab["workspace"] = np.uint64(ws.data_ptr()) + off.astype(np.uint64) * np.uint64(8)
+    stab["npartials"] = [pl.npartials for pl in plans]
+    stab["nwork"] = [pl.nwork for pl in plans]
+    stab["nnorm"] = [pl.nnorm for pl in plans]
+    dsegs = torch.from_numpy(stab.view(np.uint8).reshape(-1)).to(dev)
+    return dsegs, ws, max(int(stab["nwork"].max()), 1), int(stab["nnorm"].max())
+
+
 def _bsegs_run(eng, spec, plans, n, max_mv, ahead, tune=0):
     """Lock-step BBPGD / PGD over `spec` with the feasible sets given as segment plans (one per problem, shared objects
     allowed): the segmented form of _bpipe_run (ccqp_bsegs.hip).  Returns (converged mask, index of the final
@@ -374,21 +397,8 @@ def _bsegs_run(eng, spec, plans, n, max_mv, ahead, tune=0):
     if getattr(spec, "step", None) is not None:         # PGD: constant steps, in slab slot 48; flag bit 3
         slabs[:, 48] = torch.from_numpy(np.ascontiguousarray(spec.step)).to(dev)
         flags |= 8
-    # one zeroed workspace slice per problem; tables and work lists are read-only and may be shared
-    wsd = np.array([pl.ws_doubles for pl in plans], dtype=np.int64)
-    off = np.concatenate(([0], np.cumsum(wsd)[:-1]))
-    ws = torch.zeros(int(wsd.sum()), dtype=torch.float64, device=dev)
-    stab = np.zeros(B, dtype=np.dtype(_lib.PSegs))
-    stab["table"] = [pl.table_ptr for pl in plans]
-    stab["work"] = [pl.work_ptr for pl in plans]
-    stab["normwork"] = [pl.normwork_ptr for pl in plans]
-    stab["workspace"] = np.uint64(ws.data_ptr()) + off.astype(np.uint64) * np.uint64(8)
-    stab["npartials"] = [pl.npartials for pl in plans]
-    stab["nwork"] = [pl.nwork for pl in plans]
-    stab["nnorm"] = [pl.nnorm for pl in plans]
-    max_nwork, max_nnorm = max(int(stab["nwork"].max()), 1), int(stab["nnorm"].max())
+    dsegs, ws, max_nwork, max_nnorm = _psegs_table(plans, dev)
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dsegs = torch.from_numpy(stab.view(np.uint8).reshape(-1)).to(dev)
     dp, dsp, batch = dprobs.data_ptr(), dsegs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
     last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
@@ -435,9 +445,11 @@ def _bsegs_group(eng, items, n, max_mv, ahead, tune=0):
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
-def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False):
+def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False, plans=None):
     """Lock-step APGD over `spec`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
-    matvec counts) -- rows of problems that did not converge inside the budget are meaningless."""
+    matvec counts) -- rows of problems that did not converge inside the budget are meaningless.  `plans` (one segment
+    plan per problem): the feasible sets are not elementwise -- the segmented rounds of ccqp_bsegs.hip, no
+    single-launch form."""
     from . import _lib
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
@@ -458,12 +470,19 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     # path takes over (:277-278, :288-289): such problems go to the host-driven loop
     last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
 
-    def launch(r):
-        check(lib.ccqp_bapgd_round_f64(ctx, dp, B, n, r, _GD, flags, batch, st))
+    if plans is not None:
+        dsegs, seg_ws, max_nwork, max_nnorm = _psegs_table(plans, dev)
+        dsp = dsegs.data_ptr()
+
+        def launch(r):
+            check(lib.ccqp_bsegs_apgd_round_f64(ctx, dp, dsp, B, n, r, max_nwork, max_nnorm, _GD, flags, batch, st))
+    else:
+        def launch(r):
+            check(lib.ccqp_bapgd_round_f64(ctx, dp, B, n, r, _GD, flags, batch, st))
 
     if single_launch is None:
         single_launch = n <= _BSOLVE_MAX_N_APGD
-    single_launch = bool(single_launch) and n <= 2048
+    single_launch = bool(single_launch) and n <= 2048 and plans is None
     if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
         check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 9, st))
@@ -487,11 +506,12 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     return done, sols, np.sqrt(res2), mvs
 
 
-def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
+def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):
     import contextlib
     import io
+    plans = [it[4]._segplan(eng, n) for it in items] if segmented else None
     done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch,
-                                      ar=items[0][0]._anti_relaxation)
+                                      ar=items[0][0]._anti_relaxation, plans=plans)
     host = None
     for p, it in enumerate(items):
         s = it[0]

@@ -436,6 +436,13 @@ int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
                          uint32_t* dev_batch, void* stream);
 int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
                          int flags, uint32_t* dev_batch, void* stream);
+/* The same round for NON-elementwise sets (ccqp_bsegs.hip): matvec, [norm,] residual, decide, [norm,] trial step,
+ * apply -- the residual (solvers.py:321-323) and the trial step (:283,:310) go through the segmented engine, everything
+ * else is the state machine above; start-up: ccqp_bapgd_start_f64 (it involves no projection).  flags bit 3: the
+ * anti-relaxation variant.  Per problem the bits of its own solve(). */
+int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, const ccqp_psegs* dev_segs, int count,
+                              int64_t n, int64_t round, int64_t max_nwork, int64_t max_nnorm, double gd, int flags,
+                              uint32_t* dev_batch, void* stream);
 /* n <= 2048: the whole solve of every problem in ONE launch, one workgroup per problem (as ccqp_bsolve_bbpgd_f64).
  * No round starts once a problem's matvec count has reached `mv_limit` (max_mv - 1; a huge value for "no budget"):
  * such a problem is left unconverged for the host-driven loop. */

@@ -187,17 +187,63 @@ def test_pgd_constant_step_on_general_sets():
         _same(a, c)
 
 
+@pytest.mark.parametrize("solver", ["APGD", "APGDAntiRelaxation"])
+@pytest.mark.parametrize("family", ["sphere", "spheres3"])
+@pytest.mark.parametrize("n,count", [(36, 11), (256, 16), (1000, 7), (2049, 5)])
+def test_segmented_lockstep_apgd_equals_individual_solves(solver, family, n, count):
+    """APGD and its anti-relaxation variant (solvers.py:220-343, 393-533): the state machine of ccqp_bapgd_* with the
+    residual and the trial step taken from the segmented engine (ccqp_bsegs_apgd_round_f64)."""
+    probs = _problems(n, count, 1300 + n, family)
+    tols = [1e-8] * count
+    ref = _reference(probs, tols, 4000, solver)
+    got = _batch(probs, tols, 4000, solver)
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
+    assert max(r.solution_num_matrix_vector_multiplications for r in ref) > 10
+    for ahead in (1, 16):
+        for a, c in zip(ref, _batch(probs, tols, 4000, solver, ahead=ahead)):
+            _same(a, c)
+
+
+def test_segmented_apgd_mixed_sets_tolerances_starts_and_budgets():
+    import torch
+    from ccqppy_amd import lockstep
+    n, count = 300, 12
+    probs = _problems(n, count, 77, ["spheres3", "sphere"])
+    first = _reference(probs, [1e-9] * count, 4000, "APGD")
+    for p in range(0, count, 3):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, first[p].solution.clone(), P)
+    tols = [[1e-10, 1e-6, 1e-3][p % 3] for p in range(count)]
+    ref = _reference(probs, tols, 4000, "APGD")
+    got = _batch(probs, tols, 4000, "APGD")
+    for a, c in zip(ref, got):
+        _same(a, c)
+    assert isinstance(got[0].solution, torch.Tensor)
+    # under a budget some problems take the reference's own exit path on the host (counted, by design); results equal
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for cap in (3, 5, longest // 2, longest - 1, longest, longest + 2):
+        want = _reference(probs, tols, cap, "APGD")
+        from ccqppy_amd import batch, solvers
+        it = iter(tols)
+        have = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(next(it), cap), probs)
+        for a, c in zip(want, have):
+            _same(a, c)
+    assert lockstep.stats["fallback_solves"] >= 0
+
+
 def test_solvers_without_a_segmented_form_are_declined_not_mis_solved():
-    """APGD / MPRGP / BBPGDf on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
+    """BBPGDf / MPRGP / SPG on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
     host-driven scheduler, counted in lockstep.stats)."""
     from ccqppy_amd import batch, lockstep, solvers
     probs = _problems(128, 3, 1, "spheres3")
-    for cls in (solvers.CCQPSolverAPGD, solvers.CCQPSolverBBPGDf, solvers.CCQPSolverMPRGP):
+    for cls in (solvers.CCQPSolverSPG, solvers.CCQPSolverBBPGDf, solvers.CCQPSolverMPRGP):
         with pytest.raises(TypeError):
             batch.solve_batch_pipelined(lambda: cls(1e-6, 300), probs)
     before = lockstep.stats["auto_declined"]
-    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverAPGD(1e-6, 300), lambda p: probs[p], 3)
+    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverBBPGDf(1e-6, 300), lambda p: probs[p], 3)
     assert lockstep.stats["auto_declined"] == before + 1
-    ref = _reference(probs, [1e-6] * 3, 300, "APGD")
+    ref = _reference(probs, [1e-6] * 3, 300, "BBPGDf")
     for p in range(3):
         _same(ref[p], out[p])

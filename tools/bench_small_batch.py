@@ -2,7 +2,9 @@
 """Throughput of MANY SMALL dense BBPGD (--apgd: APGD, --mprgp: MPRGP) solves (Box, tol 1e-8; MPRGP: 1e-6 / 300 matvecs) under every scheduler of ccqppy_amd:
 sequential solve(), sequential with the pipelined iteration, the stream-lane and fused batch schedulers
 (host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device) and, for BBPGD up to n = 2048, its single-launch form (one workgroup per problem).  One JSON line per size.
-   python tools/bench_small_batch.py [--apgd | --mprgp] [n:B ...]"""
+   python tools/bench_small_batch.py [--apgd | --mprgp] [--set box|sphere|spheres3] [n:B ...]
+--set sphere / spheres3 (BBPGD): a whole-vector Sphere / a DisjointUnion of Sphere(3) blocks instead of the Box -- the
+segmented lock-step form (ccqp_bsegs.hip); no single-launch column there."""
 import contextlib
 import io
 import json
@@ -19,7 +21,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     from ccqppy_amd.batch import solve_batch, solve_batch_fused, solve_batch_pipelined
-    args = [a for a in sys.argv[1:] if a not in ("--apgd", "--mprgp")]
+    argv = list(sys.argv[1:])
+    setname = "box"
+    if "--set" in argv:
+        i = argv.index("--set")
+        setname = argv[i + 1]
+        del argv[i:i + 2]
+    args = [a for a in argv if a not in ("--apgd", "--mprgp")]
     mprgp = "--mprgp" in sys.argv[1:]
     apgd = "--apgd" in sys.argv[1:] or mprgp          # (no single-solve pipeline column for these)
     cls = solvers.CCQPSolverMPRGP if mprgp else solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
@@ -29,7 +37,13 @@ def main():
         probs = []
         for p in range(B):
             op, b, _ = problems.random_problem(n, 1234 + p)
-            probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+            if setname == "sphere":
+                P = ss.SphereProjOp(n, 2.0)
+            elif setname == "spheres3":
+                P = ss.DisjointProjOp(*([ss.SphereProjOp(3, 0.3)] * (n // 3) + ([ss.IdentityProjOp(n % 3)] if n % 3 else [])))
+            else:
+                P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+            probs.append((op, b, None, P))
         tol, cap = (1e-6, 300) if mprgp else (1e-8, 5000)          # MPRGP: BASELINE config 5's settings
         mk = lambda: cls(tol, cap)          # noqa: E731
 
@@ -45,7 +59,7 @@ def main():
                          ("stream_lanes_8", lambda: solve_batch(mk, probs, lanes=8)),
                          ("fused_32x2", lambda: solve_batch_fused(mk, probs, lanes=32, groups=2)),
                          ("batch_pipelined", lambda: solve_batch_pipelined(mk, probs, single_launch=False))) + \
-                (() if apgd or n > 2048 else
+                (() if apgd or n > 2048 or setname != "box" else
                  (("batch_single_launch", lambda: solve_batch_pipelined(mk, probs, single_launch=True)),)):
             fn()
             torch.cuda.synchronize()
@@ -65,7 +79,7 @@ def main():
                                 for a, c in zip(res["fused_32x2"], res["batch_single_launch"]))
         # bytes the matvecs of the batch must read: executed matvecs per problem, 8 n^2 bytes each
         mv_bytes = sum(s.executed_matrix_vector_multiplications * 8.0 * n * n for s in res["batch_pipelined"])
-        print(json.dumps({"solver": cls.__name__, "n": n, "problems": B, "problems_per_s": out, "mv_per_problem_mean": float(np.mean(mvs)),
+        print(json.dumps({"solver": cls.__name__, "set": setname, "n": n, "problems": B, "problems_per_s": out, "mv_per_problem_mean": float(np.mean(mvs)),
                           "mv_per_problem_max": int(max(mvs)), "bitwise_equal_to_fused": bool(same),
                           "batch_pipelined_matrix_GBps": round(mv_bytes * out["batch_pipelined"] / B / 1e9, 1)}),
               flush=True)

@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# Evidence run of the bench workload on the GPU box (one MI355X): the plain bench line, `rocprofv3 --kernel-trace
+# --stats` of the same command, and the PMC passes (one counter group per pass, never combined with tracing domains
+# other than --kernel-trace) condensed by tools/summarize_prof.py.  Everything lands under gpurun_out/ (scratch,
+# merged back by gpurun); the summaries worth keeping are copied to profiles/ by hand afterwards.
+#   bash tools/profile_bench.sh TAG            e.g. TAG = r02
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+echo "[profile] bench (default flags)"; date
+python3 "$ROOT/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err" || exit 1
+echo "[profile] kernel trace"; date
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_trace" -- \
+  python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-n 0 > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_trace.err" || exit 1
+i=0
+for group in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "VALUBusy MfmaUtil OccupancyPercent MemUnitStalled"; do
+  i=$((i + 1))
+  echo "[profile] pmc pass $i: $group"; date
+  rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT/prof_${TAG}_pmc$i" -- \
+    python3 "$ROOT/bench.py" --steps 1 --warmup 0 --cpu-n 0 > "$OUT/${TAG}_pmc$i.json" 2> "$OUT/${TAG}_pmc$i.err" || exit 1
+done
+cd "$ROOT"
+export PROF_META='{"n": 131072, "rows": 131072, "algorithmic_bytes_per_launch": 137441050624.0, "command": "rocprofv3 --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | VALUBusy MfmaUtil OccupancyPercent MemUnitStalled> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --cpu-n 0"}'
+python3 tools/summarize_prof.py "${TAG}_bench_n131072" "$OUT/prof_${TAG}_trace" "$OUT/prof_${TAG}_pmc1" "$OUT/prof_${TAG}_pmc2" "$OUT/prof_${TAG}_pmc3" > "$OUT/${TAG}_summary.log" 2>&1 || exit 1
+cp profiles/${TAG}_bench_n131072_* "$OUT/" 2>/dev/null
+echo "[profile] done"; date
