@@ -177,6 +177,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int6
     // ---- "diagonal" window?  All rows of the same length L <= SPMV_DIAG_MAXLEN and, position by position, the same
     // offset col - row (banded / circulant / regular-grid matrices): keep the L offsets once; the matvec rebuilds
     // every column index as row + offset and streams 8 instead of 12 bytes per entry.
+    // (only windows the matvec walks in transposed order, i.e. rows of ~28 entries or more: measured +17 ... +24 % at
+    // 27-129 entries per row, but -1 ... -6 % at 9 entries per row, where the window stays in entry order and the
+    // row / position of every entry costs an integer division -- profiles/r02_spmv_sweep.jsonl)
+    if ((plan[SPMV_PLAN_WORDS * w + 4] & 0xffffffffll) == 0) return;
     const int64_t rb = plan[SPMV_PLAN_WORDS * w + 0];
     const int64_t nr = plan[SPMV_PLAN_WORDS * w + 1] - rb;
     if (nr < 1 || E % nr != 0) return;

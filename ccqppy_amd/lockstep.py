@@ -74,11 +74,12 @@ def why_not_pipelined(solvers, problems, device):
         if dev is not None and dev != device:
             return ValueError("solve_batch_pipelined: operator on another device")
         P = P if P is not None else ss.IdentityProjOp(n)
+        if isinstance(P, ss.ProjOpBase):
+            P._refresh()                                 # (host-only: public parameters edited since the last use)
         if not hasattr(P, "_dev_bb_tail"):
             # Sphere / Cone / DisjointUnion: the segmented lock-step form (ccqp_bsegs.hip), BBPGD and PGD only
             if kind not in (CCQPSolverBBPGD, CCQPSolverPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation) or \
-                    not isinstance(P, ss.ProjOpBase) or \
-                    any(getattr(op, "_kind", None) is None for op, _ in P._leaves()):
+                    not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
                 return TypeError("solve_batch_pipelined needs elementwise feasible sets (PGD / BBPGD / APGD / anti-relaxation "
                                  "APGD: any set built from the seven operators), got %r" % type(P).__name__)
             if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:

@@ -224,6 +224,13 @@ class ProjOpBase(ABC):
         eng.scale(c, t1, t1)               # c * (...)
         eng.dots([(t1, t1)], slot)
 
+    def _has_device_form(self):
+        """True if every block has a device descriptor (no user callable inside): cached until a refresh finds a change."""
+        c = self.__dict__.get("_devform")
+        if c is None:
+            c = self.__dict__["_devform"] = all(getattr(op, "_kind", None) is not None for op, _ in self._leaves())
+        return c
+
     def _normal_on_device(self):
         """False where normal_vector needs the host per block: a Cone block raises (solution_spaces.py:465), scalar
         bounds raise TypeError depending on the data (:318), a host callable is called."""
@@ -689,19 +696,24 @@ class DisjointProjOp(ProjOpBase):
 
     def _refresh(self):
         ops = self.proj_ops
-        for op in ops:
-            if isinstance(op, ProjOpBase):
-                op._refresh()
-        # a child may have been refreshed on its own in the meantime (it was called directly): compare versions
-        cur = (ops, tuple(getattr(op, "_version", 0) for op in ops))
         st = self.__dict__.get("_ops_state")
-        self.__dict__["_ops_state"] = cur
-        if st is None or (st[0] is cur[0] and st[1] == cur[1]):
-            return False
-        self.__dict__.pop("_plans", None)
-        self.__dict__.pop("_segplans", None)
-        self._version = self._version + 1
-        return True
+        if st is None or st[0] is not ops:
+            # the DISTINCT children (a union is often one block object repeated: `[SphereProjOp(3)] * 1000`)
+            uniq = list({id(o): o for o in ops if isinstance(o, ProjOpBase)}.values())
+            structural = st is not None
+        else:
+            uniq, structural = st[2], False
+        for op in uniq:
+            op._refresh()
+        # a child may have been refreshed on its own in the meantime (it was called directly): compare versions
+        vers = tuple(op._version for op in uniq)
+        changed = structural or (st is not None and st[1] != vers)
+        self.__dict__["_ops_state"] = (ops, vers, uniq)
+        if changed:
+            for k in ("_plans", "_segplans", "_devform"):
+                self.__dict__.pop(k, None)
+            self._version = self._version + 1
+        return changed
 
     def _plan(self, eng, for_normal):
         cache = self.__dict__.setdefault("_plans", {})
