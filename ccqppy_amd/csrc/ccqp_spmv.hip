@@ -55,6 +55,7 @@
                                    // local-x window keeps its distinct columns; the matvec then reads no column
                                    // index at all for the window
 #define SPMV_DIAG_MAXLEN 256       // longest row of a diagonal window (its offsets live in 1 KiB of LDS)
+#define SPMV_DIAG_MINLEN 16        // shortest: below, the generic paths are as fast or faster (measured)
 #define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
                                    // products: 8 KB)
 #define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order: measured
@@ -177,15 +178,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int6
     // ---- "diagonal" window?  All rows of the same length L <= SPMV_DIAG_MAXLEN and, position by position, the same
     // offset col - row (banded / circulant / regular-grid matrices): keep the L offsets once; the matvec rebuilds
     // every column index as row + offset and streams 8 instead of 12 bytes per entry.
-    // (only windows the matvec walks in transposed order, i.e. rows of ~28 entries or more: measured +17 ... +24 % at
-    // 27-129 entries per row, but -1 ... -6 % at 9 entries per row, where the window stays in entry order and the
-    // row / position of every entry costs an integer division -- profiles/r02_spmv_sweep.jsonl)
-    if ((plan[SPMV_PLAN_WORDS * w + 4] & 0xffffffffll) == 0) return;
+    // (rows of SPMV_DIAG_MINLEN entries or more: measured +17 ... +24 % at 27-129 entries per row -- in transposed
+    // and in entry order alike -- but -1 ... -6 % at 9 entries per row, where the saved column stream no longer pays
+    // for the row / position arithmetic of every entry -- profiles/r02_spmv_sweep.jsonl)
     const int64_t rb = plan[SPMV_PLAN_WORDS * w + 0];
     const int64_t nr = plan[SPMV_PLAN_WORDS * w + 1] - rb;
     if (nr < 1 || E % nr != 0) return;
     const int L = (int)(E / nr);
-    if (L < 1 || L > SPMV_DIAG_MAXLEN) return;
+    if (L < SPMV_DIAG_MINLEN || L > SPMV_DIAG_MAXLEN) return;
     if (t == 0) notdiag = 0;
     __syncthreads();
     int bad = 0;

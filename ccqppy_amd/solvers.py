@@ -385,11 +385,16 @@ class _APGDCore(CCQPSolverBase):
         from .lockstep import _bapgd_run, _spec_from_items
         from .operators import DenseOperator
         op, eng = run.op, run.eng
-        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and hasattr(run.P, "_dev_bb_tail")
+        elementwise = hasattr(run.P, "_dev_bb_tail")
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048
+                and (elementwise or run.P._has_device_form())
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
+        # (Sphere / Cone / DisjointUnion sets: the segmented rounds, ccqp_bsegs_apgd_round_f64)
+        plans = None if elementwise else [run.P._segplan(eng, run.n)]
         done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
-                                          self.max_matrix_vector_multiplications, 4, ar=self._anti_relaxation)
+                                          self.max_matrix_vector_multiplications, 4, ar=self._anti_relaxation,
+                                          plans=plans)
         if not done[0]:
             from . import lockstep
             lockstep.stats["fallback_solves"] += 1
@@ -554,11 +559,32 @@ class _BBPGDCore(CCQPSolverBase):
         eng.mv_executed += 1 if (done[0] and k == 0) else 2 + k
         return sols[0], res[0], 1 + k
 
+    def _lockstep_segments(self, run):
+        """BBPGD with pipeline=True on a Sphere / Cone / DisjointUnion set: the whole solve on the device as a
+        segmented lock-step batch of one (ccqp_bsegs_*; dense operator, n <= 2048); None where that does not apply."""
+        from ._record import RecordingEngine
+        from .lockstep import _bsegs_run, _spec_from_items
+        from .operators import DenseOperator
+        op, eng, P = run.op, run.eng, run.P
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and not hasattr(P, "_dev_bb_tail")
+                and P._has_device_form() and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
+            return None
+        max_mv = self.max_matrix_vector_multiplications
+        done, final, sols, res = _bsegs_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n),
+                                            [P._segplan(eng, run.n)], run.n, max_mv, 4)
+        k = int(final[0])
+        eng.mv_executed += 1 if (done[0] and k == 0) else 2 + k
+        return sols[0], res[0], 1 + k
+
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
         if self.pipeline and self._fallback and self.trace is None:
             out = self._lockstep_fallback_variant(run)
+            if out is not None:
+                return out
+        if self.pipeline and not self._fallback and self.trace is None:
+            out = self._lockstep_segments(run)
             if out is not None:
                 return out
         mv_count = 0

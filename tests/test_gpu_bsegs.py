@@ -251,3 +251,29 @@ def test_solvers_without_a_segmented_form_are_declined_not_mis_solved():
     ref = _reference(probs, [1e-6] * 3, 300, "BBPGDf")
     for p in range(3):
         _same(ref[p], out[p])
+
+
+@pytest.mark.parametrize("solver", ["BBPGD", "APGD", "APGDAntiRelaxation"])
+@pytest.mark.parametrize("family", ["sphere", "spheres3", "mixed"])
+@pytest.mark.parametrize("n", [90, 700, 2048])
+def test_single_solve_pipeline_option_on_general_sets(solver, family, n):
+    """`pipeline=True` on a Sphere / DisjointUnion set: the solve runs as a segmented lock-step batch of one (dense
+    operator, n <= 2048); beyond that size, and for a solve that reaches its budget under APGD, the host-driven loop.
+    Same bits either way."""
+    from ccqppy_amd import lockstep, problems, solvers
+    op, b, _ = problems.random_problem(n, 4000 + n)
+    P = _set(n, 1, family)
+    cls = getattr(solvers, "CCQPSolver" + solver)
+    budget = 70 if family == "mixed" else 4000            # (a Cone block inside: runs to the budget)
+    before = lockstep.stats["fallback_solves"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = cls(1e-8, budget).solve(op, b, convex_proj_op=P)
+        c = cls(1e-8, budget, pipeline=True).solve(op, b, convex_proj_op=P)
+    _same(a, c)
+    if family != "mixed":
+        assert c.solution_converged and lockstep.stats["fallback_solves"] == before
+    big = problems.random_problem(2100, 1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = cls(1e-8, 300).solve(big[0], big[1], convex_proj_op=_set(2100, 0, "sphere"))
+        c = cls(1e-8, 300, pipeline=True).solve(big[0], big[1], convex_proj_op=_set(2100, 0, "sphere"))
+    _same(a, c)
