@@ -1,6 +1,7 @@
 /* Stand-alone C consumer of libccqp_hip.so: no Python, no torch.  Generates a small SPD problem on
- * the GPU, runs one matvec + epilogue + dots + Box projection, the CSR matvec and a lock-step batch of three
- * BBPGD solves through the C ABI and checks them against plain C loops on the host.  Built and run by tests/test_gpu_cabi.py:
+ * the GPU, runs one matvec + epilogue + dots + Box projection, the CSR matvec, a lock-step batch of three
+ * BBPGD solves, a DisjointUnion-like set through the segmented engine and the 1-rank RCCL exchange through the C ABI
+ * and checks them against plain C loops on the host.  Built and run by tests/test_gpu_cabi.py:
  *   gcc -std=c99 tests/c/abi_smoke.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
  *       -Lccqppy_amd -lccqp_hip -L/opt/rocm/lib -lamdhip64 -lm -o abi_smoke
  * (the define is what HIP's own headers require from a C translation unit; only hipMalloc/hipMemcpy
@@ -202,6 +203,102 @@ int main(void) {
              sqrt(hs[51]), kkt);
     }
     hipFree(vecs); hipFree(slabs); hipFree(parts); hipFree(words); hipFree(bs); hipFree(dp3);
+  }
+  /* a DisjointUnion-like feasible set through the segmented engine: 40 Sphere(3) blocks (one thread each), one
+   * Box(200), one Sphere(1000, radius 2) (chunked) -- plan on the host, table / work lists / zeroed workspace in device
+   * memory, then P(x - 0.25 g) and the Eq. 25 residual, each against a plain C loop. */
+  {
+    enum { NS = 42 };
+    ccqp_seg hs[NS];
+    int64_t off = 0;
+    for (int q = 0; q < 40; ++q, off += 3) {
+      ccqp_seg t = {CCQP_OP_SPHERE, 0, off, 3, NULL, NULL, 0.3, 0.0};
+      hs[q] = t;
+    }
+    ccqp_seg tb = {CCQP_OP_BOX, 0, off, 200, NULL, NULL, -0.25, 0.5};
+    hs[40] = tb;
+    off += 200;
+    ccqp_seg ts = {CCQP_OP_SPHERE, 0, off, 1000, NULL, NULL, 2.0, 0.0};
+    hs[41] = ts;
+    off += 1000;                                           /* 1320 <= n */
+    int64_t nwork = 0, nnorm = 0, npart = 0;
+    CHECK(ccqp_segs_plan(hs, NS, NULL, 0, &nwork, NULL, 0, &nnorm, &npart));
+    ccqp_segwork* hw = malloc((nwork + 1) * sizeof(ccqp_segwork));
+    ccqp_segwork* hn = malloc((nnorm + 1) * sizeof(ccqp_segwork));
+    CHECK(ccqp_segs_plan(hs, NS, hw, nwork, &nwork, hn, nnorm, &nnorm, &npart));
+    if (nwork != 3 || nnorm != 1 || npart != 2) bad++;    /* run of 40 small blocks; Box chunk; Sphere chunk */
+    const int64_t wsd = ccqp_segs_workspace_doubles(npart, nwork);
+    ccqp_seg* dtab;
+    ccqp_segwork *dw, *dn;
+    double *ws, *po;
+    if (hipMalloc((void**)&dtab, sizeof(hs)) || hipMalloc((void**)&dw, nwork * sizeof(ccqp_segwork)) ||
+        hipMalloc((void**)&dn, (nnorm + 1) * sizeof(ccqp_segwork)) || hipMalloc((void**)&ws, wsd * sizeof(double)) ||
+        hipMalloc((void**)&po, n * sizeof(double)))
+      return 6;
+    hipMemcpy(dtab, hs, sizeof(hs), hipMemcpyHostToDevice);
+    hipMemcpy(dw, hw, nwork * sizeof(ccqp_segwork), hipMemcpyHostToDevice);
+    hipMemcpy(dn, hn, nnorm * sizeof(ccqp_segwork), hipMemcpyHostToDevice);
+    hipMemset(ws, 0, wsd * sizeof(double));
+    hipMemset(po, 0, n * sizeof(double));
+    CHECK(ccqp_segs_project_f64(ctx, dtab, dw, nwork, dn, nnorm, npart, ws, 1.0, x, -0.25, g, NULL, po, NULL));
+    const double cres = 1.0 / (3.0 * (double)off * 1e-6);
+    CHECK(ccqp_segs_residual_sq_f64(ctx, dtab, dw, nwork, dn, nnorm, npart, ws, x, g, cres, 1e-6, 7, NULL));
+    double r2 = 0.0;
+    CHECK(ccqp_scalars_read(ctx, 7, 1, &r2, NULL));
+    hipMemcpy(hp, po, n * sizeof(double), hipMemcpyDeviceToHost);
+    double want_r2 = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {                 /* pass 0: step 0.25 (projection); pass 1: step 1e-6 (residual) */
+      const double step = pass == 0 ? 0.25 : 1e-6;
+      for (int q = 0; q < NS; ++q) {
+        double nrm = 0.0;
+        for (int64_t i = 0; i < hs[q].dim; ++i) {
+          const double u = hx[hs[q].offset + i] + (-step) * hg[hs[q].offset + i];
+          nrm += u * u;
+        }
+        nrm = sqrt(nrm);
+        for (int64_t i = 0; i < hs[q].dim; ++i) {
+          const int64_t e = hs[q].offset + i;
+          const double u = hx[e] + (-step) * hg[e];
+          double pr;
+          if (hs[q].kind == CCQP_OP_BOX) pr = u > hs[q].ub_s ? hs[q].ub_s : (u < hs[q].lb_s ? hs[q].lb_s : u);
+          else pr = nrm > hs[q].lb_s ? hs[q].lb_s * u / nrm : u;
+          if (pass == 0) {
+            if (fabs(pr - hp[e]) > 1e-13 * (fabs(pr) + 1e-300)) bad++;
+          } else {
+            const double v = cres * (hx[e] - pr);
+            want_r2 += v * v;
+          }
+        }
+      }
+    }
+    if (fabs(r2 - want_r2) > 1e-10 * want_r2 + 1e-300) bad++;
+    printf("segmented engine: %lld work items, %lld norm items, residual^2 = %.6g (C loop %.6g)\n", (long long)nwork,
+           (long long)nnorm, r2, want_r2);
+    hipFree(dtab); hipFree(dw); hipFree(dn); hipFree(ws); hipFree(po);
+    free(hw); free(hn);
+  }
+  /* the multi-GPU exchange step with the one rank a single-GPU box allows: bootstrap, sharded matvec (bitwise the
+   * plain matvec), in-place collectives on the NULL stream.  Skipped (not failed) where no RCCL can be loaded. */
+  if (ccqp_comm_rccl_version() > 0) {
+    unsigned char id[CCQP_COMM_ID_BYTES];
+    ccqp_comm* comm = NULL;
+    CHECK(ccqp_comm_unique_id(id));
+    CHECK(ccqp_comm_create(ctx, 1, 0, id, &comm));
+    double* y2;
+    if (hipMalloc((void**)&y2, n * sizeof(double))) return 7;
+    CHECK(ccqp_shard_gemv_allgather_f64(ctx, comm, A, n, x, y2, n, n, n, 0, 0, NULL));
+    CHECK(ccqp_comm_allreduce_sum_f64(comm, y2, n, NULL));
+    hipDeviceSynchronize();
+    double* hy2 = malloc(n * sizeof(double));
+    hipMemcpy(hy2, y2, n * sizeof(double), hipMemcpyDeviceToHost);
+    for (int64_t i = 0; i < n; ++i)
+      if (hy2[i] != hy[i]) bad++;
+    printf("rccl %d: sharded matvec through a 1-rank communicator matches the plain matvec\n", ccqp_comm_rccl_version());
+    CHECK(ccqp_comm_destroy(comm));
+    hipFree(y2);
+    free(hy2);
+  } else {
+    printf("rccl: not available, communicator section skipped\n");
   }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;
