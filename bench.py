@@ -55,7 +55,10 @@ def pmc_traffic(bytes_per_launch, kernel_prefix="gemv_stream_kernel"):
     profile was taken -- yields None."""
     import glob
     cur = gemv_source_hash()
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+    # newest round first; within a round the profile of the bench itself before other drivers' profiles
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True)
+    files.sort(key=lambda f: (os.path.basename(f).split("_")[0], "bench" in os.path.basename(f)), reverse=True)
+    for f in files:
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001

@@ -228,7 +228,7 @@ def gen_solvers(sparse=False, contact=False):
             entry["converged"] = bool(r.solution_converged)
             entry["res"] = float(r.solution_residual)
             entry["executed_mv"] = int(o.executed_mv)
-            if not sparse:
+            if True:
                 # per-iteration host scalars (first C.TRACE_ROWS iterations) from the oracle's `trace=` hook, taken from
                 # a re-run that must reproduce the pinned result bit for bit
                 def run_traced():

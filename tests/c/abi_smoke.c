@@ -211,6 +211,8 @@ int main(void) {
     enum { NS = 42 };
     ccqp_seg hs[NS];
     int64_t off = 0;
+    hipMemcpy(hx, x, n * sizeof(double), hipMemcpyDeviceToHost);   /* (the batch section reused the host buffers) */
+    hipMemcpy(hg, g, n * sizeof(double), hipMemcpyDeviceToHost);
     for (int q = 0; q < 40; ++q, off += 3) {
       ccqp_seg t = {CCQP_OP_SPHERE, 0, off, 3, NULL, NULL, 0.3, 0.0};
       hs[q] = t;

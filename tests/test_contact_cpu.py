@@ -41,11 +41,13 @@ def test_oracle_reproduces_reference_on_matrix_free_A(case):
     P = None if case["op"] is None else C.build_op(case["op"], C.oracle_factory(), dict(C.SUITE_ARRAYS))
     np.random.seed(case["rng_seed"])
     with np.errstate(all="ignore"):
-        r = cpu_ref.SOLVERS[case["solver"]](A, b, case["tol"], case["max_mv"], P=P, **case["kwargs"])
+        r = cpu_ref.SOLVERS[case["solver"]](A, b, case["tol"], case["max_mv"], P=P, trace=[], **case["kwargs"])
     want = ARR[case["id"] + ".x"]
     if SAME_HOST:
         assert r.solution_num_matrix_vector_multiplications == case["mv"]
         assert H.same_bits(r.solution, want)
+        assert len(r.trace) == case["trace_len"]
+        assert H.same_bits(C.trace_array(case["solver"], r.trace), ARR[case["id"] + ".trace"])
     else:
         lo, hi = case["mv_band"]
         assert lo - (hi - lo) <= r.solution_num_matrix_vector_multiplications <= hi + (hi - lo)

@@ -55,33 +55,6 @@ def _solve(case, A, b, x0):
     return s, buf.getvalue()
 
 
-# Tolerances of the per-iteration scalars.  Integer-valued columns (MV counter, backtracking count, MPRGP branch,
-# halvings of the feasible-step search) are the control flow itself: exact.  L moves by exact factors (x2, x0.9) from
-# an estimate that agrees to ~1e-15.  Residuals and BB steps are quotients of sums with cancellation: at residual
-# 1e-8 a 1e-16 difference of the matvec's rounding shows at 1e-8..1e-7 relative.
-TRACE_RTOL = {"res": 1e-6, "dd": 1e-6, "L": 1e-11, "alpha": 1e-6, "alpha_bb": 1e-6, "betak": 1e-6}
-
-
-def _check_trace(case, s):
-    """The host loop's steering scalars, iteration by iteration, against the reference-pinned trace of the fixture
-    (first C.TRACE_ROWS iterations): localises a control-flow divergence (solvers.py:302, 1098)
-    instead of only counting matvecs at the end."""
-    stored = SOLV_ARR[case["id"] + ".trace"]
-    assert len(s.trace) == case["trace_len"]
-    got = C.trace_array(case["solver"], s.trace)
-    assert got.shape == stored.shape
-    n = SOLV_ARR[case["problem"] + ".b"].shape[0]
-    # the residual is c*|x - P(x - gd*g)| with c = 1/(3n*1e-6) (solvers.py:137-139): one ulp of an O(1) iterate entry
-    # is eps*c of residual, i.e. ~eps*c*sqrt(n) in the norm -- an absolute floor no implementation can go below
-    atol = {"res": 4 * np.finfo(float).eps * np.sqrt(n) / (3 * n * 1e-6)}
-    for j, col in enumerate(C.TRACE_COLUMNS[case["solver"]]):
-        if col in C.TRACE_EXACT:
-            assert np.array_equal(got[:, j], stored[:, j]), (col, got[:, j], stored[:, j])
-        else:
-            np.testing.assert_allclose(got[:, j], stored[:, j], rtol=TRACE_RTOL[col], atol=atol.get(col, 1e-300),
-                                       equal_nan=True, err_msg="trace column " + col)
-
-
 @pytest.mark.parametrize("case", SOLV, ids=[c["id"] for c in SOLV])
 def test_solver_golden(case):
     A = _device_matrix(case["problem"])
@@ -105,7 +78,7 @@ def test_solver_golden(case):
         assert s.solution_num_matrix_vector_multiplications == case["mv"]
         assert s.executed_matrix_vector_multiplications == case["executed_mv"]
         rtol = RTOL
-        _check_trace(case, s)
+        H.check_trace(case, s, SOLV_ARR, SOLV_ARR[case["problem"] + ".b"].shape[0])
     else:
         # 6 of the 3x3 analytic APGD / anti-relaxation cases: the reference's count itself moves by
         # several MVs under a 1-ulp perturbation of (A, b) (band and x-spread recorded by

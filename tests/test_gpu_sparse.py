@@ -319,6 +319,7 @@ def test_solver_golden_sparse(case):
     max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
     np.random.seed(case["rng_seed"])
     s = getattr(solvers, "CCQPSolver" + case["solver"])(case["tol"], max_mv, **case["kwargs"])
+    s.trace = []
     with contextlib.redirect_stdout(io.StringIO()):
         s.solve(A, b, x0=C.case_x0(case, n), convex_proj_op=P)
     want = ARR[case["id"] + ".x"]
@@ -327,6 +328,7 @@ def test_solver_golden_sparse(case):
         assert s.solution_num_matrix_vector_multiplications == case["mv"]
         assert s.executed_matrix_vector_multiplications == case["executed_mv"]
         rtol = RTOL
+        H.check_trace(case, s, ARR, n)               # per-iteration steering scalars (first 32 iterations)
     else:       # the reference's own count moves under 1-ulp perturbations of b (band in the fixture)
         assert lo - (hi - lo) <= s.solution_num_matrix_vector_multiplications <= hi + (hi - lo)
         rtol = max(RTOL, 8 * case["x_spread"])
