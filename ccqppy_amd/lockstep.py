@@ -74,9 +74,9 @@ def why_not_pipelined(solvers, problems, device):
         if dev is not None and dev != device:
             return ValueError("solve_batch_pipelined: operator on another device")
         P = P if P is not None else ss.IdentityProjOp(n)
-        if isinstance(P, ss.ProjOpBase):
-            P._refresh()                                 # (host-only: public parameters edited since the last use)
         if not hasattr(P, "_dev_bb_tail"):
+            if isinstance(P, ss.ProjOpBase):
+                P._refresh()                             # (host-only: its blocks may have been edited or replaced)
             # Sphere / Cone / DisjointUnion: the segmented lock-step form (ccqp_bsegs.hip), BBPGD and PGD only
             if kind not in (CCQPSolverBBPGD, CCQPSolverPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation) or \
                     not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
@@ -131,11 +131,14 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         raise reason
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # n -> items, in order of first appearance
+    refreshed = set()
     for s, (A, b, x0, P) in zip(solvers, problems):
         op = as_operator(A)
         n = op.n
         P = P if P is not None else ss.IdentityProjOp(n)
-        P._refresh()
+        if id(P) not in refreshed:                       # once per distinct set object and call
+            refreshed.add(id(P))
+            P._refresh()
         bd = eng.to_device(b).reshape(-1)
         by_size.setdefault((n, hasattr(P, "_dev_bb_tail")), []).append(
             (s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P, isinstance(b, torch.Tensor),

