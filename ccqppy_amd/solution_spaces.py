@@ -313,9 +313,16 @@ class _ElementwiseOp(ProjOpBase):
         st = self.__dict__.get("_bounds_state")
         # the state holds references to the bound objects themselves, so the ids the caches are keyed on cannot be
         # recycled while the caches live; contents are compared bit for bit against the snapshot taken at upload
-        if st is not None and st[0] is lb and st[1] is ub and self._unchanged(lb, st[2]) \
-                and self._unchanged(ub, st[3]):
-            return False
+        if st is not None and st[0] is lb and st[1] is ub:
+            s2, s3 = st[2], st[3]
+            # fast path (a batch of many small problems calls this once per problem): small arrays, bytes snapshots
+            if (lb is None or (type(lb) is np.ndarray and type(s2) is tuple and type(s2[2]) is bytes
+                               and lb.dtype == s2[0] and lb.shape == s2[1] and lb.tobytes() == s2[2])) and \
+                    (ub is None or (type(ub) is np.ndarray and type(s3) is tuple and type(s3[2]) is bytes
+                                    and ub.dtype == s3[0] and ub.shape == s3[1] and ub.tobytes() == s3[2])):
+                return False
+            if self._unchanged(lb, s2) and self._unchanged(ub, s3):
+                return False
         self.__dict__["_bounds_state"] = (lb, ub, self._snapshot(lb), self._snapshot(ub))
         for k in ("_seg_cache", "_dev_bounds", "_single_tables", "_segplans"):
             self.__dict__.pop(k, None)

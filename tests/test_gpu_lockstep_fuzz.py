@@ -1,6 +1,7 @@
 """GPU: seeded differential fuzzing of the lock-step schedulers (batch.solve_batch_pipelined) against per-problem
 solve().  Random solver (PGD / BBPGD / BBPGDf / APGD / anti-relaxation APGD / MPRGP), batch composition (sizes 65..1300 mixed in one call, so several
-lock-step groups), elementwise sets with array / scalar / integer / default bounds, warm starts, per-problem
+lock-step groups), elementwise sets with array / scalar / integer / default bounds and -- PGD / BBPGD / APGD / AR --
+Sphere sets and DisjointUnions of small and large blocks in the same call (the segmented forms), warm starts, per-problem
 tolerances, matvec budget, run-ahead depth and matvec tuning word.  Every result must be bitwise the one of the
 problem's own solve() (x, residual, converged flag, reported and executed MV counts)."""
 import contextlib
@@ -47,6 +48,24 @@ def _set(rng, n, mprgp):
     return ss.BoxProjOp(n, lb, ub)
 
 
+def _general_set(rng, n):
+    """A non-elementwise set for the segmented lock-step forms (no Cone: a solve on it never converges, and with an
+    infinite budget in the draw that would never end -- in the reference either)."""
+    from ccqppy_amd import solution_spaces as ss
+    kind = rng.integers(3)
+    if kind == 0:
+        return ss.SphereProjOp(n, float(rng.uniform(0.3, 5.0)))
+    if kind == 1:
+        k = n // 3
+        ops = [ss.SphereProjOp(3, float(rng.uniform(0.1, 0.6)))] * k
+        if n - 3 * k:
+            ops.append(ss.IdentityProjOp(n - 3 * k))
+        return ss.DisjointProjOp(*ops)
+    a = int(rng.integers(1, n - 1))
+    lo, hi = -rng.uniform(0.05, 0.6, size=a), rng.uniform(0.05, 0.6, size=a)
+    return ss.DisjointProjOp(ss.BoxProjOp(a, lo, hi), ss.SphereProjOp(n - a, float(rng.uniform(0.3, 3.0))))
+
+
 def _bits(x):
     x = x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
     return x.view(np.uint64)
@@ -69,7 +88,8 @@ def test_lockstep_equals_individual_solves(case):
             x0 = None
             if rng.random() < 0.3:
                 x0 = torch.as_tensor(rng.uniform(-0.5, 0.5, size=n), device=b.device)
-            probs.append((op, b, x0, _set(rng, n, name == "MPRGP")))
+            general = name in ("BBPGD", "APGD", "APGDAntiRelaxation", "PGD") and rng.random() < 0.35
+            probs.append((op, b, x0, _general_set(rng, n) if general else _set(rng, n, name == "MPRGP")))
             tols.append(float(10.0 ** rng.uniform(-9, -4)) if name != "MPRGP" else float(10.0 ** rng.uniform(-7, -4)))
     order = rng.permutation(len(probs))                 # sizes interleaved in the call
     probs = [probs[i] for i in order]

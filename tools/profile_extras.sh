@@ -33,4 +33,10 @@ cp "profiles/${TAG}_ensemble.json" "$OUT/"
 echo "[extras] lock-step batches on non-elementwise sets"; date
 python3 tools/bench_small_batch.py --set spheres3 63:1024 255:1024 1023:512 2046:256 > "$OUT/${TAG}_bsegs_bench.jsonl" 2> "$OUT/${TAG}_bsegs.err" || exit 1
 python3 tools/bench_small_batch.py --set sphere 64:1024 256:1024 1024:512 2048:256 >> "$OUT/${TAG}_bsegs_bench.jsonl" 2>> "$OUT/${TAG}_bsegs.err" || exit 1
+echo "[extras] lock-step batch on a union of Sphere(3) blocks under the kernel tracer"; date
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_bsegs" -- \
+  python3 "$ROOT/tools/bsegs_profile_driver.py" 1023 512 > "$OUT/${TAG}_bsegs_driver.json" 2> "$OUT/${TAG}_bsegs_prof.err" || exit 1
+find "$OUT/prof_${TAG}_bsegs" -name "*_kernel_stats.csv" -exec cp {} "$OUT/${TAG}_bsegs_kernel_stats.csv" \;
+cd "$ROOT"
 echo "[extras] done"; date
