@@ -143,22 +143,7 @@ __device__ __forceinline__ void bbf_tail_b_body(const ccqp_pprob& q, const ccqp_
   *dxdg = ccqp_block_sum(a2, lds4);
 }
 
-// part A: the residual, the exit test, "best so far", "fall back" (thread 0 of the problem's last block)
-__device__ __forceinline__ bool bbf_decide_a(double* s, double r, double tol, double eps10) {
-  const double res = sqrt(r);
-  s[0] = r;
-  s[BP_RES2] = r;
-  if (res < tol) return true;
-  if (res < s[BP_RESMIN]) {                   // :793-796
-    s[BP_RESMIN] = res;
-    s[BP_IMPROVED] = 1.0;
-  } else {
-    s[BP_IMPROVED] = 0.0;
-  }
-  s[BP_FALLBACK] = s[BP_ALPHA] < eps10 ? 1.0 : 0.0;   // :799
-  return false;
-}
-
+// (bbf_decide_a -- part A's decision -- lives in ccqp_lockstep.h: shared with ccqp_bsegs.hip)
 __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_a_kernel(const ccqp_pprob* __restrict__ probs, int inew,
                                                                    double gd, double eps10, int64_t chunk, int nblk,
                                                                    unsigned* __restrict__ batch) {

@@ -21,34 +21,60 @@
 #include "ccqp_lockstep.h"
 #include "ccqp_segs.h"
 
-// mode 0: u = x[ix] - alpha*g[ix] (step);  mode 1: u = x[ix] - gd*g[ix] (residual).  grid (max nnorm, problems)
+// Operands of a projection launch.  mode 0: the step u = x[ix] - alpha*g[ix] -> x[inew];  mode 1: the residual's
+// u = x[ix] - gd*g[ix];  mode 2 (BBPGDf, solvers.py:799-800): the restart u = xmin - gd*gmin -> x[inew], only for
+// problems whose slab says "fall back".
+struct bsegs_io {
+  const double* x;
+  const double* y;
+  double b;
+  bool live;
+};
+
+__device__ __forceinline__ bsegs_io bsegs_operands(const ccqp_pprob& q, int mode, int ix, double gd) {
+  bsegs_io io = {nullptr, nullptr, 0.0, false};
+  if (q.slab[BP_DONE] != 0.0) return io;
+  if (mode == 2) {
+    if (q.slab[BP_FALLBACK] == 0.0) return io;
+    io.x = q.xmin;
+    io.y = q.gmin;
+    io.b = -gd;
+  } else {
+    io.x = q.x[ix];
+    io.y = q.g[ix];
+    io.b = mode == 0 ? -q.slab[BP_ALPHA] : -gd;
+  }
+  io.live = true;
+  return io;
+}
+
+// chunk sums of |u|^2 for the Sphere / Cone blocks.  grid (max nnorm, problems)
 __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_norm_kernel(const ccqp_pprob* __restrict__ probs,
                                                                 const ccqp_psegs* __restrict__ segs, int mode, int ix,
                                                                 double gd) {
   __shared__ double lds4[4];
-  const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) return;
   const ccqp_psegs& ps = segs[blockIdx.y];
   if ((int)blockIdx.x >= ps.nnorm) return;
+  const bsegs_io io = bsegs_operands(probs[blockIdx.y], mode, ix, gd);
+  if (!io.live) return;
   const ccqp_segwork w = ps.normwork[blockIdx.x];
-  const double b = mode == 0 ? -q.slab[BP_ALPHA] : -gd;
-  const double s = segs_norm_item(ps.table, w, 1.0, q.x[ix], b, q.g[ix], lds4);
+  const double s = segs_norm_item(ps.table, w, 1.0, io.x, io.b, io.y, lds4);
   if (threadIdx.x == 0) ps.workspace[w.pbase + w.chunk] = s;
 }
 
-// x[inew] = P(x[icur] - alpha*g[icur]).  grid (max nwork, problems)
+// x[inew] = P(u), u by `mode` (0: the step from x[icur]; 2: BBPGDf's restart).  grid (max nwork, problems)
 __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_step_kernel(const ccqp_pprob* __restrict__ probs,
                                                                 const ccqp_psegs* __restrict__ segs, int inew,
-                                                                int icur) {
+                                                                int icur, int mode, double gd) {
   __shared__ double lds4[4];
   __shared__ double bcast;
-  const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) return;
   const ccqp_psegs& ps = segs[blockIdx.y];
   if ((int)blockIdx.x >= ps.nwork) return;
+  const ccqp_pprob& q = probs[blockIdx.y];
+  const bsegs_io io = bsegs_operands(q, mode, icur, gd);
+  if (!io.live) return;
   const ccqp_segwork w = ps.work[blockIdx.x];
-  const double b = -q.slab[BP_ALPHA];
-  (void)segs_apply_item<0>(ps.table, w, ps.workspace, 1.0, q.x[icur], b, q.g[icur], nullptr, q.x[inew], 0.0, lds4, &bcast);
+  (void)segs_apply_item<0>(ps.table, w, ps.workspace, 1.0, io.x, io.b, io.y, nullptr, q.x[inew], 0.0, lds4, &bcast);
 }
 
 // per work item: sum (c*(x - P(x - gd*g)))^2 -> the residual partials of the problem's workspace
@@ -145,6 +171,75 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tail_kernel(const ccqp_pprob
   bp_report(batch, host, count, seq);
 }
 
+// ---- BBPGDf (solvers.py:719-819): the tail in two parts, as in ccqp_bpipe.hip.  Part A: the residual (work-item
+// sums in index order) -> exit test, "best so far", "fall back";  keep: xmin / gmin = x_new / g_new where improved;
+// restart: x_new = P(xmin - gd gmin) where the step length has collapsed (bsegs_norm / bsegs_step, mode 2);  part B:
+// dx.dx, dx.dg with the possibly replaced x_new -> alpha.
+__global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tailf_a_kernel(const ccqp_pprob* __restrict__ probs,
+                                                                   const ccqp_psegs* __restrict__ segs, double eps10,
+                                                                   unsigned* __restrict__ batch) {
+  __shared__ double lds4[4];
+  const ccqp_pprob& q = probs[blockIdx.x];
+  const bool done = q.slab[BP_DONE] != 0.0;
+  __syncthreads();                          // every wave has read the state before thread 0 may change it
+  if (done) return;
+  const ccqp_psegs& ps = segs[blockIdx.x];
+  const double* respart = ps.workspace + 3 * ps.npartials;
+  const double r = ps.nwork == 1 ? respart[0] : partial_sum_body(respart, ps.nwork, lds4);
+  if (threadIdx.x == 0 && bbf_decide_a(q.slab, r, q.tol, eps10)) {
+    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    q.slab[BP_DONE] = 1.0;
+    __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bsegs_keep_best_kernel(const ccqp_pprob* __restrict__ probs, int inew,
+                                                                     int64_t n) {
+  const ccqp_pprob& q = probs[blockIdx.y];
+  if (q.slab[BP_DONE] != 0.0 || q.slab[BP_IMPROVED] == 0.0) return;
+  copy_body(q.x[inew], q.xmin, n, blockIdx.x, gridDim.x);
+  copy_body(q.g[inew], q.gmin, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tailf_b_kernel(const ccqp_pprob* __restrict__ probs, int inew,
+                                                                   int icur, double eps10, int64_t n, int64_t chunk,
+                                                                   int nblk, unsigned* __restrict__ batch,
+                                                                   double* __restrict__ host, unsigned count,
+                                                                   double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pprob& q = probs[blockIdx.y];
+  if (q.slab[BP_DONE] != 0.0) {             // converged (now or earlier): only the roll-call
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  const double* __restrict__ xn = q.x[inew];
+  const double* __restrict__ xo = q.x[icur];
+  const double* __restrict__ gn = q.g[inew];
+  const double* __restrict__ go = q.g[icur];
+  const int bx = blockIdx.x;
+  CHUNK_RANGE(n)
+  double a1 = 0.0, a2 = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    const double dx = xn[i] - xo[i];
+    const double dg = gn[i] - go[i];
+    a1 = fma(dx, dx, a1);
+    a2 = fma(dx, dg, a2);
+  }
+  double v[2];
+  v[0] = ccqp_block_sum(a1, lds4);
+  v[1] = ccqp_block_sum(a2, lds4);
+  if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+  if (threadIdx.x == 0) {
+    const double den = v[1] + eps10;
+    q.slab[1] = v[0];
+    q.slab[2] = v[1];
+    q.slab[BP_ALPHA] = v[0] / den;
+    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    bp_report(batch, host, count, seq);
+  }
+}
+
 #define BSEGS_CHECK()                                                                    \
   BP_CHECK_BATCH();                                                                      \
   CCQP_REQUIRE(dev_segs != nullptr, "NULL segment descriptors");                         \
@@ -190,7 +285,7 @@ extern "C" int ccqp_bsegs_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, icur, gd);
-  hipLaunchKernelGGL(bsegs_step_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur);
+  hipLaunchKernelGGL(bsegs_step_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur, 0, gd);
   ccqp_bp_gemv(dev_probs, count, n, inew, 0, flags, s);
   if (with_tail) {
     int64_t chunk;
@@ -199,9 +294,19 @@ extern "C" int ccqp_bsegs_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
     if (max_nnorm > 0)
       hipLaunchKernelGGL(bsegs_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 1, inew, gd);
     hipLaunchKernelGGL(bsegs_resid_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, gd);
-    hipLaunchKernelGGL(bsegs_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur,
-                       eps10, n, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
-                       (flags & BP_FLAG_CONST_STEP) != 0, 0);
+    if (flags & BP_FLAG_FALLBACK) {
+      hipLaunchKernelGGL(bsegs_tailf_a_kernel, dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, eps10, dev_batch);
+      hipLaunchKernelGGL(bsegs_keep_best_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, n);
+      if (max_nnorm > 0)
+        hipLaunchKernelGGL(bsegs_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 2, inew, gd);
+      hipLaunchKernelGGL(bsegs_step_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur, 2, gd);
+      hipLaunchKernelGGL(bsegs_tailf_b_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, eps10,
+                         n, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration);
+    } else {
+      hipLaunchKernelGGL(bsegs_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur,
+                         eps10, n, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
+                         (flags & BP_FLAG_CONST_STEP) != 0, 0);
+    }
   }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

@@ -76,6 +76,24 @@ __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int
   return true;
 }
 
+// ---- BBPGDf (solvers.py:696-843)
+// part A: the residual, the exit test, "best so far", "fall back" (thread 0 of the problem's last block)
+__device__ __forceinline__ bool bbf_decide_a(double* s, double r, double tol, double eps10) {
+  const double res = sqrt(r);
+  s[0] = r;
+  s[BP_RES2] = r;
+  if (res < tol) return true;
+  if (res < s[BP_RESMIN]) {                   // :793-796
+    s[BP_RESMIN] = res;
+    s[BP_IMPROVED] = 1.0;
+  } else {
+    s[BP_IMPROVED] = 0.0;
+  }
+  s[BP_FALLBACK] = s[BP_ALPHA] < eps10 ? 1.0 : 0.0;   // :799
+  return false;
+}
+
+
 template <typename PROB>
 __device__ __forceinline__ ccqp_segk bp_segk_of(const PROB& q) {
   ccqp_segk k;

@@ -37,59 +37,85 @@ def _device_budget(n):
     return int(min(20000, max(256, 2.0 / max(15e-6, 8.0 * n * n / 20e9))))
 
 
+_KINDS = None
+
+
+def _lockstep_kinds():
+    global _KINDS
+    if _KINDS is None:
+        from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
+                              CCQPSolverMPRGP, CCQPSolverPGD)
+        _KINDS = (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
+                  CCQPSolverPGD)
+    return _KINDS
+
+
+def _why_not_batch(first):
+    """The batch-wide part of the argument check (the solver class)."""
+    kind = type(first)
+    if kind not in _lockstep_kinds() or getattr(first, "reuse_matvec", False):
+        return TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
+                         "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
+    return None
+
+
+def _why_not_one(kind, max_mv, s, A, b, P, device):
+    """One problem of the argument check: (reason or None, n, the set with the default filled in).  No staging, no
+    GPU work."""
+    from . import _lib
+    from . import solution_spaces as ss
+    from .operators import DenseOperator
+    if type(s) is not kind or getattr(s, "reuse_matvec", False):
+        return TypeError("solve_batch_pipelined: one solver class for the whole batch"), None, P
+    if s.max_matrix_vector_multiplications != max_mv:
+        return ValueError("solve_batch_pipelined: one matvec budget for the whole batch"), None, P
+    if hasattr(A, "matvec") and hasattr(A, "engine"):
+        op_ok = isinstance(A, DenseOperator) and A.rows == A.n
+        n = getattr(A, "n", None)
+        dev = A.A.device if op_ok else None
+    else:
+        op_ok = getattr(A, "ndim", None) == 2 and A.shape[0] == A.shape[1] and \
+            getattr(A, "layout", torch.strided) == torch.strided and not hasattr(A, "tocsr")
+        n = A.shape[1] if op_ok else None
+        dev = A.device if isinstance(A, torch.Tensor) and A.is_cuda else None
+    if not op_ok:
+        return TypeError("solve_batch_pipelined needs square dense operators"), None, P
+    if b.shape[0] != n:
+        return ValueError("solve_batch_pipelined: b does not match A"), n, P
+    if dev is not None and dev != device:
+        return ValueError("solve_batch_pipelined: operator on another device"), n, P
+    P = P if P is not None else ss.IdentityProjOp(n)
+    if not hasattr(P, "_dev_bb_tail"):
+        if isinstance(P, ss.ProjOpBase):
+            P._refresh()                                 # (host-only: its blocks may have been edited or replaced)
+        # Sphere / Cone / DisjointUnion: the segmented lock-step forms (ccqp_bsegs.hip), every solver but MPRGP
+        if kind.__name__ == "CCQPSolverMPRGP" or not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
+            return TypeError("solve_batch_pipelined needs elementwise feasible sets (all solvers but MPRGP: any set "
+                             "built from the seven operators), got %r" % type(P).__name__), n, P
+        if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
+            return ValueError("solve_batch_pipelined: the feasible set does not match b"), n, P
+        return None, n, P
+    if kind.__name__ == "CCQPSolverMPRGP" and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
+        # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
+        # sequential-sum kernels of the literal path)
+        return TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
+                         % _lib.SMALL_SEG_MAX), n, P
+    return None, n, P
+
+
 def why_not_pipelined(solvers, problems, device):
     """Argument check of solve_batch_pipelined WITHOUT any staging or GPU work: None if the lock-step scheduler can take
     the batch, else the TypeError / ValueError it would raise (returned, not raised).  `solve_batch_sharded(fused="auto")`
     decides on this alone, so that nothing raised while a batch is being staged or run can be mistaken for "does not
     apply" and silently re-solved by another scheduler."""
-    from . import _lib
-    from . import solution_spaces as ss
-    from .operators import DenseOperator, as_operator
-    from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
-                          CCQPSolverMPRGP, CCQPSolverPGD)
-    kind = type(solvers[0])
-    if kind not in (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
-                    CCQPSolverPGD) or getattr(solvers[0], "reuse_matvec", False):
-        return TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
-                         "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
-    max_mv = solvers[0].max_matrix_vector_multiplications
+    reason = _why_not_batch(solvers[0])
+    if reason is not None:
+        return reason
+    kind, max_mv = type(solvers[0]), solvers[0].max_matrix_vector_multiplications
     for s, (A, b, x0, P) in zip(solvers, problems):
-        if type(s) is not kind or getattr(s, "reuse_matvec", False):
-            return TypeError("solve_batch_pipelined: one solver class for the whole batch")
-        if s.max_matrix_vector_multiplications != max_mv:
-            return ValueError("solve_batch_pipelined: one matvec budget for the whole batch")
-        if hasattr(A, "matvec") and hasattr(A, "engine"):
-            op_ok = isinstance(A, DenseOperator) and A.rows == A.n
-            n = getattr(A, "n", None)
-            dev = A.A.device if op_ok else None
-        else:
-            op_ok = getattr(A, "ndim", None) == 2 and A.shape[0] == A.shape[1] and \
-                getattr(A, "layout", torch.strided) == torch.strided and not hasattr(A, "tocsr")
-            n = A.shape[1] if op_ok else None
-            dev = A.device if isinstance(A, torch.Tensor) and A.is_cuda else None
-        if not op_ok:
-            return TypeError("solve_batch_pipelined needs square dense operators")
-        if b.shape[0] != n:
-            return ValueError("solve_batch_pipelined: b does not match A")
-        if dev is not None and dev != device:
-            return ValueError("solve_batch_pipelined: operator on another device")
-        P = P if P is not None else ss.IdentityProjOp(n)
-        if not hasattr(P, "_dev_bb_tail"):
-            if isinstance(P, ss.ProjOpBase):
-                P._refresh()                             # (host-only: its blocks may have been edited or replaced)
-            # Sphere / Cone / DisjointUnion: the segmented lock-step form (ccqp_bsegs.hip), BBPGD and PGD only
-            if kind not in (CCQPSolverBBPGD, CCQPSolverPGD, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation) or \
-                    not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
-                return TypeError("solve_batch_pipelined needs elementwise feasible sets (PGD / BBPGD / APGD / anti-relaxation "
-                                 "APGD: any set built from the seven operators), got %r" % type(P).__name__)
-            if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
-                return ValueError("solve_batch_pipelined: the feasible set does not match b")
-            continue
-        if kind is CCQPSolverMPRGP and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
-            # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
-            # sequential-sum kernels of the literal path)
-            return TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
-                             % _lib.SMALL_SEG_MAX)
+        reason = _why_not_one(kind, max_mv, s, A, b, P, device)[0]
+        if reason is not None:
+            return reason
     return None
 
 
@@ -126,16 +152,19 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     eng = get_engine(device)
     eng.bind()
     kind = type(solvers[0])
-    reason = why_not_pipelined(solvers, problems, eng.device)
+    reason = _why_not_batch(solvers[0])
     if reason is not None:
         raise reason
     max_mv = solvers[0].max_matrix_vector_multiplications
-    by_size = {}                                        # n -> items, in order of first appearance
+    by_size = {}                                        # (n, elementwise set?) -> items, in order of first appearance
     refreshed = set()
-    for s, (A, b, x0, P) in zip(solvers, problems):
+    for s, (A, b, x0, P0) in zip(solvers, problems):
+        # argument check and staging of one problem in ONE pass (many small problems: the host side counts); the check
+        # itself does no GPU work, and the first failing problem raises before anything is launched
+        reason, n, P = _why_not_one(kind, max_mv, s, A, b, P0, eng.device)
+        if reason is not None:
+            raise reason
         op = as_operator(A)
-        n = op.n
-        P = P if P is not None else ss.IdentityProjOp(n)
         if id(P) not in refreshed:                       # once per distinct set object and call
             refreshed.add(id(P))
             P._refresh()
@@ -391,7 +420,8 @@ def _bsegs_run(eng, spec, plans, n, max_mv, ahead, tune=0):
     from .solvers import _EPS10, _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(spec)
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 7, 3)
+    fallback = bool(getattr(spec, "fallback", False))
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PProb, 9 if fallback else 7, 3)
     spec.stage_x0(vec[0])
     for j in range(3):
         tab["x"][:, j] = planes[j]
@@ -401,6 +431,11 @@ def _bsegs_run(eng, spec, plans, n, max_mv, ahead, tune=0):
     if getattr(spec, "step", None) is not None:         # PGD: constant steps, in slab slot 48; flag bit 3
         slabs[:, 48] = torch.from_numpy(np.ascontiguousarray(spec.step)).to(dev)
         flags |= 8
+    if fallback:                                        # BBPGDf: xmin = gmin = copy(x0) (solvers.py:762-763), bit 7
+        vec[7].copy_(vec[0])
+        vec[8].copy_(vec[0])
+        tab["xmin"], tab["gmin"] = planes[7], planes[8]
+        flags |= 128
     dsegs, ws, max_nwork, max_nnorm = _psegs_table(plans, dev)
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, dsp, batch = dprobs.data_ptr(), dsegs.data_ptr(), words.data_ptr() + 4 * B

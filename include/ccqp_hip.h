@@ -379,8 +379,9 @@ int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count
  * a problem with fewer items idles the rest).  Replaces the Python loops solvers.py:583-669 / 94-170 around
  * solution_spaces.py:540-560, 417-435, 470-492 as run by benchmarks/benchmark_random_ccqp.py:67-102.  Per problem
  * the bits of its own solve() (ccqp_segs_project_f64 + ccqp_segs_residual_sq_f64 + ccqp_dots_f64 + the host loop's
- * scalar arithmetic).  `workspace` must be zero on entry.  Polling, slab slots, flags bit 0 / bit 3 (PGD) and the
- * matvec tuning word: as ccqp_bpipe_*; BBPGDf (bit 7) is not available here. */
+ * scalar arithmetic).  `workspace` must be zero on entry.  Polling, slab slots, flags bit 0 / bit 3 (PGD) / bit 7
+ * (BBPGDf: xmin / gmin of ccqp_pprob; the restart P(xmin - gd gmin) is a segmented launch of its own) and the
+ * matvec tuning word: as ccqp_bpipe_*. */
 typedef struct ccqp_psegs {
   const ccqp_seg* table;
   const ccqp_segwork* work;

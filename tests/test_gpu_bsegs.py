@@ -238,17 +238,17 @@ def test_segmented_apgd_mixed_sets_tolerances_starts_and_budgets():
 
 
 def test_solvers_without_a_segmented_form_are_declined_not_mis_solved():
-    """BBPGDf / MPRGP / SPG on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
+    """MPRGP / SPG on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
     host-driven scheduler, counted in lockstep.stats)."""
     from ccqppy_amd import batch, lockstep, solvers
     probs = _problems(128, 3, 1, "spheres3")
-    for cls in (solvers.CCQPSolverSPG, solvers.CCQPSolverBBPGDf, solvers.CCQPSolverMPRGP):
+    for cls in (solvers.CCQPSolverSPG, solvers.CCQPSolverMPRGP):
         with pytest.raises(TypeError):
             batch.solve_batch_pipelined(lambda: cls(1e-6, 300), probs)
     before = lockstep.stats["auto_declined"]
-    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverBBPGDf(1e-6, 300), lambda p: probs[p], 3)
+    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), lambda p: probs[p], 3)
     assert lockstep.stats["auto_declined"] == before + 1
-    ref = _reference(probs, [1e-6] * 3, 300, "BBPGDf")
+    ref = _reference(probs, [1e-6] * 3, 300, "MPRGP")
     for p in range(3):
         _same(ref[p], out[p])
 
@@ -277,3 +277,31 @@ def test_single_solve_pipeline_option_on_general_sets(solver, family, n):
         a = cls(1e-8, 300).solve(big[0], big[1], convex_proj_op=_set(2100, 0, "sphere"))
         c = cls(1e-8, 300, pipeline=True).solve(big[0], big[1], convex_proj_op=_set(2100, 0, "sphere"))
     _same(a, c)
+
+
+@pytest.mark.parametrize("n,count", [(37, 9), (120, 30), (700, 8), (2049, 4)])
+def test_segmented_bbpgdf_fallback_variant(n, count):
+    """BBPGDf (solvers.py:719-819) on Sphere / DisjointUnion sets.  On convex problems the restart from the best iterate
+    never fires, so -- as for the elementwise form -- the matrices are made INDEFINITE (A - 2.2 I inside bounded
+    sets), where the step length collapses again and again; budgets keep the solves finite."""
+    import torch
+    from ccqppy_amd import problems
+    probs = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, 5200 + n + p)
+        A = op.A - 2.2 * torch.eye(n, dtype=torch.float64, device=op.A.device)
+        probs.append((A, b, None, _set(n, p, ["sphere", "spheres3"][p % 2])))
+    for budget in (35, 160):
+        ref = _reference(probs, [1e-9] * count, budget, "BBPGDf")
+        got = _batch(probs, [1e-9] * count, budget, "BBPGDf")
+        for a, c in zip(ref, got):
+            _same(a, c)
+    # the restart branch must have been exercised: BBPGD and BBPGDf differ on these problems
+    plain = _reference(probs, [1e-9] * count, 160, "BBPGD")
+    assert any(not np.array_equal(a.solution.cpu().numpy(), c.solution.cpu().numpy()) for a, c in zip(plain, ref))
+    convex = _problems(n, min(count, 6), 61 + n, ["sphere", "spheres3"])
+    ref = _reference(convex, [1e-8] * len(convex), 4000, "BBPGDf")
+    got = _batch(convex, [1e-8] * len(convex), 4000, "BBPGDf")
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
