@@ -414,12 +414,12 @@ def test_rejects_what_it_cannot_run():
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverSPG(1e-8), [(op, b, None, None)])
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(1e-8, reuse_matvec=True), [(op, b, None, None)])
-    # (PGD / BBPGD / APGD / AR on Sphere / Cone / DisjointUnion sets run in the segmented lock-step form since round 2 --
+    # (every solver but MPRGP runs on Sphere / Cone / DisjointUnion sets in the segmented lock-step forms since round 2 --
     # tests/test_gpu_bsegs.py; the other solvers still need elementwise sets)
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8), [(op, b, None, ss.ConeProjOp(64))])
     with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverBBPGDf(1e-8), [(op, b, None, ss.SphereProjOp(64))])
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8), [(op, b, None, ss.SphereProjOp(64))])
     class Foreign:                        # a user-defined block: no device form, the union cannot run in lock-step
         embedded_dimension = 32
 
