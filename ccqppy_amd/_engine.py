@@ -313,6 +313,15 @@ class Engine:
         if rc:
             _lib.check(rc)
 
+    def segs_feasible_steps(self, plan, x, p, alpha0, K, slot0):
+        """slab[slot0 + k] = #{i: not isclose(yf_i, P(yf)_i)}, yf = x - (alpha0 * 0.5^k) * p, k < K -- any feasible set."""
+        rc = self.lib.ccqp_segs_feasible_steps_f64(self.ctx, plan.table_ptr, plan.work_ptr, plan.nwork,
+                                                   plan.normwork_ptr, plan.nnorm, plan.npartials,
+                                                   plan.workspace(self).data_ptr(), x.data_ptr(), p.data_ptr(), alpha0,
+                                                   K, slot0, self.stream)
+        if rc:
+            _lib.check(rc)
+
     def residual_sq_elementwise(self, seg, x, g, c, gd, slot):
         rc = self.lib.ccqp_residual_sq_elementwise_f64(self.ctx, seg, x.data_ptr(), g.data_ptr(), c, gd, slot,
                                                        self.stream)

@@ -135,6 +135,7 @@ SIGNATURES = {
     "ccqp_segs_project_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _D, _P, _D, _P, _P, _P, _P],
     "ccqp_segs_residual_sq_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_segs_normal_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
+    "ccqp_segs_feasible_steps_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P, _D, _I, _I, _P],
     "ccqp_residual_sq_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],
     "ccqp_fused_dots_f64": [_P, _I, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _I64, _I,
                             _c.POINTER(Seg), _P, _P, _D, _D, _I, _P],

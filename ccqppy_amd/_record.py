@@ -205,7 +205,7 @@ def _immediate(name):
 for _name in ("mul", "muldiv", "submul", "proj_normscale", "proj_small", "isclose_mask_mul", "count_notclose",
               "normal_elementwise", "normal_sphere", "chopped_gradient", "projected_gradient_elementwise",
               "gen_spd_rows", "gen_vec", "spmv_csr", "spmv_plan", "csr_violations", "segs_project", "segs_residual_sq",
-              "segs_normal"):
+              "segs_normal", "segs_feasible_steps"):
     setattr(RecordingEngine, _name, _immediate(_name))
 
 # Engine.fill(value, out) is the public name; keep it, recorded

@@ -123,6 +123,11 @@ struct emit_residual {    // acc += (c*(x - P(u)))^2, u = x - gd*g
   }
 };
 
+struct emit_notclose {    // acc += 1 where not isclose(u, P(u))  (solvers.py:1115: `np.all(np.isclose(yf, P(yf)))` <=> 0)
+  double acc;
+  __device__ __forceinline__ void operator()(int64_t, double u, double p) { acc += ccqp_isclose(u, p) ? 0.0 : 1.0; }
+};
+
 // chunk sum of |u|^2 for one norm work item (same thread -> element map and fma chain as dot_body); valid in thread 0
 __device__ __forceinline__ double segs_norm_item(const ccqp_seg* __restrict__ table, const ccqp_segwork& w, double a,
                                                  const double* x, double b, const double* y, double* lds4) {
@@ -142,7 +147,8 @@ __device__ __forceinline__ double segs_norm_item(const ccqp_seg* __restrict__ ta
   return ccqp_block_sum(acc, lds4);
 }
 
-// One work item of the apply pass.  EPI 0: out = P(u) (- z), returns 0;  EPI 1: returns this THREAD's share of
+// One work item of the apply pass.  EPI 0: out = P(u) (- z), returns 0;  EPI 2: returns this thread's count of entries
+// with not isclose(u, P(u));  EPI 1: returns this THREAD's share of
 // sum (c*(x - P(u)))^2 over the item (chunk: elements t, t+256, ...; run of small blocks: thread t = block t's chain)
 template <int EPI>
 __device__ __forceinline__ double segs_apply_item(const ccqp_seg* __restrict__ table, const ccqp_segwork& w,
@@ -158,8 +164,12 @@ __device__ __forceinline__ double segs_apply_item(const ccqp_seg* __restrict__ t
         if constexpr (EPI == 0) {
           emit_store e = {out + sg.offset, z ? z + sg.offset : nullptr};
           segs_small(sg, u, e);
-        } else {
+        } else if constexpr (EPI == 1) {
           emit_residual e = {x + sg.offset, c, 0.0};
+          segs_small(sg, u, e);
+          racc = e.acc;
+        } else {
+          emit_notclose e = {0.0};
           segs_small(sg, u, e);
           racc = e.acc;
         }
@@ -186,10 +196,12 @@ __device__ __forceinline__ double segs_apply_item(const ccqp_seg* __restrict__ t
       const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
       if constexpr (EPI == 0) {
         os[i] = zs ? p - zs[i] : p;
-      } else {
+      } else if constexpr (EPI == 1) {
         const double d = xs[i] - p;
         const double t = c * d;
         racc = fma(t, t, racc);
+      } else {
+        racc += ccqp_isclose(v, p) ? 0.0 : 1.0;
       }
     }
   } else {
@@ -201,10 +213,12 @@ __device__ __forceinline__ double segs_apply_item(const ccqp_seg* __restrict__ t
       const double p = rule(v, i == sg.dim - 1);
       if constexpr (EPI == 0) {
         os[i] = zs ? p - zs[i] : p;
-      } else {
+      } else if constexpr (EPI == 1) {
         const double d = xs[i] - p;
         const double t = c * d;
         racc = fma(t, t, racc);
+      } else {
+        racc += ccqp_isclose(v, p) ? 0.0 : 1.0;
       }
     }
   }

@@ -87,11 +87,17 @@ extern "C" int ccqp_segs_plan(const ccqp_seg* segs, int64_t nseg, ccqp_segwork* 
   return CCQP_OK;
 }
 
-// workspace (doubles): 3 arrays of npartials chunk sums (|u|^2 | |x - xp|^2 | |xp|^2), nwork residual partials,
-// 8 doubles of arrival counters (zero on entry, left at zero)
+// workspace (doubles): 3 arrays of npartials chunk sums (|u|^2 | |x - xp|^2 | |xp|^2) + nwork residual partials -- or,
+// for the feasible-step search, CCQP_MAX_STEPS x (npartials chunk sums + nwork counts) -- then 8 doubles of arrival
+// counters (zero on entry, left at zero)
+static inline int64_t segs_counter_offset(int64_t npartials, int64_t nwork) {
+  const int64_t a = 3 * npartials + nwork, b = (int64_t)CCQP_MAX_STEPS * (npartials + nwork);
+  return a > b ? a : b;
+}
+
 extern "C" int64_t ccqp_segs_workspace_doubles(int64_t npartials, int64_t nwork) {
   if (npartials < 0 || nwork < 0) return -1;
-  return 3 * npartials + nwork + 8;
+  return segs_counter_offset(npartials, nwork) + 8;
 }
 
 // ------------------------------------------------------------------ device side (helpers: ccqp_segs.h)
@@ -282,7 +288,7 @@ static int segs_check(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* 
 }
 
 static inline unsigned* segs_counter(double* ws, int64_t npartials, int64_t nwork) {
-  return reinterpret_cast<unsigned*>(ws + 3 * npartials + nwork);
+  return reinterpret_cast<unsigned*>(ws + segs_counter_offset(npartials, nwork));
 }
 
 extern "C" int ccqp_segs_project_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
@@ -344,6 +350,74 @@ extern "C" int ccqp_segs_normal_f64(ccqp_ctx* ctx, const ccqp_seg* table, const 
   if (npartials > 0)
     hipLaunchKernelGGL(segs_normal_finish_kernel, dim3((unsigned)nwork), dim3(CCQP_BLOCK), 0, s, table, work,
                        ws + npartials, ws + 2 * npartials, out);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+
+// ------------------------------------------------------------------ MPRGP's feasible-step search on any set
+// solvers.py:1112-1118 halves alpha_f until np.all(np.isclose(yf, P(yf))), yf = x - alpha_f*p -- one projection and one
+// host synchronisation per candidate in the reference's form.  Here K candidates alpha0 * 0.5^k (the values the loop
+// visits: *0.5 is exact) are evaluated in 2 launches: chunk sums of |yf_k|^2 for the Sphere / Cone blocks (grid
+// (norm items, K)), then per work item the count of entries that are not close (grid (items, K)); counts are small
+// integers in fp64, so their sum does not depend on the order.  slab[slot0 + k] = the count of candidate k.
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_feasible_norm_kernel(const ccqp_seg* __restrict__ table,
+                                                                        const ccqp_segwork* __restrict__ normwork,
+                                                                        double* __restrict__ ws, int64_t npartials,
+                                                                        const double* x, const double* p,
+                                                                        double alpha0) {
+  __shared__ double lds4[4];
+  const int k = blockIdx.y;
+  double alpha = alpha0;
+  for (int j = 0; j < k; ++j) alpha *= 0.5;
+  const ccqp_segwork w = normwork[blockIdx.x];
+  const double s = segs_norm_item(table, w, 1.0, x, -alpha, p, lds4);
+  if (threadIdx.x == 0) ws[(int64_t)k * npartials + w.pbase + w.chunk] = s;
+}
+
+__global__ __launch_bounds__(CCQP_BLOCK) void segs_feasible_count_kernel(const ccqp_seg* __restrict__ table,
+                                                                         const ccqp_segwork* __restrict__ work,
+                                                                         double* __restrict__ ws, int64_t npartials,
+                                                                         int nwork, int K, const double* x,
+                                                                         const double* p, double alpha0,
+                                                                         unsigned* counters, double* slots) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const int k = blockIdx.y;
+  double alpha = alpha0;
+  for (int j = 0; j < k; ++j) alpha *= 0.5;
+  const ccqp_segwork w = work[blockIdx.x];
+  const double racc = segs_apply_item<2>(table, w, ws + (int64_t)k * npartials, 1.0, x, -alpha, p, nullptr, nullptr, 0.0,
+                                         lds4, &bcast);
+  const double s = ccqp_block_sum(racc, lds4);
+  if (nwork == 1) {
+    if (threadIdx.x == 0) slots[k] = s;
+    return;
+  }
+  double* cnt = ws + (int64_t)K * npartials + (int64_t)k * nwork;
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s;
+  ccqp_reduce_finish(cnt, nwork, 1, counters + k, slots + k, lds4);
+}
+
+extern "C" int ccqp_segs_feasible_steps_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work,
+                                            int64_t nwork, const ccqp_segwork* normwork, int64_t nnorm,
+                                            int64_t npartials, double* ws, const double* x, const double* p,
+                                            double alpha0, int K, int slot0, void* stream) {
+  int rc = segs_check(ctx, table, work, nwork, normwork, nnorm, npartials, ws);
+  if (rc) return rc;
+  CCQP_REQUIRE(K >= 1 && K <= CCQP_MAX_STEPS, "K outside [1, CCQP_MAX_STEPS]");
+  CCQP_REQUIRE(ccqp_slot_ok(slot0, K), "slot range outside the slab");
+  hipStream_t s = (hipStream_t)stream;
+  if (nwork == 0) {
+    CCQP_HIP(hipMemsetAsync(ctx->slots + slot0, 0, (size_t)K * sizeof(double), s));
+    return CCQP_OK;
+  }
+  CCQP_REQUIRE(x && p, "NULL vector");
+  if (nnorm > 0)
+    hipLaunchKernelGGL(segs_feasible_norm_kernel, dim3((unsigned)nnorm, K), dim3(CCQP_BLOCK), 0, s, table, normwork, ws,
+                       npartials, x, p, alpha0);
+  hipLaunchKernelGGL(segs_feasible_count_kernel, dim3((unsigned)nwork, K), dim3(CCQP_BLOCK), 0, s, table, work, ws,
+                     npartials, (int)nwork, K, x, p, alpha0, segs_counter(ws, npartials, nwork), ctx->slots + slot0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

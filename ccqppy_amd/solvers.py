@@ -909,6 +909,20 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 if tried > 1200:   # alpha_f has underflowed to 0: the reference never exits either
                     raise RuntimeError("MPRGP feasibility bisection cannot terminate "
                                        "(solvers.py:1113-1118 loops forever on this input)")
+        plan = P._segplan(eng, run.n) if isinstance(P, ss.ProjOpBase) else None
+        while plan is not None:
+            # any set with a device form: `_STEPS` candidates per pair of launches (ccqp_segs_feasible_steps_f64)
+            eng.segs_feasible_steps(plan, xk, p, alpha_f, self._STEPS, 16)
+            counts = yield from run.read(16, self._STEPS)
+            for c in counts:
+                if c == 0:
+                    return alpha_f
+                alpha_f *= 0.5
+                self._nhalve += 1
+            tried += self._STEPS
+            if tried > 1200:
+                raise RuntimeError("MPRGP feasibility bisection cannot terminate "
+                                   "(solvers.py:1113-1118 loops forever on this input)")
         while True:
             yf = run.lin(1.0, xk, -alpha_f, p)
             eng.count_notclose(yf, run.project(yf), 9)

@@ -225,6 +225,12 @@ int ccqp_segs_residual_sq_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_s
 int ccqp_segs_normal_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
                          const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* workspace,
                          const double* x, double* out, void* stream);
+/* MPRGP's feasible-step search (solvers.py:1112-1118) on any set, K <= CCQP_MAX_STEPS candidates in 2 launches:
+ * slab[slot0 + k] = #{i : not isclose(yf_i, P(yf)_i)}, yf = x - (alpha0 * 0.5^k) * p.  The host takes the first k whose
+ * count is 0 (the candidates are exactly the values the reference's halving loop visits). */
+int ccqp_segs_feasible_steps_f64(ccqp_ctx* ctx, const ccqp_seg* table, const ccqp_segwork* work, int64_t nwork,
+                                 const ccqp_segwork* normwork, int64_t nnorm, int64_t npartials, double* workspace,
+                                 const double* x, const double* p, double alpha0, int K, int slot0, void* stream);
 
 /* ---- a4: residual (Mazhar 2015 Eq. 25 as coded, solvers.py:138-139 etc.) --------------------
  * slab[slot] = sum_i v_i^2, v = c*(x - P(x - gd*g)) for an ELEMENTWISE kind over the block;

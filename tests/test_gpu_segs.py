@@ -253,3 +253,37 @@ def test_solvers_on_a_union_of_large_blocks_against_the_oracle(sname, eng):
     assert r.executed_matrix_vector_multiplications == o.executed_mv
     assert bool(r.solution_converged) == bool(o.solution_converged)
     assert np.linalg.norm(r.solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_feasible_step_candidates_in_two_launches_equal_one_by_one_evaluation(seed, eng):
+    """MPRGP's halving loop (solvers.py:1112-1118) on a non-elementwise set: K candidates per call of
+    ccqp_segs_feasible_steps_f64 against the reference's form -- one projection and one count per candidate."""
+    rng = np.random.default_rng(3000 + seed)
+    P, Po, n, ss = _random_union(rng, with_cone=False)
+    xh = Po(rng.normal(size=n) * 0.5)                     # a feasible point
+    ph = rng.normal(size=n) * [1e-3, 1.0, 50.0][seed % 3]
+    x, p = eng.to_device(xh), eng.to_device(ph)
+    plan = P._segplan(eng, n)
+    alpha0 = 0.7
+    K = 16
+    eng.segs_feasible_steps(plan, x, p, alpha0, K, 16)
+    got = [int(v) for v in eng.read(16, K)]
+    want, a = [], alpha0
+    for k in range(K):
+        yf = xh - a * ph
+        want.append(int(np.count_nonzero(~np.isclose(yf, Po(yf)))))
+        a *= 0.5
+    # (a Sphere block's norm differs from OpenBLAS' by ulps: an entry exactly on the isclose threshold may flip; the
+    # counts agree wherever no entry sits within 1e-12 of that threshold -- all of them, in practice)
+    assert got == want
+    # and against the device's own one-by-one path
+    a = alpha0
+    for k in range(K):
+        yf = eng.empty(n)
+        eng.axpby(1.0, x, -a, p, yf)
+        pr = torch.zeros_like(yf)
+        P._dev_project(eng, yf, pr)
+        eng.count_notclose(yf, pr, 9)
+        assert int(eng.read(9, 1)[0]) == got[k]
+        a *= 0.5

@@ -66,7 +66,7 @@ def test_errors_and_workspace_size():
     segs[0].kind, segs[0].dim = _lib.OP_BOX, -1
     assert lib.ccqp_segs_plan(segs, 1, None, 0, ctypes.byref(out[0]), None, 0, ctypes.byref(out[1]),
                               ctypes.byref(out[2])) != 0
-    assert lib.ccqp_segs_workspace_doubles(10, 20) == 3 * 10 + 20 + 8
+    assert lib.ccqp_segs_workspace_doubles(10, 20) == max(3 * 10 + 20, 16 * (10 + 20)) + 8
     assert lib.ccqp_segs_workspace_doubles(-1, 0) == -1
     with pytest.raises(_lib.CCQPHipError):
         _lib.check(1)
