@@ -55,7 +55,7 @@
                                    // local-x window keeps its distinct columns; the matvec then reads no column
                                    // index at all for the window
 #define SPMV_DIAG_MAXLEN 256       // longest row of a diagonal window (its offsets live in 1 KiB of LDS)
-#define SPMV_DIAG_MINLEN 16        // shortest: below, the generic paths are as fast or faster (measured)
+#define SPMV_DIAG_MINLEN 8         // shortest row of a diagonal window (measured: +1..2 % at 9 entries per row, -3 % at 5)
 #define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
                                    // products: 8 KB)
 #define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order: measured
@@ -178,9 +178,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int6
     // ---- "diagonal" window?  All rows of the same length L <= SPMV_DIAG_MAXLEN and, position by position, the same
     // offset col - row (banded / circulant / regular-grid matrices): keep the L offsets once; the matvec rebuilds
     // every column index as row + offset and streams 8 instead of 12 bytes per entry.
-    // (rows of SPMV_DIAG_MINLEN entries or more: measured +17 ... +24 % at 27-129 entries per row -- in transposed
-    // and in entry order alike -- but -1 ... -6 % at 9 entries per row, where the saved column stream no longer pays
-    // for the row / position arithmetic of every entry -- profiles/r02_spmv_sweep.jsonl)
+    // (rows of SPMV_DIAG_MINLEN entries or more: measured +17 ... +36 % at 17-129 entries per row -- in transposed and
+    // in entry order alike --, +1 ... +2 % at 9, -3 % at 5 entries per row, where per-row costs dominate the stream
+    // -- profiles/r02_spmv_sweep.jsonl)
     const int64_t rb = plan[SPMV_PLAN_WORDS * w + 0];
     const int64_t nr = plan[SPMV_PLAN_WORDS * w + 1] - rb;
     if (nr < 1 || E % nr != 0) return;
@@ -411,13 +411,22 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
         if (eo < E) prod[eo] = v[j] * prod[eo];
       }
     } else {
+      // entry order: slot j of thread t is entry t + 256 j; its (row, position) follows from slot j-1's by adding
+      // (256 / L, 256 % L) with one carry -- one integer division per thread instead of one per entry
       double xv[SPMV_SLOTS];
+      const int qs = CCQP_BLOCK / L, ms = CCQP_BLOCK % L;
+      int r = t / L, pos = t - r * L;
+      const int rlast = (E - 1) / L, plast = (E - 1) - rlast * L;
 #pragma unroll
       for (int j = 0; j < SPMV_SLOTS; ++j) {
-        int e = t + j * CCQP_BLOCK;
-        e = e < E ? e : E - 1;
-        const int r = e / L, pos = e - r * L;
-        xv[j] = x[rb + r + offs[pos]];
+        const bool in = t + j * CCQP_BLOCK < E;              // past the end: re-read the window's last entry
+        xv[j] = x[rb + (in ? r : rlast) + offs[in ? pos : plast]];
+        r += qs;
+        pos += ms;
+        if (pos >= L) {
+          pos -= L;
+          r += 1;
+        }
       }
 #pragma unroll
       for (int j = 0; j < SPMV_SLOTS; ++j) {

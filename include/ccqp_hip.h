@@ -516,7 +516,7 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  *         when `col` is given -- for every window whose entries reuse their columns (each distinct column
  *         1.5 times or more, at most 1024 of them) the sorted distinct columns plus a 16-bit local column
  *         per entry: such "local-x" windows load each x value once into LDS and stream 10 instead of 12
- *         bytes per entry; for the other windows, whether all rows have one length L <= 256 and, position by
+ *         bytes per entry; for the other windows, whether all rows have one length 8 <= L <= 256 and, position by
  *         position, the same offset col - row (banded / circulant / regular-grid matrices): such "diagonal"
  *         windows keep the L offsets once and the matvec reads NO column index for them (8 instead of 12 bytes per
  *         entry).  The plan takes ~2.3 + 2 bytes per stored entry.

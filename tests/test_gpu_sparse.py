@@ -127,7 +127,7 @@ def test_local_x_windows_are_used_where_columns_repeat_and_change_no_bit():
     assert H.same_bits(on.row_block(5000, 3000).dot(x).cpu().numpy(), y_on[5000:8000])
 
 
-@pytest.mark.parametrize("k", [16, 32, 100])
+@pytest.mark.parametrize("k", [8, 16, 32, 100])
 def test_diagonal_windows_are_used_for_repeated_offset_patterns_and_change_no_bit(k):
     """Windows whose rows all have one length and, position by position, one offset col - row (banded / circulant /
     regular-grid matrices without column reuse inside a window) keep their L offsets in the plan; the matvec then reads
@@ -175,7 +175,7 @@ def test_diagonal_windows_are_used_for_repeated_offset_patterns_and_change_no_bi
     ref = SparseOperator((ip, cols.reshape(-1), data.reshape(-1)), shape=(len(rws), m), diagonal_windows=False,
                          local_x=False)
     xb = rng.normal(size=m)
-    # (7 entries per row: below the 16 entries from which the diagonal form pays; not used)
+    # (7 entries per row: below the 8 entries from which the diagonal form pays; not used)
     assert band.summary[3] == 0
     wide = np.arange(-20, 21)                              # 41 entries per row: diagonal windows, one irregular row
     cw = (rws[:, None] + wide[None, :]).astype(np.int32)
