@@ -100,6 +100,46 @@ def test_solver_golden(case):
     assert s.solution_time > 0
 
 
+_LOCKSTEP_CASES = [c for c in SOLV if c["err"] is None and c["solver"] != "SPG" and not c["problem"].startswith("suite")
+                   and c["problem"] != "readme" and c["mv_band"][0] == c["mv_band"][1]]
+
+
+@pytest.mark.parametrize("case", _LOCKSTEP_CASES, ids=[c["id"] for c in _LOCKSTEP_CASES])
+def test_solver_golden_through_the_lockstep_scheduler(case):
+    """The same reference-pinned fixtures, solved by the DEVICE-RESIDENT forms (batch.solve_batch_pipelined: lock-step
+    rounds or the single-launch kernels; segmented forms for Sphere / Cone / DisjointUnion sets): a direct comparison
+    with the reference's results, not only the transitive one through solve().  A batch of three copies of the
+    problem; cases the scheduler does not take (MPRGP on non-elementwise or scalar-bounded sets, n <= 64) are skipped
+    by its own argument check."""
+    from ccqppy_amd import batch, lockstep
+    from ccqppy_amd._engine import get_engine
+    A = _device_matrix(case["problem"])
+    b = SOLV_ARR[case["problem"] + ".b"]
+    n = b.shape[0]
+    x0 = C.case_x0(case, n)
+    arrays = dict(C.SUITE_ARRAYS)
+    max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
+    cls = _solver_cls(case["solver"])
+
+    def make():
+        return cls(case["tol"], max_mv, **case["kwargs"])
+    probs = [(A, b, x0, None if case["op"] is None else C.build_op(case["op"], C.product_factory(), arrays))
+             for _ in range(3)]
+    if lockstep.why_not_pipelined([make() for _ in probs], probs, get_engine(0).device) is not None:
+        pytest.skip("not a lock-step case")
+    got = batch.solve_batch_pipelined(make, probs)
+    want = SOLV_ARR[case["id"] + ".x"]
+    nan = np.isnan(want)
+    for s in got:
+        assert s.solution_num_matrix_vector_multiplications == case["mv"]
+        assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+        assert bool(s.solution_converged) == case["converged"]
+        x = np.asarray(s.solution)
+        assert np.array_equal(np.isnan(x), nan)
+        scale = max(np.linalg.norm(want[~nan]), 1e-300)
+        assert np.linalg.norm((x - want)[~nan]) <= RTOL * scale + 1e-14
+
+
 def test_readme_example_stdout_and_types():
     from ccqppy_amd import solvers, solution_spaces as ss
     A = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]])
