@@ -494,6 +494,29 @@ def sparse_solver_cases():
     return cases
 
 
+# ------------------------------------------------------------------ BASELINE-size cases, pinned by the reference itself
+def big_solver_cases():
+    """The BASELINE configs that fit the build container (64 GiB, 8 cores) at their OWN sizes, run by the REFERENCE:
+    config 2 (n = 32768 APGD + Box), config 3's solver / set pair at n = 32768 (BBPGD + Cone, 64-matvec budget), and
+    two problems of config 5 (n = 8192 MPRGP + Box, tol 1e-6 / 300 matvecs, seeds 1234 + p).  Same record layout as
+    solver_cases(); fixtures store b, x, the scalars and the per-iteration trace (no matrices: both sides regenerate
+    them from the seed)."""
+    n2 = 32768
+    cases = [
+        dict(id="config2.APGD.box", problem="gen:%d:1234" % n2, solver="APGD", tol=1e-8, max_mv=5000, kwargs={},
+             op=_box_half(n2), rng_seed=1234),
+        dict(id="config3pair.BBPGD.cone", problem="gen:%d:1234" % n2, solver="BBPGD", tol=1e-8, max_mv=64, kwargs={},
+             op={"kind": "Cone", "dim": n2}, rng_seed=1234),
+        dict(id="config2size.SPG.boxcone", problem="gen:%d:1234" % n2, solver="SPG", tol=1e-8, max_mv=64, kwargs={},
+             op={"kind": "Disjoint", "ops": [_box_half(n2 // 2), {"kind": "Cone", "dim": n2 - n2 // 2}]},
+             rng_seed=1234),
+    ]
+    for p in (0, 1):
+        cases.append(dict(id="config5.MPRGP.box.p%d" % p, problem="gen:8192:%d" % (1234 + p), solver="MPRGP", tol=1e-6,
+                          max_mv=300, kwargs={}, op=_box_half(8192), rng_seed=1234))
+    return cases
+
+
 # ------------------------------------------------------------------ matrix-free (composed) operator cases
 def contact_solver_cases():
     """Problems 'contact:<m>:<n>:<seed>': A = D diag(minv) D^T + eps I handed to the reference as an object

@@ -162,12 +162,13 @@ def get_problem(pid):
     return A, b
 
 
-def gen_solvers(sparse=False, contact=False):
+def gen_solvers(sparse=False, contact=False, big=False):
     """sparse=False: the dense cases -> solvers.npz; sparse=True: the reference run with A =
     scipy.sparse.csr_matrix (it only calls `A.dot`) -> sparse.npz, which also holds the CSR arrays of the
     irregular matrices and of one small generated matrix (known-answer vectors for the product generator)."""
-    cases = C.contact_solver_cases() if contact else C.sparse_solver_cases() if sparse else C.solver_cases()
-    stem = "contact" if contact else "sparse" if sparse else "solvers"
+    cases = C.big_solver_cases() if big else C.contact_solver_cases() if contact else \
+        C.sparse_solver_cases() if sparse else C.solver_cases()
+    stem = "big" if big else "contact" if contact else "sparse" if sparse else "solvers"
     sparse = sparse or contact                   # both: A is not a dense array (no entrywise perturbation of A)
     ofac = C.oracle_factory()
     arrays = dict(C.SUITE_ARRAYS)
@@ -247,7 +248,7 @@ def gen_solvers(sparse=False, contact=False):
             # recorded and the GPU test checks against those instead.
             rng = np.random.default_rng(zlib.crc32(c["id"].encode()))
             mvs, spread = [entry["mv"]], 0.0
-            for _ in range(8):
+            for _ in range(2 if big else 8):          # (BASELINE-size cases: two probes, each is a full-size solve)
                 bp = np.asarray(b, dtype=np.float64) * (1 + rng.integers(-1, 2, size=n) * 2.0 ** -52)
                 Ap = A
                 if n <= 64 and not sparse:
@@ -297,7 +298,8 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     only = sys.argv[1:]          # e.g. `gen_golden.py sparse` regenerates just that fixture set
     steps = {"generator": gen_generator, "ops": gen_ops, "pg": gen_pg, "solvers": gen_solvers,
-             "sparse": lambda: gen_solvers(sparse=True), "contact": lambda: gen_solvers(contact=True)}
+             "sparse": lambda: gen_solvers(sparse=True), "contact": lambda: gen_solvers(contact=True),
+             "big": lambda: gen_solvers(big=True)}
     for name, fn in steps.items():
         if not only or name in only:
             fn()

@@ -18,9 +18,13 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import cases as C
 from oracle import cpu_ref
+from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
+
+BIG, BIG_ARR = H.load_big()
 
 
 class _RowSlabs:
@@ -156,4 +160,34 @@ def test_config5_n8192_mprgp_box_batch_through_sharded_entry():
     xg = got[0].solution.cpu().numpy()
     assert np.linalg.norm(xg - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
     built.clear()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", BIG, ids=[c["id"] for c in BIG])
+def test_baseline_sizes_against_the_reference_itself(case):
+    """BASELINE config 2 (n = 32768 APGD + Box), config 3's solver / set pair and an SPG + DisjointUnion(Box, Cone) solve
+    at n = 32768, two problems of config 5 (n = 8192 MPRGP + Box): the fixtures hold what the REFERENCE produced on
+    these very problems (oracle/gen_golden.py big; the matrix is regenerated from its seed on both sides, b comes from
+    the fixture).  Bar: identical reported and executed MV counts and converged flag, x within 1e-10 relative, the
+    steering scalars of the first 32 iterations."""
+    from ccqppy_amd import problems, solvers
+    _, n, seed = case["problem"].split(":")
+    n, seed = int(n), int(seed)
+    torch.cuda.empty_cache()
+    A = problems.spd_rows(n, seed)
+    b = BIG_ARR[case["problem"] + ".b"]
+    P = C.build_op(case["op"], C.product_factory(), dict(C.SUITE_ARRAYS))
+    np.random.seed(case["rng_seed"])
+    s = getattr(solvers, "CCQPSolver" + case["solver"])(case["tol"], case["max_mv"], **case["kwargs"])
+    s.trace = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        s.solve(A, b, convex_proj_op=P)
+    assert case["err"] is None and case["mv_band"][0] == case["mv_band"][1]
+    assert s.solution_num_matrix_vector_multiplications == case["mv"]
+    assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+    assert bool(s.solution_converged) == case["converged"]
+    want = BIG_ARR[case["id"] + ".x"]
+    assert np.linalg.norm(s.solution - want) <= 1e-10 * np.linalg.norm(want)
+    H.check_trace(case, s, BIG_ARR, n)
+    del A
     torch.cuda.empty_cache()
