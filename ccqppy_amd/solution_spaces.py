@@ -237,7 +237,10 @@ class ProjOpBase(ABC):
         return self._kind is not None
 
     def _dev_normal_vector(self, eng, x, out):
-        if all(op._normal_on_device() for op, _ in self._leaves()):
+        ok = self.__dict__.get("_normal_dev")             # (cached: a union may hold thousands of blocks)
+        if ok is None:
+            ok = self.__dict__["_normal_dev"] = all(op._normal_on_device() for op, _ in self._leaves())
+        if ok:
             plan = self._segplan(eng, x.numel())
             if plan is not None:
                 eng.segs_normal(plan, x, out)
@@ -324,7 +327,7 @@ class _ElementwiseOp(ProjOpBase):
             if self._unchanged(lb, s2) and self._unchanged(ub, s3):
                 return False
         self.__dict__["_bounds_state"] = (lb, ub, self._snapshot(lb), self._snapshot(ub))
-        for k in ("_seg_cache", "_dev_bounds", "_single_tables", "_segplans"):
+        for k in ("_seg_cache", "_dev_bounds", "_single_tables", "_segplans", "_normal_dev"):
             self.__dict__.pop(k, None)
         if st is not None:
             self._version = self._version + 1
@@ -727,7 +730,7 @@ class DisjointProjOp(ProjOpBase):
         changed = structural or (st is not None and st[1] != vers)
         self.__dict__["_ops_state"] = (ops, vers, uniq)
         if changed:
-            for k in ("_plans", "_segplans", "_devform"):
+            for k in ("_plans", "_segplans", "_devform", "_normal_dev"):
                 self.__dict__.pop(k, None)
             self._version = self._version + 1
         return changed
