@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--size", dest="n", type=int, default=262144)
     ap.add_argument("--max-mv", type=int, default=64)
     ap.add_argument("--bw1-gbs", type=float, default=6900.0)
-    ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce"])
+    ap.add_argument("--exchange", dest="mode", default="allgather", choices=["allgather", "allreduce", "direct"])
     ap.add_argument("--repeats", type=int, default=2)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
