@@ -18,6 +18,10 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+# seeds of the randomised union tests: 12 / 8 / 6 in the suite; CCQP_SEGS_FUZZ_CASES=N for a one-off soak
+import os  # noqa: E402
+_SOAK = int(os.environ.get("CCQP_SEGS_FUZZ_CASES", "0"))
+
 
 @pytest.fixture(scope="module")
 def eng():
@@ -111,7 +115,7 @@ def _random_union(rng, with_cone=True, arrays_only=False):
     return C.build_op(spec, fac, arrays), C.build_op(spec, ofac, arrays), C.spec_dim(spec), ss
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(_SOAK or 12))
 def test_random_unions_bitwise_equal_to_the_per_block_kernels(seed, eng):
     rng = np.random.default_rng(1000 + seed)
     P, Po, n, ss = _random_union(rng)
@@ -156,7 +160,7 @@ def test_random_unions_bitwise_equal_to_the_per_block_kernels(seed, eng):
     assert float(eng.read(6, 1)[0]) == got_r2
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_SOAK or 8))
 def test_random_unions_normal_vector_bitwise_equal_to_the_per_block_kernels(seed, eng):
     rng = np.random.default_rng(2000 + seed)
     P, Po, n, ss = _random_union(rng, with_cone=False, arrays_only=True)
@@ -255,7 +259,7 @@ def test_solvers_on_a_union_of_large_blocks_against_the_oracle(sname, eng):
     assert np.linalg.norm(r.solution - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(_SOAK or 6))
 def test_feasible_step_candidates_in_two_launches_equal_one_by_one_evaluation(seed, eng):
     """MPRGP's halving loop (solvers.py:1112-1118) on a non-elementwise set: K candidates per call of
     ccqp_segs_feasible_steps_f64 against the reference's form -- one projection and one count per candidate."""
