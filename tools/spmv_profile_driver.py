@@ -1,5 +1,6 @@
-"""Driver for rocprofv3 runs of the CSR matvec: `python3 tools/spmv_profile_driver.py n k width [scramble|stencil]`
-(k = 26 with `stencil`: 27-point-stencil pattern, local-x windows)."""
+"""Driver for rocprofv3 runs of the CSR matvec: `python3 tools/spmv_profile_driver.py n k width [scramble|stencil|nodiag]`
+(k = 26 with `stencil`: 27-point-stencil pattern, local-x windows; `nodiag`: the circulant pattern with the diagonal
+windows switched off -- the generic paths of the same plan)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,10 +19,13 @@ if len(sys.argv) > 4 and sys.argv[4] == "stencil":
     i = torch.arange(n, device=col.device, dtype=torch.int64)[:, None]
     d = torch.tensor(offs, device=col.device, dtype=torch.int64)[None, :]
     col = torch.sort(torch.remainder(i + d, n), dim=1).values.reshape(-1).to(torch.int32)
+elif len(sys.argv) > 4 and sys.argv[4] == "nodiag":
+    pass
 elif len(sys.argv) > 4:
     perm = torch.randperm(n, device=col.device, dtype=torch.int64)
     col = perm[col.long()].to(torch.int32)
-op = SparseOperator((rowptr, col, val), shape=(n, n), width=width, check=False)
+op = SparseOperator((rowptr, col, val), shape=(n, n), width=width, check=False,
+                    diagonal_windows=not (len(sys.argv) > 4 and sys.argv[4] == "nodiag"))
 x = problems.xstar(n, 1, eng.device)
 y = eng.empty(n)
 for _ in range(6):
