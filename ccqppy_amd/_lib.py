@@ -86,6 +86,24 @@ class PMprgp(ctypes.Structure):
                 ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
 
 
+class PSpg(ctypes.Structure):
+    """struct ccqp_pspg (include/ccqp_hip.h): one problem of a lock-step SPG run (device side)."""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("b", ctypes.c_void_p),
+                ("x", ctypes.c_void_p), ("g", ctypes.c_void_p), ("d", ctypes.c_void_p), ("Ad", ctypes.c_void_p),
+                ("seg", Seg), ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p)]
+
+
+class SpgHost(ctypes.Structure):
+    """struct ccqp_spg_host (include/ccqp_hip.h): host-side state of one problem of a lock-step SPG run."""
+    _fields_ = [("tol", ctypes.c_double), ("max_mv", ctypes.c_double), ("tau", ctypes.c_double),
+                ("sigma1", ctypes.c_double), ("sigma2", ctypes.c_double),
+                ("alpha", ctypes.c_double), ("betak", ctypes.c_double), ("fk", ctypes.c_double),
+                ("dd", ctypes.c_double),
+                ("mv", ctypes.c_int64), ("used", ctypes.c_int64), ("reserved_", ctypes.c_int64),
+                ("m", ctypes.c_int32), ("qlen", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("pending", ctypes.c_int32), ("have_dd", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 (BOP_GEMV, BOP_AXPBY, BOP_SCALE, BOP_COPY, BOP_FILL, BOP_DOTS, BOP_PROJ_ELEM, BOP_RESIDUAL_ELEM,
  BOP_FEASIBLE_ELEM, BOP_MPRGP_SPLIT, BOP_MPRGP_NORMAL_DOT, BOP_MPRGP_PROPORTION, BOP_FREE_GRADIENT_ELEM,
  BOP_CG_DIRECTION) = range(1, 15)
@@ -155,6 +173,9 @@ SIGNATURES = {
     "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
+    "ccqp_bspg_host_step": [_P, _P, _I64, _P, _P, _P, _P, _I],
+    "ccqp_bspg_run_f64": [_P, _P, _P, _P, _P, _I64, _P, _I, _I64, _I64, _I64, _I, _I, _I64, _P, _P, _P,
+                          _c.POINTER(_I), _P],
     "ccqp_bsegs_start_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _D, _I, _P, _P],
     "ccqp_bsegs_apgd_round_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _I, _P, _P],
     "ccqp_bsegs_iterate_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _D, _I, _I, _P, _P],

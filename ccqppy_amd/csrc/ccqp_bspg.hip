@@ -1,0 +1,427 @@
+// Lock-step SPG-QP (solvers.py:878-975) for many dense problems of one size, with the host in the loop ONCE per
+// iteration of the whole batch (opt-in: ccqppy_amd.batch.solve_batch_pipelined picks it for CCQPSolverSPG solvers that
+// carry their own np.random.RandomState).
+//
+// Why the host stays in the loop: the step length of SPG-QP is `np.random.uniform(sigma1, min(betahat, sigma2))` with
+// betahat = tau*beta + sqrt(tau**2 * beta**2 + 2*xi) -- a draw of numpy's legacy Mersenne twister and two calls of
+// libm's pow(), neither of which a kernel can reproduce bit for bit (pow(x, 2) != x*x for ~1 argument in 1200, and
+// glibc's pow is a table-driven routine of that particular libm).  What the device CAN do is all the vector work of
+// all problems at once.  One round =
+//   ctl     the host's control words (alpha, betak, mode per problem) from pinned memory into device memory
+//   step    x += betak d, g += betak Ad of the PREVIOUS iteration (:961-962), then d = P(x - alpha g) - x (:937)
+//           [segmented sets: update, norm, apply -- the projection goes through ccqp_segs.h]
+//   matvec  Ad = A d                                                       (the batched matvec of ccqp_bpipe.hip)
+//   dots    d.d, d.Ad, d.g per problem (:944-946); the last block of the last problem copies all of them to pinned
+//           host memory and raises the round's sequence number
+// and then the host, in C, problem after problem: exit test, fmax, xi, beta, betahat, the draw, fk, the queue, alpha
+// (:949-966) -- ~20 ns per problem instead of ~20 us of Python per problem and scalar read (the host-driven batch
+// scheduler's 2.7 k problems/s).  Reference: the Python loop of CCQPSolverSPG.solve as the ensemble benchmark runs it
+// (benchmarks/benchmark_random_ccqp.py:67-102).
+// Bits: the bodies are those of the single-problem kernels (axpby_body's and proj_elem_sub_kernel's expressions,
+// gemv_task, dot_body with the reduction geometry of ccqp_dots_f64), the host arithmetic is the Python loop's,
+// operation for operation, on the same libm: every problem gets exactly its own CCQPSolverSPG.solve().
+#include <math.h>
+
+#include "ccqp_lockstep.h"
+#include "ccqp_segs.h"
+
+static_assert(sizeof(ccqp_pspg) == 128 && sizeof(ccqp_spg_host) == 120, "descriptor layout changed: update _lib.py");
+
+#define SPG_ALPHA 0
+#define SPG_BETAK 1
+#define SPG_MODE 2      // 0 skip | 1 update (if due) + direction + matvec + dots | 2 update only (the budget's last round)
+#define SPG_UPDATE 3
+
+// ------------------------------------------------------------------------------------------------- host arithmetic
+// libm's pow through a pointer the compiler cannot see through: clang folds pow(x, 2.0) into x*x, which is NOT what
+// Python's and numpy's scalar `**` compute
+static double (*volatile spg_pow)(double, double) = pow;
+
+// Python's max() over the queue (oldest first): the first element unless a later one compares greater
+static inline double spg_queue_max(const double* q, int len) {
+  double m = q[0];
+  for (int i = 1; i < len; ++i)
+    if (q[i] > m) m = q[i];
+  return m;
+}
+
+static inline void spg_queue_append(ccqp_spg_host* h, double* q, double v) {   // deque(maxlen=m).append
+  if (h->qlen == h->m) {
+    for (int i = 1; i < h->m; ++i) q[i - 1] = q[i];
+    h->qlen -= 1;
+  }
+  q[h->qlen++] = v;
+}
+
+// solvers.py:949-966 for one problem (its matvec of this iteration is already counted)
+// (the draw: from `src` at the moment the loop would take it, else the given u)
+static void spg_host_step(ccqp_spg_host* h, double* q, double dd, double dAd, double dg, const ccqp_draw_source* src,
+                          double u) {
+  h->dd = dd;
+  h->have_dd = 1;
+  h->pending = 0;
+  if (sqrt(dd) <= h->tol) {                             // :949
+    h->status = 1;
+    return;
+  }
+  const double fmax = spg_queue_max(q, h->qlen);         // :953
+  const double xi = (fmax - h->fk) / dAd;                // :954
+  const double beta = (-dg) / dAd;                       // :955
+  const double t2 = spg_pow(h->tau, 2.0);                // :958  tau ** 2
+  const double b2 = spg_pow(beta, 2.0);                  //       beta ** 2
+  const double prod = t2 * b2;
+  const double twoxi = 2.0 * xi;
+  const double arg = prod + twoxi;
+  const double tb = h->tau * beta;
+  const double betahat = tb + sqrt(arg);
+  const double high = h->sigma2 < betahat ? h->sigma2 : betahat;   // Python's min(betahat, sig2): NaN stays
+  const double range = high - h->sigma1;                 // RandomState.uniform: fscale = high - low ...
+  if (!isfinite(range)) {                                // ... OverflowError('Range exceeds valid bounds')
+    h->status = 3;
+    return;
+  }
+  if (src) u = src->next_double(src->state);
+  const double ru = range * u;                           // random_uniform: low + range * next_double
+  const double betak = h->sigma1 + ru;
+  h->used += 1;
+  const double bb = betak * betak;                       // :963 (sic)  betak * betak * dg + 0.5 * (betak ** 2) * dAd
+  const double t3 = bb * dg;
+  const double hp = 0.5 * spg_pow(betak, 2.0);
+  const double t4 = hp * dAd;
+  const double inc = t3 + t4;
+  h->fk = h->fk + inc;
+  spg_queue_append(h, q, h->fk);                         // :964
+  h->alpha = dd / dAd;                                   // :966
+  h->betak = betak;
+  h->pending = 1;                                        // :961-962 are applied by the next round's step kernel
+}
+
+extern "C" int ccqp_bspg_host_step(ccqp_spg_host* host, double* queue, int64_t qstride, const double* dots,
+                                   const ccqp_draw_source* const* sources, const double* u,
+                                   const unsigned char* live, int count) {
+  CCQP_REQUIRE(host && queue && dots && (u || sources) && count >= 0, "NULL argument");
+  for (int p = 0; p < count; ++p) {
+    if (live && !live[p]) continue;
+    CCQP_REQUIRE(host[p].m >= 1 && host[p].m <= qstride && host[p].qlen >= 1 && host[p].qlen <= host[p].m,
+                 "bad queue geometry");
+    CCQP_REQUIRE(!sources || (sources[p] && sources[p]->next_double), "NULL draw source");
+    spg_host_step(host + p, queue + (int64_t)p * qstride, dots[3 * p], dots[3 * p + 1], dots[3 * p + 2],
+                  sources ? sources[p] : nullptr, u ? u[p] : 0.0);
+  }
+  return CCQP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------- kernels
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_ctl_kernel(const double* __restrict__ host_ctl,
+                                                              double* __restrict__ ctl, int n4) {
+  const int i = blockIdx.x * CCQP_BLOCK + threadIdx.x;
+  if (i < n4) ctl[i] = host_ctl[i];
+}
+
+// grid (blocks, problems).  DIRECTION: also d = P(x - alpha g) - x for an elementwise set
+template <bool DIRECTION>
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_step_kernel(const ccqp_pspg* __restrict__ probs,
+                                                               const double* __restrict__ ctl, int64_t n) {
+  const double* c = ctl + 4 * blockIdx.y;
+  const int mode = (int)c[SPG_MODE];
+  if (mode == 0) return;
+  const bool upd = c[SPG_UPDATE] != 0.0;
+  const bool dir = DIRECTION && mode == 1;
+  if (!upd && !dir) return;
+  const ccqp_pspg& q = probs[blockIdx.y];
+  const double betak = c[SPG_BETAK];
+  const double ma = -c[SPG_ALPHA];
+  const ccqp_segk sg = bp_segk_of(q);
+  double* x = q.x;
+  double* g = q.g;
+  double* d = q.d;
+  const double* Ad = q.Ad;
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  BODY_LOOP(i, n) {                   // (n, not sg.dim: a segmented run leaves `seg` empty)
+    double xi = x[i], gi = g[i];
+    if (upd) {                        // ccqp_axpby2_f64(1, x, betak, d, x, 1, g, betak, Ad, g)
+      const double t1 = 1.0 * xi;
+      const double t2 = betak * d[i];
+      xi = t1 + t2;
+      const double t3 = 1.0 * gi;
+      const double t4 = betak * Ad[i];
+      gi = t3 + t4;
+      x[i] = xi;
+      g[i] = gi;
+    }
+    if (dir) {                        // ccqp_proj_elementwise_sub_f64(seg, 1, x, -alpha, g, x, d)
+      const double t1 = 1.0 * xi;
+      const double t2 = ma * gi;
+      const double u = t1 + t2;
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      const double p = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+      d[i] = p - xi;
+    }
+  }
+}
+
+// segmented sets: chunk sums of |x - alpha g|^2 for the Sphere / Cone blocks.  grid (max nnorm, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_norm_kernel(const ccqp_pspg* __restrict__ probs,
+                                                               const ccqp_psegs* __restrict__ segs,
+                                                               const double* __restrict__ ctl) {
+  __shared__ double lds4[4];
+  const double* c = ctl + 4 * blockIdx.y;
+  if ((int)c[SPG_MODE] != 1) return;
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nnorm) return;
+  const ccqp_pspg& q = probs[blockIdx.y];
+  const ccqp_segwork w = ps.normwork[blockIdx.x];
+  const double s = segs_norm_item(ps.table, w, 1.0, q.x, -c[SPG_ALPHA], q.g, lds4);
+  if (threadIdx.x == 0) ps.workspace[w.pbase + w.chunk] = s;
+}
+
+// segmented sets: d = P(x - alpha g) - x.  grid (max nwork, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_apply_kernel(const ccqp_pspg* __restrict__ probs,
+                                                                const ccqp_psegs* __restrict__ segs,
+                                                                const double* __restrict__ ctl) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const double* c = ctl + 4 * blockIdx.y;
+  if ((int)c[SPG_MODE] != 1) return;
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nwork) return;
+  const ccqp_pspg& q = probs[blockIdx.y];
+  const ccqp_segwork w = ps.work[blockIdx.x];
+  (void)segs_apply_item<0>(ps.table, w, ps.workspace, 1.0, q.x, -c[SPG_ALPHA], q.g, q.x, q.d, 0.0, lds4, &bcast);
+}
+
+// grid (blocks, problems).  which 0: Ad = A x, g = Ad + b (start-up);  1: Ad = A g (start-up);  2: Ad = A d
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_gemv_kernel(const ccqp_pspg* __restrict__ probs,
+                                                               const double* __restrict__ ctl, int which, int64_t n) {
+  if ((int)ctl[4 * blockIdx.y + SPG_MODE] != 1) return;
+  const ccqp_pspg& q = probs[blockIdx.y];
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  if (which == 0)
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.x, q.b, q.Ad, q.g, n, n, BP_TASKS(U, n), wave, nwaves);
+  else
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, which == 1 ? q.g : q.d, nullptr, q.Ad, nullptr, n, n,
+                                             BP_TASKS(U, n), wave, nwaves);
+}
+
+// grid (nblk, problems) -- the geometry of ccqp_dots_f64 on n-vectors.  start: {g.x, g.g, g.Ad} (:923-924), else
+// {d.d, d.Ad, d.g} (:944-946).  `nlive` problems take part; the last of them to finish publishes every problem's
+// four words to pinned host memory and then the sequence number.
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_dots_kernel(const ccqp_pspg* __restrict__ probs,
+                                                               const double* __restrict__ ctl,
+                                                               double* __restrict__ out, double* __restrict__ host_out,
+                                                               int start, int64_t n, int64_t chunk, int nblk,
+                                                               unsigned* __restrict__ batch, double* __restrict__ host,
+                                                               unsigned nlive, int count, double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  __shared__ int publish;
+  if ((int)ctl[4 * blockIdx.y + SPG_MODE] != 1) return;
+  const ccqp_pspg& q = probs[blockIdx.y];
+  double v[3];
+  if (start) {
+    v[0] = dot_body(q.g, q.x, n, chunk, blockIdx.x, lds4);
+    v[1] = dot_body(q.g, q.g, n, chunk, blockIdx.x, lds4);
+    v[2] = dot_body(q.g, q.Ad, n, chunk, blockIdx.x, lds4);
+  } else {
+    v[0] = dot_body(q.d, q.d, n, chunk, blockIdx.x, lds4);
+    v[1] = dot_body(q.d, q.Ad, n, chunk, blockIdx.x, lds4);
+    v[2] = dot_body(q.d, q.g, n, chunk, blockIdx.x, lds4);
+  }
+  if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, &is_last)) return;
+  // the problem's last block; the batch-wide roll-call decides which block copies the results out
+  if (threadIdx.x == 0) {
+    double* o = out + 4 * blockIdx.y;
+    o[0] = v[0];
+    o[1] = v[1];
+    o[2] = v[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(batch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish = prev + 1u == nlive;
+    if (publish) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(batch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!publish) return;
+  for (int i = threadIdx.x; i < 4 * count; i += CCQP_BLOCK) host_out[i] = out[i];
+  // this block's stores have reached host memory before the flag does (as publish_slots_kernel, ccqp_ctx.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host + BP_MIRROR + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// --------------------------------------------------------------------------------------------------------- driver
+static int bspg_exchange(ccqp_ctx* ctx, size_t doubles) {
+  if (ctx->xchg_doubles >= doubles) return CCQP_OK;
+  if (ctx->xchg_host) {
+    CCQP_HIP(hipHostFree(ctx->xchg_host));
+    ctx->xchg_host = nullptr;
+    ctx->xchg_doubles = 0;
+  }
+  CCQP_HIP(hipHostMalloc(&ctx->xchg_host, doubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  CCQP_HIP(hipHostGetDevicePointer((void**)&ctx->xchg_host_dev, ctx->xchg_host, 0));
+  ctx->xchg_doubles = doubles;
+  return CCQP_OK;
+}
+
+static int bspg_wait(ccqp_ctx* ctx, double seq, hipStream_t s) {
+  volatile double* flag = ctx->host_slots + BP_MIRROR + 1;
+  for (int spin = 0; spin < 4000000; ++spin) {
+    if (*flag == seq) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return CCQP_OK;
+    }
+    __builtin_ia32_pause();
+  }
+  CCQP_HIP(hipStreamSynchronize(s));                    // mirror silent for a long time: wait for the queue itself
+  CCQP_REQUIRE(*flag == seq, "the device never reported the round");
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return CCQP_OK;
+}
+
+static void bspg_gemv(const ccqp_pspg* probs, const double* ctl, int count, int64_t n, int which, int flags,
+                      hipStream_t s) {
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bspg_gemv_kernel, probs, ctl, which, n);
+}
+
+extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, const ccqp_psegs* dev_segs,
+                                 ccqp_spg_host* host, double* queue, int64_t qstride,
+                                 const ccqp_draw_source* const* sources, int count, int64_t n, int64_t max_nwork,
+                                 int64_t max_nnorm, int flags, int start, int64_t max_rounds, double* dev_ctl,
+                                 double* dev_out, uint32_t* dev_batch, int* more, void* stream) {
+  BP_CHECK_BATCH();
+  CCQP_REQUIRE(host && queue && sources && dev_ctl && dev_out && more, "NULL argument");
+  for (int p = 0; p < count; ++p)
+    CCQP_REQUIRE(sources[p] && sources[p]->next_double, "NULL draw source");
+  CCQP_REQUIRE(dev_segs == nullptr || (max_nwork >= 1 && max_nwork <= 65535 && max_nnorm >= 0 && max_nnorm <= 65535),
+               "bad work-list sizes");
+  for (int p = 0; p < count; ++p)
+    CCQP_REQUIRE(host[p].m >= 1 && host[p].m <= qstride, "queue capacity m outside [1, qstride]");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = bspg_exchange(ctx, (size_t)8 * count);
+  if (rc) return rc;
+  double* hctl = ctx->xchg_host;                         // pinned: control words out, dot products in
+  double* hout = ctx->xchg_host + (size_t)4 * count;
+  double* hctl_dev = ctx->xchg_host_dev;
+  double* hout_dev = ctx->xchg_host_dev + (size_t)4 * count;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const dim3 blk(CCQP_BLOCK);
+  const dim3 vgrid(bp_vec_grid(n), count);
+  const int cgrid = (4 * count + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  ccqp_lockstep_begin(ctx, dev_batch, s);
+  double seq = 0.0;
+  *more = 0;
+
+  if (start) {
+    for (int p = 0; p < count; ++p) {
+      double* c = hctl + 4 * p;
+      c[SPG_ALPHA] = 0.0;
+      c[SPG_BETAK] = 0.0;
+      c[SPG_MODE] = host[p].status == 0 ? 1.0 : 0.0;
+      c[SPG_UPDATE] = 0.0;
+    }
+    unsigned nlive = 0;
+    for (int p = 0; p < count; ++p) nlive += host[p].status == 0;
+    if (nlive) {
+      seq += 1.0;
+      hipLaunchKernelGGL(bspg_ctl_kernel, dim3(cgrid), blk, 0, s, hctl_dev, dev_ctl, 4 * count);
+      bspg_gemv(dev_probs, dev_ctl, count, n, 0, flags, s);
+      bspg_gemv(dev_probs, dev_ctl, count, n, 1, flags, s);
+      hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, count), blk, 0, s, dev_probs, dev_ctl, dev_out, hout_dev, 1, n,
+                         chunk, nblk, dev_batch, ctx->host_slots_dev, nlive, count, seq);
+      CCQP_LAUNCH_CHECK();
+      rc = bspg_wait(ctx, seq, s);
+      if (rc) return rc;
+      for (int p = 0; p < count; ++p) {
+        ccqp_spg_host* h = host + p;
+        if (h->status != 0) continue;
+        const double* o = hout + 4 * p;
+        h->fk = o[0];                                    // sic: g.x, :923
+        h->alpha = o[1] / o[2];                          // :924
+        h->mv = 2;
+        h->used = 0;
+        h->pending = 0;
+        h->have_dd = 0;
+        h->qlen = 1;
+        queue[(int64_t)p * qstride] = h->fk;
+      }
+    }
+  }
+
+  for (int64_t round = 0;; ++round) {
+    bool any = false;
+    for (int p = 0; p < count; ++p) any = any || host[p].status == 0;
+    if (!any) break;
+    if (round >= max_rounds) {
+      *more = 1;
+      break;
+    }
+    unsigned nlive = 0;
+    for (int p = 0; p < count; ++p) {
+      ccqp_spg_host* h = host + p;
+      double* c = hctl + 4 * p;
+      c[SPG_ALPHA] = h->alpha;
+      c[SPG_BETAK] = h->betak;
+      c[SPG_UPDATE] = h->pending ? 1.0 : 0.0;
+      if (h->status != 0) {
+        c[SPG_MODE] = 0.0;
+      } else if ((double)(h->mv + 1) >= h->max_mv) {     // :938-941: the matvec that ends the budget (counted; its
+        h->mv += 1;                                      // result is never used, so it is not executed here)
+        h->status = h->have_dd ? 2 : 3;                  // (no d.d yet: the reference dies with UnboundLocalError)
+        h->pending = 0;
+        c[SPG_MODE] = 2.0;
+      } else {
+        h->mv += 1;
+        c[SPG_MODE] = 1.0;
+        nlive += 1;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    hipLaunchKernelGGL(bspg_ctl_kernel, dim3(cgrid), blk, 0, s, hctl_dev, dev_ctl, 4 * count);
+    if (dev_segs) {
+      hipLaunchKernelGGL(bspg_step_kernel<false>, vgrid, blk, 0, s, dev_probs, dev_ctl, n);
+      if (nlive) {
+        if (max_nnorm > 0)
+          hipLaunchKernelGGL(bspg_norm_kernel, dim3((unsigned)max_nnorm, count), blk, 0, s, dev_probs, dev_segs, dev_ctl);
+        hipLaunchKernelGGL(bspg_apply_kernel, dim3((unsigned)max_nwork, count), blk, 0, s, dev_probs, dev_segs, dev_ctl);
+      }
+    } else {
+      hipLaunchKernelGGL(bspg_step_kernel<true>, vgrid, blk, 0, s, dev_probs, dev_ctl, n);
+    }
+    if (!nlive) {
+      // only final updates this round: nothing to wait for, but the control words must not be overwritten while
+      // the copy kernel may still be reading them
+      CCQP_LAUNCH_CHECK();
+      CCQP_HIP(hipStreamSynchronize(s));
+      continue;
+    }
+    seq += 1.0;
+    bspg_gemv(dev_probs, dev_ctl, count, n, 2, flags, s);
+    hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, count), blk, 0, s, dev_probs, dev_ctl, dev_out, hout_dev, 0, n,
+                       chunk, nblk, dev_batch, ctx->host_slots_dev, nlive, count, seq);
+    CCQP_LAUNCH_CHECK();
+    rc = bspg_wait(ctx, seq, s);
+    if (rc) return rc;
+    for (int p = 0; p < count; ++p) {
+      if (hctl[4 * p + SPG_MODE] != 1.0) continue;
+      const double* o = hout + 4 * p;
+      spg_host_step(host + p, queue + (int64_t)p * qstride, o[0], o[1], o[2], sources[p], 0.0);
+    }
+  }
+  // the pending updates of problems that stopped (status 1: none by construction; 2: applied in their last round)
+  // are done; x of every finished problem is final once the stream has drained
+  CCQP_HIP(hipStreamSynchronize(s));
+  return CCQP_OK;
+}

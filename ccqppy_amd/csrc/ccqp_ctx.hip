@@ -62,6 +62,9 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->mv_ev_out = nullptr;
   c->gather_dev = nullptr;
   c->gather_host = nullptr;
+  c->xchg_host = nullptr;
+  c->xchg_host_dev = nullptr;
+  c->xchg_doubles = 0;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&c->partials, CCQP_PARTIALS_DOUBLES * sizeof(double));
   if (e == hipSuccess) e = hipMemset(c->partials, 0, CCQP_PARTIALS_DOUBLES * sizeof(double));
@@ -97,6 +100,7 @@ extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
   if (c->mv_ev_out) (void)hipEventDestroy(c->mv_ev_out);
   if (c->gather_dev) (void)hipFree(c->gather_dev);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
+  if (c->xchg_host) (void)hipHostFree(c->xchg_host);
   delete c;
   return CCQP_OK;
 }

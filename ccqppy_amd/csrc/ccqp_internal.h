@@ -32,6 +32,9 @@ struct ccqp_ctx {
   double* host_slots_dev;       // the same memory as the device sees it
   unsigned long long read_seq;  // sequence number of the last published read
   hipEvent_t read_event;  // marks the end of the last ccqp_scalars_read_async copy
+  double* xchg_host;      // pinned, coherent exchange area of the host-in-the-loop lock-step driver (ccqp_bspg.hip),
+  double* xchg_host_dev;  // grown on demand; the same memory as the device sees it
+  size_t xchg_doubles;
 };
 
 void ccqp_set_error(const char* fmt, ...);

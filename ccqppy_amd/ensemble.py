@@ -30,13 +30,17 @@ class BenchmarkRandomCCQP:
     """Benchmark each solver using an ensemble of randomly generated CCQPs."""
 
     def __init__(self, num_random_trials, solvers_to_benchmark, convex_proj_ops_to_benchmark, lanes=1,
-                 device=None, lockstep=True):
+                 device=None, lockstep=True, spg_seed=None):
         self.num_trials = num_random_trials
         self.solvers_to_benchmark = solvers_to_benchmark
         self.convex_proj_ops_to_benchmark = convex_proj_ops_to_benchmark
         self.lanes = lanes
         self.device = device
         self.lockstep = lockstep
+        # SPG draws from numpy's global stream (the reference's harness never seeds it, so its SPG cells differ from
+        # run to run).  spg_seed = an integer: trial t of every SPG cell draws from its own RandomState(spg_seed + t)
+        # instead -- reproducible under every scheduler, and what lets the SPG cells run in lock-step
+        self.spg_seed = spg_seed
         self.problem_sizes = np.zeros(len(convex_proj_ops_to_benchmark[0]), dtype=int)
         for i, proj_op in enumerate(self.convex_proj_ops_to_benchmark[0]):
             self.problem_sizes[i] = proj_op.embedded_dimension
@@ -51,6 +55,14 @@ class BenchmarkRandomCCQP:
         """(A, b) on the device: A = counter-hashed SPD matrix (kappa ~ 3.7), b = -A x*, x* = 1 - 2u."""
         op, b, _ = _problems.random_problem(int(problem_size), int(seed), device=self.device)
         return op, b
+
+    def _copies(self, solver, count):
+        """One solver object per trial (the reference reuses one: results are read before the next solve)."""
+        made = [copy.copy(solver) for _ in range(count)]
+        if self.spg_seed is not None and hasattr(solver, "rng") and solver.rng is None:
+            for t, s in enumerate(made):
+                s.rng = np.random.RandomState(self.spg_seed + t)
+        return made
 
     def run(self):
         shape = [len(self.solvers_to_benchmark), len(self.convex_proj_ops_to_benchmark),
@@ -72,7 +84,7 @@ class BenchmarkRandomCCQP:
                     how = "sequential"
                     if self.lanes > 1 and self.lockstep:
                         # decided on the argument check alone: whatever a lock-step run itself raises propagates
-                        made = [copy.copy(solver) for _ in batch]
+                        made = self._copies(solver, len(batch))
                         from ._engine import get_engine
                         if why_not_pipelined(made, batch, get_engine(self.device).device) is None:
                             results = solve_batch_pipelined(iter(made).__next__, batch, device=self.device)
@@ -83,13 +95,13 @@ class BenchmarkRandomCCQP:
                         pass
                     elif self.lanes > 1:
                         how = "stream lanes"
-                        results = solve_batch(lambda s=solver: copy.copy(s), batch, lanes=self.lanes,
+                        results = solve_batch(iter(self._copies(solver, len(batch))).__next__, batch, lanes=self.lanes,
                                               device=self.device)
                     else:
                         results = []
-                        for A, b, x0, op in batch:
+                        for s, (A, b, x0, op) in zip(self._copies(solver, len(batch)), batch):
                             with contextlib.redirect_stdout(io.StringIO()):
-                                results.append(copy.copy(solver).solve(A, b, convex_proj_op=op))
+                                results.append(s.solve(A, b, convex_proj_op=op))
                     self.cell_scheduler[(solver_id, proj_type_id, proj_id)] = how
                     for trial_id, r in enumerate(results):
                         idx = (solver_id, proj_type_id, proj_id, trial_id)

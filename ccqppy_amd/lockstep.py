@@ -44,9 +44,9 @@ def _lockstep_kinds():
     global _KINDS
     if _KINDS is None:
         from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
-                              CCQPSolverMPRGP, CCQPSolverPGD)
+                              CCQPSolverMPRGP, CCQPSolverPGD, CCQPSolverSPG)
         _KINDS = (CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP,
-                  CCQPSolverPGD)
+                  CCQPSolverPGD, CCQPSolverSPG)
     return _KINDS
 
 
@@ -54,8 +54,25 @@ def _why_not_batch(first):
     """The batch-wide part of the argument check (the solver class)."""
     kind = type(first)
     if kind not in _lockstep_kinds() or getattr(first, "reuse_matvec", False):
-        return TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP "
-                         "(no matvec reuse; SPG draws from numpy's RNG on the host), got %s" % kind.__name__)
+        return TypeError("solve_batch_pipelined runs CCQPSolverPGD / BBPGD / BBPGDf / APGD / APGDAntiRelaxation / MPRGP / "
+                         "SPG (no matvec reuse), got %s" % kind.__name__)
+    return None
+
+
+_SPG_MAX_M = 64
+
+
+def _why_not_spg(s):
+    """SPG in lock-step: every solver draws from its OWN RandomState (with numpy's global stream -- the reference's
+    default -- the draws of problem p start where problem p-1 stopped, which is unknown while they advance together)."""
+    if not isinstance(getattr(s, "rng", None), np.random.RandomState):
+        return TypeError("solve_batch_pipelined runs CCQPSolverSPG only with a private generator per solver: set "
+                         "solver.rng = np.random.RandomState(seed) (numpy's global stream cannot be shared by "
+                         "problems that advance together)")
+    if s.trace is not None:
+        return TypeError("solve_batch_pipelined: a traced SPG solve runs on the host-driven loop")
+    if not (isinstance(s.m, (int, np.integer)) and 1 <= s.m <= _SPG_MAX_M):
+        return ValueError("solve_batch_pipelined: SPG's queue length m must be an integer in [1, %d]" % _SPG_MAX_M)
     return None
 
 
@@ -69,6 +86,10 @@ def _why_not_one(kind, max_mv, s, A, b, P, device):
         return TypeError("solve_batch_pipelined: one solver class for the whole batch"), None, P
     if s.max_matrix_vector_multiplications != max_mv:
         return ValueError("solve_batch_pipelined: one matvec budget for the whole batch"), None, P
+    if kind.__name__ == "CCQPSolverSPG":
+        reason = _why_not_spg(s)
+        if reason is not None:
+            return reason, None, P
     if hasattr(A, "matvec") and hasattr(A, "engine"):
         op_ok = isinstance(A, DenseOperator) and A.rows == A.n
         n = getattr(A, "n", None)
@@ -116,6 +137,12 @@ def why_not_pipelined(solvers, problems, device):
         reason = _why_not_one(kind, max_mv, s, A, b, P, device)[0]
         if reason is not None:
             return reason
+    return _why_not_shared_rng(solvers)
+
+
+def _why_not_shared_rng(solvers):
+    if type(solvers[0]).__name__ == "CCQPSolverSPG" and len({id(s.rng) for s in solvers}) != len(solvers):
+        return TypeError("solve_batch_pipelined: SPG solvers of one batch must not share a RandomState object")
     return None
 
 
@@ -143,7 +170,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     from . import solution_spaces as ss
     from .operators import DenseOperator, as_operator
     from .solvers import (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation, CCQPSolverBBPGD, CCQPSolverBBPGDf,
-                          CCQPSolverMPRGP, CCQPSolverPGD)
+                          CCQPSolverMPRGP, CCQPSolverPGD, CCQPSolverSPG)
     problems = list(problems)
     solvers = [make_solver() for _ in problems]
     if not problems:
@@ -172,12 +199,16 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         by_size.setdefault((n, hasattr(P, "_dev_bb_tail")), []).append(
             (s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P, isinstance(b, torch.Tensor),
              (A, b, x0, P)))
+    reason = _why_not_shared_rng(solvers)
+    if reason is not None:
+        raise reason
     if not quiet:
         for s in solvers:
             print("solving " + s._label)
     group = {CCQPSolverBBPGD: _bpipe_group, CCQPSolverBBPGDf: _bpipe_group, CCQPSolverPGD: _bpipe_group,
              CCQPSolverAPGD: _bapgd_group,
-             CCQPSolverAPGDAntiRelaxation: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group}[kind]
+             CCQPSolverAPGDAntiRelaxation: _bapgd_group, CCQPSolverMPRGP: _bmprgp_group,
+             CCQPSolverSPG: _bspg_group}[kind]
     t1 = time.time()
     with np.errstate(all="ignore"):
         for (n, elementwise), items in by_size.items():     # one lock-step run per problem size (and kind of set)
@@ -186,6 +217,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
                     group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, single_launch)
                 elif kind in (CCQPSolverAPGD, CCQPSolverAPGDAntiRelaxation):
                     _bapgd_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, False, segmented=True)
+                elif kind is CCQPSolverSPG:
+                    _bspg_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, segmented=True)
                 else:
                     _bsegs_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
@@ -481,6 +514,107 @@ def _bsegs_group(eng, items, n, max_mv, ahead, tune=0):
         s._solution_residual = res[p]
         s._solution_num_matrix_vector_mults = mv
         s._executed_matrix_vector_mults = mv if (pgd or (done[p] and final[p] == 0)) else 2 + int(final[p])
+        eng.mv_executed += s._executed_matrix_vector_mults
+
+
+_SPG_ROUNDS = 256         # rounds per call of the C driver (keeps the Python side interruptible)
+_capsule_pointer = None
+
+
+def _draw_source(rng):
+    """Address of the numpy bitgen_t record of a RandomState: the C driver calls its next_double -- the double
+    `uniform` would consume -- exactly when the solver's own loop would."""
+    global _capsule_pointer
+    import ctypes
+    if _capsule_pointer is None:
+        f = ctypes.pythonapi.PyCapsule_GetPointer
+        f.restype, f.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+        _capsule_pointer = f
+    return _capsule_pointer(rng._bit_generator.capsule, b"BitGenerator")
+
+
+def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None):
+    """Lock-step SPG over `spec` (ccqp_bspg.hip): the vector work of every problem on the device, the scalar part of
+    each iteration on the host inside ONE C call per few hundred rounds.  Returns (host records, (B, n) x plane)."""
+    import ctypes
+    from . import _lib
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    B = len(spec)
+    nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+    vec = torch.empty((4, B, n), dtype=torch.float64, device=dev)       # planes: x, g, d, Ad
+    spec.stage_x0(vec[0])
+    partials = torch.empty((B, 3 * nblk), dtype=torch.float64, device=dev)
+    words = torch.zeros(B + 2, dtype=torch.int32, device=dev)
+    xchg = torch.zeros(8 * B, dtype=torch.float64, device=dev)          # control words | dot products
+    idx = np.arange(B, dtype=np.uint64)
+    tab = np.zeros(B, dtype=np.dtype(_lib.PSpg))
+    tab["A"], tab["lda"], tab["b"], tab["seg"] = spec.A, spec.lda, spec.b, spec.seg
+    for j, name in enumerate(("x", "g", "d", "Ad")):
+        tab[name] = np.uint64(vec.data_ptr()) + np.uint64(j) * np.uint64(8 * n * B) + idx * np.uint64(8 * n)
+    tab["partials"] = np.uint64(partials.data_ptr()) + idx * np.uint64(8 * 3 * nblk)
+    tab["counter"] = np.uint64(words.data_ptr()) + idx * np.uint64(4)
+    flags = _bpipe_flags(tab, n, tune)
+    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    if plans is not None:
+        dsegs, seg_ws, max_nwork, max_nnorm = _psegs_table(plans, dev)
+        dsp = dsegs.data_ptr()
+    else:
+        dsp, max_nwork, max_nnorm = None, 0, 0
+    host = np.zeros(B, dtype=np.dtype(_lib.SpgHost))
+    host["tol"] = spec.tol
+    host["max_mv"] = max_mv
+    host["tau"] = [s.t for s in solvers]
+    host["sigma1"] = [s.sigma1 for s in solvers]
+    host["sigma2"] = [s.sigma2 for s in solvers]
+    host["m"] = [s.m for s in solvers]
+    qstride = int(host["m"].max())
+    queue = np.zeros((B, qstride))
+    sources = np.array([_draw_source(s.rng) for s in solvers], dtype=np.uint64)
+    more = ctypes.c_int(1)
+    start = 1
+    torch.cuda.current_stream(dev).synchronize()        # x0 staged, tables copied: the C driver runs on `st`
+    while more.value:
+        _lib.check(lib.ccqp_bspg_run_f64(ctx, dprobs.data_ptr(), dsp, host.ctypes.data, queue.ctypes.data, qstride,
+                                         sources.ctypes.data, B, n, max_nwork, max_nnorm, flags, start, _SPG_ROUNDS,
+                                         xchg.data_ptr(), xchg.data_ptr() + 32 * B, words.data_ptr() + 4 * B,
+                                         ctypes.byref(more), st))
+        start = 0
+    return host, vec[0]
+
+
+def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):
+    import contextlib
+    import io
+    plans = [it[4]._segplan(eng, n) for it in items] if segmented else None
+    solvers = [it[0] for it in items]
+    host, sols = _bspg_run(eng, _spec_from_items(eng, items, n), solvers, n, max_mv, tune, plans)
+    hostx = None
+    for p, it in enumerate(items):
+        s = it[0]
+        if host["status"][p] == 3:
+            stats["fallback_solves"] += 1
+            if host["used"][p]:
+                # the reference's draw raises here, after `used` successful ones (the generator is where it would be):
+                # numpy's own OverflowError('Range exceeds valid bounds'), solvers.py:959
+                np.random.RandomState(0).uniform(low=0.0, high=np.nan)
+            # nothing drawn yet (the first draw would raise, or the budget ends before the first d.d:
+            # UnboundLocalError): the host-driven loop reproduces the reference's exception
+            A, b, x0, P = it[6]
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            continue
+        mv = int(host["mv"][p])
+        if it[5]:
+            s._solution = sols[p]
+        else:
+            if hostx is None:
+                hostx = sols.cpu().numpy()
+            s._solution = hostx[p]
+        s._solution_converged = mv < max_mv
+        s._solution_residual = np.sqrt(host["dd"][p])
+        s._solution_num_matrix_vector_mults = mv
+        # (the matvec that ends a budget is counted but its result is never used: not executed here)
+        s._executed_matrix_vector_mults = mv - (1 if host["status"][p] == 2 else 0)
         eng.mv_executed += s._executed_matrix_vector_mults
 
 

@@ -496,6 +496,70 @@ int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count
 int ccqp_bsolve_mprgp_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, double eps10,
                           double mv_limit, int flags, void* stream);
 
+/* ---- lock-step SPG-QP (solvers.py:878-975) with the HOST in the loop once per iteration of the whole batch ----
+ * SPG's step needs what the device cannot reproduce bit for bit: a draw of numpy's legacy generator and libm's
+ * pow() (`beta ** 2`, `betak ** 2`, :958,:963 -- pow(x, 2) differs from x*x in ~1 of 1200 arguments).  So the
+ * vector work of ALL problems runs in lock-step on the device (4 launches per iteration for the whole batch: control
+ * words, update + direction, matvec, three dot products per problem published to pinned host memory) and the scalar
+ * part of the iteration (:949-966) runs on the host inside ccqp_bspg_run_f64, in C, problem after problem, on the
+ * same libm as the Python loop.  The draws are taken from each problem's OWN generator at the moment the loop would
+ * take them: `sources[p]` points to a record with the layout of numpy's public `bitgen_t` (numpy/random/bitgen.h;
+ * from Python: the "BitGenerator" capsule of a np.random.RandomState), whose next_double is the double
+ * `RandomState.uniform` consumes (betak = sigma1 + (high - sigma1) * u, as numpy's random_uniform) -- one call per
+ * accepted iteration, so every generator is left exactly where the problem's own solve() would leave it.  With one
+ * shared stream the draws of problem p would start where problem p-1 stopped, which is not known while they advance
+ * together: one source per problem.
+ * Per problem the bits of its own CCQPSolverSPG.solve() with that generator; replaces the Python loop as run by
+ * benchmarks/benchmark_random_ccqp.py:67-102 over its SPG cells. */
+typedef struct ccqp_pspg {
+  const double* A;   /* n x n, row-major, leading dimension lda */
+  int64_t lda;
+  const double* b;
+  double* x;         /* x_k; x0 on entry */
+  double* g;         /* g_k = A x_k + b */
+  double* d;         /* d_k = P(x_k - alpha g_k) - x_k */
+  double* Ad;        /* A d_k (A g_0 during the start-up) */
+  ccqp_seg seg;      /* elementwise kind, offset 0, dim n (unused when dev_segs is given) */
+  double* partials;  /* ccqp_bpipe_partials_doubles(n) doubles */
+  uint32_t* counter; /* one word, zero on entry */
+} ccqp_pspg;
+/* host-side state of one problem; the caller fills the five parameters, m, and zeroes the rest */
+typedef struct ccqp_spg_host {
+  double tol, max_mv, tau, sigma1, sigma2; /* solvers.py:856-873; max_mv may be INFINITY */
+  double alpha, betak, fk, dd;             /* step length, last draw, model value (sic :923,:963), last d.d */
+  int64_t mv, used, reserved_;             /* mv_count; draws consumed */
+  int32_t m, qlen;                         /* capacity / fill of the problem's queue of model values (:931-932) */
+  int32_t status;  /* 0 running | 1 converged (:949) | 2 matvec budget (:940) | 3 hand back to the host-driven loop
+                      (the draw would raise OverflowError, or the budget ends before the first d.d: UnboundLocalError) */
+  int32_t pending; /* x += betak d; g += betak Ad (:961-962) still to be applied by the next round */
+  int32_t have_dd, pad_;
+} ccqp_spg_host;
+/* a source of uniform [0,1) doubles: the layout of numpy's bitgen_t */
+typedef struct ccqp_draw_source {
+  void* state;
+  uint64_t (*next_uint64)(void* state);
+  uint32_t (*next_uint32)(void* state);
+  double (*next_double)(void* state);
+  uint64_t (*next_raw)(void* state);
+} ccqp_draw_source;
+/* The scalar part of one iteration for the problems with live[p] != 0 (host only, no GPU work; ccqp_bspg_run_f64
+ * calls the same code): dots[3p..3p+2] = {d.d, d.Ad, d.g}; the draw comes from sources[p], or -- sources == NULL --
+ * is u[p]; queue: count rows of `qstride` >= m doubles, oldest value first. */
+int ccqp_bspg_host_step(ccqp_spg_host* host, double* queue, int64_t qstride, const double* dots,
+                        const ccqp_draw_source* const* sources, const double* u, const unsigned char* live,
+                        int count);
+/* Runs rounds until every problem has left status 0 (*more = 0) or `max_rounds` rounds have been run (*more = 1:
+ * call again with start = 0; lets the caller stay interruptible).  start != 0 first does the start-up (:921-932: g0,
+ * A g0, fk = g0.x0 (sic), alpha = g0.g0 / g0.A g0, mv = 2).
+ * dev_ctl / dev_out: 4 * count doubles of device memory each; dev_batch: two device words;
+ * dev_segs != NULL: the feasible sets as plans of the segmented engine (Sphere / Cone / DisjointUnion; max_nwork,
+ * max_nnorm as ccqp_bsegs_*), two more launches per round.  `flags`: bit 0 + the matvec's tuning word, as
+ * ccqp_bpipe_*.  BLOCKING (it waits for every round); the results are x (dev_probs[p].x) and host[p]. */
+int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, const ccqp_psegs* dev_segs, ccqp_spg_host* host,
+                      double* queue, int64_t qstride, const ccqp_draw_source* const* sources, int count, int64_t n,
+                      int64_t max_nwork, int64_t max_nnorm, int flags, int start, int64_t max_rounds, double* dev_ctl,
+                      double* dev_out, uint32_t* dev_batch, int* more, void* stream);
+
 /* ---- opt-in, NON-parity: symmetric matvec reading only the upper triangle -----------
  * y = A.x for a fully stored SYMMETRIC matrix, 4n^2 bytes of HBM traffic instead of 8n^2; optional
  * g = y + b.  a_ij (j > i) is read once and feeds y_i and y_j, so the summation order differs from

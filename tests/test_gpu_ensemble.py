@@ -74,3 +74,46 @@ def test_ensemble_grid_matches_oracle(lanes):
     assert set(out) == {"wall-clock time [s]", "number of matrix-vector multiplications", "solution residual"}
     m = out["number of matrix-vector multiplications"]
     assert np.all(m["lower_95"] <= m["mean"]) and np.all(m["mean"] <= m["upper_95"])
+
+
+def test_ensemble_spg_cells_with_private_generators():
+    """spg_seed: trial t of every SPG cell draws from RandomState(spg_seed + t) -- the same results under the
+    lock-step scheduler (ccqp_bspg.hip), the stream lanes and the sequential loop, and the MV counts of the oracle run
+    with np.random.seed(spg_seed + t) before each solve."""
+    from ccqppy_amd import solvers, solution_spaces as ss
+    from ccqppy_amd.ensemble import BenchmarkRandomCCQP
+    sizes = [7, 49, 130]
+    tol, max_mv, trials, seed = 1e-5, 5000, 3, 7
+    slv = [solvers.CCQPSolverSPG(tol, max_mv), solvers.CCQPSolverSPG(tol, max_mv, m=2, tau=0.4)]
+    fams = [[ss.IdentityProjOp(d) for d in sizes], [ss.BoxProjOp(d) for d in sizes],
+            [ss.SphereProjOp(d) for d in sizes],
+            [ss.DisjointProjOp(*[ss.SphereProjOp(3)] * (d // 3), ss.IdentityProjOp(d % 3)) for d in sizes]]
+    runs = [BenchmarkRandomCCQP(trials, slv, fams, lanes=3, spg_seed=seed).run(),
+            BenchmarkRandomCCQP(trials, slv, fams, lanes=3, lockstep=False, spg_seed=seed).run(),
+            BenchmarkRandomCCQP(trials, slv, fams, lanes=1, spg_seed=seed).run()]
+    assert set(runs[0].cell_scheduler.values()) == {"lock-step"}
+    assert set(runs[1].cell_scheduler.values()) == {"stream lanes"}
+    assert set(runs[2].cell_scheduler.values()) == {"sequential"}
+    for other in runs[1:]:
+        assert np.array_equal(runs[0]._problem_num_matrix_vector_mults, other._problem_num_matrix_vector_mults)
+        assert np.array_equal(runs[0]._problem_residual.view(np.uint64), other._problem_residual.view(np.uint64))
+        assert np.array_equal(runs[0]._problem_converged, other._problem_converged)
+    assert runs[0]._problem_converged.all()
+    # without spg_seed the SPG cells stay on the host-driven schedulers (the global stream cannot be split)
+    plain = BenchmarkRandomCCQP(1, slv[:1], [fams[1][1:2]], lanes=3).run()
+    assert set(plain.cell_scheduler.values()) == {"stream lanes"}
+    ofam = [[cpu_ref.Identity(d) for d in sizes], [cpu_ref.Box(d) for d in sizes], [cpu_ref.Sphere(d) for d in sizes],
+            [cpu_ref.Disjoint(*[cpu_ref.Sphere(3)] * (d // 3), cpu_ref.Identity(d % 3)) for d in sizes]]
+    kws = [{}, {"m": 2, "tau": 0.4}]
+    mism = 0
+    for pi, n in enumerate(sizes):
+        for t in range(trials):
+            A, b, _ = gen_ref.problem(n, t)
+            for f in range(len(fams)):
+                for s in range(len(slv)):
+                    np.random.seed(seed + t)
+                    with np.errstate(all="ignore"):
+                        o = cpu_ref.solve_spg(A, b, tol, max_mv, P=ofam[f][pi], **kws[s])
+                    mism += int(runs[0]._problem_num_matrix_vector_mults[s, f, pi, t] !=
+                                o.solution_num_matrix_vector_multiplications)
+    assert mism <= 0.05 * runs[0]._problem_num_matrix_vector_mults.size

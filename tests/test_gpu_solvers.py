@@ -100,7 +100,7 @@ def test_solver_golden(case):
     assert s.solution_time > 0
 
 
-_LOCKSTEP_CASES = [c for c in SOLV if c["err"] is None and c["solver"] != "SPG" and not c["problem"].startswith("suite")
+_LOCKSTEP_CASES = [c for c in SOLV if c["err"] is None and not c["problem"].startswith("suite")
                    and c["problem"] != "readme" and c["mv_band"][0] == c["mv_band"][1]]
 
 
@@ -110,7 +110,8 @@ def test_solver_golden_through_the_lockstep_scheduler(case):
     rounds or the single-launch kernels; segmented forms for Sphere / Cone / DisjointUnion sets): a direct comparison
     with the reference's results, not only the transitive one through solve().  A batch of three copies of the
     problem; cases the scheduler does not take (MPRGP on non-elementwise or scalar-bounded sets, n <= 64) are skipped
-    by its own argument check."""
+    by its own argument check.  SPG: every solver gets its own RandomState(rng_seed) -- the stream `np.random.seed(rng_seed)`
+    gave the reference when the fixture was made (oracle/gen_golden.py)."""
     from ccqppy_amd import batch, lockstep
     from ccqppy_amd._engine import get_engine
     A = _device_matrix(case["problem"])
@@ -122,7 +123,10 @@ def test_solver_golden_through_the_lockstep_scheduler(case):
     cls = _solver_cls(case["solver"])
 
     def make():
-        return cls(case["tol"], max_mv, **case["kwargs"])
+        s = cls(case["tol"], max_mv, **case["kwargs"])
+        if case["solver"] == "SPG":
+            s.rng = np.random.RandomState(case["rng_seed"])
+        return s
     probs = [(A, b, x0, None if case["op"] is None else C.build_op(case["op"], C.product_factory(), arrays))
              for _ in range(3)]
     if lockstep.why_not_pipelined([make() for _ in probs], probs, get_engine(0).device) is not None:
@@ -132,7 +136,9 @@ def test_solver_golden_through_the_lockstep_scheduler(case):
     nan = np.isnan(want)
     for s in got:
         assert s.solution_num_matrix_vector_multiplications == case["mv"]
-        assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+        # (lock-step SPG counts the matvec that ends a budget, :938-941, but does not execute it: nothing reads it)
+        skipped = 1 if case["solver"] == "SPG" and not case["converged"] else 0
+        assert s.executed_matrix_vector_multiplications == case["executed_mv"] - skipped
         assert bool(s.solution_converged) == case["converged"]
         x = np.asarray(s.solution)
         assert np.array_equal(np.isnan(x), nan)

@@ -2,7 +2,9 @@
 """Throughput of MANY SMALL dense BBPGD (--apgd: APGD, --mprgp: MPRGP) solves (Box, tol 1e-8; MPRGP: 1e-6 / 300 matvecs) under every scheduler of ccqppy_amd:
 sequential solve(), sequential with the pipelined iteration, the stream-lane and fused batch schedulers
 (host-driven scalars) and solve_batch_pipelined (lock-step, scalars on the device) and, for BBPGD up to n = 2048, its single-launch form (one workgroup per problem).  One JSON line per size.
-   python tools/bench_small_batch.py [--apgd | --mprgp] [--set box|sphere|spheres3] [n:B ...]
+   python tools/bench_small_batch.py [--apgd | --mprgp | --spg] [--set box|sphere|spheres3] [n:B ...]
+--spg: SPG-QP, every solver with its own RandomState(1000 + p) (what the lock-step form needs; the other schedulers get
+the same generators, so all columns solve the same thing bit for bit).
 --set sphere / spheres3 (BBPGD): a whole-vector Sphere / a DisjointUnion of Sphere(3) blocks instead of the Box -- the
 segmented lock-step form (ccqp_bsegs.hip); no single-launch column there."""
 import contextlib
@@ -27,10 +29,12 @@ def main():
         i = argv.index("--set")
         setname = argv[i + 1]
         del argv[i:i + 2]
-    args = [a for a in argv if a not in ("--apgd", "--mprgp")]
+    args = [a for a in argv if a not in ("--apgd", "--mprgp", "--spg")]
     mprgp = "--mprgp" in sys.argv[1:]
-    apgd = "--apgd" in sys.argv[1:] or mprgp          # (no single-solve pipeline column for these)
-    cls = solvers.CCQPSolverMPRGP if mprgp else solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
+    spg = "--spg" in sys.argv[1:]
+    apgd = "--apgd" in sys.argv[1:] or mprgp or spg   # (no single-solve pipeline column for these)
+    cls = solvers.CCQPSolverSPG if spg else solvers.CCQPSolverMPRGP if mprgp else \
+        solvers.CCQPSolverAPGD if apgd else solvers.CCQPSolverBBPGD
     sizes = [tuple(int(v) for v in a.split(":")) for a in args] or \
         [(64, 1024), (256, 1024), (1024, 512), (2048, 256), (4096, 128)]
     for n, B in sizes:
@@ -45,26 +49,41 @@ def main():
                 P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
             probs.append((op, b, None, P))
         tol, cap = (1e-6, 300) if mprgp else (1e-8, 5000)          # MPRGP: BASELINE config 5's settings
-        mk = lambda: cls(tol, cap)          # noqa: E731
+        pool = []                          # generators made OUTSIDE the timed region (seeding one costs ~110 us)
+
+        def refill():
+            if spg:
+                pool[:] = [np.random.RandomState(1000 + p) for p in range(B)][::-1]
+
+        class mk_factory:
+            """() -> a fresh solver; the p-th SPG solver of a run draws from RandomState(1000 + p)"""
+            def __call__(self):
+                s = cls(tol, cap)
+                if spg:
+                    s.rng = pool.pop()
+                return s
 
         def seq(pipe):
+            mk = mk_factory()
             for op, b, x0, P in probs:
                 with contextlib.redirect_stdout(io.StringIO()):
-                    (cls(tol, cap) if apgd else cls(tol, cap, pipeline=pipe)).solve(op, b, convex_proj_op=P)
+                    (mk() if apgd else cls(tol, cap, pipeline=pipe)).solve(op, b, convex_proj_op=P)
 
         out = {}
         res = {}
         for name, fn in (("sequential", lambda: seq(False)),) + \
                 ((() if apgd else (("sequential_pipelined", lambda: seq(True)),))) + (
-                         ("stream_lanes_8", lambda: solve_batch(mk, probs, lanes=8)),
-                         ("fused_32x2", lambda: solve_batch_fused(mk, probs, lanes=32, groups=2)),
-                         ("batch_pipelined", lambda: solve_batch_pipelined(mk, probs, single_launch=False))) + \
+                         ("stream_lanes_8", lambda: solve_batch(mk_factory(), probs, lanes=8)),
+                         ("fused_32x2", lambda: solve_batch_fused(mk_factory(), probs, lanes=32, groups=2)),
+                         ("batch_pipelined", lambda: solve_batch_pipelined(mk_factory(), probs, single_launch=False))) + \
                 (() if apgd or n > 2048 or setname != "box" else
-                 (("batch_single_launch", lambda: solve_batch_pipelined(mk, probs, single_launch=True)),)):
+                 (("batch_single_launch", lambda: solve_batch_pipelined(mk_factory(), probs, single_launch=True)),)):
+            refill()
             fn()
             torch.cuda.synchronize()
             best = 0.0
             for _ in range(3):
+                refill()
                 t0 = time.perf_counter()
                 r = fn()
                 torch.cuda.synchronize()

@@ -29,7 +29,8 @@ def main():
             [ss.DisjointProjOp(*[ss.SphereProjOp(3)] * (d // 3), ss.IdentityProjOp(d % 3)) for d in sizes]]
     np.random.seed(1234)
     t0 = time.perf_counter()
-    bench = BenchmarkRandomCCQP(trials, slv, fams, lanes=4).run()
+    # (spg_seed: SPG trial t draws from its own RandomState(1234 + t) -- the reference never seeds its harness)
+    bench = BenchmarkRandomCCQP(trials, slv, fams, lanes=4, spg_seed=1234).run()
     wall = time.perf_counter() - t0
     buf = io.StringIO()
     bench.process_results(stream=buf)
