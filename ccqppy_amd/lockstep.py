@@ -1,6 +1,7 @@
 """Lock-step batch schedulers: many dense problems of one size advance together, with every scalar and every branch
 decision of the solver on the device (csrc/ccqp_bpipe.hip: PGD / BBPGD / BBPGDf and APGD / anti-relaxation APGD;
-csrc/ccqp_bmprgp.hip: MPRGP).
+csrc/ccqp_bmprgp.hip: MPRGP; csrc/ccqp_bsegs.hip: the same on Sphere / Cone / DisjointUnion sets) -- or, for SPG-QP, with the
+scalar part of each iteration done in C on the host for the whole batch at once (csrc/ccqp_bspg.hip).
 
   solve_batch_pipelined   a list of (A, b, x0, set) problems -> solver objects (grouped by size)
   solve_stacked           stacked tensors A (B, n, n), b (B, n) -> stacked results, no per-problem host work
@@ -156,8 +157,9 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     schedulers of batch.py are bound by ~20 us of Python per problem and scalar read at n <= 4096; this one is not.
 
     make_solver : () -> CCQPSolverPGD, CCQPSolverBBPGD, CCQPSolverBBPGDf, CCQPSolverAPGD,
-                  CCQPSolverAPGDAntiRelaxation or CCQPSolverMPRGP (no matvec reuse), all of one class with the same
-                  max_matrix_vector_multiplications
+                  CCQPSolverAPGDAntiRelaxation, CCQPSolverMPRGP (no matvec reuse) or CCQPSolverSPG (each with its own
+                  `rng = np.random.RandomState(...)`; its generator is left where its own solve() would leave it),
+                  all of one class with the same max_matrix_vector_multiplications
     problems    : sequence of (A, b, x0, convex_proj_op); A an (n, n) device tensor / DenseOperator, the feasible set
                   elementwise (Identity / Lower / Upper / Box) or None
     Returns the list of solver objects with the usual result properties; per problem x, residual, converged flag
@@ -533,7 +535,7 @@ def _draw_source(rng):
     return _capsule_pointer(rng._bit_generator.capsule, b"BitGenerator")
 
 
-def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None):
+def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None):
     """Lock-step SPG over `spec` (ccqp_bspg.hip): the vector work of every problem on the device, the scalar part of
     each iteration on the host inside ONE C call per few hundred rounds.  Returns (host records, (B, n) x plane)."""
     import ctypes
@@ -569,7 +571,8 @@ def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None):
     host["m"] = [s.m for s in solvers]
     qstride = int(host["m"].max())
     queue = np.zeros((B, qstride))
-    sources = np.array([_draw_source(s.rng) for s in solvers], dtype=np.uint64)
+    sources = np.array([_draw_source(r) for r in (rngs if rngs is not None else [s.rng for s in solvers])],
+                       dtype=np.uint64)
     more = ctypes.c_int(1)
     start = 1
     torch.cuda.current_stream(dev).synchronize()        # x0 staged, tables copied: the C driver runs on `st`

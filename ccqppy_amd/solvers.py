@@ -668,8 +668,13 @@ class CCQPSolverSPG(CCQPSolverBase):
     _label = "SPG"
 
     def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf,
-                 m=5, tau=0.5, sigma1=0.01, sigma2=0.5):
+                 m=5, tau=0.5, sigma1=0.01, sigma2=0.5, pipeline=False):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        # Extension, OFF by default, SAME results bit for bit and the same draws from the same generator (dense
+        # operator, n <= 2048, any set built from the seven operators): the vector work of an iteration queued as four
+        # launches and its scalar part done in C between them (ccqp_bspg_run_f64, the lock-step batch driver with a
+        # batch of one) instead of ~10 ctypes calls and two scalar reads per iteration
+        self.pipeline = pipeline
         self.m = m
         self.t = tau
         self.sigma1 = sigma1
@@ -683,9 +688,41 @@ class CCQPSolverSPG(CCQPSolverBase):
     def name(self):
         return "SPG-QP"
 
+    _PIPELINE_MAX_N = 2048
+
+    def _lockstep(self, run):
+        """pipeline=True: the whole solve through the lock-step driver as a batch of one; None where that does not
+        apply (the host-driven loop below then runs, and raises what the reference raises)."""
+        from ._record import RecordingEngine
+        from .lockstep import _SPG_MAX_M, _bspg_run, _spec_from_items
+        from .operators import DenseOperator
+        op, eng, P = run.op, run.eng, run.P
+        rng = self.rng if self.rng is not None else np.random.mtrand._rand      # numpy's global legacy generator
+        elementwise = hasattr(P, "_dev_bb_tail")
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
+                and isinstance(rng, np.random.RandomState) and isinstance(self.m, (int, np.integer))
+                and 1 <= self.m <= _SPG_MAX_M and (elementwise or P._has_device_form())
+                and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
+            return None
+        plans = None if elementwise else [P._segplan(eng, run.n)]
+        host, sols = _bspg_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n), [self], run.n,
+                               self.max_matrix_vector_multiplications, plans=plans, rngs=[rng])
+        h = host[0]
+        if h["status"] == 3:
+            if h["used"]:                               # numpy's own OverflowError, after `used` successful draws (:959)
+                np.random.RandomState(0).uniform(low=0.0, high=np.nan)
+            return None                                 # nothing drawn: the loop below reproduces the exception
+        mv = int(h["mv"])
+        eng.mv_executed += mv - (1 if h["status"] == 2 else 0)
+        return sols[0], np.sqrt(h["dd"]), mv
+
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
+        if self.pipeline and self.trace is None:
+            out = self._lockstep(run)
+            if out is not None:
+                return out
         mv_count = 0
         xk = run.copy(run.x0)
         _, gk = run.mv(xk, True)

@@ -233,3 +233,39 @@ def test_a_draw_that_raises_in_the_reference_raises_here():
         got = made[0].rng.get_state()
         assert got[2] == pos[2] and np.array_equal(got[1], pos[1])
     assert seen_late >= 2
+
+
+@pytest.mark.parametrize("family", ["box", "identity", "sphere", "mixed"])
+@pytest.mark.parametrize("n", [130, 1500])
+def test_single_solves_with_pipeline_true(family, n):
+    """CCQPSolverSPG(pipeline=True): a batch of one -- with a private generator and with numpy's global one."""
+    from ccqppy_amd import lockstep, solvers
+    probs = _make_problems(n, 3, 300 + n, family)
+    max_mv = 150 if family == "mixed" else 5000
+    for k, (A, b, x0, P) in enumerate(probs):
+        out = []
+        for pipeline in (False, True):
+            np.random.seed(77 + k)
+            s = solvers.CCQPSolverSPG(1e-7, max_mv, pipeline=pipeline)
+            if k == 1:
+                s.rng = np.random.RandomState(5)
+            before = dict(lockstep.stats)
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            assert lockstep.stats == before
+            out.append((s, np.random.get_state(), s.rng.get_state() if s.rng is not None else None))
+        (a, ga, pa), (c, gc, pc) = out
+        assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert torch_equal_bits(a.solution, c.solution) and float(a.solution_residual) == float(c.solution_residual)
+        assert bool(a.solution_converged) == bool(c.solution_converged)
+        assert ga[2] == gc[2] and np.array_equal(ga[1], gc[1])           # the global stream: same position
+        if pa is not None:
+            assert pa[2] == pc[2] and np.array_equal(pa[1], pc[1])
+        # the pipelined solve really took the lock-step driver: no per-iteration dot-product reads were issued
+        assert c.executed_matrix_vector_multiplications <= a.executed_matrix_vector_multiplications
+
+
+def torch_equal_bits(x, y):
+    x = x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
+    return np.array_equal(x.view(np.uint64), y.view(np.uint64))

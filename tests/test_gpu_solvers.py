@@ -146,6 +146,47 @@ def test_solver_golden_through_the_lockstep_scheduler(case):
         assert np.linalg.norm((x - want)[~nan]) <= RTOL * scale + 1e-14
 
 
+_SPG_CASES = [c for c in SOLV if c["solver"] == "SPG"]
+
+
+@pytest.mark.parametrize("case", _SPG_CASES, ids=[c["id"] for c in _SPG_CASES])
+def test_spg_golden_with_pipeline_true(case):
+    """Every SPG fixture (the 3x3 suite and README problems, exit-path budgets and exceptions included) with
+    pipeline=True: a batch of one through the lock-step driver, drawing from numpy's GLOBAL generator exactly like the
+    reference -- the same result, the same exception, and the global stream left at the same position."""
+    from ccqppy_amd import solvers
+    A = _device_matrix(case["problem"])
+    b = SOLV_ARR[case["problem"] + ".b"]
+    n = b.shape[0]
+    x0 = C.case_x0(case, n)
+    arrays = dict(C.SUITE_ARRAYS)
+    max_mv = np.inf if case["max_mv"] is None else case["max_mv"]
+
+    def run(pipeline):
+        P = None if case["op"] is None else C.build_op(case["op"], C.product_factory(), arrays)
+        np.random.seed(case["rng_seed"])
+        s = solvers.CCQPSolverSPG(case["tol"], max_mv, pipeline=pipeline, **case["kwargs"])
+        err = None
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+        except Exception as e:                                   # noqa: BLE001
+            err = type(e).__name__
+        return s, err, np.random.get_state()
+    s, err, state = run(True)
+    ref, ref_err, ref_state = run(False)
+    assert err == ref_err == case["err"]
+    assert state[2] == ref_state[2] and np.array_equal(state[1], ref_state[1])
+    if err is not None:
+        return
+    assert s.solution_num_matrix_vector_multiplications == case["mv"] == ref.solution_num_matrix_vector_multiplications
+    assert bool(s.solution_converged) == case["converged"]
+    assert np.array_equal(np.asarray(s.solution).view(np.uint64), np.asarray(ref.solution).view(np.uint64))
+    assert float(s.solution_residual) == float(ref.solution_residual)
+    want = SOLV_ARR[case["id"] + ".x"]
+    assert np.linalg.norm(s.solution - want) <= RTOL * max(np.linalg.norm(want), 1e-300) + 1e-14
+
+
 def test_readme_example_stdout_and_types():
     from ccqppy_amd import solvers, solution_spaces as ss
     A = np.array([[2, -1, 0], [-1, 2, -1], [0, -1, 2]])

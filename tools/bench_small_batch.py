@@ -67,12 +67,15 @@ def main():
             mk = mk_factory()
             for op, b, x0, P in probs:
                 with contextlib.redirect_stdout(io.StringIO()):
-                    (mk() if apgd else cls(tol, cap, pipeline=pipe)).solve(op, b, convex_proj_op=P)
+                    solver = mk()
+                    if pipe:
+                        solver.pipeline = True
+                    solver.solve(op, b, convex_proj_op=P)
 
         out = {}
         res = {}
         for name, fn in (("sequential", lambda: seq(False)),) + \
-                ((() if apgd else (("sequential_pipelined", lambda: seq(True)),))) + (
+                ((() if apgd and not spg else (("sequential_pipelined", lambda: seq(True)),))) + (
                          ("stream_lanes_8", lambda: solve_batch(mk_factory(), probs, lanes=8)),
                          ("fused_32x2", lambda: solve_batch_fused(mk_factory(), probs, lanes=32, groups=2)),
                          ("batch_pipelined", lambda: solve_batch_pipelined(mk_factory(), probs, single_launch=False))) + \
