@@ -1,6 +1,7 @@
 /* Stand-alone C consumer of libccqp_hip.so: no Python, no torch.  Generates a small SPD problem on
  * the GPU, runs one matvec + epilogue + dots + Box projection, the CSR matvec, a lock-step batch of three
- * BBPGD solves, a DisjointUnion-like set through the segmented engine and the 1-rank RCCL exchange through the C ABI
+ * BBPGD solves, a DisjointUnion-like set through the segmented engine, a lock-step SPG batch drawing from a C generator
+ * and the 1-rank RCCL exchange through the C ABI
  * and checks them against plain C loops on the host.  Built and run by tests/test_gpu_cabi.py:
  *   gcc -std=c99 tests/c/abi_smoke.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
  *       -Lccqppy_amd -lccqp_hip -L/opt/rocm/lib -lamdhip64 -lm -o abi_smoke
@@ -21,6 +22,14 @@
       return 2;                                                                \
     }                                                                          \
   } while (0)
+
+/* a caller-supplied source of uniform [0,1) doubles for the lock-step SPG driver (any generator with numpy's bitgen_t
+ * layout will do; from Python it is a RandomState's own) */
+static double lcg_next_double(void* state) {
+  uint64_t* s = (uint64_t*)state;
+  *s = *s * 6364136223846793005ULL + 1442695040888963407ULL;
+  return (double)(*s >> 11) / 9007199254740992.0;
+}
 
 int main(void) {
   const int64_t n = 1500;
@@ -278,6 +287,78 @@ int main(void) {
            (long long)nnorm, r2, want_r2);
     hipFree(dtab); hipFree(dw); hipFree(dn); hipFree(ws); hipFree(po);
     free(hw); free(hn);
+  }
+  /* lock-step SPG-QP, two problems (one matrix, two right-hand sides), Box(-0.5, 0.5), draws from a C generator.
+   * SPG-QP's own exit test |P(x - alpha g) - x| <= tol is all the reference promises (its step length can collapse
+   * far from a KKT point), so the checks are the driver's: both problems stop on that test, draws = matvecs - 3, and a
+   * second run of the same problems and generators, cut into driver calls of 7 rounds instead of one call, ends in
+   * the same bits. */
+  {
+    const int B = 2;
+    const int64_t nblk = ccqp_bpipe_partials_doubles(n) / 3;
+    double *vec, *part, *xchg, *b2;
+    uint32_t* words;
+    if (hipMalloc((void**)&vec, 4 * B * n * sizeof(double)) || hipMalloc((void**)&part, B * 3 * nblk * sizeof(double)) ||
+        hipMalloc((void**)&xchg, 8 * B * sizeof(double)) || hipMalloc((void**)&words, (B + 2) * sizeof(uint32_t)) ||
+        hipMalloc((void**)&b2, n * sizeof(double)))
+      return 8;
+    CHECK(ccqp_gen_vec_f64(ctx, b2, n, 4321, NULL));
+    ccqp_pspg hq[2];
+    ccqp_pspg* dp;
+    if (hipMalloc((void**)&dp, sizeof(hq))) return 8;
+    double* xrun[2];
+    xrun[0] = malloc(B * n * sizeof(double));
+    xrun[1] = malloc(B * n * sizeof(double));
+    long long mvs[2][2];
+    for (int run = 0; run < 2; ++run) {
+      ccqp_spg_host hh[2];
+      double queue[2 * 5];
+      uint64_t lcg[2] = {12345, 67890};
+      ccqp_draw_source src[2];
+      const ccqp_draw_source* srcs[2];
+      hipMemset(vec, 0, 4 * B * n * sizeof(double));                 /* x0 = 0 */
+      hipMemset(words, 0, (B + 2) * sizeof(uint32_t));
+      for (int q = 0; q < B; ++q) {
+        hq[q].A = A; hq[q].lda = n; hq[q].b = q ? b2 : b;
+        hq[q].x = vec + (0 * B + q) * n; hq[q].g = vec + (1 * B + q) * n;
+        hq[q].d = vec + (2 * B + q) * n; hq[q].Ad = vec + (3 * B + q) * n;
+        hq[q].seg = seg;
+        hq[q].partials = part + q * 3 * nblk; hq[q].counter = words + q;
+        ccqp_spg_host z = {0};
+        hh[q] = z;
+        hh[q].tol = 1e-8; hh[q].max_mv = 2000; hh[q].tau = 0.5; hh[q].sigma1 = 0.01; hh[q].sigma2 = 0.5; hh[q].m = 5;
+        src[q].state = &lcg[q]; src[q].next_uint64 = NULL; src[q].next_uint32 = NULL; src[q].next_raw = NULL;
+        src[q].next_double = lcg_next_double;
+        srcs[q] = &src[q];
+      }
+      hipMemcpy(dp, hq, sizeof(hq), hipMemcpyHostToDevice);
+      hipDeviceSynchronize();
+      int more = 1, start = 1, calls = 0;
+      while (more) {
+        CHECK(ccqp_bspg_run_f64(ctx, dp, NULL, hh, queue, 5, srcs, B, n, 0, 0, 1, start, run ? 7 : 100000, xchg,
+                                xchg + 4 * B, words + B, &more, NULL));
+        start = 0;
+        calls++;
+      }
+      for (int q = 0; q < B; ++q) {
+        if (hh[q].status != 1 || !(sqrt(hh[q].dd) <= 1e-8) || hh[q].used != hh[q].mv - 3) bad++;
+        mvs[run][q] = (long long)hh[q].mv;
+        hipMemcpy(xrun[run] + q * n, hq[q].x, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (run == 0)
+          printf("lock-step SPG problem %d: %lld matvecs, %lld draws, |d| = %.3g\n", q, (long long)hh[q].mv,
+                 (long long)hh[q].used, sqrt(hh[q].dd));
+      }
+      if ((run == 0) != (calls == 1)) bad++;
+    }
+    int differ = 0;
+    for (int64_t i = 0; i < B * n; ++i) {
+      if (xrun[0][i] != xrun[1][i]) differ++;
+      if (xrun[0][i] < -0.5 || xrun[0][i] > 0.5) differ++;
+    }
+    if (differ || mvs[0][0] != mvs[1][0] || mvs[0][1] != mvs[1][1]) bad++;
+    printf("lock-step SPG: one driver call vs calls of 7 rounds: %d entries differ\n", differ);
+    free(xrun[0]); free(xrun[1]);
+    hipFree(vec); hipFree(part); hipFree(xchg); hipFree(words); hipFree(b2); hipFree(dp);
   }
   /* the multi-GPU exchange step with the one rank a single-GPU box allows: bootstrap, sharded matvec (bitwise the
    * plain matvec), in-place collectives on the NULL stream.  Skipped (not failed) where no RCCL can be loaded. */
