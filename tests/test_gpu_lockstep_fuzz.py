@@ -1,5 +1,5 @@
 """GPU: seeded differential fuzzing of the lock-step schedulers (batch.solve_batch_pipelined) against per-problem
-solve().  Random solver (PGD / BBPGD / BBPGDf / APGD / anti-relaxation APGD / MPRGP), batch composition (sizes 65..1300 mixed in one call, so several
+solve().  Random solver (PGD / BBPGD / BBPGDf / APGD / anti-relaxation APGD / MPRGP / SPG with one generator per problem), batch composition (sizes 65..1300 mixed in one call, so several
 lock-step groups), elementwise sets with array / scalar / integer / default bounds and -- PGD / BBPGD / APGD / AR --
 Sphere sets and DisjointUnions of small and large blocks in the same call (the segmented forms), warm starts, per-problem
 tolerances, matvec budget, run-ahead depth and matvec tuning word.  Every result must be bitwise the one of the
@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-NCASES = int(os.environ.get("CCQP_LOCKSTEP_FUZZ_CASES", "36"))
+NCASES = int(os.environ.get("CCQP_LOCKSTEP_FUZZ_CASES", "42"))
 
 
 def _set(rng, n, mprgp):
@@ -76,9 +76,17 @@ def test_lockstep_equals_individual_solves(case):
     import torch
     from ccqppy_amd import batch, problems, solvers
     rng = np.random.default_rng(9000 + case)
-    name = ["BBPGD", "APGD", "MPRGP", "APGDAntiRelaxation", "PGD", "BBPGDf"][case % 6]
+    name = ["BBPGD", "APGD", "MPRGP", "APGDAntiRelaxation", "PGD", "BBPGDf", "SPG"][case % 7]
     base = getattr(solvers, "CCQPSolver" + name)
-    cls = base if name != "PGD" else (lambda tol, cap: base(tol, cap, 0.3))
+    spg_seeds = iter(())
+
+    def cls(tol, cap):
+        if name == "PGD":
+            return base(tol, cap, 0.3)
+        s = base(tol, cap)
+        if name == "SPG":                               # its own generator: the k-th solver made draws from stream k
+            s.rng = np.random.RandomState(next(spg_seeds))
+        return s
     sizes = rng.choice([65, 96, 130, 257, 512, 777, 1300], size=rng.integers(1, 4), replace=False)
     probs, tols = [], []
     for n in sizes:
@@ -88,19 +96,23 @@ def test_lockstep_equals_individual_solves(case):
             x0 = None
             if rng.random() < 0.3:
                 x0 = torch.as_tensor(rng.uniform(-0.5, 0.5, size=n), device=b.device)
-            general = name in ("BBPGD", "APGD", "APGDAntiRelaxation", "PGD") and rng.random() < 0.35
+            general = name in ("BBPGD", "APGD", "APGDAntiRelaxation", "PGD", "SPG") and rng.random() < 0.35
             probs.append((op, b, x0, _general_set(rng, n) if general else _set(rng, n, name == "MPRGP")))
             tols.append(float(10.0 ** rng.uniform(-9, -4)) if name != "MPRGP" else float(10.0 ** rng.uniform(-7, -4)))
     order = rng.permutation(len(probs))                 # sizes interleaved in the call
     probs = [probs[i] for i in order]
     tols = [tols[i] for i in order]
     max_mv = [np.inf, 5000, 60, 25, 9][rng.integers(5)] if name != "MPRGP" else [3000, 60, 25, 9][rng.integers(4)]
+    if name == "SPG" and max_mv == np.inf:
+        max_mv = 5000
     ahead = int(rng.choice([1, 2, 4, 9]))
     tune = int(rng.choice([0, (1 << 1) | (2 << 4), (2 << 1) | (7 << 4) | (8 << 8), (4 << 4) | (3 << 8)]))
     ref = []
+    spg_seeds = iter(range(500, 500 + len(probs)))
     for (A, b, x0, P), tol in zip(probs, tols):
         with contextlib.redirect_stdout(io.StringIO()):
             ref.append(cls(tol, max_mv).solve(A, b, x0=x0, convex_proj_op=P))
+    spg_seeds = iter(range(500, 500 + len(probs)))
     it = iter(tols)
     from ccqppy_amd import lockstep
     before = lockstep.stats["fallback_solves"]
@@ -111,7 +123,12 @@ def test_lockstep_equals_individual_solves(case):
     assert len(got) == len(ref)
     for a, c in zip(ref, got):
         assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
-        assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+        # (lock-step SPG counts the matvec that ends a budget but does not execute it)
+        skipped = 1 if name == "SPG" and not c.solution_converged else 0
+        assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications + skipped
         assert bool(a.solution_converged) == bool(c.solution_converged)
         assert float(a.solution_residual) == float(c.solution_residual)
         assert np.array_equal(_bits(a.solution), _bits(c.solution))
+        if name == "SPG":
+            sa, sc = a.rng.get_state(), c.rng.get_state()
+            assert sa[2] == sc[2] and np.array_equal(sa[1], sc[1])

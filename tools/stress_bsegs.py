@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Consistency of the segmented lock-step forms (ccqp_bsegs_*) under a saturated memory system: batches of 512 ... 4096
-problems on Sphere and Sphere(3)-union sets, five solvers, three repetitions each.  Every repetition must give the
+problems on Sphere and Sphere(3)-union sets, six solvers (SPG: ccqp_bspg.hip, one generator per problem), three
+repetitions each.  Every repetition must give the
 same bits and matvec counts as the first one (the schedule of the workgroups differs from run to run: a race between
 a deciding block and a late reader would show as a difference), every problem must converge,
 and a sample of problems is compared with its own host-driven solve().  NO problem may fall back to the host loop.
@@ -33,11 +34,19 @@ def main():
             probs[fam] = ps
         for fam, ps in probs.items():
             for name, args in (("BBPGD", (1e-8, 5000)), ("BBPGDf", (1e-8, 5000)), ("PGD", (1e-7, 5000, 0.3)),
-                               ("APGD", (1e-8, 5000)), ("APGDAntiRelaxation", (1e-8, 5000))):
-                cls = getattr(solvers, "CCQPSolver" + name)
+                               ("APGD", (1e-8, 5000)), ("APGDAntiRelaxation", (1e-8, 5000)), ("SPG", (1e-8, 5000))):
+                base = getattr(solvers, "CCQPSolver" + name)
+                seeds = iter(())
+
+                def cls(*a, base=base, name=name):
+                    s = base(*a)
+                    if name == "SPG":                    # (ccqp_bspg.hip: the k-th solver of a run draws from stream k)
+                        s.rng = np.random.RandomState(next(seeds))
+                    return s
                 first = None
                 for rep in range(3):
                     f0 = dict(lockstep.stats)
+                    seeds = iter(range(B))
                     res = batch.solve_batch_pipelined(lambda: cls(*args), ps)
                     fb = lockstep.stats["fallback_solves"] - f0["fallback_solves"]
                     x = torch.stack([r.solution for r in res])
@@ -48,6 +57,7 @@ def main():
                         same = True
                         # a sample against the host-driven loop
                         for p in range(0, B, max(B // 8, 1)):
+                            seeds = iter([p])
                             with contextlib.redirect_stdout(io.StringIO()):
                                 one = cls(*args).solve(*ps[p][:2], convex_proj_op=ps[p][3])
                             same = same and torch.equal(one.solution, x[p]) and \
