@@ -13,9 +13,12 @@ For N > 1 the matrix is row-block sharded (one process per GPU, RCCL all-gather 
 matvec) and the SAME problem is solved: strong scaling.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (fp64 streaming GEMV): algorithmic bytes per launch / average launch
-                  duration measured with HIP events on the launch stream inside the timed region,
-                  against the 8 TB/s HBM3E peak.
+  roofline     -- dominant kernel (fp64 streaming GEMV): algorithmic bytes / duration measured with HIP events on
+                  the launch stream inside the timed region, against the 8 TB/s HBM3E peak.  A matvec of the
+                  headline size is `launches_per_matvec` launches of the kernel, each over `rows_per_launch` rows
+                  (ccqp_gemv_plan): `achieved` = bytes of a MATVEC / the events' time around all of its
+                  launches (gaps between them included); `bytes_per_launch`, `avg_launch_ms` (= that time /
+                  launches) and `traffic` are per KERNEL launch, the unit of the rocprofv3 tables under profiles/.
   cpu_baseline -- the numpy oracle (oracle/cpu_ref.py, a port of the reference; OpenBLAS threads =
                   host cores) solving THE SAME problem (the device matrix copied to the host, n = 131072,
                   ~60 s of host work) on the GPU box's host, N = 1 only; if the host has less than ~160 GiB
@@ -295,7 +298,8 @@ def main():
         rows_local = op.rows
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
         achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(mv_bytes(rows_local, n))
+        rows_per_launch, launches = eng.gemv_plan(rows_local, n)
+        traffic, traffic_src = pmc_traffic(mv_bytes(rows_per_launch, n))
         steps = max(args.steps, 1)
         line = {
             "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
@@ -342,9 +346,13 @@ def main():
                 "traffic": traffic if (traffic_src or {}).get("verified_same_source") else None,
                 "traffic_from_profile": traffic,
                 "traffic_source": traffic_src,
-                "bytes_per_launch": mv_bytes(rows_local, n),
-                "avg_launch_ms": avg_ms,
-                "launches_timed": len(gemv_ms),
+                "bytes_per_launch": mv_bytes(rows_per_launch, n),
+                "avg_launch_ms": avg_ms / launches,
+                "launches_per_matvec": launches,
+                "rows_per_launch": rows_per_launch,
+                "bytes_per_matvec": mv_bytes(rows_local, n),
+                "avg_matvec_ms": avg_ms,
+                "matvecs_timed": len(gemv_ms),
                 "solve_level_frac": mv_exec * mv_bytes(rows_local, n) / elapsed / 1e9 / HBM_PEAK_GBS,
                 "gemv_ms_per_step": float(np.sum(gemv_ms)) / steps if gemv_ms else None,
                 # N > 1: where the rest of a step goes (rank 0's own clock; the exchange includes waiting for the

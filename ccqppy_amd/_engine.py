@@ -139,6 +139,13 @@ class Engine:
         return [np.float64(h[i]) for i in range(count)]
 
     # ------------------------------------------------------------------ a1 matvec
+    def gemv_plan(self, rows, cols, variant=None):
+        """(rows per kernel launch, launches) of a rows x cols matvec."""
+        rpl, nl = ctypes.c_int64(), ctypes.c_int64()
+        v = self.gemv_variant if variant is None else variant
+        _lib.check(self.lib.ccqp_gemv_plan(self.ctx, rows, cols, v, ctypes.byref(rpl), ctypes.byref(nl)))
+        return rpl.value, nl.value
+
     def gemv(self, A, x, y, b=None, g=None, variant=None):
         """y = A.x for a (rows, cols) row-major device matrix; optionally g = y + b."""
         rows, cols = A.shape

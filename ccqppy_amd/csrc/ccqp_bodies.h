@@ -339,3 +339,10 @@ static inline void ccqp_gemv_defaults(int64_t rows, int64_t cols, int* R, int* U
   if (*U == 0) *U = (rows < 8192 && cols < 65536) ? 2 : 1;
   if (*bpc == 0) *bpc = huge ? 4 : 8;
 }
+
+// Whether the matvec is cut into launches that fill the machine once each (ccqp_gemv.hip: ROUNDS), by shape.
+// Measured (MI355X, profiles/r02_gemv_rounds.jsonl): +2.4 % at 131072^2, +1.8 % at 65536 x 131072, +1 % at 65536^2,
+// nothing at 32768^2 and below, nothing (bpc 8: -2 %) for 262144-column slabs.
+static inline bool ccqp_gemv_rounds_default(int64_t rows, int64_t cols) {
+  return (double)rows * (double)cols >= 4294967296.0 && cols <= 131072;
+}

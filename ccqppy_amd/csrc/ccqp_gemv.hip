@@ -151,34 +151,83 @@ static void launch_mfma(ccqp_ctx* ctx, int U, int bpc, hipStream_t s, const doub
 
 // variant word: bits 0-3 R (rows per wave: 1,2,4,8), bits 4-7 U (unroll: 1,2,4), bit 8 = 1 disables
 // the non-temporal A loads, bit 9 = 1 selects the MFMA form (16 rows per wave; U = columns/16 per step: 1, 2, 4;
-// shapes it does not cover fall through to the VALU form), bits 12-19 workgroups per CU (0 = default).  0 = tuned default
+// shapes it does not cover fall through to the VALU form), bits 10-11 / 20-23 the launch rounds (below), bits 12-19
+// workgroups per CU (0 = default).  0 = tuned default
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
 // yields the same bits, so this is speed only.
+struct gemv_shape {
+  int R, U, bpc;
+  bool nt, rounds;
+  int64_t cap, round_rows;
+};
+
+static gemv_shape gemv_decide(const ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant) {
+  gemv_shape d;
+  d.R = variant & 0xF;
+  d.U = (variant >> 4) & 0xF;
+  d.nt = !((variant >> 8) & 1);
+  d.bpc = (variant >> 12) & 0xFF;
+  // ROUNDS (bits 10-11: 1 = on, 2 = off, 0 = by shape; bits 20-23: tasks per wave and round, 0 = 1): the rows are
+  // cut into blocks that fill the machine exactly once -- every wave takes its share of ONE block, and the next
+  // block is the next launch on the stream.  A single persistent launch lets the waves drift apart over a 128 GiB
+  // matrix (each strides over the tasks at its own pace); restarting them together every few milliseconds keeps the
+  // window of rows in flight compact: 19.5 instead of 19.9-20.0 ms at n = 131072, 9.77 instead of 9.95 ms for a
+  // 65536 x 131072 slab, nothing to gain below 32 GiB or for 2 MiB rows (profiles/r02_gemv_rounds.jsonl).
+  // The bits of y do not depend on it (they are a function of the row and of n alone).
+  const int rounds_mode = (variant >> 10) & 3;
+  const bool rounds_shape = ccqp_gemv_rounds_default(rows, cols);
+  if (d.bpc == 0 && rounds_mode == 0 && rounds_shape) d.bpc = 8;   // (the persistent form's default for >= 64 GiB: 4)
+  ccqp_gemv_defaults(rows, cols, &d.R, &d.U, &d.bpc);
+  d.cap = (int64_t)ctx->num_cu * d.bpc;
+  int per_wave = (variant >> 20) & 0xF;
+  if (per_wave == 0) per_wave = 1;
+  d.round_rows = (int64_t)d.R * (CCQP_BLOCK / 64) * d.cap * per_wave;
+  d.rounds = (rounds_mode == 1 || (rounds_mode == 0 && rounds_shape)) && rows > d.round_rows;
+  return d;
+}
+
+extern "C" int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
+                              int64_t* launches) {
+  CCQP_REQUIRE(ctx != nullptr && rows_per_launch != nullptr && launches != nullptr, "NULL argument");
+  CCQP_REQUIRE(rows >= 0 && cols >= 0, "negative size");
+  const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
+  *rows_per_launch = d.rounds ? d.round_rows : rows;
+  *launches = d.rounds ? (rows + d.round_rows - 1) / d.round_rows : (rows > 0 ? 1 : 0);
+  return CCQP_OK;
+}
+
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
                      double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s,
                      const double* skip) {
-  int R = variant & 0xF, U = (variant >> 4) & 0xF;
-  const bool nt = !((variant >> 8) & 1);
-  int bpc = (variant >> 12) & 0xFF;
   if (((variant >> 9) & 1) && gemv_mfma_applicable(A, lda, x, cols)) {
-    launch_mfma(ctx, U == 0 ? 4 : U, bpc, s, A, lda, x, b, y, g, rows, cols, skip);
+    const int U0 = (variant >> 4) & 0xF;
+    launch_mfma(ctx, U0 == 0 ? 4 : U0, (variant >> 12) & 0xFF, s, A, lda, x, b, y, g, rows, cols, skip);
     return CCQP_OK;
   }
-  ccqp_gemv_defaults(rows, cols, &R, &U, &bpc);
+  const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
+  const int R = d.R, U = d.U;
+  const bool nt = d.nt, rounds = d.rounds;
+  const int64_t cap = d.cap, round_rows = d.round_rows;
   const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
                        (lda % 2) == 0;
-  const int64_t ntasks = (rows + R - 1) / R;
-  int64_t blocks = (ntasks + (CCQP_BLOCK / 64) - 1) / (CCQP_BLOCK / 64);
-  const int64_t cap = (int64_t)ctx->num_cu * bpc;
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
   int bad = 0;
-  switch (R) {
-    case 1: bad = launch_r<1>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
-    case 2: bad = launch_r<2>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
-    case 4: bad = launch_r<4>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
-    case 8: bad = launch_r<8>(U, aligned, nt, s, (int)blocks, A, lda, x, b, y, g, rows, cols, skip); break;
-    default: bad = 1;
+  for (int64_t r0 = 0; r0 < rows && !bad; r0 += rounds ? round_rows : rows) {
+    const int64_t nr = rounds && rows - r0 > round_rows ? round_rows : rows - r0;
+    const int64_t ntasks = (nr + R - 1) / R;
+    int64_t blocks = (ntasks + (CCQP_BLOCK / 64) - 1) / (CCQP_BLOCK / 64);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const double* Ar = A + r0 * lda;
+    const double* br = b ? b + r0 : nullptr;
+    double* yr = y + r0;
+    double* gr = g ? g + r0 : nullptr;
+    switch (R) {
+      case 1: bad = launch_r<1>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;
+      case 2: bad = launch_r<2>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;
+      case 4: bad = launch_r<4>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;
+      case 8: bad = launch_r<8>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;
+      default: bad = 1;
+    }
   }
   if (bad) {
     ccqp_set_error("ccqp_gemv_f64: unsupported variant 0x%x (R=%d, U=%d)", variant, R, U);

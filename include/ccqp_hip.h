@@ -70,9 +70,15 @@ int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
  * that depends on `cols` only, so a row block [r0, r1) of A gives bitwise the same y[r0:r1]
  * as the full matrix does -> row-sharded multi-GPU runs reproduce the 1-GPU iterates.
  * variant: 0 = default streaming kernel; other values select tuning variants.
+ * A large matrix (>= 32 GiB, rows of at most 1 MiB) is processed as several kernel launches on `stream`, each over a
+ * block of rows that fills the machine once ("rounds": measured faster than one persistent launch; same bits).
  */
 int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, double* y,
                   int64_t rows, int64_t cols, int variant, void* stream);
+/* How ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 will launch a rows x cols matvec (the streaming form): the rows every
+ * launch but the last covers, and the number of launches -- what a profile's per-launch figures refer to. */
+int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
+                   int64_t* launches);
 /* Same with a fused epilogue: y = A.x ; if g != NULL: g = y + b, one extra rounding exactly like
  * numpy's `A.dot(x) + b` (solvers.py:133,148,280,625,641,922,1065,1090).  b, y, g have `rows` entries. */
 int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x,

@@ -220,6 +220,30 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
                     y = eng.empty(rows)
                     eng.gemv(dA, dx, y, variant=R | (U << 4) | (nt << 8) | (bpc << 12))
                     assert H.same_bits(y.cpu().numpy(), base), (R, U, nt, bpc)
+    # launch rounds (ccqp_gemv.hip: what a >= 32 GiB matvec does by default), forced on a small matrix: bpc = 1 and
+    # R = 1 make a round 1024 rows on a 256-CU device, so a 5000-row matrix takes five launches; with and without
+    # the fused epilogue; 2 tasks per wave and round; explicitly off
+    rows2 = 5000
+    A2 = rng.normal(size=(rows2, 300))
+    b2 = rng.normal(size=rows2)
+    dA2, dx2, db2 = eng.to_device(A2), eng.to_device(x[:300]), eng.to_device(b2)
+    y1, g1 = eng.empty(rows2), eng.empty(rows2)
+    eng.gemv(dA2, dx2, y1, db2, g1, variant=0x800)
+    assert eng.gemv_plan(rows2, 300, 0x800) == (rows2, 1)
+    for v in (0x1411, 0x2412, 0x201411, 0x1418):
+        per, launches = eng.gemv_plan(rows2, 300, v)
+        assert launches == -(-rows2 // per) and (launches > 1 or per >= rows2)
+        y2, g2 = eng.empty(rows2), eng.empty(rows2)
+        eng.gemv(dA2, dx2, y2, db2, g2, variant=v)
+        assert H.same_bits(y2.cpu().numpy(), y1.cpu().numpy()) and H.same_bits(g2.cpu().numpy(), g1.cpu().numpy()), hex(v)
+        y3 = eng.empty(rows2)
+        eng.gemv(dA2, dx2, y3, variant=v)
+        assert H.same_bits(y3.cpu().numpy(), y1.cpu().numpy()), hex(v)
+    assert eng.gemv_plan(rows2, 300, 0x1411)[1] >= 2
+    # the default leaves small matrices to one launch and cuts the headline matrix into rounds
+    assert eng.gemv_plan(4096, 4096)[1] == 1
+    per, launches = eng.gemv_plan(131072, 131072)
+    assert launches > 1 and per * launches >= 131072
     # row blocks (what each rank of a row-sharded run computes)
     for r0, r1 in ((0, 100), (100, 389), (389, 777)):
         y = eng.empty(r1 - r0)

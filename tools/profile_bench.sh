@@ -23,7 +23,17 @@ for group in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "VALUBusy MfmaUt
     python3 "$ROOT/bench.py" --steps 1 --warmup 0 --cpu-n 0 > "$OUT/${TAG}_pmc$i.json" 2> "$OUT/${TAG}_pmc$i.err" || exit 1
 done
 cd "$ROOT"
-export PROF_META='{"n": 131072, "rows": 131072, "algorithmic_bytes_per_launch": 137441050624.0, "command": "rocprofv3 --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | VALUBusy MfmaUtil OccupancyPercent MemUnitStalled> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --cpu-n 0"}'
+# per KERNEL launch: a matvec of this size is several launches (ccqp_gemv_plan); the bench line says how many
+export PROF_META=$(python3 - "$OUT/${TAG}_bench_default.json" <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])["roofline"]
+print(json.dumps({"n": 131072, "rows": r["rows_per_launch"], "launches_per_matvec": r["launches_per_matvec"],
+                  "algorithmic_bytes_per_launch": r["bytes_per_launch"],
+                  "command": "rocprofv3 --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | "
+                             "VALUBusy MfmaUtil OccupancyPercent MemUnitStalled> --kernel-trace -- python3 bench.py "
+                             "--steps 1 --warmup 0 --cpu-n 0"}))
+PY
+)
 python3 tools/summarize_prof.py "${TAG}_bench_n131072" "$OUT/prof_${TAG}_trace" "$OUT/prof_${TAG}_pmc1" "$OUT/prof_${TAG}_pmc2" "$OUT/prof_${TAG}_pmc3" > "$OUT/${TAG}_summary.log" 2>&1 || exit 1
 cp profiles/${TAG}_bench_n131072_* "$OUT/" 2>/dev/null
 echo "[profile] done"; date
