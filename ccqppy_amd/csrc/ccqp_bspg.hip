@@ -207,13 +207,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bspg_gemv_kernel(const ccqp_pspg* 
 }
 
 // grid (nblk, problems) -- the geometry of ccqp_dots_f64 on n-vectors.  start: {g.x, g.g, g.Ad} (:923-924), else
-// {d.d, d.Ad, d.g} (:944-946).  `nlive` problems take part; the last of them to finish publishes every problem's
-// four words to pinned host memory and then the sequence number.
+// {d.d, d.Ad, d.g} (:944-946).  `nlive` of the `count` problems behind the pointers take part; the last of them to
+// finish publishes every problem's four words to pinned host memory and then the sequence number to `flag`.
 __global__ __launch_bounds__(CCQP_BLOCK) void bspg_dots_kernel(const ccqp_pspg* __restrict__ probs,
                                                                const double* __restrict__ ctl,
                                                                double* __restrict__ out, double* __restrict__ host_out,
                                                                int start, int64_t n, int64_t chunk, int nblk,
-                                                               unsigned* __restrict__ batch, double* __restrict__ host,
+                                                               unsigned* __restrict__ batch, double* __restrict__ flag,
                                                                unsigned nlive, int count, double seq) {
   __shared__ double lds4[4];
   __shared__ int is_last;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bspg_dots_kernel(const ccqp_pspg* 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(host + BP_MIRROR + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------------------------------- driver
@@ -273,8 +273,7 @@ static int bspg_exchange(ccqp_ctx* ctx, size_t doubles) {
   return CCQP_OK;
 }
 
-static int bspg_wait(ccqp_ctx* ctx, double seq, hipStream_t s) {
-  volatile double* flag = ctx->host_slots + BP_MIRROR + 1;
+static int bspg_wait(volatile double* flag, double seq, hipStream_t s) {
   for (int spin = 0; spin < 4000000; ++spin) {
     if (*flag == seq) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -293,6 +292,17 @@ static void bspg_gemv(const ccqp_pspg* probs, const double* ctl, int count, int6
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   BP_MV_LAUNCH(bspg_gemv_kernel, probs, ctl, which, n);
 }
+
+// One group of consecutive problems of the batch: its rounds are queued and awaited on their own, so that while the
+// host does the scalar work of one group the device runs the round of the other.
+struct bspg_group {
+  int p0, cnt;            // problems [p0, p0 + cnt)
+  double seq;             // rounds with a dots launch so far (the value the group's flag shows after the last one)
+  volatile double* flag;  // host_slots[BP_MIRROR + 1 + g]
+  double* flag_dev;
+  uint32_t* batch;        // the group's arrival counter
+  bool inflight;          // a round with a dots launch is queued and not yet consumed
+};
 
 extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, const ccqp_psegs* dev_segs,
                                  ccqp_spg_host* host, double* queue, int64_t qstride,
@@ -318,32 +328,47 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
   const dim3 blk(CCQP_BLOCK);
-  const dim3 vgrid(bp_vec_grid(n), count);
-  const int cgrid = (4 * count + CCQP_BLOCK - 1) / CCQP_BLOCK;
   ccqp_lockstep_begin(ctx, dev_batch, s);
-  double seq = 0.0;
+  ctx->host_slots[BP_MIRROR + 2] = -1.0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   *more = 0;
+  // two groups from 32 problems on (flags bit 3: one group) -- a half batch of that size still fills the machine's
+  // launch slots, and the host's turn-around (~50 us per round) disappears behind the other half's kernels
+  const int ngroups = (count >= 32 && !(flags & 8)) ? 2 : 1;
+  const int mvflags = flags & ~8;
+  bspg_group grp[2];
+  for (int g = 0; g < ngroups; ++g) {
+    grp[g].p0 = g == 0 ? 0 : count / 2;
+    grp[g].cnt = ngroups == 1 ? count : (g == 0 ? count / 2 : count - count / 2);
+    grp[g].seq = 0.0;
+    grp[g].flag = ctx->host_slots + BP_MIRROR + 1 + g;
+    grp[g].flag_dev = ctx->host_slots_dev + BP_MIRROR + 1 + g;
+    grp[g].batch = dev_batch + g;
+    grp[g].inflight = false;
+  }
 
-  if (start) {
+  if (start) {                                           // the whole batch as one group
+    unsigned nlive = 0;
     for (int p = 0; p < count; ++p) {
       double* c = hctl + 4 * p;
       c[SPG_ALPHA] = 0.0;
       c[SPG_BETAK] = 0.0;
       c[SPG_MODE] = host[p].status == 0 ? 1.0 : 0.0;
       c[SPG_UPDATE] = 0.0;
+      nlive += host[p].status == 0;
     }
-    unsigned nlive = 0;
-    for (int p = 0; p < count; ++p) nlive += host[p].status == 0;
     if (nlive) {
-      seq += 1.0;
-      hipLaunchKernelGGL(bspg_ctl_kernel, dim3(cgrid), blk, 0, s, hctl_dev, dev_ctl, 4 * count);
-      bspg_gemv(dev_probs, dev_ctl, count, n, 0, flags, s);
-      bspg_gemv(dev_probs, dev_ctl, count, n, 1, flags, s);
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      hipLaunchKernelGGL(bspg_ctl_kernel, dim3((4 * count + CCQP_BLOCK - 1) / CCQP_BLOCK), blk, 0, s, hctl_dev, dev_ctl,
+                         4 * count);
+      bspg_gemv(dev_probs, dev_ctl, count, n, 0, mvflags, s);
+      bspg_gemv(dev_probs, dev_ctl, count, n, 1, mvflags, s);
       hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, count), blk, 0, s, dev_probs, dev_ctl, dev_out, hout_dev, 1, n,
-                         chunk, nblk, dev_batch, ctx->host_slots_dev, nlive, count, seq);
+                         chunk, nblk, grp[0].batch, grp[0].flag_dev, nlive, count, 1.0);
       CCQP_LAUNCH_CHECK();
-      rc = bspg_wait(ctx, seq, s);
+      rc = bspg_wait(grp[0].flag, 1.0, s);
       if (rc) return rc;
+      grp[0].seq = 1.0;
       for (int p = 0; p < count; ++p) {
         ccqp_spg_host* h = host + p;
         if (h->status != 0) continue;
@@ -360,16 +385,12 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
     }
   }
 
-  for (int64_t round = 0;; ++round) {
-    bool any = false;
-    for (int p = 0; p < count; ++p) any = any || host[p].status == 0;
-    if (!any) break;
-    if (round >= max_rounds) {
-      *more = 1;
-      break;
-    }
+  // queue one round of a group; returns 1 if the group had anything to do
+  auto launch_round = [&](bspg_group& G) -> int {
+    const int p0 = G.p0, cnt = G.cnt;
     unsigned nlive = 0;
-    for (int p = 0; p < count; ++p) {
+    bool any = false;
+    for (int p = p0; p < p0 + cnt; ++p) {
       ccqp_spg_host* h = host + p;
       double* c = hctl + 4 * p;
       c[SPG_ALPHA] = h->alpha;
@@ -382,46 +403,80 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
         h->status = h->have_dd ? 2 : 3;                  // (no d.d yet: the reference dies with UnboundLocalError)
         h->pending = 0;
         c[SPG_MODE] = 2.0;
+        any = true;
       } else {
         h->mv += 1;
         c[SPG_MODE] = 1.0;
         nlive += 1;
+        any = true;
       }
     }
+    if (!any) return 0;
+    const ccqp_pspg* probs = dev_probs + p0;
+    const ccqp_psegs* segs = dev_segs ? dev_segs + p0 : nullptr;
+    double* ctl = dev_ctl + 4 * p0;
+    const dim3 vgrid(bp_vec_grid(n), cnt);
     __atomic_thread_fence(__ATOMIC_RELEASE);
-    hipLaunchKernelGGL(bspg_ctl_kernel, dim3(cgrid), blk, 0, s, hctl_dev, dev_ctl, 4 * count);
-    if (dev_segs) {
-      hipLaunchKernelGGL(bspg_step_kernel<false>, vgrid, blk, 0, s, dev_probs, dev_ctl, n);
+    hipLaunchKernelGGL(bspg_ctl_kernel, dim3((4 * cnt + CCQP_BLOCK - 1) / CCQP_BLOCK), blk, 0, s, hctl_dev + 4 * p0, ctl,
+                       4 * cnt);
+    if (segs) {
+      hipLaunchKernelGGL(bspg_step_kernel<false>, vgrid, blk, 0, s, probs, ctl, n);
       if (nlive) {
         if (max_nnorm > 0)
-          hipLaunchKernelGGL(bspg_norm_kernel, dim3((unsigned)max_nnorm, count), blk, 0, s, dev_probs, dev_segs, dev_ctl);
-        hipLaunchKernelGGL(bspg_apply_kernel, dim3((unsigned)max_nwork, count), blk, 0, s, dev_probs, dev_segs, dev_ctl);
+          hipLaunchKernelGGL(bspg_norm_kernel, dim3((unsigned)max_nnorm, cnt), blk, 0, s, probs, segs, ctl);
+        hipLaunchKernelGGL(bspg_apply_kernel, dim3((unsigned)max_nwork, cnt), blk, 0, s, probs, segs, ctl);
       }
     } else {
-      hipLaunchKernelGGL(bspg_step_kernel<true>, vgrid, blk, 0, s, dev_probs, dev_ctl, n);
+      hipLaunchKernelGGL(bspg_step_kernel<true>, vgrid, blk, 0, s, probs, ctl, n);
     }
-    if (!nlive) {
-      // only final updates this round: nothing to wait for, but the control words must not be overwritten while
-      // the copy kernel may still be reading them
-      CCQP_LAUNCH_CHECK();
-      CCQP_HIP(hipStreamSynchronize(s));
-      continue;
-    }
-    seq += 1.0;
-    bspg_gemv(dev_probs, dev_ctl, count, n, 2, flags, s);
-    hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, count), blk, 0, s, dev_probs, dev_ctl, dev_out, hout_dev, 0, n,
-                       chunk, nblk, dev_batch, ctx->host_slots_dev, nlive, count, seq);
-    CCQP_LAUNCH_CHECK();
-    rc = bspg_wait(ctx, seq, s);
-    if (rc) return rc;
-    for (int p = 0; p < count; ++p) {
+    if (!nlive) return 2;                                // only final updates: nothing will be reported
+    G.seq += 1.0;
+    bspg_gemv(probs, ctl, cnt, n, 2, mvflags, s);
+    hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, cnt), blk, 0, s, probs, ctl, dev_out + 4 * p0, hout_dev + 4 * p0, 0,
+                       n, chunk, nblk, G.batch, G.flag_dev, nlive, cnt, G.seq);
+    G.inflight = true;
+    return 1;
+  };
+  // wait for a group's queued round and do the scalar part of the iteration for its problems
+  auto finish_round = [&](bspg_group& G) -> int {
+    int r = bspg_wait(G.flag, G.seq, s);
+    if (r) return r;
+    G.inflight = false;
+    for (int p = G.p0; p < G.p0 + G.cnt; ++p) {
       if (hctl[4 * p + SPG_MODE] != 1.0) continue;
       const double* o = hout + 4 * p;
       spg_host_step(host + p, queue + (int64_t)p * qstride, o[0], o[1], o[2], sources[p], 0.0);
     }
+    return CCQP_OK;
+  };
+
+  for (int64_t round = 0;; ++round) {
+    const bool stop = round >= max_rounds;
+    int busy = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      bspg_group& G = grp[g];
+      if (G.inflight) {                                  // (queued in the previous turn of this loop)
+        rc = finish_round(G);
+        if (rc) return rc;
+      }
+      if (stop) continue;
+      const int what = launch_round(G);
+      CCQP_LAUNCH_CHECK();
+      if (what == 2) {
+        // the control words of this group must not be overwritten while the copy kernel may still be reading them
+        CCQP_HIP(hipStreamSynchronize(s));
+      }
+      busy += what != 0;
+    }
+    if (stop) {
+      bool any = false;
+      for (int p = 0; p < count; ++p) any = any || host[p].status == 0;
+      *more = any ? 1 : 0;
+      break;
+    }
+    if (!busy) break;
   }
-  // the pending updates of problems that stopped (status 1: none by construction; 2: applied in their last round)
-  // are done; x of every finished problem is final once the stream has drained
+  // x of every finished problem is final once the stream has drained
   CCQP_HIP(hipStreamSynchronize(s));
   return CCQP_OK;
 }

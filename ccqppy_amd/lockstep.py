@@ -520,6 +520,8 @@ def _bsegs_group(eng, items, n, max_mv, ahead, tune=0):
 
 
 _SPG_ROUNDS = 256         # rounds per call of the C driver (keeps the Python side interruptible)
+# A/B switch (tools, tests): True = the C driver advances the batch as ONE group instead of two alternating halves
+_SPG_ONE_GROUP = bool(int(__import__("os").environ.get("CCQP_SPG_ONE_GROUP", "0")))
 _capsule_pointer = None
 
 
@@ -555,7 +557,7 @@ def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None):
         tab[name] = np.uint64(vec.data_ptr()) + np.uint64(j) * np.uint64(8 * n * B) + idx * np.uint64(8 * n)
     tab["partials"] = np.uint64(partials.data_ptr()) + idx * np.uint64(8 * 3 * nblk)
     tab["counter"] = np.uint64(words.data_ptr()) + idx * np.uint64(4)
-    flags = _bpipe_flags(tab, n, tune)
+    flags = _bpipe_flags(tab, n, tune) | (8 if _SPG_ONE_GROUP else 0)
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     if plans is not None:
         dsegs, seg_ws, max_nwork, max_nnorm = _psegs_table(plans, dev)

@@ -560,7 +560,9 @@ int ccqp_bspg_host_step(ccqp_spg_host* host, double* queue, int64_t qstride, con
  * dev_ctl / dev_out: 4 * count doubles of device memory each; dev_batch: two device words;
  * dev_segs != NULL: the feasible sets as plans of the segmented engine (Sphere / Cone / DisjointUnion; max_nwork,
  * max_nnorm as ccqp_bsegs_*), two more launches per round.  `flags`: bit 0 + the matvec's tuning word, as
- * ccqp_bpipe_*.  BLOCKING (it waits for every round); the results are x (dev_probs[p].x) and host[p]. */
+ * ccqp_bpipe_*; from 32 problems on the batch advances as two alternating halves (the device runs one half's round
+ * while the host does the other half's scalars) unless bit 3 (8) is set -- same results either way.
+ * BLOCKING (it waits for every round); the results are x (dev_probs[p].x) and host[p]. */
 int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, const ccqp_psegs* dev_segs, ccqp_spg_host* host,
                       double* queue, int64_t qstride, const ccqp_draw_source* const* sources, int count, int64_t n,
                       int64_t max_nwork, int64_t max_nnorm, int flags, int start, int64_t max_rounds, double* dev_ctl,

@@ -269,3 +269,27 @@ def torch_equal_bits(x, y):
     x = x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
     y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
     return np.array_equal(x.view(np.uint64), y.view(np.uint64))
+
+
+@pytest.mark.parametrize("count", [31, 32, 33, 70])
+def test_two_alternating_halves_give_the_same_bits_as_one_group(monkeypatch, count):
+    """From 32 problems on the C driver advances the batch as two halves that take turns on the device; a batch with
+    very different solve lengths in the two halves (one half finishes long before the other), segmented and
+    elementwise, against the one-group form and a sample of per-problem solves."""
+    from ccqppy_amd import lockstep
+    n = 150
+    for family in ("box", "spheres3"):
+        probs = _make_problems(n, count, 1000 + count, family)
+        tols = [1e-3 if p < count // 2 else 1e-9 for p in range(count)]
+        seeds = list(range(count))
+        kws = [{}] * count
+        monkeypatch.setattr(lockstep, "_SPG_ONE_GROUP", False)
+        two = _batch(probs, tols, 3000, seeds, kws)
+        monkeypatch.setattr(lockstep, "_SPG_ONE_GROUP", True)
+        one = _batch(probs, tols, 3000, seeds, kws)
+        for a, c in zip(two, one):
+            _same(a, c)
+        idx = [0, count // 2 - 1, count // 2, count - 1]
+        ref = _reference([probs[i] for i in idx], [tols[i] for i in idx], 3000, [seeds[i] for i in idx], [{}] * 4)
+        for i, c in zip(idx, ref):
+            _same(two[i], c)
