@@ -86,3 +86,63 @@ def test_spec_staging_of_start_vectors():
     sp.x0 = torch.ones(3, 4, dtype=torch.float64)
     sp.stage_x0(plane)
     assert torch.equal(plane, torch.ones(3, 4, dtype=torch.float64))
+
+
+def test_spg_descriptor_layouts_and_draw_source():
+    """struct ccqp_pspg / ccqp_spg_host mirrors, and the address handed to the C driver as a draw source: the numpy
+    bitgen_t record of a RandomState, whose next_double is the double `uniform` / `random_sample` consume."""
+    import ctypes
+    from ccqppy_amd import _lib
+    from ccqppy_amd.lockstep import _draw_source
+    for struct, size in ((_lib.PSpg, 128), (_lib.SpgHost, 120)):
+        assert np.dtype(struct).itemsize == ctypes.sizeof(struct) == size
+    assert np.dtype(_lib.PSpg).fields["seg"][1] == 56 and np.dtype(_lib.SpgHost).fields["mv"][1] == 72
+
+    class BitGen(ctypes.Structure):                      # numpy/random/bitgen.h
+        _fields_ = [("state", ctypes.c_void_p), ("next_uint64", ctypes.c_void_p), ("next_uint32", ctypes.c_void_p),
+                    ("next_double", ctypes.c_void_p), ("next_raw", ctypes.c_void_p)]
+    rng, twin = np.random.RandomState(99), np.random.RandomState(99)
+    rec = BitGen.from_address(_draw_source(rng))
+    nxt = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p)(rec.next_double)
+    got = [nxt(rec.state) for _ in range(5)]
+    assert got == list(twin.random_sample(5))
+    assert rng.uniform(2.0, 3.0) == twin.uniform(2.0, 3.0)       # ... and the Python object saw the draws
+    # numpy's GLOBAL generator has such a record too (what pipeline=True uses without solver.rng)
+    np.random.seed(5)
+    rec = BitGen.from_address(_draw_source(np.random.mtrand._rand))
+    nxt = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p)(rec.next_double)
+    first = nxt(rec.state)
+    np.random.seed(5)
+    assert first == np.random.random_sample()
+
+
+def test_spg_argument_rules_of_the_lockstep_scheduler():
+    """SPG in lock-step: one RandomState per solver, no trace, a sane queue length -- decided without any GPU work."""
+    import torch
+    from ccqppy_amd import lockstep, solvers
+    A = torch.eye(8, dtype=torch.float64)
+    b = torch.ones(8, dtype=torch.float64)
+    probs = [(A, b, None, None), (A, b, None, None)]
+
+    def made(**kw):
+        out = []
+        for k in range(2):
+            s = solvers.CCQPSolverSPG(1e-8, 100, **kw.get("ctor", {}))
+            s.rng = kw["rng"](k) if "rng" in kw else np.random.RandomState(k)
+            if kw.get("trace"):
+                s.trace = []
+            out.append(s)
+        return out
+    dev = torch.device("cpu")
+    assert lockstep.why_not_pipelined(made(), probs, dev) is None
+    assert isinstance(lockstep.why_not_pipelined(made(rng=lambda k: None), probs, dev), TypeError)
+    shared = np.random.RandomState(0)
+    assert "share" in str(lockstep.why_not_pipelined(made(rng=lambda k: shared), probs, dev))
+    assert isinstance(lockstep.why_not_pipelined(made(rng=lambda k: np.random.default_rng(k)), probs, dev), TypeError)
+    assert "traced" in str(lockstep.why_not_pipelined(made(trace=True), probs, dev))
+    assert isinstance(lockstep.why_not_pipelined(made(ctor={"m": 0}), probs, dev), ValueError)
+    assert isinstance(lockstep.why_not_pipelined(made(ctor={"m": 65}), probs, dev), ValueError)
+    assert isinstance(lockstep.why_not_pipelined(made(ctor={"m": 2.5}), probs, dev), ValueError)
+    mixed = made()
+    mixed[1] = solvers.CCQPSolverBBPGD(1e-8, 100)
+    assert isinstance(lockstep.why_not_pipelined(mixed, probs, dev), TypeError)
