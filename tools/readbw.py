@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""What read bandwidth does this MI355X give a kernel that does NOTHING but stream the 128 GiB of the headline matrix?
+(tools/readbw.hip: each wave sums 1 MiB segments with 16-byte non-temporal loads, the matvec's access pattern without
+x, fma chains or the butterfly.)  Launch shapes: one persistent grid, one wave per segment, rounds that fill the machine
+once.  The best of them is the practical ceiling the matvec's 7.04 TB/s is to be read against.
+Compiles the kernel with hipcc into $TMPDIR at run time.      python tools/readbw.py"""
+import ctypes, json, os, subprocess, sys, tempfile
+import numpy as np, torch
+_here = os.path.dirname(os.path.abspath(__file__))
+_so = os.path.join(tempfile.gettempdir(), "libreadbw_%d.so" % os.getpid())
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", _so, os.path.join(_here, "readbw.hip")])
+lib = ctypes.CDLL(_so)
+lib.readbw_launch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+n = 131072
+A = torch.empty((n, n), dtype=torch.float64, device="cuda")
+A.fill_(1.0)
+out = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+def run(seg, grid_per_launch, rows_per_launch, U, nt):
+    nseg_total = n * n // seg
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    done = 0
+    while done < nseg_total:
+        k = min(rows_per_launch, nseg_total - done)
+        assert lib.readbw_launch(A.data_ptr() + done * seg * 8, seg, k, out.data_ptr(), grid_per_launch, U, nt, st) == 0
+        done += k
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+cfgs = []
+for U in (2, 4, 8):
+    cfgs += [("persistent grid 2048", n, 2048, n, U, 1), ("rounds 8192 segs/launch, 2048 wg", n, 2048, 8192, U, 1),
+             ("one wave per segment, 32768 wg", n, 32768, n, U, 1), ("rounds 4096 segs, 1024 wg", n, 1024, 4096, U, 1)]
+cfgs += [("seg 32768 doubles, one wave per seg, rounds 32768 segs, 8192 wg", 32768, 8192, 32768, 4, 1),
+         ("seg 524288, rounds 8192 segs, 2048 wg", 524288, 2048, 8192, 4, 1),
+         ("cached loads, rounds 8192", n, 2048, 8192, 2, 0)]
+res = {i: [] for i in range(len(cfgs))}
+for i, c in enumerate(cfgs): run(*c[1:])
+for rep in range(4):
+    for i, c in enumerate(cfgs):
+        res[i].append(run(*c[1:]))
+for i, c in enumerate(cfgs):
+    t = float(np.median(res[i]))
+    print(json.dumps({"config": c[0], "U": c[4], "ms": round(t, 3), "TBps": round(8.0 * n * n / t / 1e9, 3)}))
