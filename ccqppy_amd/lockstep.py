@@ -537,9 +537,11 @@ def _draw_source(rng):
     return _capsule_pointer(rng._bit_generator.capsule, b"BitGenerator")
 
 
-def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None):
+def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None, params=None):
     """Lock-step SPG over `spec` (ccqp_bspg.hip): the vector work of every problem on the device, the scalar part of
-    each iteration on the host inside ONE C call per few hundred rounds.  Returns (host records, (B, n) x plane)."""
+    each iteration on the host inside ONE C call per few hundred rounds.  The solver parameters and generators come
+    from `solvers` (CCQPSolverSPG objects) or from `params` = (m, tau, sigma1, sigma2) (scalars or one per problem) +
+    `rngs`.  Returns (host records, (B, n) x plane)."""
     import ctypes
     from . import _lib
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
@@ -567,10 +569,10 @@ def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None):
     host = np.zeros(B, dtype=np.dtype(_lib.SpgHost))
     host["tol"] = spec.tol
     host["max_mv"] = max_mv
-    host["tau"] = [s.t for s in solvers]
-    host["sigma1"] = [s.sigma1 for s in solvers]
-    host["sigma2"] = [s.sigma2 for s in solvers]
-    host["m"] = [s.m for s in solvers]
+    if params is None:
+        params = ([s.m for s in solvers], [s.t for s in solvers], [s.sigma1 for s in solvers],
+                  [s.sigma2 for s in solvers])
+    host["m"], host["tau"], host["sigma1"], host["sigma2"] = params
     qstride = int(host["m"].max())
     queue = np.zeros((B, qstride))
     sources = np.array([_draw_source(r) for r in (rngs if rngs is not None else [s.rng for s in solvers])],
@@ -801,13 +803,15 @@ class StackedResult:
 
 
 def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_mv=np.inf, device=None, ahead=4,
-                  tune=0, single_launch=None, step_size=0.01):
+                  tune=0, single_launch=None, step_size=0.01, rngs=None, m=5, tau=0.5, sigma1=0.01, sigma2=0.5):
     """B dense problems of one size handed over as STACKED device tensors -- A (B, n, n), b (B, n), optional x0
     (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
     (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
 
     solver        : "PGD" (constant `step_size`, one or one per problem), "BBPGD", "BBPGDf", "APGD",
-                    "APGDAntiRelaxation", "MPRGP", or the solver class
+                    "APGDAntiRelaxation", "MPRGP", "SPG" (`rngs`: B distinct np.random.RandomState objects, problem p
+                    draws from rngs[p] and leaves it where its own solve would; m, tau, sigma1, sigma2: SPG's
+                    parameters), or the solver class
     lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
                     Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
                     (scalar ones raise in the reference's normal_vector).
@@ -820,10 +824,11 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     t0 = time.time()
     name = solver if isinstance(solver, str) else {sv.CCQPSolverBBPGD: "BBPGD", sv.CCQPSolverAPGD: "APGD",
                                                    sv.CCQPSolverMPRGP: "MPRGP", sv.CCQPSolverPGD: "PGD",
-                                                   sv.CCQPSolverBBPGDf: "BBPGDf",
+                                                   sv.CCQPSolverBBPGDf: "BBPGDf", sv.CCQPSolverSPG: "SPG",
                                                    sv.CCQPSolverAPGDAntiRelaxation: "APGDAntiRelaxation"}.get(solver)
-    if name not in ("PGD", "BBPGD", "BBPGDf", "APGD", "APGDAntiRelaxation", "MPRGP"):
-        raise TypeError("solve_stacked runs PGD, BBPGD, BBPGDf, APGD, APGDAntiRelaxation or MPRGP, got %r" % (solver,))
+    if name not in ("PGD", "BBPGD", "BBPGDf", "APGD", "APGDAntiRelaxation", "MPRGP", "SPG"):
+        raise TypeError("solve_stacked runs PGD, BBPGD, BBPGDf, APGD, APGDAntiRelaxation, MPRGP or SPG, got %r"
+                        % (solver,))
     eng = get_engine(device if device is not None else (A.device if isinstance(A, torch.Tensor) else None))
     eng.bind()
     A = eng.to_device(A) if not (isinstance(A, torch.Tensor) and A.dtype == torch.float64 and A.device == eng.device) else A
@@ -844,6 +849,14 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     b = eng.to_device(b).reshape(B, n)
     if x0 is not None:
         x0 = eng.to_device(x0).reshape(B, n)
+    if name == "SPG":
+        rngs = list(rngs) if rngs is not None else []
+        if len(rngs) != B or not all(isinstance(r, np.random.RandomState) for r in rngs) or \
+                len({id(r) for r in rngs}) != B:
+            raise TypeError("solve_stacked('SPG', ...) needs rngs = B distinct np.random.RandomState objects (numpy's "
+                            "global stream cannot be shared by problems that advance together)")
+        if not (isinstance(m, (int, np.integer)) and 1 <= m <= _SPG_MAX_M):
+            raise ValueError("solve_stacked: SPG's queue length m must be an integer in [1, %d]" % _SPG_MAX_M)
 
     def is_scalar(v):
         return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
@@ -896,6 +909,14 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
                                              ar=name == "APGDAntiRelaxation")
             execd = mv
             todo = np.flatnonzero(~done)
+        elif name == "SPG":
+            host, sols = _bspg_run(eng, sp, None, n, max_mv, tune, rngs=rngs, params=(m, tau, sigma1, sigma2))
+            mv, res = host["mv"].copy(), np.sqrt(host["dd"])
+            execd = mv - (host["status"] == 2)           # (the matvec that ends a budget is counted, not executed)
+            todo = np.flatnonzero(host["status"] == 3)
+            for p in todo:
+                if host["used"][p]:                      # the reference's draw raises here: numpy's own OverflowError
+                    np.random.RandomState(0).uniform(low=0.0, high=np.nan)
         else:
             status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             todo = np.flatnonzero(status != 1.0)
@@ -922,7 +943,10 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             with contextlib.redirect_stdout(io.StringIO()):
                 args = (float(sp.tol[p]), max_mv) + ((float(sp.step[p]),) if name == "PGD" else ())
                 stats["fallback_solves"] += 1
-                s = cls(*args).solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
+                s = cls(*args) if name != "SPG" else cls(*args, m=m, tau=tau, sigma1=sigma1, sigma2=sigma2)
+                if name == "SPG":                        # (nothing drawn yet: the host loop raises what the reference raises)
+                    s.rng = rngs[p]
+                s = s.solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
             sols[p].copy_(s.solution)
             res[p], mv[p] = s.solution_residual, s.solution_num_matrix_vector_multiplications
             execd[p] = s.executed_matrix_vector_multiplications

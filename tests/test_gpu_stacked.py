@@ -99,6 +99,42 @@ def test_stacked_pgd():
             assert torch.equal(a.solution, r.solution[p])
 
 
+def test_stacked_spg():
+    """solve_stacked("SPG", ..., rngs=[RandomState, ...]): problem p draws from rngs[p] and leaves it where its own
+    solve would (ccqp_bspg.hip); non-default parameters, per-problem tolerances, warm starts, budgets."""
+    import torch
+    from ccqppy_amd import batch, lockstep, solvers, solution_spaces as ss
+    n, B = 160, 40                                       # (>= 32: the two alternating halves of the C driver)
+    A, b = _stack(n, B, 300)
+    rs = np.random.default_rng(8)
+    lo, up = -rs.uniform(0.1, 0.5, n), rs.uniform(0.1, 0.5, n)
+    tols = 10.0 ** rs.uniform(-9, -3, B)
+    x0 = torch.as_tensor(rs.uniform(-0.3, 0.3, (B, n)), device="cuda")
+    kw = dict(m=3, tau=0.4, sigma1=0.02, sigma2=0.6)
+    for cap in (5000, 23, 4):
+        rngs = [np.random.RandomState(100 + p) for p in range(B)]
+        before = dict(lockstep.stats)
+        r = batch.solve_stacked("SPG", A, b, x0=x0, lower=lo, upper=up, tol=tols, max_mv=cap, rngs=rngs, **kw)
+        assert lockstep.stats == before
+        for p in range(B):
+            a = solvers.CCQPSolverSPG(float(tols[p]), cap, **kw)
+            a.rng = np.random.RandomState(100 + p)
+            with contextlib.redirect_stdout(io.StringIO()):
+                a.solve(A[p], b[p], x0=x0[p], convex_proj_op=ss.BoxProjOp(n, lo, up))
+            assert a.solution_num_matrix_vector_multiplications == r.num_matrix_vector_multiplications[p]
+            assert bool(a.solution_converged) == bool(r.converged[p])
+            assert float(a.solution_residual) == float(r.residual[p])
+            assert torch.equal(a.solution, r.solution[p])
+            sa, sc = a.rng.get_state(), rngs[p].get_state()
+            assert sa[2] == sc[2] and np.array_equal(sa[1], sc[1])
+    with pytest.raises(TypeError, match="RandomState"):
+        batch.solve_stacked("SPG", A, b)
+    with pytest.raises(TypeError, match="RandomState"):
+        batch.solve_stacked("SPG", A, b, rngs=[np.random.RandomState(0)] * B)
+    with pytest.raises(UnboundLocalError):               # max_mv <= 3: the reference dies before its first d.d
+        batch.solve_stacked("SPG", A, b, max_mv=3, rngs=[np.random.RandomState(p) for p in range(B)])
+
+
 def test_stacked_forms_of_the_inputs():
     import torch
     from ccqppy_amd import batch, solution_spaces as ss

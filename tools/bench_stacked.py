@@ -2,7 +2,8 @@
 """Throughput of batch.solve_stacked: B dense box-QPs of size n as stacked tensors (random SPD matrices from the
 device generator, Box +-0.5, tol 1e-8; MPRGP 1e-6 / 300 matvecs), no per-problem host work.  One JSON line per
 (solver, n): problems/s, matvecs per problem, bytes of matrix the matvecs read per second.
-   python tools/bench_stacked.py [--solvers BBPGD,APGD,MPRGP] [n:B ...]"""
+   python tools/bench_stacked.py [--solvers BBPGD,APGD,MPRGP,SPG] [n:B ...]
+SPG (lock-step only, ccqp_bspg.hip): problem p draws from its own RandomState, created outside the timed region."""
 import json
 import os
 import sys
@@ -37,13 +38,17 @@ def main():
             if name == "MPRGP" and n <= 64:
                 continue
             tol, cap = (1e-6, 300) if name == "MPRGP" else (1e-8, 5000)
-            forms = [False, True] if n <= 2048 else [False]
+            forms = [False, True] if n <= 2048 and name != "SPG" else [False]
             for single in forms:
                 kw = {} if single is None else {"single_launch": single}
+                if name == "SPG":
+                    kw["rngs"] = [np.random.RandomState(p) for p in range(B)]
                 r = batch.solve_stacked(name, A, b, lower=lo, upper=up, tol=tol, max_mv=cap, **kw)
                 torch.cuda.synchronize()
                 best = 0.0
                 for _ in range(3):
+                    if name == "SPG":
+                        kw["rngs"] = [np.random.RandomState(p) for p in range(B)]
                     t0 = time.perf_counter()
                     r = batch.solve_stacked(name, A, b, lower=lo, upper=up, tol=tol, max_mv=cap, **kw)
                     torch.cuda.synchronize()
