@@ -410,6 +410,33 @@ def solver_cases():
     for s in ("APGD", "APGDAntiRelaxation"):
         cases.append(dict(id="nan.%s.x0_ones" % s, problem="gen:64:1234", solver=s, tol=1e-8, max_mv=14, kwargs={},
                           op=_box_half(64), rng_seed=1234, x0="ones"))
+    # SPG-QP beyond the Box: every kind of set, non-default parameters, budgets that end mid-run, a warm start, other
+    # sizes and generator seeds -- pins the lock-step SPG driver (ccqp_bspg.hip) directly against the reference
+    for n, seed in ((96, 21), (257, 22), (1024, 23)):
+        g = "gen:%d:%d" % (n, seed)
+        nsph = n // 3
+        many = {"kind": "Disjoint", "repeat": {"op": {"kind": "Sphere", "dim": 3, "radius": 0.3}, "count": nsph}}
+        if n - 3 * nsph:
+            many["ops"] = [{"kind": "Identity", "dim": n - 3 * nsph}]
+        q = n // 4
+        mix = {"kind": "Disjoint", "ops": [
+            {"kind": "Box", "dim": q, "lb": {"fill": -0.3}, "ub": {"fill": 0.4}},
+            {"kind": "Sphere", "dim": q, "radius": 0.7},
+            {"kind": "Upper", "dim": q, "ub": {"fill": 0.2}},
+            {"kind": "Sphere", "dim": n - 3 * q, "radius": 2.0}]}
+        tab = [("lower", {"kind": "Lower", "dim": n, "lb": {"fill": -0.2}}, {}, 5000, None, 31),
+               ("identity", None, {"m": 2}, 5000, None, 32),
+               ("sphere", {"kind": "Sphere", "dim": n, "radius": 2.0}, {"tau": 0.7}, 5000, None, 33),
+               ("spheres3", many, {"m": 8, "sigma2": 0.9}, 5000, None, 34),
+               ("mix", mix, {"sigma1": 0.1}, 5000, "ramp", 35),
+               ("mix.max23", mix, {}, 23, None, 36),
+               ("sphere.max7", {"kind": "Sphere", "dim": n, "radius": 2.0}, {}, 7, None, 37)]
+        for tag, op, kw, mx, x0, rs in tab:
+            c = dict(id="spgx%d.%s" % (n, tag), problem=g, solver="SPG", tol=1e-8, max_mv=mx, kwargs=kw, op=op,
+                     rng_seed=rs)
+            if x0:
+                c["x0"] = x0
+            cases.append(c)
     # warm start + default (infinite) MV budget
     cases.append(dict(id="warm.BBPGD", problem="gen:256:7", solver="BBPGD", tol=1e-9, max_mv=None, kwargs={},
                       op=_box_half(256), rng_seed=1234, x0="ramp"))
