@@ -39,6 +39,7 @@ def _device_budget(n):
 
 
 _KINDS = None
+_lib_mod = _ss_mod = _dense_op = None
 
 
 def _lockstep_kinds():
@@ -80,9 +81,12 @@ def _why_not_spg(s):
 def _why_not_one(kind, max_mv, s, A, b, P, device):
     """One problem of the argument check: (reason or None, n, the set with the default filled in).  No staging, no
     GPU work."""
-    from . import _lib
-    from . import solution_spaces as ss
-    from .operators import DenseOperator
+    global _lib_mod, _ss_mod, _dense_op
+    if _dense_op is None:                               # (imported once: this runs per problem of a batch)
+        from . import _lib as _lib_mod
+        from . import solution_spaces as _ss_mod
+        from .operators import DenseOperator as _dense_op
+    _lib, ss, DenseOperator = _lib_mod, _ss_mod, _dense_op
     if type(s) is not kind or getattr(s, "reuse_matvec", False):
         return TypeError("solve_batch_pipelined: one solver class for the whole batch"), None, P
     if s.max_matrix_vector_multiplications != max_mv:
