@@ -160,6 +160,11 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   // few waves in flight (a batch of one, or few problems): more loads per lane; large matrices: two rows per wave
   // (short rows: several rows per wave amortise the per-row reduction, profiles/r01g_bpipe_sweep.txt)
   if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : n <= 256 ? 6 : n <= 512 ? 7 : 1);
+  // several rows per wave: no more workgroups than there are tasks (a workgroup beyond that would load its problem's
+  // descriptor and state word only to leave -- at n = 256, four rows per wave, that was three workgroups out of four)
+  const int64_t rows_per_wave = t.U == 7 ? 2 : t.U == 6 ? 4 : 1;
+  const int64_t tasks = (n + rows_per_wave - 1) / rows_per_wave;
+  if (per > (tasks + rows_per_wg - 1) / rows_per_wg) per = (tasks + rows_per_wg - 1) / rows_per_wg;
   t.grid = dim3((unsigned)per, count);
   return t;
 }
