@@ -165,6 +165,17 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   const int64_t rows_per_wave = t.U == 7 ? 2 : t.U == 6 ? 4 : 1;
   const int64_t tasks = (n + rows_per_wave - 1) / rows_per_wave;
   if (per > (tasks + rows_per_wg - 1) / rows_per_wg) per = (tasks + rows_per_wg - 1) / rows_per_wg;
+  // very short rows (n <= 128): a task is only 2-4 KiB of matrix, so let a wave take several (~8 KiB) as long as
+  // the batch still brings >= 4096 workgroups -- the fixed cost of a workgroup (descriptor, state word) is paid
+  // less often: +5-10 % at n = 64 / 128 (sweep of 2026-10-04, profiles/r02c_bpipe_small_n.txt)
+  if ((flags >> 8) == 0) {
+    const int64_t want = 8192 / (rows_per_wave * n * 8);
+    if (want > 1) {
+      int64_t p2 = (tasks + rows_per_wg * want - 1) / (rows_per_wg * want);
+      if (p2 < 2) p2 = 2;
+      if (p2 < per && p2 * count >= 4096) per = p2;
+    }
+  }
   t.grid = dim3((unsigned)per, count);
   return t;
 }
