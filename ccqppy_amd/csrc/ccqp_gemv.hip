@@ -150,7 +150,7 @@ static void launch_mfma(ccqp_ctx* ctx, int U, int bpc, hipStream_t s, const doub
 }
 
 // variant word: bits 0-3 R (rows per wave: 1,2,4,8), bits 4-7 U (unroll: 1,2,4), bit 8 = 1 disables
-// the non-temporal A loads, bit 9 = 1 selects the MFMA form (16 rows per wave; U = columns/16 per step: 1, 2, 4;
+// the non-temporal A loads (matrices of at most 192 MiB are loaded cacheably anyway), bit 9 = 1 selects the MFMA form (16 rows per wave; U = columns/16 per step: 1, 2, 4;
 // shapes it does not cover fall through to the VALU form), bits 10-11 / 20-23 the launch rounds (below), bits 12-19
 // workgroups per CU (0 = default).  0 = tuned default
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
@@ -165,7 +165,10 @@ static gemv_shape gemv_decide(const ccqp_ctx* ctx, int64_t rows, int64_t cols, i
   gemv_shape d;
   d.R = variant & 0xF;
   d.U = (variant >> 4) & 0xF;
-  d.nt = !((variant >> 8) & 1);
+  // non-temporal matrix loads keep a big stream out of the caches (+10 % at 128 GiB); a matrix that fits the 256 MiB
+  // of MALL is re-read from there by the next matvec of a solve if it was loaded cacheably: 5000^2 36.4 -> 30.9 us,
+  // 4096^2 23.6 -> 22.6 us, 8192^2 (512 MiB) 82 us non-temporal vs 91 us cacheable (sweep of 2026-10-04)
+  d.nt = !((variant >> 8) & 1) && (double)rows * (double)cols * 8.0 > 192.0 * 1048576.0;
   d.bpc = (variant >> 12) & 0xFF;
   // ROUNDS (bits 10-11: 1 = on, 2 = off, 0 = by shape; bits 20-23: tasks per wave and round, 0 = 1): the rows are
   // cut into blocks that fill the machine exactly once -- every wave takes its share of ONE block, and the next
