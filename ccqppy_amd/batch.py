@@ -93,8 +93,9 @@ def solve_batch_sharded(make_solver, make_problem, nproblems, group=None, lanes=
     (`make_problem(p)` -> (A, b, x0, op) on this rank's GPU).  Returns {p: solver} for the local
     problems; no collective is issued on the data path.  fused=True uses the lock-step scheduler with batched
     launches (solve_batch_fused, 32 lanes in 2 groups by default), fused=False the one-stream-per-solve scheduler,
-    fused="pipelined" the device-resident lock-step scheduler (solve_batch_pipelined: BBPGD / APGD / MPRGP,
-    equal-size dense problems, elementwise sets); the default "auto" takes the lock-step scheduler where it applies
+    fused="pipelined" the device-resident lock-step scheduler (solve_batch_pipelined: every solver -- SPG with one
+    RandomState per solver --, equal-size dense problems, any set built from the seven operators except under
+    MPRGP); the default "auto" takes the lock-step scheduler where it applies
     and the fused one otherwise (all of them give bitwise the same results).
     gather=True adds ONE exchange after all solves ("host gathers the result vectors at the
     end"): every rank then gets {p: BatchResult} for ALL problems, results as host arrays."""

@@ -293,3 +293,28 @@ def test_two_alternating_halves_give_the_same_bits_as_one_group(monkeypatch, cou
         ref = _reference([probs[i] for i in idx], [tols[i] for i in idx], 3000, [seeds[i] for i in idx], [{}] * 4)
         for i, c in zip(idx, ref):
             _same(two[i], c)
+
+
+def test_batch_sharded_driver_picks_the_lockstep_form_for_spg_with_private_generators():
+    """solve_batch_sharded(fused="auto"): SPG solvers that carry their own RandomState go to the lock-step driver, SPG
+    solvers on numpy's global stream stay on the host-driven scheduler (counted as declined, not as a fall-back)."""
+    from ccqppy_amd import batch, lockstep, solvers
+    n, count = 140, 9
+    probs = _make_problems(n, count, 60, "box")
+    seeds = iter(range(200, 200 + count))
+
+    def make():
+        return _solver(1e-7, 500, next(seeds))
+    before = dict(lockstep.stats)
+    got = batch.solve_batch_sharded(make, lambda p: probs[p], count, gather=True)
+    assert lockstep.stats == before                      # taken by the lock-step scheduler, nothing handed back
+    ref = _reference(probs, [1e-7] * count, 500, list(range(200, 200 + count)), [{}] * count)
+    for p, c in enumerate(ref):
+        assert got[p].solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert float(got[p].solution_residual) == float(c.solution_residual)
+        assert np.array_equal(np.asarray(got[p].solution).view(np.uint64), c.solution.cpu().numpy().view(np.uint64))
+    np.random.seed(3)
+    plain = batch.solve_batch_sharded(lambda: solvers.CCQPSolverSPG(1e-7, 500), lambda p: probs[p], count)
+    assert lockstep.stats["auto_declined"] == before["auto_declined"] + 1
+    assert lockstep.stats["fallback_solves"] == before["fallback_solves"]
+    assert all(s.solution_converged for s in plain.values())
