@@ -220,16 +220,24 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bspg_dots_kernel(const ccqp_pspg* 
   __shared__ int publish;
   if ((int)ctl[4 * blockIdx.y + SPG_MODE] != 1) return;
   const ccqp_pspg& q = probs[blockIdx.y];
-  double v[3];
-  if (start) {
-    v[0] = dot_body(q.g, q.x, n, chunk, blockIdx.x, lds4);
-    v[1] = dot_body(q.g, q.g, n, chunk, blockIdx.x, lds4);
-    v[2] = dot_body(q.g, q.Ad, n, chunk, blockIdx.x, lds4);
-  } else {
-    v[0] = dot_body(q.d, q.d, n, chunk, blockIdx.x, lds4);
-    v[1] = dot_body(q.d, q.Ad, n, chunk, blockIdx.x, lds4);
-    v[2] = dot_body(q.d, q.g, n, chunk, blockIdx.x, lds4);
+  // three dot_body passes in one: per thread the same elements in the same order into one fma chain per product, then
+  // the block sums of ccqp_block_sum taken together (ccqp_block_sum_multi: same bits, two barriers instead of six)
+  const double* __restrict__ u = start ? q.g : q.d;     // {g.x, g.g, g.Ad}  |  {d.d, d.Ad, d.g}
+  const double* __restrict__ w0 = start ? q.x : q.d;
+  const double* __restrict__ w1 = start ? q.g : q.Ad;
+  const double* __restrict__ w2 = start ? q.Ad : q.g;
+  double v[3] = {0.0, 0.0, 0.0};
+  {
+    const int bx = blockIdx.x;
+    CHUNK_RANGE(n)
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double ui = u[i];
+      v[0] = fma(ui, w0[i], v[0]);
+      v[1] = fma(ui, w1[i], v[1]);
+      v[2] = fma(ui, w2[i], v[2]);
+    }
   }
+  ccqp_block_sum_multi<3>(v);
   if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, &is_last)) return;
   // the problem's last block; the batch-wide roll-call decides which block copies the results out
   if (threadIdx.x == 0) {
