@@ -807,7 +807,8 @@ class StackedResult:
 
 
 def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_mv=np.inf, device=None, ahead=4,
-                  tune=0, single_launch=None, step_size=0.01, rngs=None, m=5, tau=0.5, sigma1=0.01, sigma2=0.5):
+                  tune=0, single_launch=None, step_size=0.01, rngs=None, m=5, tau=0.5, sigma1=0.01, sigma2=0.5,
+                  feasible_set=None):
     """B dense problems of one size handed over as STACKED device tensors -- A (B, n, n), b (B, n), optional x0
     (B, n) -- and solved by the lock-step schedulers of solve_batch_pipelined with no per-problem work on the host
     (at n <= 512 a Python loop over the problems costs more than the GPU needs to solve them).
@@ -819,6 +820,9 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     lower / upper : bounds of the feasible set: None, a Python / numpy scalar, an (n,) or a (B, n) array / tensor.
                     Neither -> Identity, one -> Lower / Upper bound, both -> Box.  MPRGP needs array bounds
                     (scalar ones raise in the reference's normal_vector).
+    feasible_set  : instead of lower / upper: ONE *ProjOp of dimension n built from the seven operators (Sphere, Cone,
+                    DisjointUnion of any blocks, ...), shared by all problems -- the segmented lock-step forms
+                    (ccqp_bsegs.hip / ccqp_bspg.hip; every solver but MPRGP)
     tol           : one tolerance or one per problem
     Problem p gets bit for bit the result of `Solver(tol[p], max_mv).solve(A[p], b[p], x0[p], P_p)` with P_p the
     corresponding *ProjOp (tests/test_gpu_stacked.py).  Returns a StackedResult."""
@@ -865,6 +869,19 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     def is_scalar(v):
         return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
 
+    plans = None
+    if feasible_set is not None:
+        if lower is not None or upper is not None:
+            raise ValueError("solve_stacked: either lower / upper or feasible_set")
+        if hasattr(feasible_set, "_dev_bb_tail"):
+            raise TypeError("solve_stacked: an elementwise feasible_set is given through lower / upper")
+        if name == "MPRGP" or not isinstance(feasible_set, ss.ProjOpBase) or not feasible_set._has_device_form():
+            raise TypeError("solve_stacked(feasible_set=...) runs every solver but MPRGP on sets built from the seven "
+                            "operators, got %s with %r" % (name, type(feasible_set).__name__))
+        feasible_set._refresh()
+        if getattr(feasible_set, "_fixed_dim", False) and feasible_set.embedded_dimension != n:
+            raise ValueError("solve_stacked: the feasible set does not match b")
+        plans = [feasible_set._segplan(eng, n)] * B      # (the tables are read-only: one plan for all problems)
     kind = {(False, False): _lib.OP_IDENTITY, (True, False): _lib.OP_LOWER, (False, True): _lib.OP_UPPER,
             (True, True): _lib.OP_BOX}[(lower is not None, upper is not None)]
     if name == "MPRGP" and (is_scalar(lower) or is_scalar(upper) or n <= _lib.SMALL_SEG_MAX):
@@ -905,16 +922,21 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
     out = StackedResult()
     with np.errstate(all="ignore"):
         if name in ("BBPGD", "BBPGDf", "PGD"):
-            done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
+            if plans is not None:
+                done, final, sols, res = _bsegs_run(eng, sp, plans, n, max_mv, ahead, tune)
+                todo = np.zeros(0, dtype=np.int64)
+            else:
+                done, final, sols, res, todo = _bpipe_run(eng, sp, n, max_mv, ahead, tune, single_launch)
             mv = 1 + final
             execd = mv if name == "PGD" else np.where(done & (final == 0), 1, 2 + final)
         elif name in ("APGD", "APGDAntiRelaxation"):
             done, sols, res, mv = _bapgd_run(eng, sp, n, max_mv, ahead, tune, single_launch,
-                                             ar=name == "APGDAntiRelaxation")
+                                             ar=name == "APGDAntiRelaxation", plans=plans)
             execd = mv
             todo = np.flatnonzero(~done)
         elif name == "SPG":
-            host, sols = _bspg_run(eng, sp, None, n, max_mv, tune, rngs=rngs, params=(m, tau, sigma1, sigma2))
+            host, sols = _bspg_run(eng, sp, None, n, max_mv, tune, plans=plans, rngs=rngs,
+                                   params=(m, tau, sigma1, sigma2))
             mv, res = host["mv"].copy(), np.sqrt(host["dd"])
             execd = mv - (host["status"] == 2)           # (the matvec that ends a budget is counted, not executed)
             todo = np.flatnonzero(host["status"] == 3)
@@ -942,7 +964,8 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             return t.cpu().numpy() if isinstance(t, torch.Tensor) else t
         for p in todo:
             lo, up = bound(lower, p), bound(upper, p)
-            P = {_lib.OP_IDENTITY: lambda: ss.IdentityProjOp(n), _lib.OP_LOWER: lambda: ss.LowerBoundProjOp(n, lo),
+            P = feasible_set if feasible_set is not None else \
+                {_lib.OP_IDENTITY: lambda: ss.IdentityProjOp(n), _lib.OP_LOWER: lambda: ss.LowerBoundProjOp(n, lo),
                  _lib.OP_UPPER: lambda: ss.UpperBoundProjOp(n, up), _lib.OP_BOX: lambda: ss.BoxProjOp(n, lo, up)}[kind]()
             with contextlib.redirect_stdout(io.StringIO()):
                 args = (float(sp.tol[p]), max_mv) + ((float(sp.step[p]),) if name == "PGD" else ())
