@@ -385,6 +385,16 @@ int main(void) {
   } else {
     printf("rccl: not available, communicator section skipped\n");
   }
+  /* how a shape will be launched: the small matrix in one launch, the headline matrix in rounds */
+  {
+    int64_t per = 0, launches = 0;
+    CHECK(ccqp_gemv_plan(ctx, n, n, 0, &per, &launches));
+    if (per != n || launches != 1) bad++;
+    CHECK(ccqp_gemv_plan(ctx, 131072, 131072, 0, &per, &launches));
+    if (launches < 2 || per * launches < 131072) bad++;
+    printf("matvec plan: %lld x %lld -> 1 launch; 131072 x 131072 -> %lld launches of %lld rows\n", (long long)n,
+           (long long)n, (long long)launches, (long long)per);
+  }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;
   printf("x.Ax = %.15g, |g|^2 = %.15g, mismatches = %d, last error: %s\n", s[0], s[1], bad, ccqp_last_error());
