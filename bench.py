@@ -20,13 +20,25 @@ Extra objects on the JSON line:
                   launches (gaps between them included); `bytes_per_launch`, `avg_launch_ms` (= that time /
                   launches) and `traffic` are per KERNEL launch, the unit of the rocprofv3 tables under profiles/.
   cpu_baseline -- the numpy oracle (oracle/cpu_ref.py, a port of the reference; OpenBLAS threads =
-                  host cores) solving THE SAME problem (the device matrix copied to the host, n = 131072,
-                  ~60 s of host work) on the GPU box's host, N = 1 only; if the host has less than ~160 GiB
-                  of free RAM the sample is n = 65536 and the figure is scaled by bytes (stated in `sample`).
+                  host cores) solving THE SAME problem (n = 131072, ~60 s of host work) on the GPU box's host, on
+                  rank 0, at every N: at N = 1 the device matrix is copied to the host, at N > 1 rank 0 regenerates the
+                  whole matrix on its own GPU in 8192-row chunks (the generator is row-addressable, so these are the
+                  bits the ranks hold) while the other ranks wait at the final barrier; if the host has less than
+                  ~160 GiB of free RAM the sample is n = 65536 and the figure is scaled by bytes (stated in `sample`).
+                  A failure inside this leg never loses the bench line: `cpu_baseline` is then null and
+                  `cpu_baseline_error` says why.
+  box          -- host name, GPU name / unique id of rank 0's device: ties the line to the rocprofv3 tables taken
+                  on the same box (profiles/*: `box`).
 For N > 1 the roofline object also carries `exchange_ms_per_mv` (HIP events around the per-matvec vector
-exchange), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange time) and `rccl_ranks`.
+exchange), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange time) and `rccl_ranks`, and the line
+an `exchange_ab` object: after the timed steps, untimed, 50 exchanges of the n-vector by each of the three forms
+(torch all_gather_into_tensor | the C ABI's in-place RCCL all-gather on the compute stream | zero-padded
+all-reduce), HIP-event timed on the launch stream, with a check that all three leave the same bits in y on every
+rank -- the line decides by itself which exchange should be the default on the box it ran on.
+Any RCCL error ends the run with a non-zero exit code and RCCL's message on stderr: no retry, no other backend.
 """
 import argparse
+from datetime import timedelta
 import contextlib
 import io
 import json
@@ -104,35 +116,59 @@ def host_available_gib():
     return 0.0
 
 
-def cpu_baseline(op, b, x_gpu, mv_gpu, n_cpu, seed, tol, max_mv, n_metric):
-    """Time the oracle on the host cores.  n_cpu == n_metric: the SAME problem as the GPU solved (the device matrix
-    is copied to the host in row chunks; copy time reported separately, never part of the rate); otherwise a
-    smaller sample of the same generator / settings, scaled by bytes."""
+def cpu_baseline(holder, b, x_gpu, mv_gpu, n_cpu, seed, tol, max_mv, n_metric, device):
+    """Time the oracle on the host cores.  n_cpu == n_metric: the SAME problem as the GPU solved (the matrix reaches
+    the host in 8192-row chunks -- slices of the resident device matrix at N = 1, regenerated rows at N > 1 where this
+    rank holds only its block; copy time reported separately, never part of the rate); otherwise a smaller sample of
+    the same generator / settings, scaled by bytes.  `holder` = [operator]: the ONLY reference to the device matrix;
+    it is cleared here as soon as the matrix is not needed any more, so the HBM really is released."""
     from ccqppy_amd import problems
+    from ccqppy_amd.operators import DenseOperator
     from oracle import cpu_ref
     try:
-        from threadpoolctl import threadpool_info
+        # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank: the baseline is "the host cores", so the BLAS
+        # pool is raised to them here (OpenBLAS caps it at the thread count it was built for), then counted
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(limits=os.cpu_count(), user_api="blas")
         cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] + [1])
     except Exception:  # noqa: BLE001
         cores = os.cpu_count()
-    same = n_cpu == n_metric and op is not None
+    same = n_cpu == n_metric
+    resident = same and isinstance(holder[0], DenseOperator)
     if not same:
-        del op
+        holder[0] = None                                   # free the metric's matrix BEFORE the sample's is built
         torch.cuda.empty_cache()
-        op, b, _ = problems.random_problem(n_cpu, seed)
+    step = 8192
+    if resident:
+        Adev = holder[0].A
+        rows_of = lambda r0, cnt: Adev[r0:r0 + cnt]        # noqa: E731
+        how = "device matrix copied to the host"
+    else:
+        if same:
+            holder[0] = None                               # a row block of a sharded run: not what the oracle needs
+            torch.cuda.empty_cache()
+        rows_of = lambda r0, cnt: problems.spd_rows(n_cpu, seed, r0, cnt, device)   # noqa: E731
+        how = "matrix regenerated on this rank's GPU in %d-row chunks and copied to the host" % step
     t0 = time.perf_counter()
     A = np.empty((n_cpu, n_cpu), dtype=np.float64)
-    step = 8192
     for r0 in range(0, n_cpu, step):
-        A[r0:r0 + step] = op.A[r0:r0 + step].cpu().numpy()
+        cnt = min(step, n_cpu - r0)
+        A[r0:r0 + cnt] = rows_of(r0, cnt).cpu().numpy()
         if (r0 // step) % 4 == 3:
-            print("[bench] cpu_baseline: copied rows %d / %d to the host" % (r0 + step, n_cpu), file=sys.stderr, flush=True)
+            print("[bench] cpu_baseline: rows %d / %d on the host" % (r0 + cnt, n_cpu), file=sys.stderr, flush=True)
     t_copy = time.perf_counter() - t0
-    bb = b.cpu().numpy()
-    del op
+    if same:
+        bb = b.cpu().numpy()
+    else:
+        # b = -A.xstar of the SAMPLE problem, by the host (the sample is only timed, never compared with the GPU)
+        from ccqppy_amd.problems import xstar
+        bb = -A.dot(xstar(n_cpu, seed, device).cpu().numpy())
+    rows_of = Adev = None
+    holder[0] = None
     torch.cuda.empty_cache()
     lb, ub = -0.5 * np.ones(n_cpu), 0.5 * np.ones(n_cpu)
-    A[:min(n_cpu, 16384)].dot(bb)                          # warm the BLAS thread pool
+    for _ in range(2):
+        A[:min(n_cpu, 16384)].dot(bb)                      # warm the BLAS thread pool (threads are created on first use)
     print("[bench] cpu_baseline: oracle solve at n=%d on %d BLAS threads ..." % (n_cpu, cores), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     r = cpu_ref.solve_apgd(A, bb, tol, max_mv, P=cpu_ref.Box(n_cpu, lb, ub))
@@ -151,6 +187,7 @@ def cpu_baseline(op, b, x_gpu, mv_gpu, n_cpu, seed, tol, max_mv, n_metric):
         "reported_mv": int(r.solution_num_matrix_vector_multiplications),
         "solve_s": dt,
         "matrix_copy_to_host_s": t_copy,
+        "matrix_source": how,
         "host_cpus": os.cpu_count(),
     }
     if same and x_gpu is not None:
@@ -162,7 +199,108 @@ def cpu_baseline(op, b, x_gpu, mv_gpu, n_cpu, seed, tol, max_mv, n_metric):
     return out
 
 
+def box_id(device_index):
+    """Identity of the box a number was measured on: host name + the GPU's name and unique id (torch's device
+    properties; the KFD topology's `unique_id` when torch does not expose one)."""
+    import socket
+    out = {"host": socket.gethostname()}
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        out["gpu"] = pr.name
+        out["arch"] = getattr(pr, "gcnArchName", None)
+        uid = getattr(pr, "uuid", None)
+        if uid is not None:
+            out["gpu_uuid"] = str(uid)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import glob
+        ids = []
+        for f in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+            kv = dict(ln.split(None, 1) for ln in open(f).read().splitlines() if " " in ln)
+            if int(kv.get("simd_count", "0")) > 0:
+                ids.append("%x" % int(kv.get("unique_id", "0")))
+        out["kfd_unique_ids"] = ids
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+def exchange_ab(op, eng, group, backend, reps=50):
+    """N > 1, untimed: the three forms of the per-matvec vector exchange, `reps` calls each, HIP events on the launch
+    stream (first call of each form untimed: communicator / buffer set-up), and a check that all three leave the same
+    bits in y.  The vector exchanged is a real A.x slab (this rank's row block times x*); before every form the rest
+    of y is filled with NaN so that an entry a form failed to deliver cannot pass.  (Zero-padded all-reduce: x + 0 + ...
+    + 0 is exact except that it turns -0.0 into +0.0; the slab of a random matvec holds no zero.)"""
+    import torch.distributed as dist
+    from ccqppy_amd.operators import VectorExchange
+    from ccqppy_amd.problems import xstar
+    n, world = op.n, dist.get_world_size(group)
+    x = xstar(n, 99, eng.device)
+    sl = slice(op.row0, op.row0 + op.rows)
+    slab = eng.empty(op.rows)
+    eng.gemv(op.A, x, slab)
+    out, ys = {}, {}
+    for mode in ("allgather", "direct", "allreduce"):
+        if mode == "direct" and backend != "nccl":
+            out[mode] = "unavailable: %s" % backend
+            continue
+        ex = VectorExchange(n, group, mode)
+        ex.open(eng)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device=eng.device)
+        y[sl] = slab
+        ex(y, eng)                                      # set-up call, untimed
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        ex.events = []
+        for _ in range(reps):
+            ex(y, eng)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b_) for a, b_ in ex.events]
+        ex.events = None
+        # the timed calls re-exchange an already complete y; the bit check is on a fresh NaN-filled one
+        y.fill_(float("nan"))
+        y[sl] = slab
+        ex(y, eng)
+        torch.cuda.synchronize()
+        ys[mode] = y.view(torch.int64).clone()
+        out[mode] = {"mean_ms": float(np.mean(ms)), "median_ms": float(np.median(ms)), "min_ms": float(np.min(ms)),
+                     "max_ms": float(np.max(ms)), "calls": reps, "bytes_moved_per_rank": 8 * (n if mode == "allreduce" else op.rows),
+                     "launches_besides_the_collective": {"allgather": 1, "direct": 0, "allreduce": 2}[mode] if n % world == 0 else None}
+        ex.close()
+    names = list(ys)
+    same = all(bool(torch.equal(ys[names[0]], ys[m])) for m in names[1:])
+    # the same bits on every rank: xor-fold of the words, compared across ranks on the host
+    fold = int(torch.bitwise_xor(ys[names[0]][0::2], ys[names[0]][1::2]).sum().item()) if n % 2 == 0 else \
+        int(ys[names[0]].sum().item())
+    folds = [None] * world
+    dist.all_gather_object(folds, (fold, same), group=group)
+    out["bitwise_equal_forms"] = bool(all(f[1] for f in folds))
+    out["bitwise_equal_ranks"] = bool(all(f[0] == folds[0][0] for f in folds))
+    out["no_nan_left"] = not bool(torch.isnan(ys[names[0]].view(torch.float64)).any().item())
+    timed = {m: out[m]["median_ms"] for m in names}
+    out["fastest"] = min(timed, key=timed.get)
+    out["note"] = "HIP events on the launch stream around each call (rank 0's clock; includes waiting for the slowest rank)"
+    return out
+
+
 def main():
+    try:
+        _main()
+    except BaseException as e:  # noqa: BLE001
+        if isinstance(e, SystemExit):
+            raise
+        # a failed collective (RCCL) or kernel: the message, a non-zero exit code, nothing else -- no second attempt and
+        # no other backend in this process; os._exit because a process group with a failed collective may hang in
+        # its destructor, and torchrun ends the other ranks when one exits non-zero
+        import traceback
+        traceback.print_exc()
+        print("[bench] rank %s: FATAL %s: %s" % (os.environ.get("RANK", "0"), type(e).__name__, e), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(1)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -175,6 +313,7 @@ def main():
                     help="N > 1: torch.distributed all_gather_into_tensor (default) | zero-padded all_reduce | 'direct' = the "
                          "in-place RCCL all-gather of the C ABI on the compute stream (ccqp_comm_allgather_f64)")
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
+    ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the untimed A/B of the three exchanges")
     ap.add_argument("--cpu-n", type=int, default=-1,
                     help="size of the CPU-baseline problem (0 = skip); default: the metric's own n when the host has "
                          ">= 160 GiB of free RAM (~30 s copy + ~60 s oracle solve), else 65536")
@@ -196,9 +335,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(minutes=30))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timedelta(minutes=30))
         group = dist.group.WORLD
 
     from ccqppy_amd import problems, solvers, solution_spaces as ss
@@ -294,8 +433,15 @@ def main():
         except torch.cuda.OutOfMemoryError:
             sym_info = {"note": "skipped: no room for the n^2/32 workspace"}
 
+    ab = None
+    if world > 1 and not args.no_exchange_ab:
+        ab = exchange_ab(op, eng, group, backend)
+        barrier()
+
+    rows_local = op.rows
+    holder = [op]
+    del op                      # from here on `holder` owns the matrix (cpu_baseline releases it)
     if rank == 0:
-        rows_local = op.rows
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
         achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
         rows_per_launch, launches = eng.gemv_plan(rows_local, n)
@@ -365,16 +511,23 @@ def main():
                 "exchange_backend": None if exch is None else exch.backend,
             },
         }
+        line["box"] = box_id(local_rank)
+        if ab is not None:
+            line["exchange_ab"] = ab
         cpu_n = args.cpu_n
         if cpu_n < 0:
             need = 8.0 * n * n / 2.0 ** 30 + 24.0
             cpu_n = n if host_available_gib() >= need else min(n, 65536)
-        if world == 1 and cpu_n > 0:
+        line["cpu_baseline"] = None
+        if cpu_n > 0:
             x_gpu = last.solution.cpu().numpy() if isinstance(last.solution, torch.Tensor) else np.asarray(last.solution)
-            line["cpu_baseline"] = cpu_baseline(op, b, x_gpu, last.solution_num_matrix_vector_multiplications, cpu_n,
-                                                args.seed, args.tol, args.max_mv, n)
-        else:
-            line["cpu_baseline"] = None
+            try:
+                line["cpu_baseline"] = cpu_baseline(holder, b, x_gpu, last.solution_num_matrix_vector_multiplications,
+                                                    cpu_n, args.seed, args.tol, args.max_mv, n, local_rank)
+            except Exception as e:  # noqa: BLE001  (the timed region succeeded: keep the line)
+                import traceback
+                traceback.print_exc()
+                line["cpu_baseline_error"] = "%s: %s" % (type(e).__name__, e)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

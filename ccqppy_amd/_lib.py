@@ -127,6 +127,8 @@ SIGNATURES = {
     "ccqp_scalars_devptr": [_P, _c.POINTER(_P)],
     "ccqp_gemv_f64": [_P, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "ccqp_gemv_plan": [_P, _I64, _I64, _I, _c.POINTER(_I64), _c.POINTER(_I64)],
+    "ccqp_mv_timing_begin": [_I],
+    "ccqp_mv_timing_end": [_c.POINTER(_c.c_double), _I, _c.POINTER(_I)],
     "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
     "ccqp_axpby_f64": [_P, _D, _P, _D, _P, _P, _I64, _P],
     "ccqp_axpby2_f64": [_P, _D, _P, _D, _P, _P, _D, _P, _D, _P, _P, _I64, _P],

@@ -50,6 +50,26 @@ enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 #define MP_STEPS 24     // a multiple of 8
 #define MP_MAX_CANDIDATES 1208
 
+// entry snapshot of a problem's steering words (ccqp_lockstep.h: the meeting-point invariant)
+struct mp_words {
+  double done, state, it, mv, exec, dist2, ng, af, tried, acg;
+};
+__device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
+  mp_words z;
+  z.done = slab[MP_DONE];
+  z.state = slab[MP_STATE];
+  z.it = slab[MP_IT];
+  z.mv = slab[MP_MV];
+  z.exec = slab[MP_EXEC];
+  z.dist2 = slab[MP_DIST2];
+  z.ng = slab[MP_NG];
+  z.af = slab[MP_AF];
+  z.tried = slab[MP_TRIED];
+  z.acg = slab[MP_ACG];
+  __syncthreads();
+  return z;
+}
+
 __device__ __forceinline__ double mp_lin(double a, double x, double b, double y) {   // axpby_body, one element
   const double t1 = a * x;
   const double t2 = b * y;
@@ -156,7 +176,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_
 // alpha_bb = g.g / g.Ag (:1077), then g_{k+1} = copy(g_k) and p = phi(x_k, g_k) (:1066, :1081)
 __device__ __forceinline__ void bmprgp_init_alpha_body(const ccqp_pmprgp& q, int64_t n, int64_t chunk, int nblk, int bx,
                                                        double* lds4, int* is_last_p) {
-  if (q.slab[MP_DONE] != 0.0) return;
+  const mp_words z = mp_enter(q.slab);
+  if (z.done != 0.0) return;
   double v[2];
   v[0] = dot_body(q.G[0], q.G[0], n, chunk, bx, lds4);
   v[1] = dot_body(q.G[0], q.Adx, n, chunk, bx, lds4);
@@ -195,8 +216,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pm
 // ---------------------------------------------------------------------------------------------------- the stages
 // tail of an outer iteration (solvers.py:1184-1192): BB step length, exit test, swap of the iterates
 template <bool LOCKSTEP>
-__device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double s1, double r2, double eps10,
-                                        unsigned* batch) {
+__device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, const mp_words& z, double s0, double s1, double r2,
+                                        double eps10, unsigned* batch) {
   double* s = q.slab;
   const double den = s1 + eps10;
   s[MP_ABB] = s0 / den;
@@ -206,7 +227,7 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, double s0, double 
     s[MP_DONE] = 1.0;
     if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    s[MP_IT] = s[MP_IT] + 1.0;
+    s[MP_IT] = z.it + 1.0;
     s[MP_STATE] = (double)ST_M1;
   }
 }
@@ -218,15 +239,16 @@ template <bool LOCKSTEP>
 __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stage, int bx, double gd, double eps10,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
                                                   unsigned count, double seq, double* lds4, int* is_last_p) {
-  double* s = q.slab;
-  if (s[MP_DONE] != 0.0) {
+  double* s = q.slab;                         // written only (by the deciding thread); read through `z` alone
+  const mp_words z = mp_enter(s);
+  if (z.done != 0.0) {
     if (LOCKSTEP && stage == 3 && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
   const ccqp_segk sg = bp_segk_of(q);
   const int64_t n = sg.dim;
-  const int st = (int)s[MP_STATE];
-  const int it = (int)s[MP_IT];
+  const int st = (int)z.state;
+  const int it = (int)z.it;
   double* xk = q.X[it & 1];
   double* xk1 = q.X[(it + 1) & 1];
   double* gk = q.G[it & 1];
@@ -240,8 +262,8 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
         if (threadIdx.x == 0) {
           s[MP_DIST2] = v[0];
           s[MP_ACT] = (double)ACT_NONE;
-          s[MP_MV] = s[MP_MV] + 1.0;
-          s[MP_EXEC] = s[MP_EXEC] + 1.0;
+          s[MP_MV] = z.mv + 1.0;
+          s[MP_EXEC] = z.exec + 1.0;
           s[MP_STATE] = (double)ST_M1_N;
         }
         return;
@@ -259,8 +281,8 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           s[MP_AF] = acg + eps10;             // :1111
           s[MP_TRIED] = 0.0;
           s[MP_ACT] = (double)ACT_NONE;
-          s[MP_MV] = s[MP_MV] + 1.0;
-          s[MP_EXEC] = s[MP_EXEC] + 1.0;
+          s[MP_MV] = z.mv + 1.0;
+          s[MP_EXEC] = z.exec + 1.0;
           s[MP_STATE] = (double)ST_FEAS_NOW;
         }
         return;
@@ -271,8 +293,8 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
         if (threadIdx.x == 0) {
           if (st == ST_G1) {
             s[MP_ACT] = (double)ACT_AFTER_G1;
-            s[MP_MV] = s[MP_MV] + 1.0;
-            s[MP_EXEC] = s[MP_EXEC] + 1.0;
+            s[MP_MV] = z.mv + 1.0;
+            s[MP_EXEC] = z.exec + 1.0;
             s[MP_STATE] = (double)ST_ADXH;
           } else {
             s[MP_ACT] = (double)ACT_NONE;
@@ -314,8 +336,8 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           s[MP_S0] = v[0];
           s[MP_S1] = v[1];
           s[MP_ACT] = (double)ACT_NONE;
-          s[MP_EXEC] = s[MP_EXEC] + 1.0;
-          mp_tail<LOCKSTEP>(q, v[0], v[1], v[2], eps10, batch);
+          s[MP_EXEC] = z.exec + 1.0;
+          mp_tail<LOCKSTEP>(q, z, v[0], v[1], v[2], eps10, batch);
         }
         return;
       }
@@ -325,14 +347,14 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
   }
   if (stage == 2) {
     if (st == ST_M1_N) {                      // :1095
-      v[0] = normal_dot_body(sg, q.txk, gk, q.nv, s[MP_DIST2], chunk, bx, lds4);
+      v[0] = normal_dot_body(sg, q.txk, gk, q.nv, z.dist2, chunk, bx, lds4);
       if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
       if (threadIdx.x == 0) {
         s[MP_NG] = v[0];
         s[MP_STATE] = (double)ST_M1_P;
       }
     } else if (st == ST_FEAS_NOW) {           // :1112-1118, MP_STEPS candidates per pass
-      const double a0 = s[MP_AF];
+      const double a0 = z.af;
       {
         // feasible_body for the MP_STEPS candidates with ONE pair of barriers instead of one per candidate: the wave
         // sums go to LDS as they come, the four of each candidate are added (wave 0..3, as ccqp_block_sum) at the end
@@ -364,9 +386,9 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           }
         }
         s[MP_AF] = af;
-        const double tried = s[MP_TRIED];
+        const double tried = z.tried;
         if (found && tried + (double)at < (double)MP_MAX_CANDIDATES) {
-          if (s[MP_ACG] <= af) {              // :1120
+          if (z.acg <= af) {                  // :1120
             s[MP_ACT] = (double)ACT_CGFULL;
             s[MP_STATE] = (double)ST_ADXC;
           } else {
@@ -386,7 +408,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
   }
   // stage 3
   if (st == ST_M1_P) {                        // :1096-1099
-    proportion_body(q.w, gk, q.nv, q.psi, s[MP_NG], n, chunk, bx, lds4, &v[0], &v[1]);
+    proportion_body(q.w, gk, q.nv, q.psi, z.ng, n, chunk, bx, lds4, &v[0], &v[1]);
     if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
     if (threadIdx.x == 0) {
       s[MP_S0] = v[0];
@@ -405,7 +427,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
     return;
   }
   if (st == ST_HALF3) {                       // :1140-1147: xh, gh, dx, dg formed on the fly, rounded as the axpbys
-    const double maf = -s[MP_AF];
+    const double maf = -z.af;
     CHUNK_RANGE(n)
     double a0 = 0.0, a1 = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {

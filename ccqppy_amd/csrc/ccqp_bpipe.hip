@@ -93,13 +93,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_init_alpha_kernel(const ccqp
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) return;
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) return;
   double v[1];
   v[0] = dot_body(q.g[0], q.y, n, chunk, blockIdx.x, lds4);
   if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     q.slab[1] = v[0];
-    q.slab[BP_ALPHA] = q.slab[BP_GG] / v[0];
+    q.slab[BP_ALPHA] = z.gg / v[0];
   }
 }
 
@@ -150,12 +151,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_a_kernel(const ccqp_pp
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) return;
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) return;
   double v[1];
   v[0] = residual_body(bp_segk_of(q), q.x[inew], q.g[inew], q.c, gd, chunk, blockIdx.x, lds4);
   if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
-  if (threadIdx.x == 0 && bbf_decide_a(q.slab, v[0], q.tol, eps10)) {
-    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+  if (threadIdx.x == 0 && bbf_decide_a(q.slab, z, v[0], q.tol, eps10)) {
+    q.slab[BP_ITERS] = z.iters + 1.0;
     q.slab[BP_DONE] = 1.0;
     __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -169,12 +171,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pp
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) {             // converged (now or earlier): only the roll-call
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) {                      // converged (now or earlier): only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
   double v[2];
-  bbf_tail_b_body(q, bp_segk_of(q), inew, icur, q.slab[BP_IMPROVED] != 0.0, q.slab[BP_FALLBACK] != 0.0, gd, chunk,
+  bbf_tail_b_body(q, bp_segk_of(q), inew, icur, z.improved != 0.0, z.fallback != 0.0, gd, chunk,
                   blockIdx.x, lds4, &v[0], &v[1]);
   if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pp
     q.slab[1] = v[0];
     q.slab[2] = v[1];
     q.slab[BP_ALPHA] = v[0] / den;
-    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    q.slab[BP_ITERS] = z.iters + 1.0;
     bp_report(batch, host, count, seq);
   }
 }
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) {             // converged earlier: only the roll-call
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) {                      // converged earlier: only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
     q.slab[2] = v[2];
     q.slab[BP_RES2] = v[0];
     if (!const_step) q.slab[BP_ALPHA] = v[1] / den;
-    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    q.slab[BP_ITERS] = z.iters + 1.0;
     if (res < q.tol) {
       q.slab[BP_DONE] = 1.0;
       __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -401,14 +405,15 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
 // of a single-launch solve (bx = 0, nblk = 1)
 // ps != NULL: the feasible set is not elementwise -- the problem's n comes from the caller, the residual from the
 // work-item sums the segmented residual launch (ccqp_bsegs.hip) has left in ps->workspace
+// `z`: the caller's entry snapshot of the slab (ap_enter) -- this function only WRITES the slab
 template <bool LOCKSTEP>
-__device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, double gd, int64_t chunk, int nblk,
-                                                  unsigned* batch, double* host, unsigned count, double seq,
-                                                  double* lds4, int* is_last_p, int ar, const ccqp_psegs* ps = nullptr,
-                                                  int64_t n_segs = 0) {
+__device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_words& z, int bx, double gd,
+                                                  int64_t chunk, int nblk, unsigned* batch, double* host,
+                                                  unsigned count, double seq, double* lds4, int* is_last_p, int ar,
+                                                  const ccqp_psegs* ps = nullptr, int64_t n_segs = 0) {
   double* s = q.slab;
   double v[8];
-  if (s[AP_PHASE] == 0.0) {
+  if (z.phase == 0.0) {
     // the matvec of y_k has run; next: the first trial step.  (All blocks meet so that the state changes only
     // after every block has read it.)
     if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, is_last_p)) return;
@@ -416,15 +421,15 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       s[AP_PHASE] = 1.0;
       s[AP_ACT] = 1.0;
       s[AP_FIRST] = 1.0;
-      s[AP_MV] = s[AP_MV] + 1.0;
+      s[AP_MV] = z.mv + 1.0;
       if (LOCKSTEP) bp_report(batch, host, count, seq);
     }
     return;
   }
   const ccqp_segk sg = bp_segk_of(q);
   const int64_t n = ps ? n_segs : sg.dim;
-  const int it = (int)s[AP_IT];
-  const bool first = s[AP_FIRST] != 0.0;
+  const int it = (int)z.it;
+  const bool first = z.first != 0.0;
   const double* __restrict__ x1 = q.X[(it + 1) & 1];
   const double* __restrict__ yk = q.Y[it & 1];
   const double* __restrict__ Ayk = q.Ayk;
@@ -491,13 +496,13 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       s[0] = v[0];
       s[1] = v[1];
     } else {
-      r1 = s[AP_R1];
-      r2 = s[AP_R2];
+      r1 = z.r1;
+      r2 = z.r2;
     }
     for (int k = 2; k < 6; ++k) s[k] = v[k];
     s[6] = v[7];
     s[7] = v[6];
-    double L = s[AP_L];
+    double L = z.L;
     const double l1 = v[2] * 0.5;
     const double l2 = v[3];
     const double r3 = v[4];
@@ -505,9 +510,9 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
     const double r4 = hL * v[5];
     const double lhs = l1 + l2;
     const double rhs = ((r1 + r2) + r3) + r4;
-    s[AP_MV] = s[AP_MV] + 1.0;
+    s[AP_MV] = z.mv + 1.0;
     if (lhs <= rhs) {                                    // solvers.py:302
-      const double thk = s[AP_THK];
+      const double thk = z.thk;
       const double tt = thk * thk;
       const double root = sqrt(4.0 + tt);
       const double m1 = (-thk) * thk;
@@ -518,7 +523,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, int bx, d
       const double res = sqrt(v[6]);
       s[AP_RES2] = v[6];
       bool improved = false;
-      if (ar && res < s[AP_RESMIN]) {                    // :501-503  xhat = copy(x_{k+1})
+      if (ar && res < z.resmin) {                        // :501-503  xhat = copy(x_{k+1})
         s[AP_RESMIN] = res;
         improved = true;
       }
@@ -559,11 +564,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
-  if (q.slab[AP_DONE] != 0.0) {            // converged earlier: only the roll-call
+  const ap_words z = ap_enter(q.slab);
+  if (z.done != 0.0) {                     // converged earlier: only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
-  bapgd_decide_body<true>(q, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar,
+  bapgd_decide_body<true>(q, z, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar,
                           segs ? segs + blockIdx.y : nullptr, n_segs);
 }
 
@@ -711,7 +717,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_bbpgd_kernel(const ccqp_ppr
         const double r = residual_body(sg, q.x[inew], q.g[inew], q.c, gd, chunk, 0, lds4);
         if (threadIdx.x == 0) {
           s[BP_ALPHA] = sh[0];
-          sh[3] = bbf_decide_a(s, r, q.tol, eps10) ? 1.0 : 0.0;
+          bp_words z;                         // (one workgroup owns the slab: thread 0 is its only reader and writer)
+          z.alpha = sh[0];
+          z.resmin = s[BP_RESMIN];
+          sh[3] = bbf_decide_a(s, z, r, q.tol, eps10) ? 1.0 : 0.0;
           sh[1] = r;
         }
         __syncthreads();
@@ -794,13 +803,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_kernel(const ccqp_papg
   bapgd_init_L_body(q, n, chunk, 1, 0, lds4, &is_last);
   __syncthreads();
   for (;;) {
-    if (s[AP_MV] >= mv_limit) break;
+    const ap_words z = ap_enter(s);            // the round's snapshot (the matvec does not change the slab)
+    if (z.done != 0.0 || z.mv >= mv_limit) break;
     bapgd_gemv_body<4, ALIGNED, false>(q, 0, n, wave, nwaves);
     __syncthreads();
-    bapgd_decide_body<false>(q, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar);
+    bapgd_decide_body<false>(q, z, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar);
     __syncthreads();
-    if (s[AP_DONE] != 0.0) break;
-    bapgd_apply_body(q, 0, 1);
+    bapgd_apply_body(q, 0, 1);                 // (nothing to do for a problem that has just converged)
     __syncthreads();
   }
 }

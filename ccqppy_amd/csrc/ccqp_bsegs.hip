@@ -105,7 +105,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tail_kernel(const ccqp_pprob
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) {             // converged earlier: only the roll-call
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) {                      // converged earlier: only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tail_kernel(const ccqp_pprob
   s[2] = v[1];
   s[BP_RES2] = r;
   if (!const_step) s[BP_ALPHA] = v[0] / den;
-  s[BP_ITERS] = s[BP_ITERS] + 1.0;
+  s[BP_ITERS] = z.iters + 1.0;
   if (res < q.tol) {
     s[BP_DONE] = 1.0;
     __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,14 +181,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tailf_a_kernel(const ccqp_pp
                                                                    unsigned* __restrict__ batch) {
   __shared__ double lds4[4];
   const ccqp_pprob& q = probs[blockIdx.x];
-  const bool done = q.slab[BP_DONE] != 0.0;
-  __syncthreads();                          // every wave has read the state before thread 0 may change it
-  if (done) return;
+  const bp_words z = bp_enter(q.slab);      // (one block per problem; the same entry discipline all the same)
+  if (z.done != 0.0) return;
   const ccqp_psegs& ps = segs[blockIdx.x];
   const double* respart = ps.workspace + 3 * ps.npartials;
   const double r = ps.nwork == 1 ? respart[0] : partial_sum_body(respart, ps.nwork, lds4);
-  if (threadIdx.x == 0 && bbf_decide_a(q.slab, r, q.tol, eps10)) {
-    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+  if (threadIdx.x == 0 && bbf_decide_a(q.slab, z, r, q.tol, eps10)) {
+    q.slab[BP_ITERS] = z.iters + 1.0;
     q.slab[BP_DONE] = 1.0;
     __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tailf_b_kernel(const ccqp_pp
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_pprob& q = probs[blockIdx.y];
-  if (q.slab[BP_DONE] != 0.0) {             // converged (now or earlier): only the roll-call
+  const bp_words z = bp_enter(q.slab);
+  if (z.done != 0.0) {                      // converged (now or earlier): only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsegs_tailf_b_kernel(const ccqp_pp
     q.slab[1] = v[0];
     q.slab[2] = v[1];
     q.slab[BP_ALPHA] = v[0] / den;
-    q.slab[BP_ITERS] = q.slab[BP_ITERS] + 1.0;
+    q.slab[BP_ITERS] = z.iters + 1.0;
     bp_report(batch, host, count, seq);
   }
 }

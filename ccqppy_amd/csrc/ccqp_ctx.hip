@@ -30,6 +30,47 @@ __global__ void publish_slots_kernel(const double* __restrict__ slots, double* _
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- matvec timing hook
+int ccqp_mvt_on = 0;
+static hipEvent_t* g_mvt_ev = nullptr;
+static int g_mvt_cap = 0, g_mvt_n = 0;
+
+void ccqp_mvt_mark(hipStream_t s, int end) {
+  if (!ccqp_mvt_on || g_mvt_n >= g_mvt_cap) return;
+  (void)hipEventRecord(g_mvt_ev[2 * g_mvt_n + end], s);
+  if (end) ++g_mvt_n;
+}
+
+extern "C" int ccqp_mv_timing_begin(int max_pairs) {
+  CCQP_REQUIRE(max_pairs >= 1 && max_pairs <= (1 << 20), "max_pairs outside [1, 2^20]");
+  CCQP_REQUIRE(!ccqp_mvt_on, "a timing session is already open");
+  if (max_pairs > g_mvt_cap) {
+    hipEvent_t* ev = new hipEvent_t[2 * (size_t)max_pairs];
+    for (int i = 0; i < 2 * g_mvt_cap; ++i) ev[i] = g_mvt_ev[i];
+    for (int i = 2 * g_mvt_cap; i < 2 * max_pairs; ++i) CCQP_HIP(hipEventCreate(&ev[i]));
+    delete[] g_mvt_ev;
+    g_mvt_ev = ev;
+    g_mvt_cap = max_pairs;
+  }
+  g_mvt_n = 0;
+  ccqp_mvt_on = 1;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_mv_timing_end(double* ms_out, int cap, int* count) {
+  CCQP_REQUIRE(ccqp_mvt_on, "no timing session is open");
+  ccqp_mvt_on = 0;
+  if (count) *count = g_mvt_n;
+  if (g_mvt_n == 0) return CCQP_OK;
+  CCQP_HIP(hipEventSynchronize(g_mvt_ev[2 * (g_mvt_n - 1) + 1]));
+  for (int i = 0; i < g_mvt_n && i < cap && ms_out; ++i) {
+    float ms = 0.f;
+    CCQP_HIP(hipEventElapsedTime(&ms, g_mvt_ev[2 * i], g_mvt_ev[2 * i + 1]));
+    ms_out[i] = (double)ms;
+  }
+  return CCQP_OK;
+}
+
 extern "C" int ccqp_abi_version(void) { return CCQP_ABI_VERSION; }
 
 extern "C" const char* ccqp_last_error(void) { return g_err; }

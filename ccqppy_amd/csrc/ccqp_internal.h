@@ -39,6 +39,10 @@ struct ccqp_ctx {
 
 void ccqp_set_error(const char* fmt, ...);
 
+// matvec timing hook (ccqp_mv_timing_begin / _end, ccqp_ctx.hip): event pairs around the batched matvec launches
+extern int ccqp_mvt_on;
+void ccqp_mvt_mark(hipStream_t s, int end);
+
 #define CCQP_REQUIRE(cond, msg)                                   \
   do {                                                            \
     if (!(cond)) {                                                \

@@ -41,6 +41,51 @@ static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 192 && sizeof(ccqp
               "descriptor layout changed: update ccqppy_amd/_lib.py and the tests");
 
 #ifdef __HIPCC__
+// ---- the meeting-point invariant, structurally ----------------------------------------------------------------------
+// A kernel with a meeting point (bp_meet) may have its problem's slab CHANGED by the block that arrives last while
+// other blocks of the same launch are still starting.  Every such kernel (and every body function it is made of)
+// therefore takes ONE by-value snapshot of the steering words at its entry -- every thread, before anything else --
+// followed by a workgroup barrier (bp_enter / ap_enter / mp_enter below), and works from the snapshot alone: no thread
+// reads the slab again; the deciding thread only WRITES it, computing from the snapshot (each word is written at most
+// once per launch, by that one thread, so the snapshot is the current value wherever it is used).  The rule "a function
+// with a meeting point never reads the slab" is enforced textually by tests/test_lockstep_lint_cpu.py.  (Kernels
+// without a meeting point -- matvec, apply, step -- change nothing and may read the slab wherever they like: launches
+// are ordered by the stream.)  Unused words of a snapshot cost nothing: their loads are dead code.
+struct bp_words {                            // BBPGD / PGD / BBPGDf (ccqp_bpipe.hip, ccqp_bsegs.hip)
+  double done, alpha, iters, gg, resmin, improved, fallback;
+};
+__device__ __forceinline__ bp_words bp_enter(const double* __restrict__ slab) {
+  bp_words z;
+  z.done = slab[BP_DONE];
+  z.alpha = slab[BP_ALPHA];
+  z.iters = slab[BP_ITERS];
+  z.gg = slab[BP_GG];
+  z.resmin = slab[BP_RESMIN];
+  z.improved = slab[BP_IMPROVED];
+  z.fallback = slab[BP_FALLBACK];
+  __syncthreads();
+  return z;
+}
+
+struct ap_words {                            // APGD / anti-relaxation APGD
+  double done, phase, mv, it, first, r1, r2, L, thk, resmin;
+};
+__device__ __forceinline__ ap_words ap_enter(const double* __restrict__ slab) {
+  ap_words z;
+  z.done = slab[AP_DONE];
+  z.phase = slab[AP_PHASE];
+  z.mv = slab[AP_MV];
+  z.it = slab[AP_IT];
+  z.first = slab[AP_FIRST];
+  z.r1 = slab[AP_R1];
+  z.r2 = slab[AP_R2];
+  z.L = slab[AP_L];
+  z.thk = slab[AP_THK];
+  z.resmin = slab[AP_RESMIN];
+  __syncthreads();
+  return z;
+}
+
 // Block sums v[0..nred) of this block -> sums over the problem's nblk blocks, in the LAST block to arrive (the
 // pattern of ccqp_reduce_finish with a per-problem area and counter).  Returns true in that block only, with the
 // sums valid in thread 0.  nred == 0: a plain "all blocks have passed" meeting point -- state that every block reads
@@ -49,8 +94,10 @@ __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int
                                         double* lds4, int* is_last) {
   // Every wave of this block has read the state words of the launch (phase / state / done) before anybody may change
   // them: the block that turns out to be the last changes them right after this function, and a path without a
-  // reduction (nred == 0) has no barrier of its own.  (Without this barrier a late wave read the NEW state once per
+  // reduction (nred == 0) has no barrier of its own.  (Without a barrier a late wave read the NEW state once per
   // ~10^4 decisions under a saturated memory system and took another branch: an APGD solve that never converged.)
+  // The callers' entry snapshot (*_enter above) already ends in a barrier; this one keeps the meeting point safe
+  // on its own.
   __syncthreads();
   if (nblk == 1) return true;
   if (threadIdx.x == 0) {
@@ -78,18 +125,18 @@ __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int
 
 // ---- BBPGDf (solvers.py:696-843)
 // part A: the residual, the exit test, "best so far", "fall back" (thread 0 of the problem's last block)
-__device__ __forceinline__ bool bbf_decide_a(double* s, double r, double tol, double eps10) {
+__device__ __forceinline__ bool bbf_decide_a(double* s, const bp_words& z, double r, double tol, double eps10) {
   const double res = sqrt(r);
   s[0] = r;
   s[BP_RES2] = r;
   if (res < tol) return true;
-  if (res < s[BP_RESMIN]) {                   // :793-796
+  if (res < z.resmin) {                       // :793-796
     s[BP_RESMIN] = res;
     s[BP_IMPROVED] = 1.0;
   } else {
     s[BP_IMPROVED] = 0.0;
   }
-  s[BP_FALLBACK] = s[BP_ALPHA] < eps10 ? 1.0 : 0.0;   // :799
+  s[BP_FALLBACK] = z.alpha < eps10 ? 1.0 : 0.0;       // :799
   return false;
 }
 
@@ -198,6 +245,12 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
     else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \
   } while (0)
 #define BP_MV_LAUNCH(KERNEL, ...)                                          \
+  do {                                                                     \
+    if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);                                  \
+    BP_MV_LAUNCH_A(KERNEL, __VA_ARGS__);                                   \
+    if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);                                  \
+  } while (0)
+#define BP_MV_LAUNCH_A(KERNEL, ...)                                        \
   do {                                                                     \
     if (t.aligned) {                                                       \
       if (t.nt == 2) BP_MV_LAUNCH_U(KERNEL, true, true, __VA_ARGS__);      \

@@ -58,9 +58,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void pipe_bb_tail_kernel(ccqp_segk sg, 
                                                                   double gd, double tol, double eps10, int64_t chunk,
                                                                   double* partials, int nblk, double* slots,
                                                                   double* host) {
-  if (slots[PIPE_DONE] != 0.0) return;        // (no block of a skipped launch touches the arrival counter)
   __shared__ double lds4[4];
   __shared__ int is_last;
+  // entry snapshot + barrier (ccqp_lockstep.h, the meeting-point invariant): every wave of this block has read the
+  // words the problem's last block will change before the block takes its ticket; nothing below reads the slab again
+  const double done0 = slots[PIPE_DONE];
+  const double iters0 = slots[PIPE_ITERS];
+  __syncthreads();
+  if (done0 != 0.0) return;                   // (no block of a skipped launch touches the arrival counter)
   double r, s1, s2;
   bb_tail_body(sg, xn, xo, gn, go, c, gd, chunk, blockIdx.x, lds4, &r, &s1, &s2);
   if (nblk > 1) {
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void pipe_bb_tail_kernel(ccqp_segk sg, 
     const double res = sqrt(r);
     const double den = s2 + eps10;
     const double alpha = s1 / den;
-    const double iters = slots[PIPE_ITERS] + 1.0;
+    const double iters = iters0 + 1.0;
     const double done = res < tol ? 1.0 : 0.0;
     slots[0] = r;
     slots[1] = s1;

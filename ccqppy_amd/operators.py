@@ -116,26 +116,60 @@ class VectorExchange:
 
     def _gather_into(self, full, mine, eng):
         src = self._staged(mine, eng) if mine.device == full.device else mine.clone()
-        chunks = list(full.chunk(self.world))
+        if self.backend == "nccl":
+            # RCCL: an error here is an error of the run -- no second attempt through another call, no other backend
+            self.dist.all_gather_into_tensor(full, src, group=self.group)
+            return
         try:
             self.dist.all_gather_into_tensor(full, src, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            self.dist.all_gather(chunks, src, group=self.group)
+        except (RuntimeError, NotImplementedError):      # a CPU backend without the flat form (tests only)
+            self.dist.all_gather(list(full.chunk(self.world)), src, group=self.group)
 
     def __call__(self, y, eng=None):
         """y holds this rank's slab at [row0, row0+rows); on return every rank holds all of y."""
         if self.world == 1:
             return
         ev = None
-        if self.events is not None and y.is_cuda:
+        st = None
+        if y.is_cuda:
             st = eng.torch_stream if eng is not None else torch.cuda.current_stream(y.device)
+        if self.events is not None and st is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(st)
-        self._exchange(y, eng)
+        if st is not None and eng is not None and not self.direct:
+            # torch.distributed orders a collective against torch's CURRENT stream only: make that the stream the
+            # engine launched the staging copy and the matvec on (a lane engine, or a caller inside another
+            # `with torch.cuda.stream(...)` who has not re-bound), so copy, matvec and collective share one order
+            with torch.cuda.stream(st):
+                self._exchange(y, eng)
+        else:
+            self._exchange(y, eng)
         self.calls += 1
         if ev is not None:
             ev[1].record(st)
             self.events.append(ev)
+
+    def open(self, eng):
+        """Create the C-ABI RCCL communicator of mode="direct" now (collective: every rank of the group must call it;
+        a barrier of the process group follows, so no rank runs ahead into a matvec while another is still inside
+        ncclCommInitRank).  RowShardedOperator calls this at construction.  While this exchange is in use no
+        torch.distributed collective of the same ranks may be IN FLIGHT on another stream (two communicators with
+        concurrent collectives is the known RCCL/NCCL deadlock pattern): the solvers issue none."""
+        if self.direct and self._comm is None and self.world > 1:
+            self._direct_comm(eng)
+            self.dist.barrier(group=self.group)
+
+    def close(self):
+        """Destroy the C-ABI communicator (idempotent; also run when the exchange is garbage-collected)."""
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm is not None:
+            try:
+                self._comm_lib.ccqp_comm_destroy(comm)
+            except Exception:  # noqa: BLE001
+                pass
+
+    def __del__(self):
+        self.close()
 
     def _direct_comm(self, eng):
         """The C-ABI communicator of this exchange (created once: rank 0's unique id travels over the process group)."""
@@ -153,6 +187,7 @@ class VectorExchange:
             comm = ctypes.c_void_p()
             _lib.check(lib.ccqp_comm_create(eng.ctx, self.world, self.rank, idbuf, ctypes.byref(comm)))
             self._comm = comm
+            self._comm_lib = lib
         return self._comm
 
     def _exchange_direct(self, y, eng):
@@ -440,6 +475,7 @@ class RowShardedOperator:
         self.A = A_local
         self.n = n
         self.exchange = VectorExchange(n, group, mode)
+        self.exchange.open(self.engine)
         self.row0, self.rows = self.exchange.row0, self.exchange.rows
         assert tuple(A_local.shape) == (self.rows, n), "local block must be rows [row0, row0+rows) x n"
 

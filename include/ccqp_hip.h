@@ -79,6 +79,14 @@ int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, 
  * launch but the last covers, and the number of launches -- what a profile's per-launch figures refer to. */
 int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
                    int64_t* launches);
+/* Measurement hook (kernel-level roofline figures measured live, not only under a profiler): between
+ * begin and end every BATCHED matvec launch of the lock-step drivers (ccqp_bpipe_*, ccqp_bapgd_*, ccqp_bmprgp_*,
+ * ccqp_bsegs_*, ccqp_bspg_*) is bracketed by a pair of HIP events on its own stream, up to `max_pairs` of them (later
+ * launches are not timed).  ccqp_mv_timing_end waits for the last recorded event, writes the elapsed milliseconds of
+ * the first min(cap, recorded) launches to ms_out, the number recorded to *count, and switches the hook off.  One
+ * recorder per process (one process per GPU); never changes a result bit. */
+int ccqp_mv_timing_begin(int max_pairs);
+int ccqp_mv_timing_end(double* ms_out, int cap, int* count);
 /* Same with a fused epilogue: y = A.x ; if g != NULL: g = y + b, one extra rounding exactly like
  * numpy's `A.dot(x) + b` (solvers.py:133,148,280,625,641,922,1065,1090).  b, y, g have `rows` entries. */
 int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x,

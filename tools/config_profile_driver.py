@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""One BASELINE config per call, as a program that can stand directly behind `rocprofv3 ... --` and that prints a
+JSON line with a `roofline` object measured LIVE (HIP events on the launch stream around every matvec launch):
+
+    python3 tools/config_profile_driver.py 2      # n = 32768  APGD  + Box          (1 solve per repetition)
+    python3 tools/config_profile_driver.py 3      # n = 131072 BBPGD + Cone, 64 MVs (1 solve per repetition)
+    python3 tools/config_profile_driver.py 5      # 128 x n = 8192 MPRGP + Box through solve_batch_pipelined
+                                                  # (the 1-GPU share of the 1024-problem batch)
+    options: --reps R (timed repetitions, default 2)  --warm W (default 1)  --ahead K (config 5: rounds queued ahead)
+
+roofline.achieved = algorithmic bytes of all matvecs executed in the timed repetitions / the summed event time of
+their launches (configs 2, 3: Engine.gemv_events, one pair per matvec = `launches_per_matvec` kernel launches;
+config 5: the C ABI's ccqp_mv_timing_* hook, one pair per batched launch -- launches of rounds in which no problem
+multiplies are part of the sum, so the figure is the conservative one); `full_launch` is the same for the launches
+that carry the whole batch.  `traffic` is looked up in a committed PMC summary of the same kernel and reported only
+when that summary was taken of the same sources (sha1)."""
+import argparse
+import contextlib
+import ctypes
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SOURCES = {
+    "dense": ("ccqppy_amd/csrc/ccqp_gemv.hip", "ccqppy_amd/csrc/ccqp_bodies.h", "ccqppy_amd/csrc/ccqp_internal.h"),
+    "bmprgp": ("ccqppy_amd/csrc/ccqp_bmprgp.hip", "ccqppy_amd/csrc/ccqp_lockstep.h", "ccqppy_amd/csrc/ccqp_bodies.h",
+               "ccqppy_amd/csrc/ccqp_internal.h"),
+}
+
+
+def mv_bytes(rows, n):
+    return 8.0 * (rows * n + n + rows)
+
+
+def source_hash(which):
+    import hashlib
+    h = hashlib.sha1()
+    for rel in SOURCES[which]:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def traffic_lookup(kernel_prefix, bytes_per_launch, which, tag_hint):
+    """(traffic or None, source record) from the newest profiles/*_pmc.json that holds this kernel at this size."""
+    import glob
+    cur = source_hash(which)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True)
+    files.sort(key=lambda f: (os.path.basename(f).split("_")[0], tag_hint in os.path.basename(f)), reverse=True)
+    for f in files:
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        for k, e in d.items():
+            if not isinstance(e, dict) or kernel_prefix not in k or "hbm_traffic_bytes_per_launch" not in e:
+                continue
+            if e.get("algorithmic_bytes_per_launch") != bytes_per_launch:
+                continue
+            same = e.get("kernel_source_sha1") == cur
+            return (e["hbm_traffic_bytes_per_launch"] if same else None), {
+                "file": os.path.relpath(f, ROOT), "kernel": k, "kernel_source_sha1": e.get("kernel_source_sha1"),
+                "current_source_sha1": cur, "verified_same_source": same,
+                "traffic_from_profile": e["hbm_traffic_bytes_per_launch"], "box": e.get("box")}
+    return None, None
+
+
+def dense_config(which, args):
+    from bench import box_id, HBM_PEAK_GBS
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    if which == "2":
+        n, label = 32768, "config 2: n=32768 dense random-SPD fp64 + BoxProjOp(+-0.5), CCQPSolverAPGD(1e-8, 5000)"
+        make, P = (lambda: solvers.CCQPSolverAPGD(1e-8, 5000)), ss.BoxProjOp(n, -0.5, 0.5)
+    else:
+        n, label = 131072, "config 3: n=131072 dense random-SPD fp64 + ConeProjOp, CCQPSolverBBPGD(1e-8, max_mv=64)"
+        make, P = (lambda: solvers.CCQPSolverBBPGD(1e-8, 64)), ss.ConeProjOp(n)
+    op, b, _ = problems.random_problem(n, 1234)
+
+    def solve():
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return make().solve(op, b, convex_proj_op=P)
+
+    for _ in range(args.warm):
+        solve()
+    torch.cuda.synchronize()
+    eng.gemv_events = []
+    mv0 = eng.mv_executed
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        r = solve()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mv = eng.mv_executed - mv0
+    ms = [a.elapsed_time(b_) for a, b_ in eng.gemv_events]
+    eng.gemv_events = None
+    rpl, launches = eng.gemv_plan(n, n)
+    achieved = mv_bytes(n, n) / (np.mean(ms) * 1e-3) / 1e9
+    traffic, src = traffic_lookup("gemv_stream_kernel", mv_bytes(rpl, n), "dense", "config" + which)
+    return {
+        "config": label, "n": n, "repetitions": args.reps, "wall_s_per_solve": dt / args.reps,
+        "executed_mv_per_solve": mv // args.reps, "reported_mv": int(r.solution_num_matrix_vector_multiplications),
+        "converged": bool(r.solution_converged), "residual": float(r.solution_residual),
+        "mv_per_s": mv / dt,
+        "roofline": {
+            "bound": "hbm", "kernel": "gemv_stream_kernel (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "bytes_per_matvec": mv_bytes(n, n), "avg_matvec_ms": float(np.mean(ms)), "matvecs_timed": len(ms),
+            "launches_per_matvec": launches, "rows_per_launch": rpl, "bytes_per_launch": mv_bytes(rpl, n),
+            "avg_launch_ms": float(np.mean(ms)) / launches,
+            "solve_level_frac": mv * mv_bytes(n, n) / dt / 1e9 / HBM_PEAK_GBS,
+            "gemv_ms_per_solve": float(np.sum(ms)) / args.reps,
+            "other_ms_per_solve": 1e3 * dt / args.reps - float(np.sum(ms)) / args.reps,
+        },
+        "kernel_source_sha1": source_hash("dense"), "box": box_id(0),
+    }
+
+
+def config5(args):
+    from bench import box_id, HBM_PEAK_GBS
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    lib = eng.lib
+    n, B = args.size, args.problems
+    lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
+    probs = []
+    for p in range(B):
+        op, b, _ = problems.random_problem(n, 1234 + p, device=0)
+        probs.append((op, b, None, ss.BoxProjOp(n, lb, ub)))
+    make = lambda: solvers.CCQPSolverMPRGP(1e-6, 300)       # noqa: E731
+    fb0 = lockstep.stats["fallback_solves"]
+    for _ in range(args.warm):
+        lockstep.solve_batch_pipelined(make, probs, device=0, ahead=args.ahead)
+    torch.cuda.synchronize()
+    # untimed-hook repetitions first (the wall-clock figure), then ONE repetition with the event pairs
+    best, timing = None, {}
+    for _ in range(args.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tm = {}
+        res = lockstep.solve_batch_pipelined(make, probs, device=0, ahead=args.ahead, timing=tm)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, timing = dt, tm
+    cap = 4096
+    lib.ccqp_mv_timing_begin(cap)
+    t0 = time.perf_counter()
+    res = lockstep.solve_batch_pipelined(make, probs, device=0, ahead=args.ahead)
+    torch.cuda.synchronize()
+    dt_hook = time.perf_counter() - t0
+    buf = (ctypes.c_double * cap)()
+    cnt = ctypes.c_int()
+    lib.ccqp_mv_timing_end(buf, cap, ctypes.byref(cnt))
+    ms = np.array(buf[:min(cnt.value, cap)])
+    mv = sum(r.executed_matrix_vector_multiplications for r in res)
+    total_bytes = mv * mv_bytes(n, n)
+    achieved = total_bytes / (ms.sum() * 1e-3) / 1e9
+    full = ms[ms >= 0.9 * ms.max()]
+    full_bytes = B * mv_bytes(n, n)
+    traffic, src = traffic_lookup("bmprgp_gemv_kernel", full_bytes, "bmprgp", "config5")
+    return {
+        "config": "config 5 (1-GPU share): %d x (n=%d dense random-SPD fp64 + BoxProjOp(array bounds +-0.5), "
+                  "CCQPSolverMPRGP(1e-6, 300)), solve_batch_pipelined (lock-step rounds, ahead=%d)" % (B, n, args.ahead),
+        "n": n, "problems": B, "wall_s": best, "problems_per_s": B / best, "executed_mv": int(mv),
+        "mv_per_s": mv / best, "converged": int(sum(bool(r.solution_converged) for r in res)),
+        "fallback_solves": lockstep.stats["fallback_solves"] - fb0,
+        "reported_mv_first8": [int(r.solution_num_matrix_vector_multiplications) for r in res[:8]],
+        "host_split": timing, "wall_s_with_event_pairs": dt_hook,
+        "roofline": {
+            "bound": "hbm", "kernel": "bmprgp_gemv_kernel (ccqp_bmprgp_round_f64 / _start_f64)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "launches_timed": int(len(ms)), "launch_ms_sum": float(ms.sum()), "launch_ms_max": float(ms.max()),
+            "bytes_all_matvecs": total_bytes,
+            "full_launch": {"launches": int(len(full)), "bytes_per_launch": full_bytes,
+                            "avg_launch_ms": float(full.mean()),
+                            "achieved": full_bytes / (full.mean() * 1e-3) / 1e9,
+                            "frac": full_bytes / (full.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "solve_level_frac": total_bytes / best / 1e9 / HBM_PEAK_GBS,
+            "not_matvec_ms": 1e3 * best - float(ms.sum()),
+        },
+        "kernel_source_sha1": source_hash("bmprgp"), "box": box_id(0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", choices=["2", "3", "5"])
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--warm", type=int, default=1)
+    ap.add_argument("--ahead", type=int, default=4)
+    ap.add_argument("--problems", type=int, default=128)
+    ap.add_argument("--size", type=int, default=8192)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    line = config5(args) if args.which == "5" else dense_config(args.which, args)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
