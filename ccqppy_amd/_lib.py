@@ -212,6 +212,7 @@ SIGNATURES = {
     "ccqp_symv_upper_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
     "ccqp_spmv_plan_words": [_I64, _I64],
     "ccqp_spmv_plan_csr": [_P, _P, _P, _I64, _I64, _P, _c.POINTER(_I64), _P],
+    "ccqp_spmv_plan_set": [_P, _P, _I64, _I, _c.POINTER(_I64), _P],
     "ccqp_spmv_csr_f64": [_P, _P, _P, _P, _P, _c.POINTER(_I64), _P, _P, _P, _P, _I64, _I64, _I64, _I, _P],
     "ccqp_csr_validate": [_P, _P, _P, _I64, _I64, _I64, _I, _P],
     "ccqp_gen_spd_rows_f64": [_P, _P, _I64, _I64, _I64, _I64, _c.c_uint64, _P],

@@ -163,7 +163,8 @@ extern "C" int ccqp_comm_allreduce_sum_f64(ccqp_comm* comm, double* buf, int64_t
 
 // One row-sharded matvec: y[rank*per + i] = A_local[i, :] . x for i < rows_local, then the exchange, all on `stream`.
 // y must hold per * nranks doubles (rows_local <= per; only the last non-empty rank may be short, so the first
-// `cols`-many... the first n entries ARE the assembled vector).  mode 0: in-place all-gather of `per` doubles per rank;
+// `cols`-many... the first n entries ARE the assembled vector; the padding behind a short rank's rows is zeroed).
+// mode 0: in-place all-gather of `per` doubles per rank;
 // mode 1: the rest of y zeroed, then an all-reduce (north_star's wording; adds exact zeros, `nranks` times the bytes).
 extern "C" int ccqp_shard_gemv_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda,
                                              const double* x, double* y, int64_t rows_local, int64_t per,
@@ -180,6 +181,10 @@ extern "C" int ccqp_shard_gemv_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, con
     if (rc) return rc;
     CCQP_LAUNCH_CHECK();
   }
+  // a short last rank: the rest of its slab is padding -- zeroed, so that no rank ever receives uninitialised words
+  // beyond the assembled vector (they lie at y[n ...) of every rank after the exchange)
+  if (mode == 0 && rows_local < per)
+    CCQP_HIP(hipMemsetAsync(mine + rows_local, 0, (size_t)(per - rows_local) * sizeof(double), s));
   if (comm->nranks == 1) return CCQP_OK;
   if (mode == 0) return ccqp_comm_allgather_f64(comm, y, per, stream);
   const int64_t total = per * comm->nranks, lo = (int64_t)comm->rank * per, hi = lo + rows_local;

@@ -55,7 +55,11 @@
                                    // local-x window keeps its distinct columns; the matvec then reads no column
                                    // index at all for the window
 #define SPMV_DIAG_MAXLEN 256       // longest row of a diagonal window (its offsets live in 1 KiB of LDS)
-#define SPMV_DIAG_MINLEN 8         // shortest row of a diagonal window (measured: +1..2 % at 9 entries per row, -3 % at 5)
+#define SPMV_DIAG_MINLEN 2         // shortest row of a diagonal window
+#define SPMV_SHORT_MAX 16          // diagonal windows with rows of at most this many entries take the thread-per-row
+                                   // path (spmv_short_rows): round 2's generic phases were VALU-bound there (80 % VALU
+                                   // busy, 1.6 L1 accesses per entry at 9 entries per row, profiles/r01_spmv_16777216k8_*)
+#define SPMV_NODIAG 1              // ccqp_spmv_plan_set: keep every window off the diagonal paths (tuning / A-B switch)
 #define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
                                    // products: 8 KB)
 #define SPMV_TRANSPOSE_ROWS 64     // windows with more rows than this (shorter rows) stay in entry order: measured
@@ -178,14 +182,17 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_localx_kernel(const int6
     // ---- "diagonal" window?  All rows of the same length L <= SPMV_DIAG_MAXLEN and, position by position, the same
     // offset col - row (banded / circulant / regular-grid matrices): keep the L offsets once; the matvec rebuilds
     // every column index as row + offset and streams 8 instead of 12 bytes per entry.
-    // (rows of SPMV_DIAG_MINLEN entries or more: measured +17 ... +36 % at 17-129 entries per row -- in transposed and
-    // in entry order alike --, +1 ... +2 % at 9, -3 % at 5 entries per row, where per-row costs dominate the stream
-    // -- profiles/r02_spmv_sweep.jsonl)
+    // (measured +17 ... +36 % at 17-129 entries per row -- in transposed and in entry order alike --
+    // profiles/r02_spmv_sweep.jsonl; rows of up to SPMV_SHORT_MAX entries take a path of their own, spmv_short_rows)
     const int64_t rb = plan[SPMV_PLAN_WORDS * w + 0];
     const int64_t nr = plan[SPMV_PLAN_WORDS * w + 1] - rb;
     if (nr < 1 || E % nr != 0) return;
     const int L = (int)(E / nr);
     if (L < SPMV_DIAG_MINLEN || L > SPMV_DIAG_MAXLEN) return;
+    // short rows take the thread-per-row path, which transposes the window's values through LDS with the row stride
+    // padded to an odd number of doubles: the padded window must fit (it does not for full windows of 2, 4, 6 entries
+    // per row, which stay on the generic paths)
+    if (L <= SPMV_SHORT_MAX && nr * (int64_t)(L | 1) > SPMV_LDS) return;
     if (t == 0) notdiag = 0;
     __syncthreads();
     int bad = 0;
@@ -246,6 +253,32 @@ extern "C" int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, const in
   return CCQP_OK;
 }
 
+// Tuning / A-B switch on a finished plan: SPMV_NODIAG sends every diagonal window back to the generic paths (same
+// bits -- the paths differ in what they read, not in what they add); `summary`, if given, is updated to match.
+__global__ __launch_bounds__(CCQP_BLOCK) void spmv_plan_nodiag_kernel(int64_t* __restrict__ plan, int64_t nwin,
+                                                                      int64_t* __restrict__ ndiag) {
+  const int64_t w = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x;
+  if (w < nwin && (plan[SPMV_PLAN_WORDS * w + 4] & SPMV_DIAG))
+    plan[SPMV_PLAN_WORDS * w + 4] &= 0xffffffffll | SPMV_UNIFORM;   // keep the transposed-order words, drop flag + length
+  if (w == 0) *ndiag = 0;
+}
+
+extern "C" int ccqp_spmv_plan_set(ccqp_ctx* ctx, int64_t* plan, int64_t nnz, int flags, int64_t* summary,
+                                  void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && plan != nullptr, "NULL argument");
+  CCQP_REQUIRE(nnz >= 0, "negative size");
+  CCQP_REQUIRE((flags & ~SPMV_NODIAG) == 0, "unknown flag");
+  if (flags & SPMV_NODIAG) {
+    const int64_t nwin = spmv_windows(nnz);
+    const int64_t grid = (nwin + CCQP_BLOCK - 1) / CCQP_BLOCK;
+    hipLaunchKernelGGL(spmv_plan_nodiag_kernel, dim3((unsigned)grid), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, plan,
+                       nwin, plan + spmv_off_counts(nwin) + 3);
+    CCQP_LAUNCH_CHECK();
+    if (summary) summary[3] = 0;
+  }
+  return CCQP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ matvec
 // v of the lane `s` places up, for the butterfly steps inside a 16-lane row: DPP register moves instead of
 // two ds_bpermute round trips per step.  Lane 0 of a subgroup (the only lane whose sum is stored) sees the
@@ -267,6 +300,69 @@ __device__ __forceinline__ double spmv_subgroup_sum(double v) {
   if (W >= 4) v = v + spmv_dpp<0x4E>(v);     // quad_perm [2,3,0,1] == lane ^ 2
   if (W >= 2) v = v + spmv_dpp<0xB1>(v);     // quad_perm [1,0,3,2] == lane ^ 1
   return v;
+}
+
+// ---- diagonal window with SHORT rows (L <= SPMV_SHORT_MAX entries each, all rows alike, col = row + offs[position]):
+// one THREAD per row.  The values arrive coalesced in entry order and are transposed through LDS (row stride padded to
+// an odd number of doubles: conflict-free); thread i then gathers x[row_i + offs[p]] for p = 0 .. L-1 -- consecutive
+// threads read consecutive x, i.e. every gather is a coalesced load -- and adds the row's products in the canonical
+// order in registers: no row pointers, no column stream, no products in LDS, no subgroup butterflies.
+// Canonical order for a row of L <= 16 entries: entry p sits alone in canonical lane p (lane sum = +0.0 + product), all
+// other lanes hold +0.0; butterfly steps 32 and 16 add +0.0 (the identity: no lane sum is -0.0), steps 8, 4, 2, 1 are
+// the 15 additions below (lane 0's operands; a + b == b + a bitwise).
+template <bool EPI>
+__device__ __forceinline__ void spmv_short_rows(const double* __restrict__ val, const int32_t* __restrict__ uc,
+                                                const double* __restrict__ x, const double* __restrict__ b,
+                                                double* __restrict__ y, double* __restrict__ g, double* lds,
+                                                int64_t rb, int64_t nzb, int E, int L, int64_t elast) {
+  const int t = threadIdx.x;
+  const int nr = E / L;
+  const int LP = L | 1;
+  double v[SPMV_SLOTS];
+#pragma unroll
+  for (int j = 0; j < SPMV_SLOTS; ++j) {
+    const int64_t e = nzb + t + j * CCQP_BLOCK;
+    v[j] = __builtin_nontemporal_load(val + (e < elast ? e : elast));
+  }
+  // the window's L offsets: uniform for the workgroup (scalar loads), so every gather below is "scalar base + one
+  // 32-bit lane offset" (words past L are never used; they lie inside the window's SPMV_XS slots)
+  const double* xd[SPMV_SHORT_MAX];
+#pragma unroll
+  for (int p = 0; p < SPMV_SHORT_MAX; ++p) xd[p] = x + (rb + uc[p]);
+  {
+    const int qs = CCQP_BLOCK / L, ms = CCQP_BLOCK % L;
+    int r = t / L, pos = t - r * L;
+#pragma unroll
+    for (int j = 0; j < SPMV_SLOTS; ++j) {
+      if (t + j * CCQP_BLOCK < E) lds[r * LP + pos] = v[j];
+      r += qs;
+      pos += ms;
+      if (pos >= L) {
+        pos -= L;
+        r += 1;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < nr; i += CCQP_BLOCK) {
+    const double* vr = lds + i * LP;
+    double q[SPMV_SHORT_MAX];
+#pragma unroll
+    for (int p = 0; p < SPMV_SHORT_MAX; ++p) q[p] = p < L ? xd[p][i] : 0.0;
+#pragma unroll
+    for (int p = 0; p < SPMV_SHORT_MAX; ++p)
+      if (p < L) {
+        const double pr = vr[p] * q[p];
+        q[p] = 0.0 + pr;
+      }
+#pragma unroll
+    for (int h = SPMV_SHORT_MAX / 2; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int p = 0; p < h; ++p) q[p] = q[p] + q[p + h];
+    }
+    y[rb + i] = q[0];
+    if (EPI) g[rb + i] = q[0] + b[rb + i];
+  }
 }
 
 template <int W, bool EPI>
@@ -295,6 +391,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   const bool uniform = (pw[4] & SPMV_UNIFORM) != 0;
   const bool localx = (pw[4] & SPMV_LOCALX) != 0;
   const bool diag = (pw[4] & SPMV_DIAG) != 0;
+  if (diag && (int)((pw[4] >> 40) & 0xffff) <= SPMV_SHORT_MAX) {
+    if (E > 0)
+      spmv_short_rows<EPI>(val, ucol + (int64_t)blockIdx.x * SPMV_XS, x, b, y, g, prod, rb, nzb, E,
+                           (int)((pw[4] >> 40) & 0xffff), nzb + E - 1);
+    return;
+  }
   const int t = threadIdx.x;
   const int l = t % W;
   const int64_t nrows = re - rb;

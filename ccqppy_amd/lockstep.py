@@ -579,17 +579,26 @@ def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None, para
     host["m"], host["tau"], host["sigma1"], host["sigma2"] = params
     qstride = int(host["m"].max())
     queue = np.zeros((B, qstride))
-    sources = np.array([_draw_source(r) for r in (rngs if rngs is not None else [s.rng for s in solvers])],
-                       dtype=np.uint64)
+    gens = list(rngs if rngs is not None else [s.rng for s in solvers])
+    sources = np.array([_draw_source(r) for r in gens], dtype=np.uint64)
     more = ctypes.c_int(1)
     start = 1
     torch.cuda.current_stream(dev).synchronize()        # x0 staged, tables copied: the C driver runs on `st`
-    while more.value:
-        _lib.check(lib.ccqp_bspg_run_f64(ctx, dprobs.data_ptr(), dsp, host.ctypes.data, queue.ctypes.data, qstride,
-                                         sources.ctypes.data, B, n, max_nwork, max_nnorm, flags, start, _SPG_ROUNDS,
-                                         xchg.data_ptr(), xchg.data_ptr() + 32 * B, words.data_ptr() + 4 * B,
-                                         ctypes.byref(more), st))
-        start = 0
+    # The ctypes call releases the GIL and the C driver draws from the generators' bitgen_t records directly: hold each
+    # generator's own lock meanwhile (numpy's methods take it before they draw), so another Python thread using the
+    # same generator -- the process-wide np.random one of a batch-of-one `pipeline=True` solve above all -- waits
+    # instead of racing on the MT19937 state.  (Distinct locks, taken in one global order.)
+    import contextlib
+    locks = sorted({id(g._bit_generator.lock): g._bit_generator.lock for g in gens}.items())
+    with contextlib.ExitStack() as held:
+        for _, lk in locks:
+            held.enter_context(lk)
+        while more.value:
+            _lib.check(lib.ccqp_bspg_run_f64(ctx, dprobs.data_ptr(), dsp, host.ctypes.data, queue.ctypes.data, qstride,
+                                             sources.ctypes.data, B, n, max_nwork, max_nnorm, flags, start, _SPG_ROUNDS,
+                                             xchg.data_ptr(), xchg.data_ptr() + 32 * B, words.data_ptr() + 4 * B,
+                                             ctypes.byref(more), st))
+            start = 0
     return host, vec[0]
 
 

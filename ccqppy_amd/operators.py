@@ -312,9 +312,8 @@ class SparseOperator:
         self.diagonal_windows = diagonal_windows
         self.plan, self.summary = self.engine.spmv_plan(self.rowptr, self.col, self.nnz, local_x)
         if not diagonal_windows and self.summary[3]:
-            nwin = self.nnz // 1792 + 1                # (SPMV_CAP; plan word 4 of every window: clear SPMV_DIAG, bit 34)
-            self.plan[4:5 * nwin:5] &= ~(1 << 34)
-            self.summary[3] = 0
+            _check(self.engine.lib.ccqp_spmv_plan_set(self.engine.ctx, self.plan.data_ptr(), self.nnz, 1, self.summary,
+                                                      self.engine.stream))
 
     @property
     def shape(self):

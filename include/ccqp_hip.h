@@ -596,7 +596,7 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
  *         when `col` is given -- for every window whose entries reuse their columns (each distinct column
  *         1.5 times or more, at most 1024 of them) the sorted distinct columns plus a 16-bit local column
  *         per entry: such "local-x" windows load each x value once into LDS and stream 10 instead of 12
- *         bytes per entry; for the other windows, whether all rows have one length 8 <= L <= 256 and, position by
+ *         bytes per entry; for the other windows, whether all rows have one length 2 <= L <= 256 and, position by
  *         position, the same offset col - row (banded / circulant / regular-grid matrices): such "diagonal"
  *         windows keep the L offsets once and the matvec reads NO column index for them (8 instead of 12 bytes per
  *         entry).  The plan takes ~2.3 + 2 bytes per stored entry.
@@ -612,6 +612,9 @@ int ccqp_symv_upper_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const doubl
 int64_t ccqp_spmv_plan_words(int64_t rows, int64_t nnz);
 int ccqp_spmv_plan_csr(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, int64_t rows, int64_t nnz,
                        int64_t* plan, int64_t* summary, void* stream);
+/* Tuning / A-B switch on a finished plan (same bits of y either way): flags bit 0 = send every "diagonal" window back
+ * to the generic paths; `summary` (may be NULL) is updated to match. */
+int ccqp_spmv_plan_set(ccqp_ctx* ctx, int64_t* plan, int64_t nnz, int flags, int64_t* summary, void* stream);
 int ccqp_spmv_csr_f64(ccqp_ctx* ctx, const int64_t* rowptr, const int32_t* col, const double* val,
                       const int64_t* plan, const int64_t* summary, const double* x, const double* b, double* y,
                       double* g, int64_t rows, int64_t cols, int64_t nnz, int width, void* stream);

@@ -144,9 +144,15 @@ def _fuzz(case_id, sparse):
         po, perr = _run(lambda: oracle(Ap, bp))
         if perr is None:
             mvs.append(po.solution_num_matrix_vector_multiplications)
-            den = max(np.linalg.norm(o.solution), 1e-300)
+            # the spread sample: only where both solutions are finite (a diverging case is compared entry by entry for
+            # finiteness below and contributes no spread -- an explicit exclusion), scaled by the largest entry first so
+            # that the norms of huge but finite iterates cannot overflow to inf / inf
             if np.all(np.isfinite(po.solution)) and np.all(np.isfinite(o.solution)):
-                spread = max(spread, float(np.linalg.norm(po.solution - o.solution) / den))
+                scale = max(float(np.max(np.abs(o.solution))), 1e-300)
+                den = max(float(np.linalg.norm(o.solution / scale)), 1e-300)
+                sample = float(np.linalg.norm((po.solution - o.solution) / scale) / den)
+                assert np.isfinite(sample), (spec, sname, "spread sample is not finite")
+                spread = max(spread, sample)
     lo, hi = min(mvs), max(mvs)
     got = r.solution_num_matrix_vector_multiplications
     if lo == hi:
