@@ -190,6 +190,8 @@ SIGNATURES = {
     "ccqp_bmprgp_partial_rows": [],
     "ccqp_bmprgp_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bmprgp_round_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _P, _P],
+    "ccqp_bsegs_mprgp_start_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _D, _I, _P, _P],
+    "ccqp_bsegs_mprgp_round_f64": [_P, _P, _P, _I, _I64, _I64, _I64, _I64, _D, _D, _I, _P, _P],
     "ccqp_bb_tail_elementwise_f64": [_P, _c.POINTER(Seg), _P, _P, _P, _P, _D, _D, _I, _P],
     "ccqp_isclose_mask_mul_f64": [_P, _P, _P, _P, _I, _P, _I64, _P],
     "ccqp_count_notclose_f64": [_P, _P, _P, _I64, _I, _P],

@@ -19,6 +19,7 @@
 // The bodies are those of the single-problem kernels (ccqp_bodies.h), so every problem gets bit for bit the result
 // of its own CCQPSolverMPRGP.solve() (tests/test_gpu_bmprgp.py).
 #include "ccqp_lockstep.h"
+#include "ccqp_segs.h"
 
 // slab slots of one problem
 #define MP_S0 0          // dx.dx | beta.beta
@@ -41,7 +42,8 @@
 #define MP_MV BP_ITERS   // 50: the reference's mv_count
 #define MP_RES2 BP_RES2  // 51
 
-enum { ST_M1 = 0, ST_M1_N, ST_M1_P, ST_AP, ST_FEAS_NOW, ST_FEAS_WAIT, ST_HALF3, ST_G1, ST_ADXC, ST_ADXH };
+enum { ST_M1 = 0, ST_M1_N, ST_M1_P, ST_AP, ST_FEAS_NOW, ST_FEAS_WAIT, ST_HALF3, ST_G1, ST_ADXC, ST_ADXH,
+       ST_TAIL /* segmented form only: A dx done, dx.dx / dx.Adx known, the residual on its way */ };
 enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 
 // Candidate steps alpha_f * 0.5^k per feasibility pass.  The host-driven loop tries 8 per launch; the values visited
@@ -52,7 +54,7 @@ enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 
 // entry snapshot of a problem's steering words (ccqp_lockstep.h: the meeting-point invariant)
 struct mp_words {
-  double done, state, it, mv, exec, dist2, ng, af, tried, acg;
+  double done, state, it, mv, exec, dist2, ng, af, tried, acg, s0, s1;
 };
 __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   mp_words z;
@@ -66,6 +68,8 @@ __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   z.af = slab[MP_AF];
   z.tried = slab[MP_TRIED];
   z.acg = slab[MP_ACG];
+  z.s0 = slab[MP_S0];
+  z.s1 = slab[MP_S1];
   __syncthreads();
   return z;
 }
@@ -612,6 +616,604 @@ extern "C" int ccqp_bsolve_mprgp_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   else
     hipLaunchKernelGGL((bsolve_mprgp_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, eps10,
                        mv_limit, n);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// =====================================================================================================================
+// Lock-step MPRGP on feasible sets that are NOT elementwise: Sphere, DisjointUnion with blocks of any size (Cone has no
+// normal vector: solution_spaces.py:465 raises, and so does the host-driven loop such a problem is left to).
+// Reference: CCQPSolverMPRGP.solve (solvers.py:1026-1200) around SphereProjOp / DisjointProjOp.__call__ and
+// .normal_vector (solution_spaces.py:389-403, 417-435, 512-525, 540-560) -- per iteration four projections, one normal
+// vector and up to dozens of feasibility probes, each a Python loop over the blocks.
+// The state machine, slab and matvec kernel are those of the elementwise form above; every place the set enters goes
+// through the segmented engine (ccqp_segs.h) with per-problem block tables (struct ccqp_psegs, as ccqp_bsegs.hip).  A
+// ROUND is ten launches for the whole batch, each acting on a problem according to its state:
+//   1 matvec        A x_k + b | A p | A x_{k+1} + b | A dx                                      (bmprgp_gemv_kernel)
+//   2 reduce A      M1: counters -> M1_N;  AP: psi.p, p.Ap -> alpha_cg, FEAS_NOW;  G1: -> "after G1";  FEAS_WAIT ->
+//                   FEAS_NOW;  ADXC / ADXH: dx.dx, dx.Adx -> TAIL
+//   3 seg norm 1    chunk sums of |u|^2 for the Sphere blocks, u = x_k | x_k - alpha_f 0.5^k p (K candidates) |
+//                   x_{k+1} - gd g_{k+1} | x_{k+1}
+//   4 seg apply 1   M1_N: P(x_k) -> psi, 1 - delta, normal vector (small blocks finished, large ones: sums);
+//                   FEAS_NOW: counts of entries with not isclose(y_f, P(y_f)) per work item and candidate;
+//                   TAIL: per work item sum (c (x - P(x - gd g)))^2;  after G1: p = isclose(x, P(x)) g, dx = x_{k+1} - x_k
+//   5 seg finish    M1_N: normal vector of the large blocks
+//   6 reduce B      M1_N: n.g -> M1_P;  FEAS_NOW: the decision (full CG step | half step | another pass | give up);
+//                   TAIL: residual = work-item sums in index order, BB step, exit test, swap -> M1
+//   7 reduce C      M1_P: beta.beta, psi.psi -> AP (| proportioning: left to the host loop);  HALF3: BB dots of the
+//                   half step;  and the batch's roll-call
+//   8 apply         full CG step: x_{k+1}, g_{k+1}, dx;  half step: x_h, g_h into scratch vectors
+//   9 seg norm 2    |y|^2 (full step)  |  |x_h - alpha g_h|^2 (half step)
+//  10 seg apply 2   full step: p = psi_y - (psi_y Ap / p.Ap) p with psi_y = isclose(y, P(y)) g_{k+1};  half step:
+//                   x_{k+1} = P(x_h - alpha g_h)
+// Bits: per element and per sum the arithmetic of the host-driven loop's launches (ccqp_segs_project_f64,
+// ccqp_isclose_mask_mul_f64, ccqp_segs_normal_f64, ccqp_dots_f64, ccqp_chopped_gradient_f64,
+// ccqp_segs_feasible_steps_f64, ccqp_cg_direction_f64, ccqp_segs_residual_sq_f64) and the host's scalar steps, so
+// every problem gets exactly the result of its own CCQPSolverMPRGP.solve() (tests/test_gpu_bsegs.py).
+#define MPS_STEPS CCQP_MAX_STEPS          // feasibility candidates per pass (the workspace holds this many norm rows)
+
+// what a segmented launch of the FIRST group (3-5) has to do for this problem
+enum { SEG1_NONE = 0, SEG1_NORMAL, SEG1_FEAS, SEG1_TAIL, SEG1_AFTER_G1 };
+__device__ __forceinline__ int mps_what1(const double* s) {
+  if (s[MP_DONE] != 0.0) return SEG1_NONE;
+  switch ((int)s[MP_STATE]) {
+    case ST_M1_N: return SEG1_NORMAL;
+    case ST_FEAS_NOW: return SEG1_FEAS;
+    case ST_TAIL: return SEG1_TAIL;
+    case ST_ADXH: return (int)s[MP_ACT] == ACT_AFTER_G1 ? SEG1_AFTER_G1 : SEG1_NONE;
+    default: return SEG1_NONE;
+  }
+}
+
+// start-up modes of the segmented launches (mode > 0); mode 0 = by state (round, first group), -1 = by action (second)
+enum { MPS_BY_STATE = 0, MPS_START_X = 1, MPS_START_RES = 2, MPS_START_P = 3, MPS_BY_ACTION = -1 };
+
+// chunk sums of |u|^2 for the Sphere / Cone blocks.  grid (max nnorm, problems, K)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_norm_kernel(const ccqp_pmprgp* __restrict__ probs,
+                                                              const ccqp_psegs* __restrict__ segs, int mode,
+                                                              double gd) {
+  __shared__ double lds4[4];
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nnorm) return;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  const int k = blockIdx.z;
+  const double* x = nullptr;
+  const double* y = nullptr;
+  double b = 0.0;
+  int64_t row = 0;                             // which row of npartials chunk sums of the workspace
+  if (mode == MPS_START_X) {
+    x = q.dx;                                  // x0, staged there by the caller
+  } else if (mode == MPS_START_RES) {
+    if (s[MP_DONE] != 0.0) return;
+    x = q.X[0];
+    y = q.G[0];
+    b = -gd;
+  } else if (mode == MPS_START_P) {
+    if (s[MP_DONE] != 0.0) return;
+    x = q.X[0];
+  } else if (mode == MPS_BY_STATE) {
+    const int it = (int)s[MP_IT];
+    switch (mps_what1(s)) {
+      case SEG1_NORMAL: x = q.X[it & 1]; break;
+      case SEG1_FEAS: {
+        double alpha = s[MP_AF];
+        for (int j = 0; j < k; ++j) alpha *= 0.5;   // the reference's `alpha_f *= 0.5`, k times
+        x = q.X[it & 1];
+        y = q.p;
+        b = -alpha;
+        row = k;
+        break;
+      }
+      case SEG1_TAIL: x = q.X[(it + 1) & 1]; y = q.G[(it + 1) & 1]; b = -gd; break;
+      case SEG1_AFTER_G1: x = q.X[(it + 1) & 1]; break;
+      default: return;
+    }
+    if (k > 0 && row == 0) return;             // only the feasibility search has more than one candidate
+  } else {
+    if (s[MP_DONE] != 0.0) return;
+    const int act = (int)s[MP_ACT];
+    const int it = (int)s[MP_IT];
+    if (act == ACT_CGFULL) {
+      x = q.X[(it + 1) & 1];                   // y = x_k - alpha_cg p, written by the apply launch
+    } else if (act == ACT_HALF) {
+      x = q.txk;                               // x_h
+      y = q.w;                                 // g_h
+      b = -s[MP_AHALF];
+    } else {
+      return;
+    }
+  }
+  const ccqp_segwork w = ps.normwork[blockIdx.x];
+  const double sum = segs_norm_item(ps.table, w, 1.0, x, b, y, lds4);
+  if (threadIdx.x == 0) ps.workspace[row * ps.npartials + w.pbase + w.chunk] = sum;
+}
+
+// ---- per-element epilogues of the apply launches (segs_apply_emit: emit(gi, u, P(u)))
+struct mps_emit_start_x {      // x_k = P(x0), x_{k+1} = copy (:1063-1064)
+  double* x0;
+  double* x1;
+  __device__ __forceinline__ void operator()(int64_t i, double, double p) {
+    x0[i] = p;
+    x1[i] = p;
+  }
+};
+struct mps_emit_residual {     // sum (c (x - P(x - gd g)))^2, this thread's share
+  const double* x;
+  double c, acc;
+  __device__ __forceinline__ void operator()(int64_t i, double, double p) {
+    const double d = x[i] - p;
+    const double v = c * d;
+    acc = fma(v, v, acc);
+  }
+};
+struct mps_emit_free {         // out = isclose(x, P(x)) * g   [+ g1 = copy(g)]  [+ dx = x - xk]
+  const double* g;
+  double* out;
+  double* gcopy;
+  const double* xk;
+  double* dx;
+  __device__ __forceinline__ void operator()(int64_t i, double u, double p) {
+    const double gi = g[i];
+    out[i] = (ccqp_isclose(u, p) ? 1.0 : 0.0) * gi;
+    if (gcopy) gcopy[i] = gi;
+    if (dx) dx[i] = mp_lin(1.0, u, -1.0, xk[i]);
+  }
+};
+struct mps_emit_count {        // entries with not isclose(y_f, P(y_f))
+  double acc;
+  __device__ __forceinline__ void operator()(int64_t, double u, double p) { acc += ccqp_isclose(u, p) ? 0.0 : 1.0; }
+};
+struct mps_emit_split {        // psi = isclose(x, P(x)) g, w = 1 - isclose  (:1090-1094)
+  const double* g;
+  double* psi;
+  double* w;
+  __device__ __forceinline__ void operator()(int64_t i, double x, double xp) const {
+    const bool close = ccqp_isclose(x, xp);
+    psi[i] = (close ? 1.0 : 0.0) * g[i];
+    w[i] = close ? 0.0 : 1.0;
+  }
+};
+struct mps_emit_cg {           // psi_y = isclose(y, P(y)) g1;  p = psi_y - (psi_y Ap / pAp) p   (:1132-1135)
+  const double* g1;
+  const double* Ap;
+  double* p;
+  double pAp;
+  __device__ __forceinline__ void operator()(int64_t i, double u, double pr) {
+    const double ps = (ccqp_isclose(u, pr) ? 1.0 : 0.0) * g1[i];
+    const double t1 = ps * Ap[i];
+    const double beta = t1 / pAp;
+    const double t2 = beta * p[i];
+    p[i] = ps - t2;
+  }
+};
+struct mps_emit_store {
+  double* out;
+  __device__ __forceinline__ void operator()(int64_t i, double, double p) { out[i] = p; }
+};
+
+// grid (max nwork, problems, K)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_apply_kernel(const ccqp_pmprgp* __restrict__ probs,
+                                                               const ccqp_psegs* __restrict__ segs, int mode,
+                                                               double gd) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nwork) return;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  const int k = blockIdx.z;
+  const ccqp_segwork w = ps.work[blockIdx.x];
+  double* ws = ps.workspace;
+  if (mode == MPS_START_X) {
+    mps_emit_start_x e = {q.X[0], q.X[1]};
+    segs_apply_emit(ps.table, w, ws, 1.0, q.dx, 0.0, nullptr, e, lds4, &bcast);
+    return;
+  }
+  if (s[MP_DONE] != 0.0) return;
+  const int it = (int)s[MP_IT];
+  if (mode == MPS_START_RES) {
+    mps_emit_residual e = {q.X[0], q.c, 0.0};
+    segs_apply_emit(ps.table, w, ws, 1.0, q.X[0], -gd, q.G[0], e, lds4, &bcast);
+    const double sum = ccqp_block_sum(e.acc, lds4);
+    if (threadIdx.x == 0) ws[3 * ps.npartials + blockIdx.x] = sum;
+    return;
+  }
+  if (mode == MPS_START_P) {                   // g_{k+1} = copy(g_k), p = phi(x_k, g_k)  (:1066, :1081)
+    mps_emit_free e = {q.G[0], q.p, q.G[1], nullptr, nullptr};
+    segs_apply_emit(ps.table, w, ws, 1.0, q.X[0], 0.0, nullptr, e, lds4, &bcast);
+    return;
+  }
+  if (mode == MPS_BY_ACTION) {
+    const int act = (int)s[MP_ACT];
+    if (act == ACT_CGFULL) {
+      mps_emit_cg e = {q.G[(it + 1) & 1], q.Ap, q.p, s[MP_PAP]};
+      segs_apply_emit(ps.table, w, ws, 1.0, q.X[(it + 1) & 1], 0.0, nullptr, e, lds4, &bcast);
+    } else if (act == ACT_HALF) {
+      mps_emit_store e = {q.X[(it + 1) & 1]};
+      segs_apply_emit(ps.table, w, ws, 1.0, q.txk, -s[MP_AHALF], q.w, e, lds4, &bcast);
+    }
+    return;
+  }
+  switch (mps_what1(s)) {
+    case SEG1_NORMAL: {
+      if (k > 0) return;
+      mps_emit_split e = {q.G[it & 1], q.psi, q.w};
+      segs_normal_project_item(ps.table, w, ws, ws + ps.npartials, ws + 2 * ps.npartials, q.X[it & 1], q.nv, e, lds4,
+                               &bcast);
+      return;
+    }
+    case SEG1_FEAS: {
+      double alpha = s[MP_AF];
+      for (int j = 0; j < k; ++j) alpha *= 0.5;
+      mps_emit_count e = {0.0};
+      segs_apply_emit(ps.table, w, ws + (int64_t)k * ps.npartials, 1.0, q.X[it & 1], -alpha, q.p, e, lds4, &bcast);
+      const double sum = ccqp_block_sum(e.acc, lds4);
+      if (threadIdx.x == 0) ws[(int64_t)MPS_STEPS * ps.npartials + (int64_t)k * ps.nwork + blockIdx.x] = sum;
+      return;
+    }
+    case SEG1_TAIL: {
+      if (k > 0) return;
+      mps_emit_residual e = {q.X[(it + 1) & 1], q.c, 0.0};
+      segs_apply_emit(ps.table, w, ws, 1.0, q.X[(it + 1) & 1], -gd, q.G[(it + 1) & 1], e, lds4, &bcast);
+      const double sum = ccqp_block_sum(e.acc, lds4);
+      if (threadIdx.x == 0) ws[3 * ps.npartials + blockIdx.x] = sum;
+      return;
+    }
+    case SEG1_AFTER_G1: {                      // :1157-1162
+      if (k > 0) return;
+      mps_emit_free e = {q.G[(it + 1) & 1], q.p, nullptr, q.X[it & 1], q.dx};
+      segs_apply_emit(ps.table, w, ws, 1.0, q.X[(it + 1) & 1], 0.0, nullptr, e, lds4, &bcast);
+      return;
+    }
+    default:
+      return;
+  }
+}
+
+// normal vector of the large blocks (launch 5).  grid (max nwork, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_normal_finish_kernel(const ccqp_pmprgp* __restrict__ probs,
+                                                                       const ccqp_psegs* __restrict__ segs) {
+  __shared__ double lds4[4];
+  __shared__ double bcast;
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  if ((int)blockIdx.x >= ps.nwork || ps.npartials == 0) return;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  if (mps_what1(q.slab) != SEG1_NORMAL) return;
+  const ccqp_segwork w = ps.work[blockIdx.x];
+  segs_normal_finish_item(ps.table, w, ps.workspace + ps.npartials, ps.workspace + 2 * ps.npartials, q.nv, lds4, &bcast);
+}
+
+// the work items' sums added in index order (ccqp_reduce_finish's order; one item: the sum itself) -- all threads call
+__device__ __forceinline__ double mps_item_sum(const double* part, int nwork, double* lds4) {
+  if (nwork == 1) return part[0];
+  return partial_sum_body(part, nwork, lds4);
+}
+
+// start-up decision: residual of (x_k, g_k), exit test (:1070-1073).  One block per problem.
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_init_res_kernel(const ccqp_pmprgp* __restrict__ probs,
+                                                                  const ccqp_psegs* __restrict__ segs,
+                                                                  unsigned* __restrict__ batch) {
+  __shared__ double lds4[4];
+  const ccqp_pmprgp& q = probs[blockIdx.x];
+  const ccqp_psegs& ps = segs[blockIdx.x];
+  const double r = mps_item_sum(ps.workspace + 3 * ps.npartials, ps.nwork, lds4);
+  if (threadIdx.x != 0) return;
+  double* s = q.slab;
+  s[MP_S2] = r;
+  s[MP_RES2] = r;
+  s[MP_MV] = 1.0;
+  s[MP_EXEC] = 1.0;
+  s[MP_IT] = 0.0;
+  s[MP_STATE] = (double)ST_M1;
+  s[MP_ACT] = (double)ACT_NONE;
+  if (sqrt(r) >= q.tol) {                      // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
+    s[MP_DONE] = 0.0;
+  } else {
+    s[MP_DONE] = 1.0;
+    __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// launch 2.  grid (nblk, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_a_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n,
+                                                                  double eps10, int64_t chunk, int nblk) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  double* s = q.slab;                          // written only (by the deciding thread); read through `z` alone
+  const mp_words z = mp_enter(s);
+  if (z.done != 0.0) return;
+  const int bx = blockIdx.x;
+  double v[2];
+  switch ((int)z.state) {
+    case ST_M1:                                // g_k = A x_k + b has run (:1086)
+      if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        s[MP_ACT] = (double)ACT_NONE;
+        s[MP_MV] = z.mv + 1.0;
+        s[MP_EXEC] = z.exec + 1.0;
+        s[MP_STATE] = (double)ST_M1_N;
+      }
+      return;
+    case ST_AP:                                // :1100-1111
+      v[0] = dot_body(q.psi, q.p, n, chunk, bx, lds4);
+      v[1] = dot_body(q.p, q.Ap, n, chunk, bx, lds4);
+      if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        const double acg = v[0] / v[1];
+        s[MP_S0] = v[0];
+        s[MP_S1] = v[1];
+        s[MP_ACG] = acg;
+        s[MP_PAP] = v[1];
+        s[MP_AF] = acg + eps10;
+        s[MP_TRIED] = 0.0;
+        s[MP_ACT] = (double)ACT_NONE;
+        s[MP_MV] = z.mv + 1.0;
+        s[MP_EXEC] = z.exec + 1.0;
+        s[MP_STATE] = (double)ST_FEAS_NOW;
+      }
+      return;
+    case ST_G1:                                // g_{k+1} = A x_{k+1} + b has run (:1152)
+    case ST_FEAS_WAIT:
+      if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        if ((int)z.state == ST_G1) {
+          s[MP_ACT] = (double)ACT_AFTER_G1;
+          s[MP_MV] = z.mv + 1.0;
+          s[MP_EXEC] = z.exec + 1.0;
+          s[MP_STATE] = (double)ST_ADXH;
+        } else {
+          s[MP_ACT] = (double)ACT_NONE;
+          s[MP_STATE] = (double)ST_FEAS_NOW;
+        }
+      }
+      return;
+    case ST_ADXC:
+    case ST_ADXH:                              // A dx has run (:1129 / :1163): the BB dots; the residual follows
+      v[0] = dot_body(q.dx, q.dx, n, chunk, bx, lds4);
+      v[1] = dot_body(q.dx, q.Adx, n, chunk, bx, lds4);
+      if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        s[MP_S0] = v[0];
+        s[MP_S1] = v[1];
+        s[MP_ACT] = (double)ACT_NONE;
+        s[MP_EXEC] = z.exec + 1.0;
+        s[MP_STATE] = (double)ST_TAIL;
+      }
+      return;
+    default:
+      return;
+  }
+}
+
+// launch 6.  grid (nblk, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_b_kernel(const ccqp_pmprgp* __restrict__ probs,
+                                                                  const ccqp_psegs* __restrict__ segs, int64_t n,
+                                                                  double eps10, int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  __shared__ double cnt[MPS_STEPS];
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const ccqp_psegs& ps = segs[blockIdx.y];
+  double* s = q.slab;                          // written only (by the deciding thread); read through `z` alone
+  const mp_words z = mp_enter(s);
+  if (z.done != 0.0) return;
+  const int it = (int)z.it;
+  double v[1];
+  switch ((int)z.state) {
+    case ST_M1_N:                              // n(x_k).g_k (:1095-1096)
+      v[0] = dot_body(q.nv, q.G[it & 1], n, chunk, blockIdx.x, lds4);
+      if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, &is_last)) return;
+      if (threadIdx.x == 0) {
+        s[MP_NG] = v[0];
+        s[MP_STATE] = (double)ST_M1_P;
+      }
+      return;
+    case ST_FEAS_NOW: {                        // :1112-1120, MPS_STEPS candidates per pass
+      if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+      const double* counts = ps.workspace + (int64_t)MPS_STEPS * ps.npartials;
+      for (int k = 0; k < MPS_STEPS; ++k) {    // (small integers: their sum does not depend on the order)
+        const double c = mps_item_sum(counts + (int64_t)k * ps.nwork, ps.nwork, lds4);
+        if (threadIdx.x == 0) cnt[k] = c;
+      }
+      if (threadIdx.x != 0) return;
+      double af = z.af;
+      int found = 0, at = 0;
+      for (int k = 0; k < MPS_STEPS; ++k) {
+        if (k < 8) s[MP_COUNTS + k] = cnt[k];
+        if (!found) {
+          if (cnt[k] == 0.0) {
+            found = 1;
+            at = k;
+          } else {
+            af *= 0.5;
+          }
+        }
+      }
+      s[MP_AF] = af;
+      const double tried = z.tried;
+      if (found && tried + (double)at < (double)MP_MAX_CANDIDATES) {
+        if (z.acg <= af) {                     // :1120
+          s[MP_ACT] = (double)ACT_CGFULL;
+          s[MP_STATE] = (double)ST_ADXC;
+        } else {
+          s[MP_STATE] = (double)ST_HALF3;
+        }
+      } else if (found || tried + (double)MPS_STEPS >= (double)MP_MAX_CANDIDATES) {
+        s[MP_DONE] = 2.0;                      // alpha_f has underflowed: the reference never exits, the host loop raises
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        s[MP_TRIED] = tried + (double)MPS_STEPS;
+        s[MP_STATE] = (double)ST_FEAS_WAIT;
+      }
+      return;
+    }
+    case ST_TAIL: {                            // :1184-1192
+      if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
+      const double r = mps_item_sum(ps.workspace + 3 * ps.npartials, ps.nwork, lds4);
+      if (threadIdx.x == 0) mp_tail<true>(q, z, z.s0, z.s1, r, eps10, batch);
+      return;
+    }
+    default:
+      return;
+  }
+}
+
+// launch 7.  grid (nblk, problems); the batch's roll-call
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_c_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n,
+                                                                  double eps10, int64_t chunk, int nblk,
+                                                                  unsigned* __restrict__ batch,
+                                                                  double* __restrict__ host, unsigned count,
+                                                                  double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  double* s = q.slab;                          // written only (by the deciding thread); read through `z` alone
+  const mp_words z = mp_enter(s);
+  const int bx = blockIdx.x;
+  if (z.done != 0.0) {
+    if (bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    return;
+  }
+  const int it = (int)z.it;
+  const double* gk = q.G[it & 1];
+  double v[2];
+  if ((int)z.state == ST_M1_P) {               // :1096-1099
+    proportion_body(q.w, gk, q.nv, q.psi, z.ng, n, chunk, bx, lds4, &v[0], &v[1]);
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (threadIdx.x == 0) {
+      s[MP_S0] = v[0];
+      s[MP_S1] = v[1];
+      if (v[0] < v[1]) {
+        s[MP_STATE] = (double)ST_AP;
+      } else {
+        s[MP_DONE] = 3.0;                      // a proportioning step (:1165-1182): left to the host-driven loop
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bp_report(batch, host, count, seq);
+    }
+    return;
+  }
+  if ((int)z.state == ST_HALF3) {              // :1140-1147
+    const double maf = -z.af;
+    const double* xk = q.X[it & 1];
+    CHUNK_RANGE(n)
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double xi = xk[i], gi = gk[i];
+      const double xh = mp_lin(1.0, xi, maf, q.p[i]);
+      const double gh = mp_lin(1.0, gi, maf, q.Ap[i]);
+      const double dx = mp_lin(1.0, xh, -1.0, xi);
+      const double dg = mp_lin(1.0, gh, -1.0, gi);
+      a0 = fma(dx, dx, a0);
+      a1 = fma(dx, dg, a1);
+    }
+    v[0] = ccqp_block_sum(a0, lds4);
+    v[1] = ccqp_block_sum(a1, lds4);
+    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
+    if (threadIdx.x == 0) {
+      const double den = v[1] + eps10;
+      s[MP_S0] = v[0];
+      s[MP_S1] = v[1];
+      s[MP_AHALF] = v[0] / den;
+      s[MP_ACT] = (double)ACT_HALF;
+      s[MP_STATE] = (double)ST_G1;
+      bp_report(batch, host, count, seq);
+    }
+    return;
+  }
+  if (bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+}
+
+// launch 8: the elementwise part of the update.  grid (blocks, problems)
+__global__ __launch_bounds__(CCQP_BLOCK) void mps_apply_elem_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[MP_DONE] != 0.0) return;
+  const int act = (int)s[MP_ACT];
+  const int it = (int)s[MP_IT];
+  const double* __restrict__ xk = q.X[it & 1];
+  const double* __restrict__ gk = q.G[it & 1];
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  if (act == ACT_CGFULL) {                     // :1125-1128
+    double* __restrict__ xk1 = q.X[(it + 1) & 1];
+    double* __restrict__ gk1 = q.G[(it + 1) & 1];
+    const double macg = -s[MP_ACG];
+    BODY_LOOP(i, n) {
+      const double xi = xk[i];
+      const double y = mp_lin(1.0, xi, macg, q.p[i]);
+      xk1[i] = y;
+      gk1[i] = mp_lin(1.0, gk[i], macg, q.Ap[i]);
+      q.dx[i] = mp_lin(1.0, y, -1.0, xi);
+    }
+  } else if (act == ACT_HALF) {                // :1140-1141 (x_h, g_h into scratch: psi / w / nv / txk are dead here)
+    const double maf = -s[MP_AF];
+    BODY_LOOP(i, n) {
+      q.txk[i] = mp_lin(1.0, xk[i], maf, q.p[i]);
+      q.w[i] = mp_lin(1.0, gk[i], maf, q.Ap[i]);
+    }
+  }
+}
+
+#define MPS_CHECK()                                                                       \
+  BP_CHECK_BATCH();                                                                       \
+  CCQP_REQUIRE(dev_segs != nullptr, "NULL segment descriptors");                          \
+  CCQP_REQUIRE(max_nwork >= 1 && max_nnorm >= 0 && max_nwork < 2147483647, "bad work-list bounds")
+
+// Start-up of all solves (solvers.py:1063-1081).  Expects x0 staged in `dx`, slabs, counters and every problem's
+// segment workspace zero.
+extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, const ccqp_psegs* dev_segs,
+                                          int count, int64_t n, int64_t max_nwork, int64_t max_nnorm, double gd,
+                                          int flags, uint32_t* dev_batch, void* stream) {
+  MPS_CHECK();
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count), blk(CCQP_BLOCK);
+  ccqp_lockstep_begin(ctx, dev_batch, s);
+  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
+  hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 1, n);
+  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
+  hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
+  hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 2, n);
+  hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
+  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+  hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// Round `round` >= 1 of all live solves: the ten launches above.
+extern "C" int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, const ccqp_psegs* dev_segs,
+                                          int count, int64_t n, int64_t round, int64_t max_nwork, int64_t max_nnorm,
+                                          double gd, double eps10, int flags, uint32_t* dev_batch, void* stream) {
+  MPS_CHECK();
+  CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
+  const dim3 gwk((unsigned)max_nwork, count, MPS_STEPS), gnk((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count, MPS_STEPS);
+  const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 0, n);
+  hipLaunchKernelGGL(mps_reduce_a_kernel, rgrid, blk, 0, s, dev_probs, n, eps10, chunk, nblk);
+  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gnk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);
+  hipLaunchKernelGGL(mps_apply_kernel, gwk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);
+  hipLaunchKernelGGL(mps_normal_finish_kernel, gw, blk, 0, s, dev_probs, dev_segs);
+  hipLaunchKernelGGL(mps_reduce_b_kernel, rgrid, blk, 0, s, dev_probs, dev_segs, n, eps10, chunk, nblk, dev_batch);
+  hipLaunchKernelGGL(mps_reduce_c_kernel, rgrid, blk, 0, s, dev_probs, n, eps10, chunk, nblk, dev_batch,
+                     ctx->host_slots_dev, (unsigned)count, (double)round);
+  hipLaunchKernelGGL(mps_apply_elem_kernel, dim3(bp_vec_grid(n), count), blk, 0, s, dev_probs, n);
+  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_ACTION, gd);
+  hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_ACTION, gd);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -225,4 +225,197 @@ __device__ __forceinline__ double segs_apply_item(const ccqp_seg* __restrict__ t
   return racc;
 }
 
+// One work item of an apply pass with a caller-supplied epilogue: emit(gi, u, p) receives, for every element of the
+// item, its index in the whole vector, the input u = a*x + b*y and the projection P(u) -- computed exactly as
+// segs_apply_item computes them (same block-norm finish, same Sphere / Cone rule), so anything built on this has the bits
+// of the single-problem launches.  `emit` is per thread (it may accumulate).
+template <class Emit>
+__device__ __forceinline__ void segs_apply_emit(const ccqp_seg* __restrict__ table, const ccqp_segwork& w,
+                                                const double* __restrict__ part, double a, const double* x, double b,
+                                                const double* y, Emit& emit, double* lds4, double* bcast) {
+  if (w.type == 0) {
+    if ((int)threadIdx.x < w.chunk) {
+      const ccqp_seg sg = table[w.seg + threadIdx.x];
+      if (sg.dim > 0 && sg.dim <= CCQP_SMALL_SEG_MAX) {
+        const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
+        struct shifted {
+          Emit& e;
+          int64_t off;
+          __device__ __forceinline__ void operator()(int64_t i, double uu, double pp) { e(off + i, uu, pp); }
+        } sh = {emit, sg.offset};
+        segs_small(sg, u, sh);
+      }
+    }
+    return;
+  }
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  const segs_in u = {x + sg.offset, y ? y + sg.offset : nullptr, a, b};
+  if (sg.kind <= CCQP_OP_BOX) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = u(i);
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      emit(sg.offset + i, v, ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub));
+    }
+  } else {
+    const double n2 = segs_finish(part + w.pbase, nblk, lds4, bcast);
+    segs_norm_rule rule;
+    rule.setup(sg, n2, u(sg.dim - 1));
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = u(i);
+      emit(sg.offset + i, v, rule(v, i == sg.dim - 1));
+    }
+  }
+}
+
+// normal_vector of one work item, pass 2 of 3 (after the chunk sums of |x|^2): xp = P(x) into `out`, chunk sums of
+// |x - xp|^2 (and |xp|^2 for Spheres) into dpart / lpart; small blocks finish here with their normal vector in `out`
+// (solution_spaces.py:146-160,222-236,306-322,389-403,92-98).  extra(gi, x_i, xp_i) sees every element's projection
+// before `out` is turned into the normal vector (the lock-step MPRGP derives psi and 1 - delta from it).
+template <class Extra>
+__device__ __forceinline__ void segs_normal_project_item(const ccqp_seg* __restrict__ table, const ccqp_segwork& w,
+                                                         const double* __restrict__ part, double* __restrict__ dpart,
+                                                         double* __restrict__ lpart, const double* x, double* out,
+                                                         Extra& extra, double* lds4, double* bcast) {
+  if (w.type == 0) {
+    if ((int)threadIdx.x >= w.chunk) return;
+    const ccqp_seg sg = table[w.seg + threadIdx.x];
+    const int64_t d = sg.dim;
+    if (d <= 0 || d > CCQP_SMALL_SEG_MAX) return;
+    const double* xs = x + sg.offset;
+    double* os = out + sg.offset;
+    if (sg.kind == CCQP_OP_IDENTITY) {
+      for (int64_t i = 0; i < d; ++i) {
+        extra(sg.offset + i, xs[i], xs[i]);
+        os[i] = 0.0;
+      }
+      return;
+    }
+    const segs_in u = {xs, nullptr, 1.0, 0.0};
+    emit_store e = {os, nullptr};
+    segs_small(sg, u, e);
+    double dist2 = 0.0;
+    for (int64_t i = 0; i < d; ++i) {
+      extra(sg.offset + i, xs[i], os[i]);
+      const double df = xs[i] - os[i];
+      dist2 = fma(df, df, dist2);
+    }
+    const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
+    if (sg.kind == CCQP_OP_SPHERE) {
+      double l2 = 0.0;
+      for (int64_t i = 0; i < d; ++i) l2 = fma(os[i], os[i], l2);
+      const double len = sqrt(l2);
+      const bool on = !outside && ccqp_isclose(len, sg.lb_s);
+      for (int64_t i = 0; i < d; ++i) os[i] = on ? os[i] / len : 0.0;
+      return;
+    }
+    const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+    const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+    for (int64_t i = 0; i < d; ++i) {
+      double nv = 0.0;
+      if (!outside) {
+        const double xp = os[i];
+        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+        if (has_ub && ccqp_isclose(xp, ub)) nv = 1.0;
+        else if (has_lb && ccqp_isclose(xp, lb)) nv = -1.0;
+      }
+      os[i] = nv;
+    }
+    return;
+  }
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  const double* xs = x + sg.offset;
+  double* os = out + sg.offset;
+  double dacc = 0.0, lacc = 0.0;
+  if (sg.kind <= CCQP_OP_BOX) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = xs[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
+      extra(sg.offset + i, v, p);
+      os[i] = p;
+      const double df = v - p;
+      dacc = fma(df, df, dacc);
+    }
+  } else {
+    const double n2 = segs_finish(part + w.pbase, nblk, lds4, bcast);
+    segs_norm_rule rule;
+    rule.setup(sg, n2, xs[sg.dim - 1]);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+      const double v = xs[i];
+      const double p = rule(v, i == sg.dim - 1);
+      extra(sg.offset + i, v, p);
+      os[i] = p;
+      const double df = v - p;
+      dacc = fma(df, df, dacc);
+      lacc = fma(p, p, lacc);
+    }
+  }
+  const double ds = ccqp_block_sum(dacc, lds4);
+  const double ls = ccqp_block_sum(lacc, lds4);
+  if (threadIdx.x == 0) {
+    dpart[w.pbase + w.chunk] = ds;
+    lpart[w.pbase + w.chunk] = ls;
+  }
+}
+
+struct segs_no_extra {
+  __device__ __forceinline__ void operator()(int64_t, double, double) const {}
+};
+
+// normal_vector, pass 3 of 3: large blocks only, in place on `out` (which holds xp)
+__device__ __forceinline__ void segs_normal_finish_item(const ccqp_seg* __restrict__ table, const ccqp_segwork& w,
+                                                        const double* __restrict__ dpart,
+                                                        const double* __restrict__ lpart, double* out, double* lds4,
+                                                        double* bcast) {
+  if (w.type == 0) return;
+  const ccqp_seg sg = table[w.seg];
+  int64_t chunk;
+  int nblk;
+  segs_geometry(sg.dim, &chunk, &nblk);
+  const int64_t lo = (int64_t)w.chunk * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > sg.dim) hi = sg.dim;
+  double* os = out + sg.offset;
+  if (sg.kind == CCQP_OP_IDENTITY) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = 0.0;
+    return;
+  }
+  const double dist2 = segs_finish(dpart + w.pbase, nblk, lds4, bcast);
+  const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
+  if (sg.kind == CCQP_OP_SPHERE) {
+    const double len = sqrt(segs_finish(lpart + w.pbase, nblk, lds4, bcast));
+    const bool on = !outside && ccqp_isclose(len, sg.lb_s);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = on ? os[i] / len : 0.0;
+    return;
+  }
+  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
+  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
+    double nv = 0.0;
+    if (!outside) {
+      const double v = os[i];
+      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
+      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
+      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
+    }
+    os[i] = nv;
+  }
+}
+
 #endif  // __HIPCC__

@@ -147,88 +147,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void segs_normal_project_kernel(const c
   __shared__ double lds4[4];
   __shared__ double bcast;
   const ccqp_segwork w = work[blockIdx.x];
-  if (w.type == 0) {
-    if ((int)threadIdx.x >= w.chunk) return;
-    const ccqp_seg sg = table[w.seg + threadIdx.x];
-    const int64_t d = sg.dim;
-    if (d <= 0 || d > CCQP_SMALL_SEG_MAX) return;
-    const double* xs = x + sg.offset;
-    double* os = out + sg.offset;
-    if (sg.kind == CCQP_OP_IDENTITY) {
-      for (int64_t i = 0; i < d; ++i) os[i] = 0.0;
-      return;
-    }
-    const segs_in u = {xs, nullptr, 1.0, 0.0};
-    emit_store e = {os, nullptr};
-    segs_small(sg, u, e);
-    double dist2 = 0.0;
-    for (int64_t i = 0; i < d; ++i) {
-      const double df = xs[i] - os[i];
-      dist2 = fma(df, df, dist2);
-    }
-    const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
-    if (sg.kind == CCQP_OP_SPHERE) {
-      double l2 = 0.0;
-      for (int64_t i = 0; i < d; ++i) l2 = fma(os[i], os[i], l2);
-      const double len = sqrt(l2);
-      const bool on = !outside && ccqp_isclose(len, sg.lb_s);
-      for (int64_t i = 0; i < d; ++i) os[i] = on ? os[i] / len : 0.0;
-      return;
-    }
-    const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
-    const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
-    for (int64_t i = 0; i < d; ++i) {
-      double nv = 0.0;
-      if (!outside) {
-        const double xp = os[i];
-        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-        if (has_ub && ccqp_isclose(xp, ub)) nv = 1.0;
-        else if (has_lb && ccqp_isclose(xp, lb)) nv = -1.0;
-      }
-      os[i] = nv;
-    }
-    return;
-  }
-  const ccqp_seg sg = table[w.seg];
-  int64_t chunk;
-  int nblk;
-  segs_geometry(sg.dim, &chunk, &nblk);
-  const int64_t lo = (int64_t)w.chunk * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  const double* xs = x + sg.offset;
-  double* os = out + sg.offset;
-  double dacc = 0.0, lacc = 0.0;
-  if (sg.kind <= CCQP_OP_BOX) {
-    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-      const double v = xs[i];
-      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-      const double p = ccqp_proj_elem(sg.kind, sg.flags, v, lb, ub);
-      os[i] = p;
-      const double df = v - p;
-      dacc = fma(df, df, dacc);
-    }
-  } else {
-    const double n2 = segs_finish(part + w.pbase, nblk, lds4, &bcast);
-    segs_norm_rule rule;
-    rule.setup(sg, n2, xs[sg.dim - 1]);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-      const double v = xs[i];
-      const double p = rule(v, i == sg.dim - 1);
-      os[i] = p;
-      const double df = v - p;
-      dacc = fma(df, df, dacc);
-      lacc = fma(p, p, lacc);
-    }
-  }
-  const double ds = ccqp_block_sum(dacc, lds4);
-  const double ls = ccqp_block_sum(lacc, lds4);
-  if (threadIdx.x == 0) {
-    dpart[w.pbase + w.chunk] = ds;
-    lpart[w.pbase + w.chunk] = ls;
-  }
+  segs_no_extra none;
+  segs_normal_project_item(table, w, part, dpart, lpart, x, out, none, lds4, &bcast);
 }
 
 // normal_vector, launch 3 of 3: large blocks only, in place on `out` (which holds xp)
@@ -240,40 +160,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void segs_normal_finish_kernel(const cc
   __shared__ double lds4[4];
   __shared__ double bcast;
   const ccqp_segwork w = work[blockIdx.x];
-  if (w.type == 0) return;
-  const ccqp_seg sg = table[w.seg];
-  int64_t chunk;
-  int nblk;
-  segs_geometry(sg.dim, &chunk, &nblk);
-  const int64_t lo = (int64_t)w.chunk * chunk;
-  int64_t hi = lo + chunk;
-  if (hi > sg.dim) hi = sg.dim;
-  double* os = out + sg.offset;
-  if (sg.kind == CCQP_OP_IDENTITY) {
-    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = 0.0;
-    return;
-  }
-  const double dist2 = segs_finish(dpart + w.pbase, nblk, lds4, &bcast);
-  const bool outside = !ccqp_isclose(sqrt(dist2), 0.0);
-  if (sg.kind == CCQP_OP_SPHERE) {
-    const double len = sqrt(segs_finish(lpart + w.pbase, nblk, lds4, &bcast));
-    const bool on = !outside && ccqp_isclose(len, sg.lb_s);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) os[i] = on ? os[i] / len : 0.0;
-    return;
-  }
-  const bool has_ub = sg.kind == CCQP_OP_UPPER || sg.kind == CCQP_OP_BOX;
-  const bool has_lb = sg.kind == CCQP_OP_LOWER || sg.kind == CCQP_OP_BOX;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-    double nv = 0.0;
-    if (!outside) {
-      const double v = os[i];
-      const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-      const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
-      if (has_ub && ccqp_isclose(v, ub)) nv = 1.0;
-      else if (has_lb && ccqp_isclose(v, lb)) nv = -1.0;
-    }
-    os[i] = nv;
-  }
+  segs_normal_finish_item(table, w, dpart, lpart, out, lds4, &bcast);
 }
 
 // ------------------------------------------------------------------ C ABI

@@ -56,9 +56,10 @@
                                    // index at all for the window
 #define SPMV_DIAG_MAXLEN 256       // longest row of a diagonal window (its offsets live in 1 KiB of LDS)
 #define SPMV_DIAG_MINLEN 2         // shortest row of a diagonal window
-#define SPMV_SHORT_MAX 16          // diagonal windows with rows of at most this many entries take the thread-per-row
-                                   // path (spmv_short_rows): round 2's generic phases were VALU-bound there (80 % VALU
-                                   // busy, 1.6 L1 accesses per entry at 9 entries per row, profiles/r01_spmv_16777216k8_*)
+#define SPMV_SHORT_MAX 64          // diagonal windows with rows of at most this many entries take the threads-per-row
+                                   // path (spmv_short_rows: 1 / 2 / 4 threads per row up to 16 / 32 / 64 entries):
+                                   // round 2's generic phases were VALU-bound there (80 % VALU busy, 1.6 L1 accesses
+                                   // per entry at 9 entries per row, profiles/r01_spmv_16777216k8_*)
 #define SPMV_NODIAG 1              // ccqp_spmv_plan_set: keep every window off the diagonal paths (tuning / A-B switch)
 #define SPMV_XS 1024               // most distinct columns of a local-x window (their x values share the LDS of the
                                    // products: 8 KB)
@@ -303,18 +304,21 @@ __device__ __forceinline__ double spmv_subgroup_sum(double v) {
 }
 
 // ---- diagonal window with SHORT rows (L <= SPMV_SHORT_MAX entries each, all rows alike, col = row + offs[position]):
-// one THREAD per row.  The values arrive coalesced in entry order and are transposed through LDS (row stride padded to
-// an odd number of doubles: conflict-free); thread i then gathers x[row_i + offs[p]] for p = 0 .. L-1 -- consecutive
-// threads read consecutive x, i.e. every gather is a coalesced load -- and adds the row's products in the canonical
-// order in registers: no row pointers, no column stream, no products in LDS, no subgroup butterflies.
-// Canonical order for a row of L <= 16 entries: entry p sits alone in canonical lane p (lane sum = +0.0 + product), all
-// other lanes hold +0.0; butterfly steps 32 and 16 add +0.0 (the identity: no lane sum is -0.0), steps 8, 4, 2, 1 are
-// the 15 additions below (lane 0's operands; a + b == b + a bitwise).
-template <bool EPI>
+// S = 1, 2 or 4 THREADS per row (L <= 16, 32, 64), each taking the positions p = s, s + S, s + 2S, ... (at most 16).
+// The values arrive coalesced in entry order and are transposed through LDS (row stride padded to an odd number of
+// doubles: conflict-free); thread (i, s) then gathers x[row_i + offs[p]] -- the threads of consecutive rows read
+// consecutive x, i.e. every gather instruction is S coalesced runs -- and adds its products in the canonical order in
+// registers: no row pointers, no column stream, no products in LDS, no 16-accumulator subgroup loops.
+// Canonical order for a row of L <= 64 entries: entry p sits alone in canonical lane p (lane sum = +0.0 + product), the
+// other lanes hold +0.0.  Thread s owns the lanes s + S j, so the butterfly steps 32 ... S pair lanes of ONE thread
+// (slots j and j + h, h = 8, 4, 2, 1 -- for S < 4 the first steps only add +0.0 to sums that are never -0.0: skipped),
+// and the steps S/2 ... 1 pair neighbouring threads (DPP, as spmv_subgroup_sum).  Lane 0's operands; a + b == b + a.
+template <int S, bool EPI>
 __device__ __forceinline__ void spmv_short_rows(const double* __restrict__ val, const int32_t* __restrict__ uc,
                                                 const double* __restrict__ x, const double* __restrict__ b,
                                                 double* __restrict__ y, double* __restrict__ g, double* lds,
-                                                int64_t rb, int64_t nzb, int E, int L, int64_t elast) {
+                                                int32_t* offs, int64_t rb, int64_t nzb, int E, int L, int64_t elast) {
+  constexpr int Q = 16;                        // positions per thread
   const int t = threadIdx.x;
   const int nr = E / L;
   const int LP = L | 1;
@@ -324,11 +328,7 @@ __device__ __forceinline__ void spmv_short_rows(const double* __restrict__ val, 
     const int64_t e = nzb + t + j * CCQP_BLOCK;
     v[j] = __builtin_nontemporal_load(val + (e < elast ? e : elast));
   }
-  // the window's L offsets: uniform for the workgroup (scalar loads), so every gather below is "scalar base + one
-  // 32-bit lane offset" (words past L are never used; they lie inside the window's SPMV_XS slots)
-  const double* xd[SPMV_SHORT_MAX];
-#pragma unroll
-  for (int p = 0; p < SPMV_SHORT_MAX; ++p) xd[p] = x + (rb + uc[p]);
+  if (t < L) offs[t] = uc[t];
   {
     const int qs = CCQP_BLOCK / L, ms = CCQP_BLOCK % L;
     int r = t / L, pos = t - r * L;
@@ -344,24 +344,39 @@ __device__ __forceinline__ void spmv_short_rows(const double* __restrict__ val, 
     }
   }
   __syncthreads();
-  for (int i = t; i < nr; i += CCQP_BLOCK) {
-    const double* vr = lds + i * LP;
-    double q[SPMV_SHORT_MAX];
+  const int sl = t % S;
+  // (all threads of a wave run the loop together: the DPP steps read lanes of rows past the end, whose q are +0.0)
+  for (int i0 = 0; i0 < nr; i0 += CCQP_BLOCK / S) {
+    const int i = i0 + t / S;
+    const bool live = i < nr;
+    const double* __restrict__ xr = x + rb + (live ? i : 0);
+    const double* vr = lds + (live ? i : 0) * LP;
+    double q[Q];
 #pragma unroll
-    for (int p = 0; p < SPMV_SHORT_MAX; ++p) q[p] = p < L ? xd[p][i] : 0.0;
-#pragma unroll
-    for (int p = 0; p < SPMV_SHORT_MAX; ++p)
-      if (p < L) {
-        const double pr = vr[p] * q[p];
-        q[p] = 0.0 + pr;
-      }
-#pragma unroll
-    for (int h = SPMV_SHORT_MAX / 2; h >= 1; h >>= 1) {
-#pragma unroll
-      for (int p = 0; p < h; ++p) q[p] = q[p] + q[p + h];
+    for (int j = 0; j < Q; ++j) {
+      const int p = sl + S * j;
+      q[j] = (live && p < L) ? xr[offs[p]] : 0.0;
     }
-    y[rb + i] = q[0];
-    if (EPI) g[rb + i] = q[0] + b[rb + i];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int p = sl + S * j;
+      if (live && p < L) {
+        const double pr = vr[p] * q[j];
+        q[j] = 0.0 + pr;
+      }
+    }
+#pragma unroll
+    for (int h = Q / 2; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int j = 0; j < h; ++j) q[j] = q[j] + q[j + h];
+    }
+    double sum = q[0];
+    if (S >= 4) sum = sum + spmv_dpp<0x4E>(sum);     // quad_perm [2,3,0,1] == lane ^ 2
+    if (S >= 2) sum = sum + spmv_dpp<0xB1>(sum);     // quad_perm [1,0,3,2] == lane ^ 1
+    if (live && sl == 0) {
+      y[rb + i] = sum;
+      if (EPI) g[rb + i] = sum + b[rb + i];
+    }
   }
 }
 
@@ -392,9 +407,12 @@ __global__ __launch_bounds__(CCQP_BLOCK) void spmv_stream_kernel(const int64_t* 
   const bool localx = (pw[4] & SPMV_LOCALX) != 0;
   const bool diag = (pw[4] & SPMV_DIAG) != 0;
   if (diag && (int)((pw[4] >> 40) & 0xffff) <= SPMV_SHORT_MAX) {
-    if (E > 0)
-      spmv_short_rows<EPI>(val, ucol + (int64_t)blockIdx.x * SPMV_XS, x, b, y, g, prod, rb, nzb, E,
-                           (int)((pw[4] >> 40) & 0xffff), nzb + E - 1);
+    const int Ls = (int)((pw[4] >> 40) & 0xffff);
+    const int32_t* ucw = ucol + (int64_t)blockIdx.x * SPMV_XS;
+    if (E <= 0) return;
+    if (Ls <= 16) spmv_short_rows<1, EPI>(val, ucw, x, b, y, g, prod, offs, rb, nzb, E, Ls, nzb + E - 1);
+    else if (Ls <= 32) spmv_short_rows<2, EPI>(val, ucw, x, b, y, g, prod, offs, rb, nzb, E, Ls, nzb + E - 1);
+    else spmv_short_rows<4, EPI>(val, ucw, x, b, y, g, prod, offs, rb, nzb, E, Ls, nzb + E - 1);
     return;
   }
   const int t = threadIdx.x;

@@ -114,10 +114,15 @@ def _why_not_one(kind, max_mv, s, A, b, P, device):
     if not hasattr(P, "_dev_bb_tail"):
         if isinstance(P, ss.ProjOpBase):
             P._refresh()                                 # (host-only: its blocks may have been edited or replaced)
-        # Sphere / Cone / DisjointUnion: the segmented lock-step forms (ccqp_bsegs.hip), every solver but MPRGP
-        if kind.__name__ == "CCQPSolverMPRGP" or not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
-            return TypeError("solve_batch_pipelined needs elementwise feasible sets (all solvers but MPRGP: any set "
-                             "built from the seven operators), got %r" % type(P).__name__), n, P
+        # Sphere / Cone / DisjointUnion: the segmented lock-step forms (ccqp_bsegs.hip; MPRGP: ccqp_bmprgp.hip)
+        if not isinstance(P, ss.ProjOpBase) or not P._has_device_form():
+            return TypeError("solve_batch_pipelined needs feasible sets built from the seven operators, got %r"
+                             % type(P).__name__), n, P
+        if kind.__name__ == "CCQPSolverMPRGP" and not P._normal_everywhere_on_device():
+            # a Cone block has no normal vector (the reference raises NotImplementedError, solution_spaces.py:465, and so
+            # does the host-driven loop this problem is left to); scalar bounds make normal_vector raise a TypeError
+            return TypeError("solve_batch_pipelined runs MPRGP on sets whose normal_vector exists on the device (no "
+                             "Cone block, array bounds), got %r" % type(P).__name__), n, P
         if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
             return ValueError("solve_batch_pipelined: the feasible set does not match b"), n, P
         return None, n, P
@@ -225,6 +230,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
                     _bapgd_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, False, segmented=True)
                 elif kind is CCQPSolverSPG:
                     _bspg_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, segmented=True)
+                elif kind is CCQPSolverMPRGP:
+                    _bmprgp_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune, segmented=True)
                 else:
                     _bsegs_group(eng, items[lo:lo + _BPIPE_MAX], n, max_mv, ahead, tune)
     dt = time.time() - t0
@@ -263,6 +270,49 @@ def _bpipe_poll_loop(eng, B, launch, last_round, ahead):
     return k
 
 
+def _bpipe_poll_many(runs, ahead):
+    """_bpipe_poll_loop for several independent lock-step runs at once (each with its own engine = its own stream and
+    host mirror; `run.eng`, `run.B`, `run.launch(k)`, `run.last`): the host round-robins between them, keeping each at
+    most `ahead` rounds beyond its own last report, until each has converged or reached its last round.  With two runs
+    on two streams the device always has one run's matvec to execute while the other run's small decision kernels and
+    their launch gaps go by.  Sets `run.k` = rounds queued."""
+    import ctypes
+    state = (ctypes.c_double * 2)()
+    active = []
+    for r in runs:
+        r.k = 0
+        if r.last >= 1:                                  # the first round is queued before the first look at the mirror
+            r.k = 1
+            r.launch(1)
+            if r.last > 1:
+                active.append(r)
+    idle = 0
+    while active:
+        moved = False
+        for r in list(active):
+            r.eng.lib.ccqp_bpipe_poll(r.eng.ctx, state)
+            if state[0] >= r.B:
+                active.remove(r)
+                moved = True
+            elif r.k - state[1] < ahead:
+                r.k += 1
+                r.launch(r.k)
+                moved = True
+                if r.k >= r.last:                        # (the last round of a budget may report nothing)
+                    active.remove(r)
+        if moved:
+            idle = 0
+            continue
+        idle += 1
+        if idle > 2000000:                               # every mirror silent for ~1 s: wait for the queues themselves
+            for r in active:
+                r.eng.torch_stream.synchronize()
+                r.eng.lib.ccqp_bpipe_poll(r.eng.ctx, state)
+                if state[1] != r.k and state[0] < r.B:
+                    raise RuntimeError("solve_batch_pipelined: the device never reported round %d" % r.k)
+            idle = 0
+
+
 class _Spec:
     """What a lock-step run needs to know about its B problems of size n, as arrays: matrix / right-hand-side
     addresses, leading dimensions, set descriptors (struct ccqp_seg records), tolerances, and the start vectors
@@ -271,6 +321,17 @@ class _Spec:
 
     def __len__(self):
         return self.B
+
+    def part(self, lo, hi):
+        """Problems [lo, hi) as a spec of their own (views / slices, nothing copied)."""
+        sp = _Spec()
+        sp.B, sp.n = hi - lo, self.n
+        sp.A, sp.lda, sp.b, sp.seg, sp.tol = self.A[lo:hi], self.lda[lo:hi], self.b[lo:hi], self.seg[lo:hi], self.tol[lo:hi]
+        sp.x0 = None if self.x0 is None else self.x0[lo:hi]
+        sp.keep = self.keep
+        sp.step = None if getattr(self, "step", None) is None else self.step[lo:hi]
+        sp.fallback = getattr(self, "fallback", False)
+        return sp
 
     def stage_x0(self, plane):
         x0 = self.x0
@@ -727,61 +788,138 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segme
         eng.mv_executed += int(mvs[p])
 
 
-def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
+class _MprgpRun:
+    """One lock-step MPRGP run over `spec` on engine `eng` (ccqp_bmprgp_*): construction allocates the workspace, stages
+    x0 and queues the start-up on the engine's stream; `launch(r)` queues round r; `finish()` waits for the queue and
+    returns (status, (B, n) final iterates, residuals, reported matvecs, executed matvecs)."""
+
+    def __init__(self, eng, spec, n, max_mv, tune=0, single_launch=None, plans=None):
+        """plans: one segment plan per problem (solution_spaces._SegPlan, shared objects allowed) for feasible sets that
+        are not elementwise -- the segmented form (ccqp_bsegs_mprgp_*); None: elementwise sets from spec.seg."""
+        from . import _lib
+        from .solvers import _EPS10, _GD
+        self.eng, self.n, self.max_mv = eng, n, max_mv
+        lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+        self.B = B = len(spec)
+        names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
+        vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PMprgp, len(names),
+                                                             int(lib.ccqp_bmprgp_partial_rows()))
+        spec.stage_x0(vec[1] if plans is None else vec[10])             # x0 staged in X[1] (segmented form: in dx)
+        tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
+        tab["G"][:, 0], tab["G"][:, 1] = planes[2], planes[3]
+        for j, name in enumerate(names[4:]):
+            tab[name] = planes[4 + j]
+        flags = _bpipe_flags(tab, n, tune)
+        dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+        dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
+        check = _lib.check
+        # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where a problem
+        # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
+        self.last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
+        gd, eps10 = _GD, float(_EPS10)
+
+        def launch(r):
+            check(lib.ccqp_bmprgp_round_f64(ctx, dp, B, n, r, gd, eps10, flags, batch, st))
+
+        self.launch = launch
+        if plans is not None:
+            dsegs, seg_ws, max_nwork, max_nnorm = _psegs_table(plans, dev)
+            dsp = dsegs.data_ptr()
+
+            def launch_segs(r):
+                check(lib.ccqp_bsegs_mprgp_round_f64(ctx, dp, dsp, B, n, r, max_nwork, max_nnorm, gd, eps10, flags,
+                                                     batch, st))
+
+            self.launch = launch_segs
+            self.single_launch = False
+            check(lib.ccqp_bsegs_mprgp_start_f64(ctx, dp, dsp, B, n, max_nwork, max_nnorm, gd, flags, batch, st))
+            self.vec, self.slabs, self.keep = vec, slabs, (keep, words, dprobs, dsegs, seg_ws)
+            return
+        if single_launch is None:
+            single_launch = n <= _BSOLVE_MAX_N_MPRGP
+        self.single_launch = single_launch = bool(single_launch) and n <= 2048
+        if single_launch:
+            # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
+            check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, B, n, gd, eps10, float(min(max_mv - 1, _device_budget(n))),
+                                            flags & 1, st))
+            self.last = 0
+        else:
+            check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, gd, flags, batch, st))
+        self.vec, self.slabs, self.keep = vec, slabs, (keep, words, dprobs)
+
+    def finish(self):
+        vec, slabs, B, dev = self.vec, self.slabs, self.B, self.eng.device
+        h = slabs[:, 32:56].cpu().numpy()               # blocking: the queue has drained
+        status, its = h[:, 17], h[:, 8].astype(np.int64)
+        mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
+        if not self.single_launch and not np.isfinite(self.max_mv) and not (status != 0.0).all():
+            raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
+        if B == 1:
+            sols = vec[int((its[0] + 1) % 2)]
+        else:
+            sel = torch.from_numpy((its + 1) % 2).to(dev)
+            sols = vec[0:2][sel, torch.arange(B, device=dev)]
+        self.keep = None
+        return status, sols, np.sqrt(res2), mvs, execd
+
+
+_HALVES_DEFAULT = False          # (measured slower for MPRGP: see _bmprgp_run)
+_HALF_MIN_PROBLEMS = 32          # a batch advances as two alternating halves from this many problems on ...
+_HALF_MIN_BYTES = 2.0 ** 30      # ... if one round of matvecs reads at least this much (else launches bind, not HBM)
+_half_lanes = {}
+
+
+def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=None, plans=None):
     """Lock-step MPRGP over `spec`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
-    matvecs); status 1 = converged, anything else = not finished here (rows meaningless)."""
-    from . import _lib
-    from .solvers import _EPS10, _GD
-    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    matvecs); status 1 = converged, anything else = not finished here (rows meaningless).
+    `halves=True` (an A/B option, OFF by default) advances the batch as TWO runs on two streams, the host alternating
+    between them, so that one half's decision stages and vector update -- small launches, a few tens of microseconds
+    each, during which the memory system idles -- go by under the other half's matvec.  Every problem is independent,
+    so the results are those of one run, bit for bit.  Measured on config 5's share (128 x n = 8192, round 3,
+    profiles/r03_sweep_config5_halves.jsonl): 410.8 problems/s against 421.5 for the single run -- two 32 GiB matvec
+    kernels sharing the machine stream worse than one 64 GiB kernel by more than the 0.8 % of a round the small
+    launches take -- so the scheme that pays for SPG (whose host turn-around is 10x longer) is not the default here."""
     B = len(spec)
-    names = ("X0", "X1", "G0", "G1", "p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PMprgp, len(names),
-                                                         int(lib.ccqp_bmprgp_partial_rows()))
-    spec.stage_x0(vec[1])                                               # x0 staged in X[1]
-    tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
-    tab["G"][:, 0], tab["G"][:, 1] = planes[2], planes[3]
-    for j, name in enumerate(names[4:]):
-        tab[name] = planes[4 + j]
-    flags = _bpipe_flags(tab, n, tune)
-    dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
-    dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
-    check = _lib.check
-    # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where a problem
-    # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
-    last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
-
-    def launch(r):
-        check(lib.ccqp_bmprgp_round_f64(ctx, dp, B, n, r, _GD, float(_EPS10), flags, batch, st))
-
-    if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N_MPRGP
-    single_launch = bool(single_launch) and n <= 2048
-    if single_launch:
-        # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
-        check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, B, n, _GD, float(_EPS10),
-                                        float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
-    else:
-        check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, _GD, flags, batch, st))
-        _bpipe_poll_loop(eng, B, launch, last, ahead)
-    h = slabs[:, 32:56].cpu().numpy()                   # blocking: the queue has drained
-    status, its = h[:, 17], h[:, 8].astype(np.int64)
-    mvs, res2, execd = h[:, 18].astype(np.int64), h[:, 19], h[:, 20].astype(np.int64)
-    if not single_launch and not np.isfinite(max_mv) and not (status != 0.0).all():
-        raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
-    if B == 1:
-        sols = vec[int((its[0] + 1) % 2)]
-    else:
-        sel = torch.from_numpy((its + 1) % 2).to(dev)
-        sols = vec[0:2][sel, torch.arange(B, device=dev)]
-    del keep
-    return status, sols, np.sqrt(res2), mvs, execd
+    single = plans is None and (n <= _BSOLVE_MAX_N_MPRGP if single_launch is None else bool(single_launch)) and n <= 2048
+    if halves is None:
+        halves = _HALVES_DEFAULT and (not single) and B >= _HALF_MIN_PROBLEMS and 8.0 * n * n * B >= _HALF_MIN_BYTES
+    if not halves or B < 2:
+        run = _MprgpRun(eng, spec, n, max_mv, tune, single_launch, plans)
+        if run.last >= 1:
+            _bpipe_poll_loop(eng, B, run.launch, run.last, ahead)
+        return run.finish()
+    from ._engine import make_lanes
+    lanes = _half_lanes.get(eng.index)
+    if lanes is None:
+        lanes = _half_lanes[eng.index] = make_lanes(eng.index, 2)
+    cur = eng.torch_stream
+    cut = (B + 1) // 2
+    runs = []
+    for lane, (lo, hi) in zip(lanes, ((0, cut), (cut, B))):
+        lane.torch_stream.wait_stream(cur)               # the caller's matrices / vectors are ready on ITS stream
+        lane.gemv_variant = eng.gemv_variant
+        with torch.cuda.stream(lane.torch_stream):
+            runs.append(_MprgpRun(lane, spec.part(lo, hi), n, max_mv, tune, single_launch,
+                                  None if plans is None else plans[lo:hi]))
+    _bpipe_poll_many(runs, ahead)
+    outs = []
+    for r in runs:
+        with torch.cuda.stream(r.eng.torch_stream):
+            outs.append(r.finish())
+    for lane in lanes:
+        cur.wait_stream(lane.torch_stream)               # (and every later use of the lanes starts by waiting for `cur`)
+    with torch.cuda.stream(cur):
+        sols = torch.cat([o[1].reshape(-1, n) for o in outs])
+    return (np.concatenate([o[0] for o in outs]), sols, np.concatenate([o[2] for o in outs]),
+            np.concatenate([o[3] for o in outs]), np.concatenate([o[4] for o in outs]))
 
 
-def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
+def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):
     import contextlib
     import io
+    plans = [it[4]._segplan(eng, n) for it in items] if segmented else None
     status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune,
-                                                single_launch)
+                                                single_launch, plans=plans)
     host = None
     for p, it in enumerate(items):
         s = it[0]

@@ -236,10 +236,15 @@ class ProjOpBase(ABC):
         bounds raise TypeError depending on the data (:318), a host callable is called."""
         return self._kind is not None
 
-    def _dev_normal_vector(self, eng, x, out):
-        ok = self.__dict__.get("_normal_dev")             # (cached: a union may hold thousands of blocks)
+    def _normal_everywhere_on_device(self):
+        """True if normal_vector of every block runs on the device (cached: a union may hold thousands of blocks)."""
+        ok = self.__dict__.get("_normal_dev")
         if ok is None:
             ok = self.__dict__["_normal_dev"] = all(op._normal_on_device() for op, _ in self._leaves())
+        return ok
+
+    def _dev_normal_vector(self, eng, x, out):
+        ok = self._normal_everywhere_on_device()
         if ok:
             plan = self._segplan(eng, x.numel())
             if plan is not None:

@@ -502,6 +502,19 @@ typedef struct ccqp_pmprgp {
   double tol;
 } ccqp_pmprgp;
 int ccqp_bmprgp_partial_rows(void);
+/* MPRGP in lock-step on feasible sets that are NOT elementwise (Sphere, DisjointUnion with blocks of any size; a Cone
+ * block has no normal vector, solution_spaces.py:465): the state machine, slab and descriptors of ccqp_bmprgp_* with
+ * the projections, the normal vector (solution_spaces.py:389-403, 512-525), the feasible-step search (solvers.py:
+ * 1112-1118, CCQP_MAX_STEPS candidates per pass) and the Eq. 25 residual taken from the segmented engine -- per problem
+ * a struct ccqp_psegs as for ccqp_bsegs_*.  A round is ten launches for the whole batch.  start: x0 staged in `dx`
+ * (NOT in X[1]), slabs, counters and segment workspaces zero.  Polling, flags, status words: as ccqp_bmprgp_*.  Per
+ * problem the bits of its own CCQPSolverMPRGP.solve(). */
+int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, const struct ccqp_psegs* dev_segs, int count,
+                               int64_t n, int64_t max_nwork, int64_t max_nnorm, double gd, int flags,
+                               uint32_t* dev_batch, void* stream);
+int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, const struct ccqp_psegs* dev_segs, int count,
+                               int64_t n, int64_t round, int64_t max_nwork, int64_t max_nnorm, double gd, double eps10,
+                               int flags, uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,

@@ -73,6 +73,30 @@ def test_lockstep_mprgp_equals_individual_solves(n, count):
     assert max(r.solution_num_matrix_vector_multiplications for r in ref) > 10
 
 
+@pytest.mark.parametrize("n,count,segmented", [(300, 9, False), (1500, 5, False), (384, 7, True)])
+def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
+    """The A/B option of lockstep._bmprgp_run: the batch as two runs on two streams, the host alternating between them
+    (a CPU test covers the polling logic; this one the streams, the staging on lane engines and the reassembly).  Same
+    bits as one run -- on elementwise sets and through the segmented form."""
+    from ccqppy_amd import lockstep, solution_spaces as ss
+    probs = _problems(n, count, 4100 + n)
+    if segmented:
+        probs = [(A, b, x0, ss.DisjointProjOp(ss.SphereProjOp(n // 2, 0.6 + 0.1 * p), ss.BoxProjOp(n - n // 2, -0.3 * np.ones(n - n // 2), 0.4 * np.ones(n - n // 2))))
+                 for p, (A, b, x0, _) in enumerate(probs)]
+    tols = [1e-6] * count
+    one = _batch(probs, tols, 3000, single_launch=False)
+    monkeypatch.setattr(lockstep, "_HALVES_DEFAULT", True)
+    monkeypatch.setattr(lockstep, "_HALF_MIN_PROBLEMS", 2)
+    monkeypatch.setattr(lockstep, "_HALF_MIN_BYTES", 0.0)
+    for ahead in (1, 4):
+        two = _batch(probs, tols, 3000, single_launch=False, ahead=ahead)
+        for a, c in zip(one, two):
+            _same(a, c)
+    ref = _reference(probs[:2], tols[:2], 3000)
+    for a, c in zip(ref, one[:2]):
+        _same(a, c)
+
+
 def test_tight_bounds_exercise_every_branch():
     """Narrow boxes: many active constraints, so proportioning steps, expansion half-steps and full CG steps all
     occur (the executed-minus-reported MV difference counts the uncounted A.dx products of each)."""

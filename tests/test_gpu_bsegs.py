@@ -40,6 +40,13 @@ def _set(n, p, family):
         if n - 3 * k:
             ops.append(ss.IdentityProjOp(n - 3 * k))
         return ss.DisjointProjOp(*ops)
+    if family == "mixed_nocone":                  # as "mixed", every block with a normal vector (MPRGP's sets)
+        half = n // 2
+        q = (n - half) // 3
+        lo, hi = -0.3 * np.ones(half) - 0.01 * p, 0.4 * np.ones(half)
+        return ss.DisjointProjOp(ss.BoxProjOp(half, lo, hi),
+                                 ss.DisjointProjOp(ss.SphereProjOp(q, 0.7), ss.LowerBoundProjOp(q, -0.2 * np.ones(q))),
+                                 ss.SphereProjOp(n - half - 2 * q, 0.3 + 0.05 * p))
     if family == "mixed":                         # small and large blocks, elementwise and norm-based, nested
         half = n // 2
         q = (n - half) // 3
@@ -237,20 +244,77 @@ def test_segmented_apgd_mixed_sets_tolerances_starts_and_budgets():
     assert lockstep.stats["fallback_solves"] >= 0
 
 
-def test_solvers_without_a_segmented_form_are_declined_not_mis_solved():
-    """MPRGP / SPG on a non-elementwise set: the argument check says so (and solve_batch_sharded goes to the
-    host-driven scheduler, counted in lockstep.stats)."""
-    from ccqppy_amd import batch, lockstep, solvers
+def test_what_has_no_lockstep_form_is_declined_not_mis_solved():
+    """SPG without private generators, and MPRGP on a set with a block whose normal_vector does not run on the device (a
+    Cone block: the reference raises NotImplementedError, solution_spaces.py:465; scalar bounds: a TypeError): the
+    argument check says so, and solve_batch_sharded goes to the host-driven scheduler (counted in lockstep.stats),
+    which raises what the reference raises."""
+    from ccqppy_amd import batch, lockstep, solvers, solution_spaces as ss
     probs = _problems(128, 3, 1, "spheres3")
-    for cls in (solvers.CCQPSolverSPG, solvers.CCQPSolverMPRGP):
-        with pytest.raises(TypeError):
-            batch.solve_batch_pipelined(lambda: cls(1e-6, 300), probs)
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverSPG(1e-6, 300), probs)
+    cone = _problems(128, 3, 1, "mixed")
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), cone)
     before = lockstep.stats["auto_declined"]
-    out = batch.solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), lambda p: probs[p], 3)
+    with pytest.raises(NotImplementedError):
+        batch.solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), lambda p: cone[p], 3)
     assert lockstep.stats["auto_declined"] == before + 1
-    ref = _reference(probs, [1e-6] * 3, 300, "MPRGP")
-    for p in range(3):
-        _same(ref[p], out[p])
+    scalar = [(A, b, x0, ss.DisjointProjOp(ss.BoxProjOp(64, -0.5, 0.5), ss.SphereProjOp(64, 1.0))) for A, b, x0, _ in probs]
+    with pytest.raises(TypeError):
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), scalar)
+
+
+@pytest.mark.parametrize("family", ["sphere", "spheres3", "mixed_nocone"])
+@pytest.mark.parametrize("n,count", [(36, 11), (256, 24), (1000, 9), (2049, 6), (4500, 4)])
+def test_segmented_lockstep_mprgp_equals_individual_solves(family, n, count):
+    """MPRGP in lock-step on Sphere / DisjointUnion sets (ccqp_bsegs_mprgp_*): four projections, the normal vector, the
+    feasible-step search and the residual of every iteration through the segmented engine.  Per problem the bits of its
+    own solve(): reported and executed matvecs, converged flag, residual, x.  Reference loop: solvers.py:1026-1200 around
+    solution_spaces.py:389-403, 417-435, 512-525, 540-560."""
+    probs = _problems(n, count, 1900 + n, family)
+    tols = [1e-6] * count
+    ref = _reference(probs, tols, 3000, "MPRGP")
+    got = _batch(probs, tols, 3000, "MPRGP")
+    assert len(got) == count
+    for a, c in zip(ref, got):
+        assert c.solution_converged
+        _same(a, c)
+    assert max(r.solution_num_matrix_vector_multiplications for r in ref) > 5
+
+
+def test_segmented_lockstep_mprgp_budgets_starts_and_the_sharded_entry():
+    """Different sets in one batch, warm and trivial starts, mixed tolerances, every kind of matvec budget (a problem that
+    would reach it takes the reference's own exit path on the host, counted), and `solve_batch_sharded` picking the
+    lock-step scheduler by itself (no declined batch any more)."""
+    import torch
+    from ccqppy_amd import batch, lockstep, solvers
+    n, count = 384, 12
+    probs = _problems(n, count, 77, ["spheres3", "mixed_nocone", "sphere"])
+    first = _reference(probs, [1e-7] * count, 3000, "MPRGP")
+    for p in range(0, count, 3):
+        A, b, _, P = probs[p]
+        probs[p] = (A, b, first[p].solution.clone(), P)
+    tols = [[1e-7, 1e-5, 1e-3, 1e30][p % 4] for p in range(count)]
+    ref = _reference(probs, tols, 3000, "MPRGP")
+    got = _batch(probs, tols, 3000, "MPRGP", ahead=1)
+    for a, c in zip(ref, got):
+        _same(a, c)
+    assert any(r.solution_num_matrix_vector_multiplications == 1 for r in ref)       # x0 already meets tol
+    longest = max(r.solution_num_matrix_vector_multiplications for r in ref)
+    for cap in (3, 4, 5, longest // 2, longest, longest + 3):
+        want = _reference(probs, tols, cap, "MPRGP")
+        it = iter(tols)
+        have = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(next(it), cap), probs)
+        for a, c in zip(want, have):
+            _same(a, c)
+    before = dict(lockstep.stats)
+    sharded = batch.solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(1e-6, 3000), lambda p: probs[p], count)
+    assert lockstep.stats == before
+    want = _reference(probs, [1e-6] * count, 3000, "MPRGP")
+    for p in range(count):
+        _same(want[p], sharded[p])
+    assert isinstance(got[0].solution, torch.Tensor)
 
 
 @pytest.mark.parametrize("solver", ["BBPGD", "APGD", "APGDAntiRelaxation"])

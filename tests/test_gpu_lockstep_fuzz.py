@@ -96,7 +96,7 @@ def test_lockstep_equals_individual_solves(case):
             x0 = None
             if rng.random() < 0.3:
                 x0 = torch.as_tensor(rng.uniform(-0.5, 0.5, size=n), device=b.device)
-            general = name in ("BBPGD", "APGD", "APGDAntiRelaxation", "PGD", "SPG") and rng.random() < 0.35
+            general = rng.random() < 0.35               # (every solver has a segmented lock-step form)
             probs.append((op, b, x0, _general_set(rng, n) if general else _set(rng, n, name == "MPRGP")))
             tols.append(float(10.0 ** rng.uniform(-9, -4)) if name != "MPRGP" else float(10.0 ** rng.uniform(-7, -4)))
     order = rng.permutation(len(probs))                 # sizes interleaved in the call

@@ -192,6 +192,48 @@ def test_diagonal_windows_are_used_for_repeated_offset_patterns_and_change_no_bi
     assert H.same_bits(band.dot(xb).cpu().numpy()[8990:9010], want)
 
 
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 20, 31, 32, 33, 40, 63, 64, 65])
+def test_short_row_diagonal_windows_take_the_threads_per_row_path_and_change_no_bit(L):
+    """Diagonal windows whose rows hold at most 64 entries are multiplied by 1 / 2 / 4 THREADS per row (up to 16 / 32 /
+    64 entries; ccqp_spmv.hip, spmv_short_rows): values transposed through LDS, coalesced x gathers, the canonical
+    order as additions in registers plus at most two DPP steps.  Same bits as the generic paths and as the canonical
+    order, with and without the epilogue, for full and ragged last windows; full windows of 2, 4, 6 entries per row do
+    not fit the padded LDS layout and stay generic; 65 entries per row take round 2's diagonal path."""
+    from ccqppy_amd.operators import SparseOperator
+    rng = np.random.default_rng(100 + L)
+    rows = 40000 + 7 * L
+    offs = np.sort(rng.choice(np.arange(1, 400), size=L, replace=False)) * 5000      # no column shared inside a window
+    offs[L // 3] += 1                                          # (not all offsets multiples of one stride)
+    m = rows + int(offs.max()) + 1
+    cols = (np.arange(rows)[:, None] + offs[None, :]).astype(np.int32)
+    data = rng.normal(size=cols.shape)
+    data[17, L // 2] = -0.0                                    # a product of -0.0: the lane sum starts from +0.0
+    ip = np.arange(rows + 1, dtype=np.int64) * L
+    x = rng.normal(size=m)
+    x[cols[23, 0]] = 0.0
+    on = SparseOperator((ip, cols.reshape(-1), data.reshape(-1)), shape=(rows, m))
+    off = SparseOperator((ip, cols.reshape(-1), data.reshape(-1)), shape=(rows, m), diagonal_windows=False, local_x=False)
+    nwin = on.nnz // 1792 + 1
+    assert on.summary[2] == 0 and off.summary[3] == 0
+    if L in (2, 4, 6):
+        assert on.summary[3] <= 1                              # (only a ragged last window can fit)
+    else:
+        assert on.summary[3] >= nwin - 1
+    y_on, y_off = on.dot(x).cpu().numpy(), off.dot(x).cpu().numpy()
+    assert H.same_bits(y_on, y_off)
+    for lo in (0, 10, rows // 2, rows - 40):
+        want = H.spmv_canonical(ip[lo:lo + 41] - ip[lo], cols[lo:lo + 40].reshape(-1), data[lo:lo + 40].reshape(-1), x)
+        assert H.same_bits(y_on[lo:lo + 40], want)
+    b = rng.normal(size=rows)
+    eng = on.engine
+    yd, gd = eng.empty(rows), eng.empty(rows)
+    on.apply(eng, eng.to_device(x), yd, eng.to_device(b), gd)
+    assert H.same_bits(yd.cpu().numpy(), y_on) and H.same_bits(gd.cpu().numpy(), y_on + b)
+    # row blocks re-plan for themselves (other window boundaries, a ragged last window)
+    assert H.same_bits(on.row_block(1234, 7001).dot(x).cpu().numpy(), y_on[1234:8235])
+    assert H.same_bits(on.row_block(rows - 50, 50).dot(x).cpu().numpy(), y_on[rows - 50:])
+
+
 def test_duplicate_and_unsorted_columns_inside_rows():
     """CSR does not forbid repeated or unsorted columns within a row: every stored entry contributes, in storage
     order, on every path (entry order, transposed, local-x)."""

@@ -57,6 +57,52 @@ def test_poll_loop_stops_at_the_budget_without_waiting_for_a_report():
     assert _bpipe_poll_loop(_eng(dev), 3, dev.launch, 1, 4) == 1 and dev.polls == 0       # last round: no wait
 
 
+@pytest.mark.parametrize("ahead", [1, 4])
+def test_poll_many_keeps_every_run_within_its_own_run_ahead(ahead):
+    """Two lock-step runs advanced together (the two halves of a large MPRGP batch, each on its own engine): rounds of
+    each are queued in order, never more than `ahead` beyond that run's own last report, and each run stops on its own
+    convergence or budget."""
+    from ccqppy_amd.lockstep import _bpipe_poll_many
+    devs = [_FakeDevice(B=5, lag=0, done_at=17), _FakeDevice(B=3, lag=0, done_at=9), _FakeDevice(B=2, lag=0, done_at=10 ** 9)]
+    lasts = [np.inf, np.inf, 12]
+    runs = []
+    for d, last in zip(devs, lasts):
+        eng = types.SimpleNamespace(lib=d, ctx=None, device=None, torch_stream=None)
+        runs.append(types.SimpleNamespace(eng=eng, B=d.B, launch=d.launch, last=last))
+    _bpipe_poll_many(runs, ahead)
+    assert 17 <= runs[0].k <= 17 + ahead and 9 <= runs[1].k <= 9 + ahead and runs[2].k == 12
+    for d, r in zip(devs, runs):
+        assert d.queued == r.k and d.max_ahead <= ahead
+    # no round at all / a single round: nothing is waited for
+    d = _FakeDevice(B=1, lag=0, done_at=10 ** 9)
+    eng = types.SimpleNamespace(lib=d, ctx=None, device=None, torch_stream=None)
+    r0 = types.SimpleNamespace(eng=eng, B=1, launch=d.launch, last=0)
+    _bpipe_poll_many([r0], ahead)
+    assert r0.k == 0 and d.queued == 0
+    r1 = types.SimpleNamespace(eng=eng, B=1, launch=d.launch, last=1)
+    _bpipe_poll_many([r1], ahead)
+    assert r1.k == 1 and d.polls == 0
+
+
+def test_spec_part_slices_every_array():
+    import torch
+    from ccqppy_amd.lockstep import _Spec
+    sp = _Spec()
+    sp.B, sp.n = 5, 3
+    sp.A = np.arange(5, dtype=np.uint64)
+    sp.lda = np.arange(5, dtype=np.int64) + 10
+    sp.b = np.arange(5, dtype=np.uint64) + 20
+    sp.seg = np.zeros(5, dtype=np.int8)
+    sp.tol = np.linspace(0.1, 0.5, 5)
+    sp.x0 = [None, torch.ones(3), None, None, torch.zeros(3)]
+    sp.keep, sp.step, sp.fallback = None, None, False
+    h = sp.part(3, 5)
+    assert len(h) == 2 and h.n == 3 and list(h.A) == [3, 4] and list(h.lda) == [13, 14] and list(h.b) == [23, 24]
+    assert h.x0[0] is None and h.x0[1] is sp.x0[4] and h.tol[1] == sp.tol[4]
+    sp.x0 = None
+    assert sp.part(0, 2).x0 is None
+
+
 def test_descriptor_dtypes_match_the_c_structs():
     from ccqppy_amd import _lib
     for struct, size in ((_lib.Seg, 56), (_lib.PProb, 192), (_lib.PApgd, 192), (_lib.PMprgp, 224)):

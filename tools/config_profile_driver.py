@@ -94,7 +94,8 @@ def dense_config(which, args):
     for _ in range(args.warm):
         solve()
     torch.cuda.synchronize()
-    eng.gemv_events = []
+    # wall-clock first, WITHOUT the event pairs (creating and recording two timing events per matvec costs the host
+    # loop ~0.2 ms per matvec -- a third of a solve at n = 32768), then the same repetitions with them for the kernel
     mv0 = eng.mv_executed
     t0 = time.perf_counter()
     for _ in range(args.reps):
@@ -102,6 +103,12 @@ def dense_config(which, args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     mv = eng.mv_executed - mv0
+    eng.gemv_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        solve()
+    torch.cuda.synchronize()
+    dt_events = time.perf_counter() - t0
     ms = [a.elapsed_time(b_) for a, b_ in eng.gemv_events]
     eng.gemv_events = None
     rpl, launches = eng.gemv_plan(n, n)
@@ -122,6 +129,7 @@ def dense_config(which, args):
             "solve_level_frac": mv * mv_bytes(n, n) / dt / 1e9 / HBM_PEAK_GBS,
             "gemv_ms_per_solve": float(np.sum(ms)) / args.reps,
             "other_ms_per_solve": 1e3 * dt / args.reps - float(np.sum(ms)) / args.reps,
+            "wall_s_per_solve_with_event_pairs": dt_events / args.reps,
         },
         "kernel_source_sha1": source_hash("dense"), "box": box_id(0),
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Consistency of the segmented lock-step forms (ccqp_bsegs_*) under a saturated memory system: batches of 512 ... 4096
-problems on Sphere and Sphere(3)-union sets, six solvers (SPG: ccqp_bspg.hip, one generator per problem), three
+problems on Sphere and Sphere(3)-union sets, seven solvers (SPG: ccqp_bspg.hip, one generator per problem; MPRGP:
+ccqp_bsegs_mprgp_*), three
 repetitions each.  Every repetition must give the
 same bits and matvec counts as the first one (the schedule of the workgroups differs from run to run: a race between
 a deciding block and a late reader would show as a difference), every problem must converge,
@@ -34,7 +35,8 @@ def main():
             probs[fam] = ps
         for fam, ps in probs.items():
             for name, args in (("BBPGD", (1e-8, 5000)), ("BBPGDf", (1e-8, 5000)), ("PGD", (1e-7, 5000, 0.3)),
-                               ("APGD", (1e-8, 5000)), ("APGDAntiRelaxation", (1e-8, 5000)), ("SPG", (1e-8, 5000))):
+                               ("APGD", (1e-8, 5000)), ("APGDAntiRelaxation", (1e-8, 5000)), ("SPG", (1e-8, 5000)),
+                               ("MPRGP", (1e-6, 3000))):
                 base = getattr(solvers, "CCQPSolver" + name)
                 seeds = iter(())
 
