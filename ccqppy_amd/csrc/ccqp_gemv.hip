@@ -126,6 +126,110 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_mfma_kernel(const double* __r
   }
 }
 
+// ------------------------------------------------------------------ LDS-staged form (A/B variant, bit 24 of the variant word)
+// north_star words the matvec as "coalesced HBM row reads, LDS-staged A-tiles"; this is that kernel, kept selectable
+// so the phrase is answered by a measurement (profiles/r03_gemv_lds_ab.md) and not only by the guide's rule for GEMV
+// ("operand streamed once and not shared across waves: load straight to VGPRs; an LDS round trip is pure overhead").
+// One wave owns R consecutive rows, as in the VALU form.  Per 128-column step it issues R + 1 LDS-DMA loads
+// (`global_load_lds_dwordx4`: 1 KiB of each row, non-temporal, and the matching 1 KiB of x out of L2) into one slot of
+// its PRIVATE ring of S slots -- no VGPR destination, so S - 1 steps (S = 4: 9 KiB per wave) are in flight instead of
+// one -- waits with a counted `s_waitcnt vmcnt`, reads the slot back with ds_read_b128 and runs the same fma chain:
+// lane l still accumulates columns {128k + 2l, 128k + 2l + 1} in increasing k into one accumulator per row, hence the
+// SAME BITS as the VALU form.  No barrier anywhere (a wave reads only what it has loaded itself).
+// LDS: 4 waves x S x (R + 1) KiB = 48 KiB per workgroup at R = 2, S = 4 => 3 workgroups (12 waves) per CU.
+// Needs cols % 128 == 0 and 16-byte aligned A / x / lda; other shapes take the VALU form.
+template <int R, int S, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __restrict__ A, int64_t lda,
+                                                              const double* __restrict__ x,
+                                                              const double* __restrict__ b, double* __restrict__ y,
+                                                              double* __restrict__ g, int64_t rows, int64_t cols,
+                                                              int64_t ntasks, const double* __restrict__ skip) {
+#if defined(__HIP_DEVICE_COMPILE__)             // (the host pass only needs the launch stub)
+  if (skip != nullptr && *skip != 0.0) return;
+  constexpr int PIECE = 1024;                   // bytes one wave instruction moves: 64 lanes x 16 B
+  constexpr int SLOT = (R + 1) * PIECE;
+  __shared__ __attribute__((aligned(16))) char ring[(CCQP_BLOCK / 64) * S * SLOT];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  char* const mine = ring + (threadIdx.x >> 6) * (S * SLOT);
+  const int64_t nsteps = cols / 128;
+  for (int64_t task = wave; task < ntasks; task += nwaves) {
+    const int64_t r0 = task * R;
+    const double* rp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t row = r0 + r;
+      if (row > rows - 1) row = rows - 1;       // clamp: tail rows re-read a valid row, never stored
+      rp[r] = A + row * lda + 2 * lane;
+    }
+    const double* xp = x + 2 * lane;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    // every ds_read of the previous task has returned (its values fed the fma chain) before a slot is written again
+    auto issue = [&](int64_t step) {
+      char* slot = mine + (int)(step % S) * SLOT;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        __builtin_amdgcn_global_load_lds(rp[r] + step * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
+                                         16, 0, NT ? 2 : 0);
+      __builtin_amdgcn_global_load_lds(xp + step * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16,
+                                       0, 0);
+    };
+    for (int64_t p = 0; p < S - 1 && p < nsteps; ++p) issue(p);
+    for (int64_t s = 0; s < nsteps; ++s) {
+      if (s + S - 1 < nsteps) {
+        issue(s + S - 1);
+        // steps s+1 .. s+S-1 may stay in flight: (S - 1) * (R + 1) loads
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 1)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last S - 1 steps of a row: drain
+      }
+      const char* slot = mine + (int)(s % S) * SLOT;
+      const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+        acc[r] = fma(av.x, xv.x, acc[r]);
+        acc[r] = fma(av.y, xv.y, acc[r]);
+      }
+      asm volatile("" ::: "memory");            // the slot's reads stay ahead of the DMA that refills it
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = r0 + r;
+      if (lane == r && row < rows) {
+        y[row] = acc[r];
+        if (g) g[row] = acc[r] + b[row];
+      }
+    }
+  }
+#endif
+}
+
+static bool gemv_lds_applicable(const double* A, int64_t lda, const double* x, int64_t cols) {
+  return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (lda % 2) == 0 &&
+         cols > 0 && (cols % 128) == 0;
+}
+
+#define GEMV_LDS_R 2
+#define GEMV_LDS_BPC 3                          // workgroups per CU the 48 KiB ring allows
+
+static void launch_lds(int64_t blocks, bool nt, hipStream_t s, const double* A, int64_t lda, const double* x,
+                       const double* b, double* y, double* g, int64_t rows, int64_t cols, const double* skip) {
+  constexpr int R = GEMV_LDS_R;
+  const int64_t ntasks = (rows + R - 1) / R;
+  if (nt)
+    hipLaunchKernelGGL((gemv_lds_kernel<R, 4, true>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y, g,
+                       rows, cols, ntasks, skip);
+  else
+    hipLaunchKernelGGL((gemv_lds_kernel<R, 4, false>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y,
+                       g, rows, cols, ntasks, skip);
+}
+
 static bool gemv_mfma_applicable(const double* A, int64_t lda, const double* x, int64_t cols) {
   return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (lda % 2) == 0 &&
          cols > 0 && (cols % 64) == 0;
@@ -152,7 +256,7 @@ static void launch_mfma(ccqp_ctx* ctx, int U, int bpc, hipStream_t s, const doub
 // variant word: bits 0-3 R (rows per wave: 1,2,4,8), bits 4-7 U (unroll: 1,2,4), bit 8 = 1 disables
 // the non-temporal A loads (matrices of at most 192 MiB are loaded cacheably anyway), bit 9 = 1 selects the MFMA form (16 rows per wave; U = columns/16 per step: 1, 2, 4;
 // shapes it does not cover fall through to the VALU form), bits 10-11 / 20-23 the launch rounds (below), bits 12-19
-// workgroups per CU (0 = default).  0 = tuned default
+// workgroups per CU (0 = default), bit 24 = 1 selects the LDS-staged form (same bits as the default).  0 = tuned default
 // (interleaved sweep on MI355X: tools/gemv_sweep.py, profiles/r01_gemv_sweep.md).  Every choice
 // yields the same bits, so this is speed only.
 struct gemv_shape {
@@ -189,10 +293,18 @@ static gemv_shape gemv_decide(const ccqp_ctx* ctx, int64_t rows, int64_t cols, i
   return d;
 }
 
+// the LDS-staged form has its own rows per wave and workgroups per CU; launch rounds as the default
+static int gemv_lds_variant(int variant) {
+  int bpc = (variant >> 12) & 0xFF;
+  if (bpc == 0 || bpc > GEMV_LDS_BPC) bpc = GEMV_LDS_BPC;
+  return (variant & ~0xFF00F) | GEMV_LDS_R | (bpc << 12);
+}
+
 extern "C" int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
                               int64_t* launches) {
   CCQP_REQUIRE(ctx != nullptr && rows_per_launch != nullptr && launches != nullptr, "NULL argument");
   CCQP_REQUIRE(rows >= 0 && cols >= 0, "negative size");
+  if (((variant >> 24) & 1) && cols > 0 && cols % 128 == 0) variant = gemv_lds_variant(variant);   // (aligned operands assumed)
   const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
   *rows_per_launch = d.rounds ? d.round_rows : rows;
   *launches = d.rounds ? (rows + d.round_rows - 1) / d.round_rows : (rows > 0 ? 1 : 0);
@@ -207,6 +319,8 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
     launch_mfma(ctx, U0 == 0 ? 4 : U0, (variant >> 12) & 0xFF, s, A, lda, x, b, y, g, rows, cols, skip);
     return CCQP_OK;
   }
+  const bool lds = ((variant >> 24) & 1) && gemv_lds_applicable(A, lda, x, cols);
+  if (lds) variant = gemv_lds_variant(variant);
   const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
   const int R = d.R, U = d.U;
   const bool nt = d.nt, rounds = d.rounds;
@@ -224,6 +338,10 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
     const double* br = b ? b + r0 : nullptr;
     double* yr = y + r0;
     double* gr = g ? g + r0 : nullptr;
+    if (lds) {
+      launch_lds(blocks, nt, s, Ar, lda, x, br, yr, gr, nr, cols, skip);
+      continue;
+    }
     switch (R) {
       case 1: bad = launch_r<1>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;
       case 2: bad = launch_r<2>(U, aligned, nt, s, (int)blocks, Ar, lda, x, br, yr, gr, nr, cols, skip); break;

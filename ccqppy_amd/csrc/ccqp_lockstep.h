@@ -184,7 +184,8 @@ static inline int bp_vec_grid(int64_t n) {
 
 // `flags` of the entry points: bit 0 = 16-byte aligned operands; the rest is a TUNING word that never changes a
 // result bit (0 = defaults): bits 1-2 matrix loads 0 default / 1 cacheable / 2 non-temporal, bits 4-6 columns
-// per wave step in units of 128 (1, 2, 4; 7 / 6 = two / four rows per wave, one step), bits 8.. workgroups per problem.
+// per wave step in units of 128 (1, 2, 4; 7 / 6 = two / four rows per wave, one step; 3 / 5 = two rows per wave, two / four
+// steps), bits 8.. workgroups per problem.
 struct bp_mv_tuning {
   bool aligned;
   int nt, U;
@@ -209,7 +210,7 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : n <= 256 ? 6 : n <= 512 ? 7 : 1);
   // several rows per wave: no more workgroups than there are tasks (a workgroup beyond that would load its problem's
   // descriptor and state word only to leave -- at n = 256, four rows per wave, that was three workgroups out of four)
-  const int64_t rows_per_wave = t.U == 7 ? 2 : t.U == 6 ? 4 : 1;
+  const int64_t rows_per_wave = (t.U == 7 || t.U == 3 || t.U == 5) ? 2 : t.U == 6 ? 4 : 1;
   const int64_t tasks = (n + rows_per_wave - 1) / rows_per_wave;
   if (per > (tasks + rows_per_wg - 1) / rows_per_wg) per = (tasks + rows_per_wg - 1) / rows_per_wg;
   // very short rows (n <= 128): a task is only 2-4 KiB of matrix, so let a wave take several (~8 KiB) as long as
@@ -228,9 +229,10 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 }
 
 // The matvec kernels' first template argument is a CODE: 1, 2, 4 = one row per wave and that many 128-column
-// steps in flight; 8 / 9 = two / four rows per wave, one step (8: the large-matrix form of ccqp_gemv.hip).
-#define BP_R(C) ((C) == 8 ? 2 : (C) == 9 ? 4 : 1)
-#define BP_U(C) ((C) >= 8 ? 1 : (C))
+// steps in flight; 8 / 9 = two / four rows per wave, one step (8: the large-matrix form of ccqp_gemv.hip); 10 / 11 = two
+// rows per wave, two / four steps in flight (tuning-word values 3 / 5).
+#define BP_R(C) ((C) == 8 || (C) == 10 || (C) == 11 ? 2 : (C) == 9 ? 4 : 1)
+#define BP_U(C) ((C) == 10 ? 2 : (C) == 11 ? 4 : (C) >= 8 ? 1 : (C))
 #define BP_TASKS(C, n) (((n) + BP_R(C) - 1) / BP_R(C))
 
 // launches KERNEL<code, ALIGNED, NT>(args...) for the tuning `t`
@@ -240,6 +242,8 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   do {                                                                \
     if (t.U == 7) BP_MV_LAUNCH1(KERNEL, 8, AL, NTT, __VA_ARGS__);     \
     else if (t.U == 6) BP_MV_LAUNCH1(KERNEL, 9, AL, NTT, __VA_ARGS__); \
+    else if (t.U == 3) BP_MV_LAUNCH1(KERNEL, 10, AL, NTT, __VA_ARGS__); \
+    else if (t.U == 5) BP_MV_LAUNCH1(KERNEL, 11, AL, NTT, __VA_ARGS__); \
     else if (t.U >= 4) BP_MV_LAUNCH1(KERNEL, 4, AL, NTT, __VA_ARGS__); \
     else if (t.U == 2) BP_MV_LAUNCH1(KERNEL, 2, AL, NTT, __VA_ARGS__); \
     else BP_MV_LAUNCH1(KERNEL, 1, AL, NTT, __VA_ARGS__);              \

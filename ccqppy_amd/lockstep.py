@@ -969,7 +969,7 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
                     (scalar ones raise in the reference's normal_vector).
     feasible_set  : instead of lower / upper: ONE *ProjOp of dimension n built from the seven operators (Sphere, Cone,
                     DisjointUnion of any blocks, ...), shared by all problems -- the segmented lock-step forms
-                    (ccqp_bsegs.hip / ccqp_bspg.hip; every solver but MPRGP)
+                    (ccqp_bsegs.hip / ccqp_bspg.hip / ccqp_bmprgp.hip; MPRGP: no Cone block, array bounds)
     tol           : one tolerance or one per problem
     Problem p gets bit for bit the result of `Solver(tol[p], max_mv).solve(A[p], b[p], x0[p], P_p)` with P_p the
     corresponding *ProjOp (tests/test_gpu_stacked.py).  Returns a StackedResult."""
@@ -1022,10 +1022,13 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
             raise ValueError("solve_stacked: either lower / upper or feasible_set")
         if hasattr(feasible_set, "_dev_bb_tail"):
             raise TypeError("solve_stacked: an elementwise feasible_set is given through lower / upper")
-        if name == "MPRGP" or not isinstance(feasible_set, ss.ProjOpBase) or not feasible_set._has_device_form():
-            raise TypeError("solve_stacked(feasible_set=...) runs every solver but MPRGP on sets built from the seven "
-                            "operators, got %s with %r" % (name, type(feasible_set).__name__))
+        if not isinstance(feasible_set, ss.ProjOpBase) or not feasible_set._has_device_form():
+            raise TypeError("solve_stacked(feasible_set=...) needs a set built from the seven operators, got %r"
+                            % type(feasible_set).__name__)
         feasible_set._refresh()
+        if name == "MPRGP" and not feasible_set._normal_everywhere_on_device():
+            raise TypeError("solve_stacked('MPRGP', feasible_set=...) needs a set whose normal_vector exists on the device "
+                            "(no Cone block -- the reference raises NotImplementedError --, array bounds)")
         if getattr(feasible_set, "_fixed_dim", False) and feasible_set.embedded_dimension != n:
             raise ValueError("solve_stacked: the feasible set does not match b")
         plans = [feasible_set._segplan(eng, n)] * B      # (the tables are read-only: one plan for all problems)
@@ -1091,7 +1094,7 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
                 if host["used"][p]:                      # the reference's draw raises here: numpy's own OverflowError
                     np.random.RandomState(0).uniform(low=0.0, high=np.nan)
         else:
-            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune, single_launch)
+            status, sols, res, mv, execd = _bmprgp_run(eng, sp, n, max_mv, ahead, tune, single_launch, plans=plans)
             todo = np.flatnonzero(status != 1.0)
     mv, execd, res = np.array(mv, dtype=np.int64), np.array(execd, dtype=np.int64), np.array(res, dtype=np.float64)
     if B == 1:

@@ -414,12 +414,13 @@ def test_rejects_what_it_cannot_run():
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverSPG(1e-8), [(op, b, None, None)])
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverAPGD(1e-8, reuse_matvec=True), [(op, b, None, None)])
-    # (every solver but MPRGP runs on Sphere / Cone / DisjointUnion sets in the segmented lock-step forms since round 2 --
-    # tests/test_gpu_bsegs.py; the other solvers still need elementwise sets)
+    # (every solver runs on Sphere / Cone / DisjointUnion sets in the segmented lock-step forms -- tests/test_gpu_bsegs.py;
+    # MPRGP needs a normal vector for every block: a Cone has none, solution_spaces.py:465)
     with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8), [(op, b, None, ss.ConeProjOp(64))])
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 300), [(op, b, None, ss.ConeProjOp(64))])
     with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8), [(op, b, None, ss.SphereProjOp(64))])
+        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 300),
+                                    [(op, b, None, ss.DisjointProjOp(ss.SphereProjOp(32), ss.ConeProjOp(32)))])
     class Foreign:                        # a user-defined block: no device form, the union cannot run in lock-step
         embedded_dimension = 32
 

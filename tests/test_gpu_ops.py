@@ -244,6 +244,21 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
     assert eng.gemv_plan(4096, 4096)[1] == 1
     per, launches = eng.gemv_plan(131072, 131072)
     assert launches > 1 and per * launches >= 131072
+    # the LDS-staged form (variant bit 24: rows through an LDS ring by LDS-DMA loads): the SAME bits as the default, on
+    # shapes it covers (cols % 128 == 0; 1, 2, 3 and many 128-column steps; an odd row count; epilogue; row blocks), and
+    # a silent fall-through to the default on the others
+    for rows3, cols3 in ((5, 128), (333, 256), (64, 384), (1001, 4096), (777, 2050)):
+        A3 = rng.normal(size=(rows3, cols3))
+        x3, b3 = rng.normal(size=cols3), rng.normal(size=rows3)
+        dA3, dx3, db3 = eng.to_device(A3), eng.to_device(x3), eng.to_device(b3)
+        ya, ga, yb, gb = eng.empty(rows3), eng.empty(rows3), eng.empty(rows3), eng.empty(rows3)
+        eng.gemv(dA3, dx3, ya, db3, ga)
+        for v in (1 << 24, (1 << 24) | (1 << 8), (1 << 24) | (1 << 12)):
+            eng.gemv(dA3, dx3, yb, db3, gb, variant=v)
+            assert H.same_bits(yb.cpu().numpy(), ya.cpu().numpy()) and H.same_bits(gb.cpu().numpy(), ga.cpu().numpy())
+        yc = eng.empty(rows3 - rows3 // 2)
+        eng.gemv(dA3[rows3 // 2:], dx3, yc, variant=1 << 24)
+        assert H.same_bits(yc.cpu().numpy(), ya.cpu().numpy()[rows3 // 2:])
     # row blocks (what each rank of a row-sharded run computes)
     for r0, r1 in ((0, 100), (100, 389), (389, 777)):
         y = eng.empty(r1 - r0)
