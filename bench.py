@@ -13,12 +13,13 @@ For N > 1 the matrix is row-block sharded (one process per GPU, RCCL all-gather 
 matvec) and the SAME problem is solved: strong scaling.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (fp64 streaming GEMV): algorithmic bytes / duration measured with HIP events on
-                  the launch stream inside the timed region, against the 8 TB/s HBM3E peak.  A matvec of the
-                  headline size is `launches_per_matvec` launches of the kernel, each over `rows_per_launch` rows
-                  (ccqp_gemv_plan): `achieved` = bytes of a MATVEC / the events' time around all of its
-                  launches (gaps between them included); `bytes_per_launch`, `avg_launch_ms` (= that time /
-                  launches) and `traffic` are per KERNEL launch, the unit of the rocprofv3 tables under profiles/.
+  roofline     -- dominant kernel (fp64 streaming GEMV; `kernel` names the form this shape runs as, ccqp_gemv_form):
+                  algorithmic bytes / duration measured with HIP events on the launch stream inside the timed region,
+                  against the 8 TB/s HBM3E peak.  A matvec is `launches_per_matvec` launches of the kernel, each over
+                  `rows_per_launch` rows (ccqp_gemv_plan; the headline size: ONE persistent launch of the LDS-staged
+                  form): `achieved` = bytes of a MATVEC / the events' time around all of its launches (gaps between
+                  them included); `bytes_per_launch`, `avg_launch_ms` (= that time / launches) and `traffic` are per
+                  KERNEL launch, the unit of the rocprofv3 tables under profiles/.
   cpu_baseline -- the numpy oracle (oracle/cpu_ref.py, a port of the reference; OpenBLAS threads =
                   host cores) solving THE SAME problem (n = 131072, ~60 s of host work) on the GPU box's host, on
                   rank 0, at every N: at N = 1 the device matrix is copied to the host, at N > 1 rank 0 regenerates the
@@ -445,7 +446,8 @@ def _main():
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
         achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
         rows_per_launch, launches = eng.gemv_plan(rows_local, n)
-        traffic, traffic_src = pmc_traffic(mv_bytes(rows_per_launch, n))
+        form = eng.gemv_form(rows_local, n)              # the kernel this shape runs as: its name in a rocprofv3 table
+        traffic, traffic_src = pmc_traffic(mv_bytes(rows_per_launch, n), form)
         steps = max(args.steps, 1)
         line = {
             "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
@@ -484,7 +486,9 @@ def _main():
             "extension_symmetric": sym_info,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "gemv_stream_kernel (ccqp_gemv_f64)",
+                "kernel": "%s (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64%s)" % (
+                    form, "; rows through per-wave LDS rings by LDS-DMA loads, one persistent launch"
+                    if form == "gemv_lds_kernel" else ""),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -146,6 +146,13 @@ class Engine:
         _lib.check(self.lib.ccqp_gemv_plan(self.ctx, rows, cols, v, ctypes.byref(rpl), ctypes.byref(nl)))
         return rpl.value, nl.value
 
+    def gemv_form(self, rows, cols, variant=None):
+        """Name of the kernel a rows x cols matvec runs as (aligned operands assumed)."""
+        buf = ctypes.create_string_buffer(64)
+        v = self.gemv_variant if variant is None else variant
+        _lib.check(self.lib.ccqp_gemv_form(self.ctx, rows, cols, v, buf, 64))
+        return buf.value.decode()
+
     def gemv(self, A, x, y, b=None, g=None, variant=None):
         """y = A.x for a (rows, cols) row-major device matrix; optionally g = y + b."""
         rows, cols = A.shape

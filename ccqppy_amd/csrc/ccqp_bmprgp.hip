@@ -18,6 +18,8 @@
 // x_k / x_{k+1} and g_k / g_{k+1} live in two buffers each, addressed by the parity of the outer-iteration count.
 // The bodies are those of the single-problem kernels (ccqp_bodies.h), so every problem gets bit for bit the result
 // of its own CCQPSolverMPRGP.solve() (tests/test_gpu_bmprgp.py).
+#include <stdlib.h>
+
 #include "ccqp_lockstep.h"
 #include "ccqp_segs.h"
 
@@ -105,36 +107,63 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_x_kernel(const ccqp_pm
   bmprgp_init_x_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
-template <int U, bool ALIGNED, bool NT>
-__device__ __forceinline__ void bmprgp_gemv_body(const ccqp_pmprgp& q, int init, int64_t n, int64_t wave,
-                                                 int64_t nwaves) {
+// which matvec a problem runs in this launch, by `init` / its state: false = none
+struct bmprgp_mv {
+  const double* x;
+  const double* b;
+  double* y;
+  double* g;
+};
+__device__ __forceinline__ bool bmprgp_mv_operands(const ccqp_pmprgp& q, int init, bmprgp_mv* m) {
+  m->b = nullptr;
+  m->g = nullptr;
   if (init == 1) {                            // g_k = A x_k + b
-    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[0], q.b, q.ytmp, q.G[0], n, n, BP_TASKS(U, n), wave, nwaves);
-    return;
+    m->x = q.X[0];
+    m->b = q.b;
+    m->y = q.ytmp;
+    m->g = q.G[0];
+    return true;
   }
-  if (q.slab[MP_DONE] != 0.0) return;
+  if (q.slab[MP_DONE] != 0.0) return false;
   if (init == 2) {                            // A g_k (solvers.py:1077)
-    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.G[0], nullptr, q.Adx, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
-    return;
+    m->x = q.G[0];
+    m->y = q.Adx;
+    return true;
   }
   const int it = (int)q.slab[MP_IT];
   switch ((int)q.slab[MP_STATE]) {
     case ST_M1:
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[it & 1], q.b, q.ytmp, q.G[it & 1], n, n, BP_TASKS(U, n), wave, nwaves);
-      break;
+      m->x = q.X[it & 1];
+      m->b = q.b;
+      m->y = q.ytmp;
+      m->g = q.G[it & 1];
+      return true;
     case ST_AP:
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.p, nullptr, q.Ap, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
-      break;
+      m->x = q.p;
+      m->y = q.Ap;
+      return true;
     case ST_G1:
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.ytmp, q.G[(it + 1) & 1], n, n, BP_TASKS(U, n), wave, nwaves);
-      break;
+      m->x = q.X[(it + 1) & 1];
+      m->b = q.b;
+      m->y = q.ytmp;
+      m->g = q.G[(it + 1) & 1];
+      return true;
     case ST_ADXC:
     case ST_ADXH:
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.dx, nullptr, q.Adx, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
-      break;
+      m->x = q.dx;
+      m->y = q.Adx;
+      return true;
     default:
-      break;                                  // ST_FEAS_WAIT: no matvec this round
+      return false;                           // ST_FEAS_WAIT: no matvec this round
   }
+}
+
+template <int U, bool ALIGNED, bool NT>
+__device__ __forceinline__ void bmprgp_gemv_body(const ccqp_pmprgp& q, int init, int64_t n, int64_t wave,
+                                                 int64_t nwaves) {
+  bmprgp_mv m;
+  if (!bmprgp_mv_operands(q, init, &m)) return;
+  gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, m.x, m.b, m.y, m.g, n, n, BP_TASKS(U, n), wave, nwaves);
 }
 
 template <int U, bool ALIGNED, bool NT>
@@ -142,6 +171,65 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmpr
                                                                  int64_t n) {
   bmprgp_gemv_body<U, ALIGNED, NT>(probs[blockIdx.y], init, n, (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6),
                                    (int64_t)gridDim.x * (CCQP_BLOCK / 64));
+}
+
+// The same matvec with the rows staged through per-wave LDS rings by LDS-DMA loads (gemv_lds_body, ccqp_bodies.h: same
+// bits): few long-lived workgroups, 15-21 KiB in flight per wave.  Tuning word: loads = 3; bits 4-6 pick the ring
+// (0: R = 2, S = 8, 4 waves per workgroup; 1: R = 4, S = 4, 2 waves; 2: R = 4, S = 4, 4 waves; 3: R = 2, S = 4, 4 waves).
+// Needs n % 128 == 0 and aligned operands.  An A/B form: it ties the VALU form at config 5's shape
+// (profiles/r03_bmv_sweep_lds.jsonl) -- 64 KiB rows leave the ring little to stream between two row ends.
+template <int R, int S>
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_lds_kernel(const ccqp_pmprgp* __restrict__ probs, int init,
+                                                                     int64_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  bmprgp_mv m;
+  if (!bmprgp_mv_operands(q, init, &m)) return;
+  constexpr int RING = S * (R + 1) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  gemv_lds_body<R, S, true>(q.A, q.lda, m.x, m.b, m.y, m.g, n, n, (n + R - 1) / R, (int64_t)blockIdx.x * wpb + w,
+                            (int64_t)gridDim.x * wpb, ring + w * RING, res);
+#endif
+}
+
+template <int R, int S>
+static int bmprgp_launch_gemv_lds(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
+                                  int wpb, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) {
+    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bmprgp_gemv_lds_kernel<R, S>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  // workgroups per problem: the tuning word's, else one workgroup per CU over the whole batch (at least 1 per problem)
+  int64_t per = flags >> 8;
+  if (per <= 0) per = ctx->num_cu / count > 0 ? ctx->num_cu / count : 1;
+  const int64_t tasks = (n + R - 1) / R;
+  if (per > (tasks + wpb - 1) / wpb) per = (tasks + wpb - 1) / wpb;
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
+  hipLaunchKernelGGL((bmprgp_gemv_lds_kernel<R, S>), dim3((unsigned)per, count), dim3(64 * wpb), lds, s, dev_probs, init,
+                     n);
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
+  return CCQP_OK;
+}
+
+// launches the round's matvec: the LDS-DMA form where the tuning word asks for it (loads = 3) and the shape allows
+static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
+                              hipStream_t s) {
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  if (((flags >> 1) & 3) == 3 && t.aligned && n % 128 == 0) {
+    switch ((flags >> 4) & 7) {
+      case 1: return bmprgp_launch_gemv_lds<4, 4>(ctx, dev_probs, count, n, init, flags, 2, s);
+      case 2: return bmprgp_launch_gemv_lds<4, 4>(ctx, dev_probs, count, n, init, flags, 4, s);
+      case 3: return bmprgp_launch_gemv_lds<2, 4>(ctx, dev_probs, count, n, init, flags, 4, s);
+      default: return bmprgp_launch_gemv_lds<2, 8>(ctx, dev_probs, count, n, init, flags, 4, s);
+    }
+  }
+  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, init, n);
+  return CCQP_OK;
 }
 
 // residual of the start (exit test :1070-1073)
@@ -239,10 +327,15 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, const mp_words& z,
 // stage = 1, 2, 3; grid (nblk, problems)
 // LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call in stage 3, converged counter); otherwise
 // the problem of a single-launch solve (bx = 0, nblk = 1)
-template <bool LOCKSTEP>
+// SEQ: one workgroup walks the problem's chunks itself, one call per chunk (bmprgp_tail_fused_kernel): the meeting point
+// is bp_meet_seq on `seqpart` (LDS, MP_STEPS x nblk doubles) -- same partial sums, same order, same bits
+#define MP_MEET(NRED) \
+  (SEQ ? bp_meet_seq(seqpart, bx, nblk, NRED, v, lds4) : bp_meet(q.partials, q.counter, nblk, NRED, v, lds4, is_last_p))
+template <bool LOCKSTEP, bool SEQ = false>
 __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stage, int bx, double gd, double eps10,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
-                                                  unsigned count, double seq, double* lds4, int* is_last_p) {
+                                                  unsigned count, double seq, double* lds4, int* is_last_p,
+                                                  double* seqpart = nullptr) {
   double* s = q.slab;                         // written only (by the deciding thread); read through `z` alone
   const mp_words z = mp_enter(s);
   if (z.done != 0.0) {
@@ -262,7 +355,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
     switch (st) {
       case ST_M1: {                           // :1090-1094
         v[0] = split_body(sg, xk, gk, q.txk, q.psi, q.w, chunk, bx, lds4);
-        if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
+        if (!MP_MEET(1)) return;
         if (threadIdx.x == 0) {
           s[MP_DIST2] = v[0];
           s[MP_ACT] = (double)ACT_NONE;
@@ -275,7 +368,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
       case ST_AP: {                           // :1100-1106
         v[0] = dot_body(q.psi, q.p, n, chunk, bx, lds4);
         v[1] = dot_body(q.p, q.Ap, n, chunk, bx, lds4);
-        if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
+        if (!MP_MEET(2)) return;
         if (threadIdx.x == 0) {
           const double acg = v[0] / v[1];
           s[MP_S0] = v[0];
@@ -293,7 +386,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
       }
       case ST_FEAS_WAIT:
       case ST_G1: {
-        if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, is_last_p)) return;
+        if (!MP_MEET(0)) return;
         if (threadIdx.x == 0) {
           if (st == ST_G1) {
             s[MP_ACT] = (double)ACT_AFTER_G1;
@@ -335,7 +428,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           v[2] = a2;
           ccqp_block_sum_multi<3>(v);
         }
-        if (!bp_meet(q.partials, q.counter, nblk, 3, v, lds4, is_last_p)) return;
+        if (!MP_MEET(3)) return;
         if (threadIdx.x == 0) {
           s[MP_S0] = v[0];
           s[MP_S1] = v[1];
@@ -352,7 +445,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
   if (stage == 2) {
     if (st == ST_M1_N) {                      // :1095
       v[0] = normal_dot_body(sg, q.txk, gk, q.nv, z.dist2, chunk, bx, lds4);
-      if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
+      if (!MP_MEET(1)) return;
       if (threadIdx.x == 0) {
         s[MP_NG] = v[0];
         s[MP_STATE] = (double)ST_M1_P;
@@ -374,7 +467,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
             v[k] = ((wsum[4 * k] + wsum[4 * k + 1]) + wsum[4 * k + 2]) + wsum[4 * k + 3];
         __syncthreads();
       }
-      if (!bp_meet(q.partials, q.counter, nblk, MP_STEPS, v, lds4, is_last_p)) return;
+      if (!MP_MEET(MP_STEPS)) return;
       if (threadIdx.x == 0) {
         double af = a0;
         int found = 0, at = 0;
@@ -413,7 +506,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
   // stage 3
   if (st == ST_M1_P) {                        // :1096-1099
     proportion_body(q.w, gk, q.nv, q.psi, z.ng, n, chunk, bx, lds4, &v[0], &v[1]);
-    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
+    if (!MP_MEET(2)) return;
     if (threadIdx.x == 0) {
       s[MP_S0] = v[0];
       s[MP_S1] = v[1];
@@ -445,7 +538,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
     }
     v[0] = ccqp_block_sum(a0, lds4);
     v[1] = ccqp_block_sum(a1, lds4);
-    if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, is_last_p)) return;
+    if (!MP_MEET(2)) return;
     if (threadIdx.x == 0) {
       const double den = v[1] + eps10;
       s[MP_S0] = v[0];
@@ -471,6 +564,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
   bmprgp_stage_body<true>(probs[blockIdx.y], stage, blockIdx.x, gd, eps10, chunk, nblk, batch, host, count, seq, lds4,
                           &is_last);
 }
+
+#undef MP_MEET
 
 __device__ __forceinline__ void bmprgp_apply_body(const ccqp_pmprgp& q, int bx, int nbx) {
   const double* s = q.slab;
@@ -523,6 +618,32 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmp
   bmprgp_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
+// The three stages and the update of a round in ONE launch, one workgroup per problem: the workgroup walks the problem's
+// chunks itself (bp_meet_seq), so the stages need no inter-workgroup meeting and follow each other behind workgroup
+// barriers: four launches, with their gaps, become one.  Same bodies, same partial sums in the same order: the bits of
+// the four launches.  Used where a round is bound by its launches -- problems of ONE chunk (n <= 2048), 64 or more of
+// them; at config 5's shape (4 chunks, 128 problems) one workgroup walking 12 chunk passes measured SLOWER than the four
+// launches over 512 workgroups (not-matvec time of a solve 6.7 against 4.7 ms, profiles/r03_config5_fused_tail_ab.json),
+// so longer problems keep the four launches (MP_FUSED_MAX_BLK is the kernel's capacity, MP_FUSED_USE_BLK the rule).
+#define MP_FUSED_MAX_BLK 8
+#define MP_FUSED_USE_BLK 1
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
+                                                                       double eps10, int64_t chunk, int nblk,
+                                                                       unsigned* __restrict__ batch,
+                                                                       double* __restrict__ host, unsigned count,
+                                                                       double seq) {
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  __shared__ double seqpart[MP_STEPS * MP_FUSED_MAX_BLK];
+  const ccqp_pmprgp& q = probs[blockIdx.x];
+  for (int stage = 1; stage <= 3; ++stage) {
+    for (int bx = 0; bx < nblk; ++bx)
+      bmprgp_stage_body<true, true>(q, stage, bx, gd, eps10, chunk, nblk, batch, host, count, seq, lds4, &is_last, seqpart);
+    __syncthreads();
+  }
+  bmprgp_apply_body(q, 0, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------- entry points
 // Start-up of all solves (solvers.py:1063-1081).  Expects x0 staged in X[1], slabs and counters zero.
 extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd,
@@ -535,10 +656,11 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   const dim3 vgrid(bp_vec_grid(n), count), rgrid(nblk, count), blk(CCQP_BLOCK);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bmprgp_init_x_kernel, vgrid, blk, 0, s, dev_probs);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 1, n);
+  int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 2, n);
+  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(bmprgp_init_alpha_kernel, rgrid, blk, 0, s, dev_probs, n, chunk, nblk);
   hipLaunchKernelGGL(bmprgp_init_p_kernel, vgrid, blk, 0, s, dev_probs);
   CCQP_LAUNCH_CHECK();
@@ -555,12 +677,27 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 0, n);
-  for (int stage = 1; stage <= 3; ++stage)
-    hipLaunchKernelGGL(bmprgp_stage_kernel, rgrid, blk, 0, s, dev_probs, stage, gd, eps10, chunk, nblk, dev_batch,
+  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s);
+  if (rc) return rc;
+  // (by shape; CCQP_MPRGP_FUSED_TAIL=0 in the environment keeps the four launches: the A/B switch of the tools)
+  static const bool allow_fused = [] {
+    const char* e = getenv("CCQP_MPRGP_FUSED_TAIL");
+    return !(e && e[0] == '0');
+  }();
+  static const bool force_fused = [] {
+    const char* e = getenv("CCQP_MPRGP_FUSED_TAIL");
+    return e && e[0] == '2';                    // (2: wherever the kernel can run -- the A/B of the rule above)
+  }();
+  const bool fuse = allow_fused && count >= 64 && nblk <= (force_fused ? MP_FUSED_MAX_BLK : MP_FUSED_USE_BLK);
+  if (fuse) {
+    hipLaunchKernelGGL(bmprgp_tail_fused_kernel, dim3(count), blk, 0, s, dev_probs, gd, eps10, chunk, nblk, dev_batch,
                        ctx->host_slots_dev, (unsigned)count, (double)round);
-  hipLaunchKernelGGL(bmprgp_apply_kernel, dim3(bp_vec_grid(n), count), blk, 0, s, dev_probs);
+  } else {
+    for (int stage = 1; stage <= 3; ++stage)
+      hipLaunchKernelGGL(bmprgp_stage_kernel, rgrid, blk, 0, s, dev_probs, stage, gd, eps10, chunk, nblk, dev_batch,
+                         ctx->host_slots_dev, (unsigned)count, (double)round);
+    hipLaunchKernelGGL(bmprgp_apply_kernel, dim3(bp_vec_grid(n), count), blk, 0, s, dev_probs);
+  }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -1176,12 +1313,13 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   ccqp_lockstep_begin(ctx, dev_batch, s);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 1, n);
+  int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
+  if (rc) return rc;
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 2, n);
+  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
@@ -1202,8 +1340,8 @@ extern "C" int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
   const dim3 gwk((unsigned)max_nwork, count, MPS_STEPS), gnk((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count, MPS_STEPS);
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, 0, n);
+  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(mps_reduce_a_kernel, rgrid, blk, 0, s, dev_probs, n, eps10, chunk, nblk);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gnk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gwk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);

@@ -329,6 +329,109 @@ __device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t 
   for (int64_t task = wave; task < ntasks; task += nwaves)
     gemv_task<R, U, ALIGNED, NT>(A, lda, x, b, y, g, rows, cols, task);
 }
+// ---- the matvec with its rows staged through a per-wave LDS ring by LDS-DMA loads (global_load_lds_dwordx4)
+// One wave owns R consecutive rows per task, as in gemv_task.  Per 128-column step it issues R + 1 LDS-DMA loads (1 KiB
+// of each row, non-temporal, and the matching 1 KiB of x out of L2) into one slot of its PRIVATE ring of S slots -- no
+// VGPR destination, so S - 1 steps (21 KiB per wave at R = 2, S = 8) are in flight instead of one or two -- waits with
+// a counted `s_waitcnt vmcnt`, reads the slot back with ds_read_b128 and runs the same fma chain: lane l accumulates
+// columns {128k + 2l, 128k + 2l + 1} in increasing k into one accumulator per row, hence the SAME BITS as gemv_task.
+// The ring runs CONTINUOUSLY across the wave's tasks (the loads of the next rows are in flight while the last steps of
+// the current ones are consumed; no drain at a row end), in groups of GEMV_LDS_GROUP results: row sums are parked in
+// LDS (`res`) and stored -- with the `+ b` epilogue -- after the group's last load has landed, so no ordinary load or
+// store is ever in flight beside the DMA (hipcc would answer with vmcnt(0), and stores count on the same counter).
+// No barrier anywhere: a wave reads only what it has loaded itself.  Needs cols % 128 == 0 and 16-byte aligned rows / x.
+#define GEMV_LDS_RESCAP 128        // row sums a wave parks before it flushes them (doubles of LDS per wave)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int R, int S, bool NT>
+__device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
+                                              const double* __restrict__ b, double* __restrict__ y,
+                                              double* __restrict__ g, int64_t rows, int64_t cols, int64_t ntasks,
+                                              int64_t wave, int64_t nwaves, char* mine, double* res) {
+  constexpr int PIECE = 1024;                   // bytes one wave instruction moves: 64 lanes x 16 B
+  constexpr int SLOT = (R + 1) * PIECE;
+  constexpr int GROUP = GEMV_LDS_RESCAP / R;    // tasks per flush
+  const int lane = threadIdx.x & 63;
+  const int64_t nsteps = cols / 128;
+  const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
+  const double* xp = x + 2 * lane;
+  for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
+    const int kn = (int)(mytasks - k0 < GROUP ? mytasks - k0 : GROUP);
+    const int64_t total = (int64_t)kn * nsteps;
+    // ---- issue cursor: (task ik of the group, step is), ring slot islot, steps issued so far
+    int ik = 0, islot = 0;
+    int64_t is = 0, issued = 0;
+    const double* irp[R];
+    auto rows_of = [&](int k) {
+      const int64_t r0 = (wave + (k0 + k) * nwaves) * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r;
+        if (row > rows - 1) row = rows - 1;     // clamp: tail rows re-read a valid row, never stored
+        irp[r] = A + row * lda + 2 * lane;
+      }
+    };
+    rows_of(0);
+    auto issue_next = [&]() {
+      char* slot = mine + islot * SLOT;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE), 16,
+                                         0, NT ? 2 : 0);
+      __builtin_amdgcn_global_load_lds(xp + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
+                                       0);
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++issued;
+      if (++is == nsteps) {
+        is = 0;
+        if (++ik < kn) rows_of(ik);
+      }
+    };
+    for (int p = 0; p < S - 1 && issued < total; ++p) issue_next();
+    int cslot = 0;
+    for (int kk = 0; kk < kn; ++kk) {
+      double acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+      for (int64_t s = 0; s < nsteps; ++s) {
+        if (issued < total) {
+          issue_next();
+          // the S - 1 newest steps may stay in flight: (S - 1) * (R + 1) loads
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last S - 1 steps of a group: drain
+        }
+        const char* slot = mine + cslot * SLOT;
+        const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+          acc[r] = fma(av.x, xv.x, acc[r]);
+          acc[r] = fma(av.y, xv.y, acc[r]);
+        }
+        cslot = cslot + 1 == S ? 0 : cslot + 1;
+        asm volatile("" ::: "memory");          // the slot's reads stay ahead of the DMA that refills it
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lane == r) res[kk * R + r] = acc[r];
+    }
+    // ---- flush: every DMA of the group has landed (the last steps waited for vmcnt(0))
+    for (int j = lane; j < kn * R; j += 64) {
+      const int kk = j / R, r = j - kk * R;
+      const int64_t row = (wave + (k0 + kk) * nwaves) * R + r;
+      if (row < rows) {
+        const double v = res[j];
+        y[row] = v;
+        if (g) g[row] = v + b[row];             // `A.dot(x) + b`: one more rounding, as numpy
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stores count on the DMA's counter)
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
 #endif  // __HIPCC__
 
 // Default (R, U, workgroups per CU) of the matvec for a shape: host-side, shared by both launch forms.

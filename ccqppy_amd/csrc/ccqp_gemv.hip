@@ -127,17 +127,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_mfma_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------ LDS-staged form (A/B variant, bit 24 of the variant word)
-// north_star words the matvec as "coalesced HBM row reads, LDS-staged A-tiles"; this is that kernel, kept selectable
-// so the phrase is answered by a measurement (profiles/r03_gemv_lds_ab.md) and not only by the guide's rule for GEMV
-// ("operand streamed once and not shared across waves: load straight to VGPRs; an LDS round trip is pure overhead").
-// One wave owns R consecutive rows, as in the VALU form.  Per 128-column step it issues R + 1 LDS-DMA loads
-// (`global_load_lds_dwordx4`: 1 KiB of each row, non-temporal, and the matching 1 KiB of x out of L2) into one slot of
-// its PRIVATE ring of S slots -- no VGPR destination, so S - 1 steps (S = 4: 9 KiB per wave) are in flight instead of
-// one -- waits with a counted `s_waitcnt vmcnt`, reads the slot back with ds_read_b128 and runs the same fma chain:
-// lane l still accumulates columns {128k + 2l, 128k + 2l + 1} in increasing k into one accumulator per row, hence the
-// SAME BITS as the VALU form.  No barrier anywhere (a wave reads only what it has loaded itself).
-// LDS: 4 waves x S x (R + 1) KiB = 48 KiB per workgroup at R = 2, S = 4 => 3 workgroups (12 waves) per CU.
-// Needs cols % 128 == 0 and 16-byte aligned A / x / lda; other shapes take the VALU form.
+// north_star words the matvec as "coalesced HBM row reads, LDS-staged A-tiles"; this is that kernel (body and full
+// description: gemv_lds_body, ccqp_bodies.h): the rows travel through a per-wave LDS ring by LDS-DMA loads, many steps in
+// flight, continuously across the wave's tasks -- same lane -> column map and fma chain, hence the SAME BITS as the
+// VALU form.  The guide's rule for GEMV is "load straight to VGPRs; an LDS round trip is pure overhead"; measured here
+// (profiles/r03_gemv_lds_ab.md) the deep ring with ONE workgroup per CU reads the headline matrix FASTER than any
+// VGPR form (fewer, longer row streams), which is why it is selectable and, where it wins, the default.
+// LDS: 4 waves x (S x (R + 1) KiB ring + 1 KiB of parked row sums) per workgroup.
 template <int R, int S, bool NT>
 __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __restrict__ A, int64_t lda,
                                                               const double* __restrict__ x,
@@ -146,67 +142,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
                                                               int64_t ntasks, const double* __restrict__ skip) {
 #if defined(__HIP_DEVICE_COMPILE__)             // (the host pass only needs the launch stub)
   if (skip != nullptr && *skip != 0.0) return;
-  constexpr int PIECE = 1024;                   // bytes one wave instruction moves: 64 lanes x 16 B
-  constexpr int SLOT = (R + 1) * PIECE;
-  __shared__ __attribute__((aligned(16))) char ring[(CCQP_BLOCK / 64) * S * SLOT];
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
-  char* const mine = ring + (threadIdx.x >> 6) * (S * SLOT);
-  const int64_t nsteps = cols / 128;
-  for (int64_t task = wave; task < ntasks; task += nwaves) {
-    const int64_t r0 = task * R;
-    const double* rp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int64_t row = r0 + r;
-      if (row > rows - 1) row = rows - 1;       // clamp: tail rows re-read a valid row, never stored
-      rp[r] = A + row * lda + 2 * lane;
-    }
-    const double* xp = x + 2 * lane;
-    double acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    // every ds_read of the previous task has returned (its values fed the fma chain) before a slot is written again
-    auto issue = [&](int64_t step) {
-      char* slot = mine + (int)(step % S) * SLOT;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        __builtin_amdgcn_global_load_lds(rp[r] + step * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
-                                         16, 0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds(xp + step * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16,
-                                       0, 0);
-    };
-    for (int64_t p = 0; p < S - 1 && p < nsteps; ++p) issue(p);
-    for (int64_t s = 0; s < nsteps; ++s) {
-      if (s + S - 1 < nsteps) {
-        issue(s + S - 1);
-        // steps s+1 .. s+S-1 may stay in flight: (S - 1) * (R + 1) loads
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 1)) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last S - 1 steps of a row: drain
-      }
-      const char* slot = mine + (int)(s % S) * SLOT;
-      const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
-        acc[r] = fma(av.x, xv.x, acc[r]);
-        acc[r] = fma(av.y, xv.y, acc[r]);
-      }
-      asm volatile("" ::: "memory");            // the slot's reads stay ahead of the DMA that refills it
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t row = r0 + r;
-      if (lane == r && row < rows) {
-        y[row] = acc[r];
-        if (g) g[row] = acc[r] + b[row];
-      }
-    }
-  }
+  // dynamic LDS: the four waves' rings, then their parked row sums
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int RING = S * (R + 1) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;      // (launched with 1, 2 or 4 waves per workgroup)
+  const int64_t wave = (int64_t)blockIdx.x * wpb + w;
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  gemv_lds_body<R, S, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves, ring + w * RING, res);
 #endif
 }
 
@@ -215,19 +158,75 @@ static bool gemv_lds_applicable(const double* A, int64_t lda, const double* x, i
          cols > 0 && (cols % 128) == 0;
 }
 
-#define GEMV_LDS_R 2
-#define GEMV_LDS_BPC 3                          // workgroups per CU the 48 KiB ring allows
+// ring shapes selectable by the variant word: bits 25-27 slots S = 4 (code + 1), bits 28-29 rows per wave R = 2, 4, 1, 8
+// (codes 0 .. 3), bit 30 / bit 23: 2 / 1 waves per workgroup instead of 4; LDS per workgroup = waves x (S x (R + 1) KiB
+// + 1 KiB), at most 160 KiB per CU -- a ring that does not fit (or is not instantiated) is shortened to the next one
+struct gemv_lds_shape {
+  int R, S, bpc_max, wpb;      // wpb: waves per workgroup
+  size_t lds;
+};
 
-static void launch_lds(int64_t blocks, bool nt, hipStream_t s, const double* A, int64_t lda, const double* x,
-                       const double* b, double* y, double* g, int64_t rows, int64_t cols, const double* skip) {
-  constexpr int R = GEMV_LDS_R;
+static gemv_lds_shape gemv_lds_decode(int variant) {
+  gemv_lds_shape h;
+  static const int rows_of[4] = {2, 4, 1, 8};
+  h.R = rows_of[(variant >> 28) & 3];
+  h.wpb = ((variant >> 23) & 1) ? 1 : ((variant >> 30) & 1) ? 2 : CCQP_BLOCK / 64;
+  const int want = 4 * (((variant >> 25) & 7) + 1);
+  static const int have[4][3] = {{12, 8, 4}, {8, 4, 4}, {16, 8, 4}, {4, 4, 4}};   // instantiated depths, by R code
+  const int* row = have[(variant >> 28) & 3];
+  h.S = 4;
+  for (int i = 0; i < 3; ++i) {
+    const size_t need = (size_t)h.wpb * ((size_t)row[i] * (h.R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+    if (row[i] <= want && need <= 160 * 1024) {
+      h.S = row[i];
+      break;
+    }
+  }
+  h.lds = (size_t)h.wpb * ((size_t)h.S * (h.R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  h.bpc_max = (int)((160 * 1024) / h.lds);
+  if (h.bpc_max < 1) h.bpc_max = 1;
+  return h;
+}
+
+template <int R, int S>
+static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, hipStream_t s, const double* A, int64_t lda,
+                         const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                         const double* skip) {
   const int64_t ntasks = (rows + R - 1) / R;
+  static bool raised = false;                   // more than 64 KiB of dynamic LDS has to be asked for once per kernel
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds_kernel<R, S, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds_kernel<R, S, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return 1;
+    raised = true;
+  }
   if (nt)
-    hipLaunchKernelGGL((gemv_lds_kernel<R, 4, true>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y, g,
-                       rows, cols, ntasks, skip);
-  else
-    hipLaunchKernelGGL((gemv_lds_kernel<R, 4, false>), dim3((unsigned)blocks), dim3(CCQP_BLOCK), 0, s, A, lda, x, b, y,
+    hipLaunchKernelGGL((gemv_lds_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
                        g, rows, cols, ntasks, skip);
+  else
+    hipLaunchKernelGGL((gemv_lds_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
+                       g, rows, cols, ntasks, skip);
+  return 0;
+}
+
+static int launch_lds(const gemv_lds_shape& h, int64_t blocks, bool nt, hipStream_t s, const double* A, int64_t lda,
+                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+                      const double* skip) {
+#define LDS_CASE(RR, SS) \
+  if (h.R == RR && h.S == SS) return launch_lds_rs<RR, SS>(blocks, nt, h.lds, h.wpb, s, A, lda, x, b, y, g, rows, cols, skip)
+  LDS_CASE(1, 4);
+  LDS_CASE(1, 8);
+  LDS_CASE(1, 16);
+  LDS_CASE(2, 4);
+  LDS_CASE(2, 8);
+  LDS_CASE(2, 12);
+  LDS_CASE(4, 4);
+  LDS_CASE(4, 8);
+  LDS_CASE(8, 4);
+#undef LDS_CASE
+  return 1;
 }
 
 static bool gemv_mfma_applicable(const double* A, int64_t lda, const double* x, int64_t cols) {
@@ -295,16 +294,41 @@ static gemv_shape gemv_decide(const ccqp_ctx* ctx, int64_t rows, int64_t cols, i
 
 // the LDS-staged form has its own rows per wave and workgroups per CU; launch rounds as the default
 static int gemv_lds_variant(int variant) {
+  const gemv_lds_shape h = gemv_lds_decode(variant);
   int bpc = (variant >> 12) & 0xFF;
-  if (bpc == 0 || bpc > GEMV_LDS_BPC) bpc = GEMV_LDS_BPC;
-  return (variant & ~0xFF00F) | GEMV_LDS_R | (bpc << 12);
+  if (bpc == 0 || bpc > h.bpc_max) bpc = h.bpc_max;
+  return (variant & ~0xFF00F) | h.R | (bpc << 12);
+}
+
+// ---- which form a matvec takes.  variant == 0 (the tuned default): matrices of 2^31 elements (16 GiB) or more whose
+// shape the LDS-staged form covers take IT -- one persistent launch, one 2-wave workgroup per CU, GEMV_AUTO_LDS below
+// (measured +1.5 ... +3 % over the VALU form in launch rounds from 16 GiB slabs to the 128 GiB headline matrix,
+// profiles/r03_gemv_lds_ab.md; below that size the VALU form wins); (variant & 0xF) == 0xF forces the VALU form with its
+// shape defaults (the A/B switch).  Same bits whichever form runs.
+#define GEMV_AUTO_LDS ((1 << 24) | (1 << 28) | (0 << 25) | (1 << 12) | (2 << 10) | (1 << 30))   // R = 4, S = 4, 2 waves, 1 wg/CU
+static int gemv_resolve(int variant, int64_t rows, int64_t cols, bool lds_ok) {
+  if ((variant & 0xF) == 0xF) return variant & ~0xF;
+  if (variant == 0 && lds_ok && (double)rows * (double)cols >= 2147483648.0) return GEMV_AUTO_LDS;
+  return variant;
+}
+
+extern "C" int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen) {
+  CCQP_REQUIRE(ctx != nullptr && name != nullptr && buflen > 0, "NULL argument");
+  const bool lds_ok = cols > 0 && cols % 128 == 0;              // (16-byte aligned operands assumed)
+  variant = gemv_resolve(variant, rows, cols, lds_ok);
+  const char* k = ((variant >> 24) & 1) && lds_ok ? "gemv_lds_kernel"
+                  : ((variant >> 9) & 1) && cols % 64 == 0 ? "gemv_mfma_kernel" : "gemv_stream_kernel";
+  strncpy(name, k, (size_t)buflen - 1);
+  name[buflen - 1] = 0;
+  return CCQP_OK;
 }
 
 extern "C" int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
                               int64_t* launches) {
   CCQP_REQUIRE(ctx != nullptr && rows_per_launch != nullptr && launches != nullptr, "NULL argument");
   CCQP_REQUIRE(rows >= 0 && cols >= 0, "negative size");
-  if (((variant >> 24) & 1) && cols > 0 && cols % 128 == 0) variant = gemv_lds_variant(variant);   // (aligned operands assumed)
+  variant = gemv_resolve(variant, rows, cols, cols > 0 && cols % 128 == 0);                     // (aligned operands assumed)
+  if (((variant >> 24) & 1) && cols > 0 && cols % 128 == 0) variant = gemv_lds_variant(variant);
   const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
   *rows_per_launch = d.rounds ? d.round_rows : rows;
   *launches = d.rounds ? (rows + d.round_rows - 1) / d.round_rows : (rows > 0 ? 1 : 0);
@@ -314,6 +338,7 @@ extern "C" int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int var
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b,
                      double* y, double* g, int64_t rows, int64_t cols, int variant, hipStream_t s,
                      const double* skip) {
+  variant = gemv_resolve(variant, rows, cols, gemv_lds_applicable(A, lda, x, cols));
   if (((variant >> 9) & 1) && gemv_mfma_applicable(A, lda, x, cols)) {
     const int U0 = (variant >> 4) & 0xF;
     launch_mfma(ctx, U0 == 0 ? 4 : U0, (variant >> 12) & 0xFF, s, A, lda, x, b, y, g, rows, cols, skip);
@@ -339,7 +364,11 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
     double* yr = y + r0;
     double* gr = g ? g + r0 : nullptr;
     if (lds) {
-      launch_lds(blocks, nt, s, Ar, lda, x, br, yr, gr, nr, cols, skip);
+      const gemv_lds_shape h = gemv_lds_decode(variant);
+      int64_t lb = (ntasks + h.wpb - 1) / h.wpb;
+      if (lb > cap) lb = cap;
+      if (lb < 1) lb = 1;
+      bad = launch_lds(h, lb, nt, s, Ar, lda, x, br, yr, gr, nr, cols, skip);
       continue;
     }
     switch (R) {

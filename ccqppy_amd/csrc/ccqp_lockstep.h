@@ -123,6 +123,25 @@ __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int
   return true;
 }
 
+// The same meeting point for ONE workgroup that walks the problem's nblk chunks itself, one call per chunk (the fused
+// stage launch of ccqp_bmprgp.hip): the chunk sums go to LDS (`part`, nred x nblk doubles), the call for the LAST chunk
+// adds them in index order with the code above -- the same partial sums in the same order, hence the same bits -- and
+// returns true; the earlier calls return false.  No inter-workgroup traffic, no counter.
+__device__ __forceinline__ bool bp_meet_seq(double* part, int bx, int nblk, int nred, double* v, double* lds4) {
+  __syncthreads();
+  if (nblk == 1) return true;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < nred; ++k) part[k * nblk + bx] = v[k];
+  __syncthreads();
+  if (bx != nblk - 1) return false;
+  for (int k = 0; k < nred; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += part[k * nblk + i];
+    v[k] = ccqp_block_sum(acc, lds4);
+  }
+  return true;
+}
+
 // ---- BBPGDf (solvers.py:696-843)
 // part A: the residual, the exit test, "best so far", "fall back" (thread 0 of the problem's last block)
 __device__ __forceinline__ bool bbf_decide_a(double* s, const bp_words& z, double r, double tol, double eps10) {
@@ -207,7 +226,9 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
   if (per < 1) per = 1;
   // few waves in flight (a batch of one, or few problems): more loads per lane; large matrices: two rows per wave
   // (short rows: several rows per wave amortise the per-row reduction, profiles/r01g_bpipe_sweep.txt)
-  if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 7 : n <= 256 ? 6 : n <= 512 ? 7 : 1);
+  // (n >= 4096: two rows per wave with TWO steps in flight -- 4 loads per lane instead of 2: 9.90 against 10.04 ms for
+  // config 5's 128 x 8192^2 launch, profiles/r03_bmv_sweep.jsonl)
+  if (t.U == 0) t.U = per * count * rows_per_wg < 16384 ? 4 : (n >= 4096 ? 3 : n <= 256 ? 6 : n <= 512 ? 7 : 1);
   // several rows per wave: no more workgroups than there are tasks (a workgroup beyond that would load its problem's
   // descriptor and state word only to leave -- at n = 256, four rows per wave, that was three workgroups out of four)
   const int64_t rows_per_wave = (t.U == 7 || t.U == 3 || t.U == 5) ? 2 : t.U == 6 ? 4 : 1;

@@ -69,9 +69,11 @@ int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
  * A is row-major with leading dimension lda (doubles).  Row sums are accumulated in an order
  * that depends on `cols` only, so a row block [r0, r1) of A gives bitwise the same y[r0:r1]
  * as the full matrix does -> row-sharded multi-GPU runs reproduce the 1-GPU iterates.
- * variant: 0 = default streaming kernel; other values select tuning variants.
- * A large matrix (>= 32 GiB, rows of at most 1 MiB) is processed as several kernel launches on `stream`, each over a
- * block of rows that fills the machine once ("rounds": measured faster than one persistent launch; same bits).
+ * variant: 0 = tuned default; other values select tuning variants and the A/B forms (MFMA: bit 9; rows staged through
+ * LDS rings by LDS-DMA loads: bit 24; (variant & 0xF) == 0xF: the VALU form even where the default would not take it)
+ * -- see DESIGN.md 3.1 and ccqp_gemv.hip.  Default by size: from 16 GiB on (columns a multiple of 128, aligned) the
+ * LDS-staged form as ONE persistent launch; below, the VALU form -- as several launches over row blocks that fill the
+ * machine once ("rounds") where the LDS form does not apply to a >= 32 GiB matrix.  Same bits whichever runs.
  */
 int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, double* y,
                   int64_t rows, int64_t cols, int variant, void* stream);
@@ -79,6 +81,9 @@ int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, 
  * launch but the last covers, and the number of launches -- what a profile's per-launch figures refer to. */
 int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64_t* rows_per_launch,
                    int64_t* launches);
+/* Name of the kernel a rows x cols matvec runs as ("gemv_stream_kernel" | "gemv_lds_kernel" | "gemv_mfma_kernel";
+ * 16-byte aligned operands assumed): the key of its rows in a rocprofv3 table. */
+int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen);
 /* Measurement hook (kernel-level roofline figures measured live, not only under a profiler): between
  * begin and end every BATCHED matvec launch of the lock-step drivers (ccqp_bpipe_*, ccqp_bapgd_*, ccqp_bmprgp_*,
  * ccqp_bsegs_*, ccqp_bspg_*) is bracketed by a pair of HIP events on its own stream, up to `max_pairs` of them (later

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "ccqp_hip.h"
@@ -385,15 +386,25 @@ int main(void) {
   } else {
     printf("rccl: not available, communicator section skipped\n");
   }
-  /* how a shape will be launched: the small matrix in one launch, the headline matrix in rounds */
+  /* how a shape will be launched: the small matrix in one launch of the VALU form; the headline matrix as ONE
+     persistent launch of the LDS-staged form by default, in launch rounds when the VALU form is forced (0xF) */
   {
     int64_t per = 0, launches = 0;
+    char form[64];
     CHECK(ccqp_gemv_plan(ctx, n, n, 0, &per, &launches));
     if (per != n || launches != 1) bad++;
+    CHECK(ccqp_gemv_form(ctx, n, n, 0, form, 64));
+    if (strcmp(form, "gemv_stream_kernel")) bad++;
     CHECK(ccqp_gemv_plan(ctx, 131072, 131072, 0, &per, &launches));
+    if (launches != 1 || per != 131072) bad++;
+    CHECK(ccqp_gemv_form(ctx, 131072, 131072, 0, form, 64));
+    if (strcmp(form, "gemv_lds_kernel")) bad++;
+    CHECK(ccqp_gemv_plan(ctx, 131072, 131072, 0xF, &per, &launches));
     if (launches < 2 || per * launches < 131072) bad++;
-    printf("matvec plan: %lld x %lld -> 1 launch; 131072 x 131072 -> %lld launches of %lld rows\n", (long long)n,
-           (long long)n, (long long)launches, (long long)per);
+    CHECK(ccqp_gemv_form(ctx, 131072, 131072, 0xF, form, 64));
+    if (strcmp(form, "gemv_stream_kernel")) bad++;
+    printf("matvec plan: %lld x %lld -> 1 launch; 131072 x 131072 -> 1 launch (LDS-staged), VALU form: %lld launches of "
+           "%lld rows\n", (long long)n, (long long)n, (long long)launches, (long long)per);
   }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;

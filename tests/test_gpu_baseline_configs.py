@@ -76,6 +76,15 @@ def test_config3_n131072_bbpgd_cone_own_size():
     assert r8.executed_matrix_vector_multiplications == budget + 1
     assert torch.equal(x1.view(torch.int64), r8.solution.view(torch.int64))
     assert float(r1.solution_residual) == float(r8.solution_residual)
+    # the headline matrix runs the LDS-staged form of the matvec by default (ccqp_gemv.hip): the same bits as the VALU
+    # form in launch rounds (forced: variant 0xF) and as the MFMA-free default of every row block
+    eng = op.engine
+    assert eng.gemv_form(n, n) == "gemv_lds_kernel" and eng.gemv_form(n, n, 0xF) == "gemv_stream_kernel"
+    ya, yb, ga, gb = eng.empty(n), eng.empty(n), eng.empty(n), eng.empty(n)
+    eng.gemv(op.A, x1, ya, b, ga)
+    eng.gemv(op.A, x1, yb, b, gb, variant=0xF)
+    assert torch.equal(ya.view(torch.int64), yb.view(torch.int64)) and torch.equal(ga.view(torch.int64), gb.view(torch.int64))
+    del ya, yb, ga, gb
     # one iterate further than the budget allows changes x (the budget, not a stall, ended the solve)
     r_more = _bbpgd(op, b, P, budget + 1)
     assert r_more.solution_num_matrix_vector_multiplications == budget + 1

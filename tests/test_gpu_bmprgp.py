@@ -97,6 +97,84 @@ def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
         _same(a, c)
 
 
+@pytest.mark.parametrize("n,count", [(300, 70), (2049, 64), (4500, 66)])
+def test_fused_stage_launch_of_wide_batches_changes_no_bit(n, count):
+    """From 64 problems of at most 8 reduction chunks on, the three decision stages and the update of a round are ONE
+    launch with one workgroup per problem walking the chunks itself (bmprgp_tail_fused_kernel, bp_meet_seq) instead of
+    four launches with inter-workgroup meeting points.  Same partial sums in the same order: the results of the same
+    problems solved in a narrower batch (the four-launch form) and of their own solve()."""
+    probs = _problems(n, count, 5200 + n, width=0.25)
+    tols = [1e-6] * count
+    wide = _batch(probs, tols, 3000, single_launch=False)
+    narrow = _batch(probs[:40], tols[:40], 3000, single_launch=False) + _batch(probs[40:], tols[40:], 3000, single_launch=False)
+    for a, c in zip(narrow, wide):
+        assert c.solution_converged
+        _same(a, c)
+    ref = _reference(probs[::17], tols[::17], 3000)
+    for a, c in zip(ref, wide[::17]):
+        _same(a, c)
+    assert len({c.solution_num_matrix_vector_multiplications for c in wide}) >= 1
+
+
+def test_fused_stage_launch_forced_on_longer_problems_in_a_child_process():
+    """The fused launch walks up to 8 chunks per problem (bp_meet_seq); by default it is used for one-chunk problems only
+    (it measured slower at config 5's shape).  CCQP_MPRGP_FUSED_TAIL=2 forces it wherever it can run -- read once per
+    process, hence a child process: 64 problems of n = 2049 (2 chunks) and n = 4500 (3 chunks) against their own solve()."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import contextlib, io, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from ccqppy_amd import batch, lockstep, problems, solvers, solution_spaces as ss
+for n in (2049, 4500):
+    probs = []
+    for p in range(64):
+        op, b, _ = problems.random_problem(n, 7700 + n + p)
+        probs.append((op, b, None, ss.BoxProjOp(n, -0.25 * np.ones(n) - 0.01 * (p %% 5), 0.35 * np.ones(n))))
+    before = lockstep.stats["fallback_solves"]
+    got = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 3000), probs, single_launch=False)
+    assert lockstep.stats["fallback_solves"] == before
+    for p in range(0, 64, 9):
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = solvers.CCQPSolverMPRGP(1e-6, 3000).solve(*probs[p][:2], convex_proj_op=probs[p][3])
+        c = got[p]
+        assert c.solution_converged and torch.equal(one.solution.view(torch.int64), c.solution.view(torch.int64))
+        assert one.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+        assert one.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+        assert float(one.solution_residual) == float(c.solution_residual)
+print("FUSED-OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CCQP_MPRGP_FUSED_TAIL="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FUSED-OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_matvec_timing_hook_of_the_c_abi():
+    """ccqp_mv_timing_begin / _end: HIP event pairs around the batched matvec launches of a lock-step run, on their own
+    stream -- what tools/config_profile_driver.py turns into config 5's live roofline object.  Results are untouched."""
+    import ctypes
+    from ccqppy_amd import _lib
+    n, count = 700, 6
+    probs = _problems(n, count, 31)
+    tols = [1e-6] * count
+    plain = _batch(probs, tols, 3000, single_launch=False)
+    lib = _lib.load()
+    _lib.check(lib.ccqp_mv_timing_begin(64))
+    assert lib.ccqp_mv_timing_begin(64) != 0              # one session at a time
+    timed = _batch(probs, tols, 3000, single_launch=False)
+    buf, cnt = (ctypes.c_double * 64)(), ctypes.c_int()
+    _lib.check(lib.ccqp_mv_timing_end(buf, 64, ctypes.byref(cnt)))
+    assert lib.ccqp_mv_timing_end(buf, 64, ctypes.byref(cnt)) != 0     # closed
+    rounds = max(c.executed_matrix_vector_multiplications for c in timed)
+    assert 2 <= cnt.value <= 64 and cnt.value >= min(rounds, 64) - 1
+    ms = [buf[i] for i in range(cnt.value)]
+    assert all(0.0 < t < 50.0 for t in ms)
+    for a, c in zip(plain, timed):
+        _same(a, c)
+
+
 def test_tight_bounds_exercise_every_branch():
     """Narrow boxes: many active constraints, so proportioning steps, expansion half-steps and full CG steps all
     occur (the executed-minus-reported MV difference counts the uncounted A.dx products of each)."""

@@ -240,20 +240,29 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
         eng.gemv(dA2, dx2, y3, variant=v)
         assert H.same_bits(y3.cpu().numpy(), y1.cpu().numpy()), hex(v)
     assert eng.gemv_plan(rows2, 300, 0x1411)[1] >= 2
-    # the default leaves small matrices to one launch and cuts the headline matrix into rounds
-    assert eng.gemv_plan(4096, 4096)[1] == 1
-    per, launches = eng.gemv_plan(131072, 131072)
-    assert launches > 1 and per * launches >= 131072
+    # the default: small matrices in one launch of the VALU form; from 16 GiB on ONE persistent launch of the LDS-staged
+    # form (where it applies: columns a multiple of 128); the VALU form (forced: 0xF) cuts the headline matrix into rounds
+    assert eng.gemv_plan(4096, 4096)[1] == 1 and eng.gemv_form(4096, 4096) == "gemv_stream_kernel"
+    assert eng.gemv_plan(131072, 131072) == (131072, 1) and eng.gemv_form(131072, 131072) == "gemv_lds_kernel"
+    assert eng.gemv_form(16384, 131072) == "gemv_lds_kernel" and eng.gemv_form(32768, 32768) == "gemv_stream_kernel"
+    assert eng.gemv_form(131072, 131000) == "gemv_stream_kernel"
+    per, launches = eng.gemv_plan(131072, 131072, 0xF)
+    assert launches > 1 and per * launches >= 131072 and eng.gemv_form(131072, 131072, 0xF) == "gemv_stream_kernel"
     # the LDS-staged form (variant bit 24: rows through an LDS ring by LDS-DMA loads): the SAME bits as the default, on
     # shapes it covers (cols % 128 == 0; 1, 2, 3 and many 128-column steps; an odd row count; epilogue; row blocks), and
     # a silent fall-through to the default on the others
-    for rows3, cols3 in ((5, 128), (333, 256), (64, 384), (1001, 4096), (777, 2050)):
+    for rows3, cols3 in ((5, 128), (333, 256), (64, 384), (1001, 4096), (777, 2050), (300001, 128)):
         A3 = rng.normal(size=(rows3, cols3))
         x3, b3 = rng.normal(size=cols3), rng.normal(size=rows3)
         dA3, dx3, db3 = eng.to_device(A3), eng.to_device(x3), eng.to_device(b3)
         ya, ga, yb, gb = eng.empty(rows3), eng.empty(rows3), eng.empty(rows3), eng.empty(rows3)
         eng.gemv(dA3, dx3, ya, db3, ga)
-        for v in (1 << 24, (1 << 24) | (1 << 8), (1 << 24) | (1 << 12)):
+        # (bits 25-27: ring slots 4 (code + 1); bits 28-29: rows per wave 2 / 4 / 1; bit 30: 2 waves per workgroup;
+        #  bits 10-11 = 2: one persistent launch; bits 12-19: workgroups per CU)
+        for v in (1 << 24, (1 << 24) | (1 << 8), (1 << 24) | (1 << 12), (1 << 24) | (1 << 25) | (2 << 10),
+                  (1 << 24) | (2 << 25) | (1 << 12), (1 << 24) | (1 << 28) | (2 << 10) | (1 << 12),
+                  (1 << 24) | (2 << 28) | (3 << 25), (1 << 24) | (1 << 30) | (2 << 10) | (1 << 12),
+                  (1 << 24) | (1 << 30) | (1 << 25) | (2 << 12)):
             eng.gemv(dA3, dx3, yb, db3, gb, variant=v)
             assert H.same_bits(yb.cpu().numpy(), ya.cpu().numpy()) and H.same_bits(gb.cpu().numpy(), ga.cpu().numpy())
         yc = eng.empty(rows3 - rows3 // 2)

@@ -112,15 +112,16 @@ def dense_config(which, args):
     ms = [a.elapsed_time(b_) for a, b_ in eng.gemv_events]
     eng.gemv_events = None
     rpl, launches = eng.gemv_plan(n, n)
+    form = eng.gemv_form(n, n)
     achieved = mv_bytes(n, n) / (np.mean(ms) * 1e-3) / 1e9
-    traffic, src = traffic_lookup("gemv_stream_kernel", mv_bytes(rpl, n), "dense", "config" + which)
+    traffic, src = traffic_lookup(form, mv_bytes(rpl, n), "dense", "config" + which)
     return {
         "config": label, "n": n, "repetitions": args.reps, "wall_s_per_solve": dt / args.reps,
         "executed_mv_per_solve": mv // args.reps, "reported_mv": int(r.solution_num_matrix_vector_multiplications),
         "converged": bool(r.solution_converged), "residual": float(r.solution_residual),
         "mv_per_s": mv / dt,
         "roofline": {
-            "bound": "hbm", "kernel": "gemv_stream_kernel (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64)",
+            "bound": "hbm", "kernel": "%s (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64)" % form,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src,
             "bytes_per_matvec": mv_bytes(n, n), "avg_matvec_ms": float(np.mean(ms)), "matvecs_timed": len(ms),
