@@ -377,8 +377,10 @@ def _main():
     mv0 = eng.mv_executed
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    step_end = []                                       # host clock after each step's solve() returned (its last scalar
+    for _ in range(args.steps):                         # read is blocking, so the step's device work is done by then)
         last = step()
+        step_end.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     mv_exec = eng.mv_executed - mv0
@@ -457,6 +459,7 @@ def _main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "step_ms": [round(1e3 * (b_ - a), 3) for a, b_ in zip([t0] + step_end[:-1], step_end)],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -339,8 +339,16 @@ __device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t 
 // the current ones are consumed; no drain at a row end), in groups of GEMV_LDS_GROUP results: row sums are parked in
 // LDS (`res`) and stored -- with the `+ b` epilogue -- after the group's last load has landed, so no ordinary load or
 // store is ever in flight beside the DMA (hipcc would answer with vmcnt(0), and stores count on the same counter).
-// No barrier anywhere: a wave reads only what it has loaded itself.  Needs cols % 128 == 0 and 16-byte aligned rows / x.
+// No barrier anywhere: a wave reads only what it has loaded itself.  Needs an even cols >= 128 and 16-byte aligned rows / x.
 #define GEMV_LDS_RESCAP 128        // row sums a wave parks before it flushes them (doubles of LDS per wave)
+struct gemv_lds_desc {             // operands of one matrix of the multi-matrix form (gemv_lds_multi_body)
+  const double* A;
+  int64_t lda;
+  const double* x;
+  const double* b;
+  double* y;
+  double* g;
+};
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int R, int S, bool NT>
 __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
@@ -351,7 +359,12 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
   constexpr int SLOT = (R + 1) * PIECE;
   constexpr int GROUP = GEMV_LDS_RESCAP / R;    // tasks per flush
   const int lane = threadIdx.x & 63;
-  const int64_t nsteps = cols / 128;
+  // full 128-column steps, then -- cols even, not a multiple of 128 -- one more step in which only the lanes whose two
+  // columns exist load and accumulate (gemv_task's column tail: same lane -> column map, same place in the chain)
+  const int64_t nfull = cols / 128;
+  const int tail = (int)(cols - nfull * 128);
+  const bool mine_in_tail = 2 * lane < tail;
+  const int64_t nsteps = nfull + (tail ? 1 : 0);
   const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
   const double* xp = x + 2 * lane;
   for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
@@ -373,12 +386,14 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
     rows_of(0);
     auto issue_next = [&]() {
       char* slot = mine + islot * SLOT;
+      if (is < nfull || mine_in_tail) {         // (the tail step: lanes past the last column issue nothing)
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE), 16,
-                                         0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds(xp + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
-                                       0);
+        for (int r = 0; r < R; ++r)
+          __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
+                                           16, 0, NT ? 2 : 0);
+        __builtin_amdgcn_global_load_lds(xp + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
+                                         0);
+      }
       islot = islot + 1 == S ? 0 : islot + 1;
       ++issued;
       if (++is == nsteps) {
@@ -401,12 +416,14 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last S - 1 steps of a group: drain
         }
         const char* slot = mine + cslot * SLOT;
-        const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+        if (s < nfull || mine_in_tail) {
+          const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
-          acc[r] = fma(av.x, xv.x, acc[r]);
-          acc[r] = fma(av.y, xv.y, acc[r]);
+          for (int r = 0; r < R; ++r) {
+            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+            acc[r] = fma(av.x, xv.x, acc[r]);
+            acc[r] = fma(av.y, xv.y, acc[r]);
+          }
         }
         cslot = cslot + 1 == S ? 0 : cslot + 1;
         asm volatile("" ::: "memory");          // the slot's reads stay ahead of the DMA that refills it
@@ -428,6 +445,109 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stores count on the DMA's counter)
+  }
+}
+// ---- the same ring over MANY matrices of one size (the batched matvec of the lock-step forms): the wave's tasks are
+// T = wave, wave + nwaves, ... over the concatenation of `nlive` matrices (task T = rows [R t, R t + R) of matrix T / tpp,
+// t = T % tpp), so the 2 x 256 waves of a persistent grid work through ONE matrix after the other, close together.
+// D (in LDS: descriptor reads must not be ordinary loads -- they would drain the ring) holds each matrix's operands.
+template <int R, int S, bool NT>
+__device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int nlive, int64_t n, int64_t wave,
+                                                    int64_t nwaves, char* mine, double* res) {
+  constexpr int PIECE = 1024;
+  constexpr int SLOT = (R + 1) * PIECE;
+  constexpr int GROUP = GEMV_LDS_RESCAP / R;
+  const int lane = threadIdx.x & 63;
+  const int64_t nfull = n / 128;
+  const int tail = (int)(n - nfull * 128);
+  const bool mine_in_tail = 2 * lane < tail;
+  const int64_t nsteps = nfull + (tail ? 1 : 0);
+  const int64_t tpp = (n + R - 1) / R;         // tasks per matrix
+  const int64_t ntasks = (int64_t)nlive * tpp;
+  const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
+  for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
+    const int kn = (int)(mytasks - k0 < GROUP ? mytasks - k0 : GROUP);
+    const int64_t total = (int64_t)kn * nsteps;
+    int ik = 0, islot = 0;
+    int64_t is = 0, issued = 0;
+    const double* irp[R];
+    const double* ixp;
+    auto rows_of = [&](int k) {
+      const int64_t T = wave + (k0 + k) * nwaves;
+      const int64_t m = T / tpp, t = T - m * tpp;
+      const gemv_lds_desc d = D[m];
+      const int64_t r0 = t * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r;
+        if (row > n - 1) row = n - 1;           // clamp: tail rows re-read a valid row, never stored
+        irp[r] = d.A + row * d.lda + 2 * lane;
+      }
+      ixp = d.x + 2 * lane;
+    };
+    rows_of(0);
+    auto issue_next = [&]() {
+      char* slot = mine + islot * SLOT;
+      if (is < nfull || mine_in_tail) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
+                                           16, 0, NT ? 2 : 0);
+        __builtin_amdgcn_global_load_lds(ixp + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
+                                         0);
+      }
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++issued;
+      if (++is == nsteps) {
+        is = 0;
+        if (++ik < kn) rows_of(ik);
+      }
+    };
+    for (int p = 0; p < S - 1 && issued < total; ++p) issue_next();
+    int cslot = 0;
+    for (int kk = 0; kk < kn; ++kk) {
+      double acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+      for (int64_t s = 0; s < nsteps; ++s) {
+        if (issued < total) {
+          issue_next();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = mine + cslot * SLOT;
+        if (s < nfull || mine_in_tail) {
+          const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+            acc[r] = fma(av.x, xv.x, acc[r]);
+            acc[r] = fma(av.y, xv.y, acc[r]);
+          }
+        }
+        cslot = cslot + 1 == S ? 0 : cslot + 1;
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = ccqp_wave_sum(acc[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lane == r) res[kk * R + r] = acc[r];
+    }
+    for (int j = lane; j < kn * R; j += 64) {
+      const int kk = j / R, r = j - kk * R;
+      const int64_t T = wave + (k0 + kk) * nwaves;
+      const int64_t m = T / tpp, t = T - m * tpp;
+      const int64_t row = t * R + r;
+      if (row < n) {
+        const gemv_lds_desc d = D[m];
+        const double v = res[j];
+        d.y[row] = v;
+        if (d.g) d.g[row] = v + d.b[row];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 }
 #endif  // __HIP_DEVICE_COMPILE__

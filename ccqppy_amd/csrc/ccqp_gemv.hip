@@ -155,7 +155,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
 
 static bool gemv_lds_applicable(const double* A, int64_t lda, const double* x, int64_t cols) {
   return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (lda % 2) == 0 &&
-         cols > 0 && (cols % 128) == 0;
+         cols >= 128 && (cols % 2) == 0;
 }
 
 // ring shapes selectable by the variant word: bits 25-27 slots S = 4 (code + 1), bits 28-29 rows per wave R = 2, 4, 1, 8
@@ -314,7 +314,7 @@ static int gemv_resolve(int variant, int64_t rows, int64_t cols, bool lds_ok) {
 
 extern "C" int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen) {
   CCQP_REQUIRE(ctx != nullptr && name != nullptr && buflen > 0, "NULL argument");
-  const bool lds_ok = cols > 0 && cols % 128 == 0;              // (16-byte aligned operands assumed)
+  const bool lds_ok = cols >= 128 && cols % 2 == 0;             // (16-byte aligned operands assumed)
   variant = gemv_resolve(variant, rows, cols, lds_ok);
   const char* k = ((variant >> 24) & 1) && lds_ok ? "gemv_lds_kernel"
                   : ((variant >> 9) & 1) && cols % 64 == 0 ? "gemv_mfma_kernel" : "gemv_stream_kernel";
@@ -327,8 +327,8 @@ extern "C" int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int var
                               int64_t* launches) {
   CCQP_REQUIRE(ctx != nullptr && rows_per_launch != nullptr && launches != nullptr, "NULL argument");
   CCQP_REQUIRE(rows >= 0 && cols >= 0, "negative size");
-  variant = gemv_resolve(variant, rows, cols, cols > 0 && cols % 128 == 0);                     // (aligned operands assumed)
-  if (((variant >> 24) & 1) && cols > 0 && cols % 128 == 0) variant = gemv_lds_variant(variant);
+  variant = gemv_resolve(variant, rows, cols, cols >= 128 && cols % 2 == 0);                   // (aligned operands assumed)
+  if (((variant >> 24) & 1) && cols >= 128 && cols % 2 == 0) variant = gemv_lds_variant(variant);
   const gemv_shape d = gemv_decide(ctx, rows, cols, variant);
   *rows_per_launch = d.rounds ? d.round_rows : rows;
   *launches = d.rounds ? (rows + d.round_rows - 1) / d.round_rows : (rows > 0 ? 1 : 0);

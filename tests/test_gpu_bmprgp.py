@@ -151,6 +151,23 @@ print("FUSED-OK")
     assert out.returncode == 0 and "FUSED-OK" in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("n,count", [(256, 9), (1000, 7), (2050, 5), (130, 70)])
+def test_lds_dma_forms_of_the_batched_matvec_change_no_bit(n, count):
+    """Tuning word loads = 3: the batched matvec with its rows staged through per-wave LDS rings by LDS-DMA loads
+    (gemv_lds_body / gemv_lds_multi_body) -- ring codes 0-3: workgroups per problem; 4-7: ONE persistent grid whose waves
+    walk the live problems' matrices in order.  Full steps, a column tail (1000, 2050, 130), problems that converge at
+    different rounds (dead problems drop out of the persistent form's list).  Same bits as the default form."""
+    probs = _problems(n, count, 6100 + n, width=0.25)
+    tols = [[1e-6, 1e-4, 1e30][p % 3] for p in range(count)]
+    base = _batch(probs, tols, 3000, single_launch=False)
+    for code in range(8):
+        for per in ((0, 3) if code < 4 else (0,)):
+            got = _batch(probs, tols, 3000, single_launch=False, tune=(3 << 1) | (code << 4) | (per << 8))
+            for a, c in zip(base, got):
+                _same(a, c)
+    assert any(c.solution_num_matrix_vector_multiplications == 1 for c in base)
+
+
 def test_matvec_timing_hook_of_the_c_abi():
     """ccqp_mv_timing_begin / _end: HIP event pairs around the batched matvec launches of a lock-step run, on their own
     stream -- what tools/config_profile_driver.py turns into config 5's live roofline object.  Results are untouched."""

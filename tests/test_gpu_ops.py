@@ -245,13 +245,15 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
     assert eng.gemv_plan(4096, 4096)[1] == 1 and eng.gemv_form(4096, 4096) == "gemv_stream_kernel"
     assert eng.gemv_plan(131072, 131072) == (131072, 1) and eng.gemv_form(131072, 131072) == "gemv_lds_kernel"
     assert eng.gemv_form(16384, 131072) == "gemv_lds_kernel" and eng.gemv_form(32768, 32768) == "gemv_stream_kernel"
-    assert eng.gemv_form(131072, 131000) == "gemv_stream_kernel"
+    assert eng.gemv_form(131072, 131000) == "gemv_lds_kernel" and eng.gemv_form(131072, 131001) == "gemv_stream_kernel"
     per, launches = eng.gemv_plan(131072, 131072, 0xF)
     assert launches > 1 and per * launches >= 131072 and eng.gemv_form(131072, 131072, 0xF) == "gemv_stream_kernel"
-    # the LDS-staged form (variant bit 24: rows through an LDS ring by LDS-DMA loads): the SAME bits as the default, on
-    # shapes it covers (cols % 128 == 0; 1, 2, 3 and many 128-column steps; an odd row count; epilogue; row blocks), and
-    # a silent fall-through to the default on the others
-    for rows3, cols3 in ((5, 128), (333, 256), (64, 384), (1001, 4096), (777, 2050), (300001, 128)):
+    # the LDS-staged form (variant bit 24: rows through an LDS ring by LDS-DMA loads): the SAME bits as the VALU form, on
+    # shapes it covers (an even number of columns >= 128: 1, 2, 3 and many 128-column steps, with and without a column
+    # tail; an odd row count; epilogue; row blocks; more tasks per wave than one flush group), and a silent fall-through
+    # to the VALU form on the others (odd or fewer than 128 columns)
+    for rows3, cols3 in ((5, 128), (333, 256), (64, 384), (1001, 4096), (777, 2050), (300001, 128), (50, 300), (9, 130),
+                         (33, 254), (7, 129), (11, 126)):
         A3 = rng.normal(size=(rows3, cols3))
         x3, b3 = rng.normal(size=cols3), rng.normal(size=rows3)
         dA3, dx3, db3 = eng.to_device(A3), eng.to_device(x3), eng.to_device(b3)

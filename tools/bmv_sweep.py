@@ -3,7 +3,8 @@
 of a lock-step MPRGP start-up (g = A x + b; A g) timed with the C ABI's event hook, for a list of tuning words --
 interleaved over several rounds in ONE process.  Prints one JSON line per tuning word (ms and TB/s of matrix bytes).
     python tools/bmv_sweep.py [--problems 128] [--size 8192] [--rounds 4] [--tunes 0,0x70,0x30,...]
-tuning word: bits 1-2 loads (0 default / 1 cacheable / 2 non-temporal / 3 the LDS-DMA form), bits 4-6 rows x steps per wave (1, 2, 4 = one row,
+tuning word: bits 1-2 loads (0 default / 1 cacheable / 2 non-temporal / 3 the LDS-DMA forms: bits 4-6 then pick the ring,
+4-7 = one persistent grid walking the problems in order), bits 4-6 rows x steps per wave (1, 2, 4 = one row,
 that many steps; 7 / 6 = two / four rows, one step; 3 / 5 = two rows, two / four steps), bits 8.. workgroups per problem."""
 import argparse
 import ctypes

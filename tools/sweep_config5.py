@@ -29,14 +29,13 @@ def main():
         op, b, _ = problems.random_problem(n, 1234 + p, device=0)
         probs.append((op, b, None, ss.BoxProjOp(n, lb, ub)))
     make = lambda: solvers.CCQPSolverMPRGP(1e-6, 300)       # noqa: E731
-    variants = [("one run (round 2)", dict(halves=False, ahead=4, tune=0)),
-                ("two halves", dict(halves=True, ahead=4, tune=0))]
-    for per in (32, 64, 128, 256, 1024):
-        variants.append(("one run, %d workgroups per problem" % per, dict(halves=False, ahead=4, tune=per << 8)))
-    for per in (64, 128, 256):
-        variants.append(("one run, 4 rows per wave, %d wg" % per, dict(halves=False, ahead=4, tune=(6 << 4) | (per << 8))))
-    variants.append(("one run, ahead 8", dict(halves=False, ahead=8, tune=0)))
-    variants.append(("one run (repeat)", dict(halves=False, ahead=4, tune=0)))
+    variants = [("default (two rows x two steps per wave, one run)", dict(halves=False, ahead=4, tune=0)),
+                ("round 2's matvec (two rows x one step per wave)", dict(halves=False, ahead=4, tune=7 << 4)),
+                ("two alternating halves", dict(halves=True, ahead=4, tune=0)),
+                ("persistent LDS-DMA matvec (R 4, S 4, 2 waves per CU)", dict(halves=False, ahead=4, tune=(3 << 1) | (4 << 4))),
+                ("LDS-DMA matvec, 16 workgroups per problem", dict(halves=False, ahead=4, tune=(3 << 1) | (16 << 8))),
+                ("256 workgroups per problem", dict(halves=False, ahead=4, tune=256 << 8)),
+                ("default (repeat)", dict(halves=False, ahead=4, tune=0))]
     ref = None
     for label, kw in variants:
         lockstep._HALVES_DEFAULT = bool(kw["halves"])
