@@ -232,26 +232,11 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
       // bandwidth instead of overlapping and splitting it, while the small kernels of the other
       // groups still overlap with them.
       // (one stream per device; the host side of this library is driven by one thread per process)
-      static hipStream_t mv_streams[64] = {nullptr};
-      CCQP_REQUIRE(!ctx->mv_serialize || (ctx->device >= 0 && ctx->device < 64), "device index out of range");
-      hipStream_t& mv_stream = mv_streams[ctx->mv_serialize ? ctx->device : 0];
-      if (ctx->mv_serialize) {
-        if (!mv_stream) {
-          int prev = 0;
-          CCQP_HIP(hipGetDevice(&prev));
-          CCQP_HIP(hipSetDevice(ctx->device));
-          const hipError_t e = hipStreamCreateWithFlags(&mv_stream, hipStreamNonBlocking);
-          (void)hipSetDevice(prev);
-          CCQP_HIP(e);
-        }
-        if (!ctx->mv_ev_in) {
-          CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_in, hipEventDisableTiming));
-          CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_out, hipEventDisableTiming));
-        }
-        CCQP_HIP(hipEventRecord(ctx->mv_ev_in, s));
-        CCQP_HIP(hipStreamWaitEvent(mv_stream, ctx->mv_ev_in, 0));
+      hipStream_t ms = s;
+      {
+        const int rc = ccqp_mv_stream_enter(ctx, s, &ms);
+        if (rc) return rc;
       }
-      hipStream_t ms = ctx->mv_serialize ? mv_stream : s;
       for (int i = 0; i < count; ++i) {
         const ccqp_bop& o = host[i];
         CCQP_REQUIRE(o.n >= 0 && o.n2 >= 0 && o.lda >= o.n2, "batched matvec: bad shape");
@@ -262,11 +247,7 @@ static int launch_group(ccqp_ctx* ctx, int opcode, int count, const ccqp_bop* ho
                                   const_cast<double*>(o.p[4]), o.n, o.n2, 0, ms, nullptr);
         if (rc) return rc;
       }
-      if (ctx->mv_serialize) {
-        CCQP_HIP(hipEventRecord(ctx->mv_ev_out, mv_stream));
-        CCQP_HIP(hipStreamWaitEvent(s, ctx->mv_ev_out, 0));
-      }
-      return CCQP_OK;
+      return ccqp_mv_stream_leave(ctx, s, ms);
     }
     default:
       ccqp_set_error("ccqp_batch_run_f64: unknown opcode %d", opcode);

@@ -275,8 +275,8 @@ static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, 
 }
 
 // launches the round's matvec: the LDS-DMA form where the tuning word asks for it (loads = 3) and the shape allows
-static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
-                              hipStream_t s) {
+static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
+                                 hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   if (((flags >> 1) & 3) == 3 && t.aligned && n % 2 == 0 && n >= 128) {
     const int code = (flags >> 4) & 7;
@@ -295,6 +295,19 @@ static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int c
   }
   BP_MV_LAUNCH(bmprgp_gemv_kernel, dev_probs, init, n);
   return CCQP_OK;
+}
+
+// (ccqp_batch_serialize_matvecs on: the launch goes to the device's matvec stream, chained behind `s`, and `s` waits for it
+// -- two half-batches on two streams then multiply one after the other while each one's decision stages and vector
+// update go by under the other's matvec)
+static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
+                              hipStream_t s) {
+  hipStream_t ms = s;
+  int rc = ccqp_mv_stream_enter(ctx, s, &ms);
+  if (rc) return rc;
+  rc = bmprgp_launch_gemv_on(ctx, dev_probs, count, n, init, flags, ms);
+  if (rc) return rc;
+  return ccqp_mv_stream_leave(ctx, s, ms);
 }
 
 // residual of the start (exit test :1070-1073)

@@ -41,6 +41,42 @@ void ccqp_mvt_mark(hipStream_t s, int end) {
   if (end) ++g_mvt_n;
 }
 
+// All matvec groups of a process that ask for it go through ONE dedicated stream per device (event-chained to the
+// caller's stream): matvecs of different lanes / half-batches then run one after the other at full bandwidth instead of
+// overlapping and splitting it, while the small kernels of the other lanes still overlap with them.
+// (the host side of this library is driven by one thread per process)
+int ccqp_mv_stream_enter(ccqp_ctx* ctx, hipStream_t s, hipStream_t* ms) {
+  *ms = s;
+  if (!ctx->mv_serialize) return CCQP_OK;
+  static hipStream_t mv_streams[64] = {nullptr};
+  CCQP_REQUIRE(ctx->device >= 0 && ctx->device < 64, "device index out of range");
+  hipStream_t& mv_stream = mv_streams[ctx->device];
+  if (!mv_stream) {
+    int prev = 0;
+    CCQP_HIP(hipGetDevice(&prev));
+    CCQP_HIP(hipSetDevice(ctx->device));
+    const hipError_t e = hipStreamCreateWithFlags(&mv_stream, hipStreamNonBlocking);
+    (void)hipSetDevice(prev);
+    CCQP_HIP(e);
+  }
+  if (mv_stream == s) return CCQP_OK;
+  if (!ctx->mv_ev_in) {
+    CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_in, hipEventDisableTiming));
+    CCQP_HIP(hipEventCreateWithFlags(&ctx->mv_ev_out, hipEventDisableTiming));
+  }
+  CCQP_HIP(hipEventRecord(ctx->mv_ev_in, s));
+  CCQP_HIP(hipStreamWaitEvent(mv_stream, ctx->mv_ev_in, 0));
+  *ms = mv_stream;
+  return CCQP_OK;
+}
+
+int ccqp_mv_stream_leave(ccqp_ctx* ctx, hipStream_t s, hipStream_t ms) {
+  if (ms == s) return CCQP_OK;
+  CCQP_HIP(hipEventRecord(ctx->mv_ev_out, ms));
+  CCQP_HIP(hipStreamWaitEvent(s, ctx->mv_ev_out, 0));
+  return CCQP_OK;
+}
+
 extern "C" int ccqp_mv_timing_begin(int max_pairs) {
   CCQP_REQUIRE(max_pairs >= 1 && max_pairs <= (1 << 20), "max_pairs outside [1, 2^20]");
   CCQP_REQUIRE(!ccqp_mvt_on, "a timing session is already open");

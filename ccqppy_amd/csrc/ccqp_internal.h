@@ -39,6 +39,12 @@ struct ccqp_ctx {
 
 void ccqp_set_error(const char* fmt, ...);
 
+// ccqp_batch_serialize_matvecs: with the switch on, a group of matvec launches leaves the caller's stream `s` for the
+// process-wide matvec stream of the context's device (*ms; event-chained behind what `s` holds) and `s` waits for the
+// group afterwards; with it off *ms = s and both calls do nothing (ccqp_ctx.hip)
+int ccqp_mv_stream_enter(struct ccqp_ctx* ctx, hipStream_t s, hipStream_t* ms);
+int ccqp_mv_stream_leave(struct ccqp_ctx* ctx, hipStream_t s, hipStream_t ms);
+
 // matvec timing hook (ccqp_mv_timing_begin / _end, ccqp_ctx.hip): event pairs around the batched matvec launches
 extern int ccqp_mvt_on;
 void ccqp_mvt_mark(hipStream_t s, int end);

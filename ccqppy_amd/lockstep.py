@@ -195,7 +195,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         raise reason
     max_mv = solvers[0].max_matrix_vector_multiplications
     by_size = {}                                        # (n, elementwise set?) -> items, in order of first appearance
-    refreshed = set()
+    refreshed, memo = set(), {}
     for s, (A, b, x0, P0) in zip(solvers, problems):
         # argument check and staging of one problem in ONE pass (many small problems: the host side counts); the check
         # itself does no GPU work, and the first failing problem raises before anything is launched
@@ -205,7 +205,10 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
         op = as_operator(A)
         if id(P) not in refreshed:                       # once per distinct set object and call
             refreshed.add(id(P))
-            P._refresh()
+            if hasattr(P, "_dev_bb_tail"):
+                P._refresh(memo)                         # (elementwise sets over shared bound arrays: one comparison)
+            else:
+                P._refresh()
         bd = eng.to_device(b).reshape(-1)
         by_size.setdefault((n, hasattr(P, "_dev_bb_tail")), []).append(
             (s, op, bd, None if x0 is None else eng.to_device(x0).reshape(-1), P, isinstance(b, torch.Tensor),
@@ -866,6 +869,8 @@ class _MprgpRun:
 _HALVES_DEFAULT = False          # (measured slower for MPRGP: see _bmprgp_run)
 _HALF_MIN_PROBLEMS = 32          # a batch advances as two alternating halves from this many problems on ...
 _HALF_MIN_BYTES = 2.0 ** 30      # ... if one round of matvecs reads at least this much (else launches bind, not HBM)
+_HALVES_CHAINED = True           # the halves' matvecs go through ONE stream, one after the other (False: the free-running
+                                 # form of the first A/B, whose two matvec kernels share the machine)
 _half_lanes = {}
 
 
@@ -888,6 +893,7 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=
         if run.last >= 1:
             _bpipe_poll_loop(eng, B, run.launch, run.last, ahead)
         return run.finish()
+    from . import _lib
     from ._engine import make_lanes
     lanes = _half_lanes.get(eng.index)
     if lanes is None:
@@ -898,6 +904,7 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=
     for lane, (lo, hi) in zip(lanes, ((0, cut), (cut, B))):
         lane.torch_stream.wait_stream(cur)               # the caller's matrices / vectors are ready on ITS stream
         lane.gemv_variant = eng.gemv_variant
+        _lib.check(lane.lib.ccqp_batch_serialize_matvecs(lane.ctx, 1 if _HALVES_CHAINED else 0))
         with torch.cuda.stream(lane.torch_stream):
             runs.append(_MprgpRun(lane, spec.part(lo, hi), n, max_mv, tune, single_launch,
                                   None if plans is None else plans[lo:hi]))

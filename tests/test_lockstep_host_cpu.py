@@ -192,3 +192,35 @@ def test_spg_argument_rules_of_the_lockstep_scheduler():
     mixed = made()
     mixed[1] = solvers.CCQPSolverBBPGD(1e-8, 100)
     assert isinstance(lockstep.why_not_pipelined(mixed, probs, dev), TypeError)
+
+
+@pytest.mark.parametrize("n", [64, 5000])          # (bytes snapshots up to 16 KiB, array snapshots beyond)
+def test_refresh_memo_shares_snapshots_between_operators_and_still_sees_edits(n):
+    """solve_batch_pipelined's staging pass compares a bound array with its snapshot once per pass and bound OBJECT:
+    operators over the same arrays share one state; an in-place edit, a reassignment, or an operator refreshed on its
+    own in between are still seen by every operator (the reference re-reads its bounds at every call,
+    solution_spaces.py:363-366)."""
+    from ccqppy_amd import solution_spaces as ss
+    lb, ub = -np.ones(n), np.ones(n)
+    ops = [ss.BoxProjOp(n, lb, ub) for _ in range(4)]
+    ops[3]._refresh()                                      # one of them already has a state (and snapshots) of its own
+    memo = {}
+    assert [P._refresh(memo) for P in ops] == [False] * 4
+    assert all(P._bounds_state is ops[0]._bounds_state for P in ops)
+    assert [P._refresh({}) for P in ops] == [False] * 4    # a new pass: nothing changed
+    v0 = [P._version for P in ops]
+    lb[3] = -2.0                                           # in-place edit: every operator's caches are stale
+    memo = {}
+    assert [P._refresh(memo) for P in ops] == [True] * 4
+    assert [P._version for P in ops] == [v + 1 for v in v0]
+    assert [P._refresh({}) for P in ops] == [False] * 4
+    ub[5] = 3.0
+    assert ops[1]._refresh() is True                       # refreshed on its own (e.g. called directly) ...
+    memo = {}
+    assert [P._refresh(memo) for P in ops] == [True, False, True, True]    # ... the others still notice in the pass
+    ops[2].lower_bound = lb.copy()                         # reassignment: another object, the same bits
+    memo = {}
+    assert ops[2]._refresh(memo) is True and [P._refresh(memo) for P in ops[:2]] == [False, False]
+    ident = [ss.IdentityProjOp(n) for _ in range(3)]
+    memo = {}
+    assert [P._refresh(memo) for P in ident] == [False] * 3

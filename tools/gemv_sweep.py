@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--bpc", default="4,8,16")
     ap.add_argument("--variants", default="", help="explicit variant words (hex, comma separated) instead of the R/U/nt/bpc "
                                                   "product; bit 9 (0x200) = the MFMA form")
+    ap.add_argument("--pad", type=int, default=0, help="doubles of padding behind every row (lda = cols + pad)")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -38,8 +39,11 @@ def main():
     eng = get_engine(0)
     for shape in args.shapes.split(","):
         rows, cols = (int(v) for v in shape.split("x"))
-        A = torch.empty((rows, cols), dtype=torch.float64, device="cuda")
-        eng.gen_spd_rows(A, 0, cols, 1234) if rows <= cols else A.normal_()
+        if args.pad:
+            A = torch.empty((rows, cols + args.pad), dtype=torch.float64, device="cuda").normal_()[:, :cols]
+        else:
+            A = torch.empty((rows, cols), dtype=torch.float64, device="cuda")
+            eng.gen_spd_rows(A, 0, cols, 1234) if rows <= cols else A.normal_()
         x = torch.randn(cols, dtype=torch.float64, device="cuda")
         y = torch.empty(rows, dtype=torch.float64, device="cuda")
         variants = [0]
@@ -60,7 +64,7 @@ def main():
         res = []
         for v in variants:
             t = np.array(times[v])
-            res.append(dict(shape=shape, variant=hex(v), mfma=(v >> 9) & 1, R=v & 0xF, U=(v >> 4) & 0xF, nt=1 - ((v >> 8) & 1),
+            res.append(dict(shape=shape, lda=int(A.stride(0)), variant=hex(v), mfma=(v >> 9) & 1, R=v & 0xF, U=(v >> 4) & 0xF, nt=1 - ((v >> 8) & 1),
                             bpc=(v >> 12) & 0xFF, med_ms=float(np.median(t)), min_ms=float(t.min()),
                             gbs_med=nbytes / float(np.median(t)) / 1e6, gbs_best=nbytes / float(t.min()) / 1e6))
         res.sort(key=lambda r: r["med_ms"])

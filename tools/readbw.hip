@@ -32,3 +32,58 @@ extern "C" int readbw_launch(const double* a, int64_t seg, int64_t nseg, double*
   else return 1;
   return hipGetLastError() != hipSuccess;
 }
+
+// ---- the same question for LDS-DMA loads (global_load_lds_dwordx4: no VGPR destination): a persistent grid whose waves
+// each stream R consecutive segments at a time through a private ring of S slots (the matvec's LDS form without x, the
+// LDS reads, the fma chains and the butterflies); nothing consumes the data
+// blocked = 0: wave w takes tasks w, w + nw, ... (the machine reads a moving band of nw * R segments); 1: wave w takes
+// the contiguous run of tasks [w * mytasks, (w + 1) * mytasks) (nw streams spread evenly over the whole array)
+template <int R, int S>
+__global__ void read_lds_kernel(const double* __restrict__ a, int64_t seg, int64_t nseg, int blocked) {
+  extern __shared__ char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  char* mine = lds + (threadIdx.x >> 6) * (S * R * 1024);
+  const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * wpb;
+  const int64_t ntasks = nseg / R, steps = seg / 128;
+  const int64_t mytasks = blocked ? ntasks / nw : wave < ntasks ? (ntasks - wave + nw - 1) / nw : 0;
+  const int64_t total = mytasks * steps;
+  const int64_t dtask = blocked ? 1 : nw;
+  int64_t task = blocked ? wave * mytasks : wave, k = 0;
+  int slot = 0;
+  for (int64_t i = 0; i < total; ++i) {
+    const double* p = a + task * R * seg + k * 128 + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      __builtin_amdgcn_global_load_lds(p + r * seg, (__attribute__((address_space(3))) void*)(mine + (slot * R + r) * 1024), 16, 0, 2);
+    slot = slot + 1 == S ? 0 : slot + 1;
+    if (++k == steps) {
+      k = 0;
+      task += dtask;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * R) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int R, int S>
+static int launch_lds(const double* a, int64_t seg, int64_t nseg, int grid, int wpb, int blocked, hipStream_t s) {
+  if (blocked && (nseg / R) % ((int64_t)grid * wpb)) return 4;
+  const size_t bytes = (size_t)wpb * S * R * 1024;
+  if (hipFuncSetAttribute((const void*)read_lds_kernel<R, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 2;
+  hipLaunchKernelGGL((read_lds_kernel<R, S>), dim3(grid), dim3(64 * wpb), bytes, s, a, seg, nseg, blocked);
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int readbw_lds_launch(const double* a, int64_t seg, int64_t nseg, int grid, int wpb, int R, int S, int blocked, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (seg % 128 || nseg % R || (size_t)wpb * S * R * 1024 > 160 * 1024) return 3;
+  if (R == 4 && S == 4) return launch_lds<4, 4>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 4 && S == 8) return launch_lds<4, 8>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 2 && S == 8) return launch_lds<2, 8>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 8 && S == 4) return launch_lds<8, 4>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 1 && S == 16) return launch_lds<1, 16>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 2 && S == 4) return launch_lds<2, 4>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 1 && S == 8) return launch_lds<1, 8>(a, seg, nseg, grid, wpb, blocked, s);
+  if (R == 4 && S == 2) return launch_lds<4, 2>(a, seg, nseg, grid, wpb, blocked, s);
+  return 1;
+}

@@ -41,4 +41,34 @@ for rep in range(4):
         res[i].append(run(*c[1:]))
 for i, c in enumerate(cfgs):
     t = float(np.median(res[i]))
-    print(json.dumps({"config": c[0], "U": c[4], "ms": round(t, 3), "TBps": round(8.0 * n * n / t / 1e9, 3)}))
+    print(json.dumps({"config": c[0], "U": c[4], "ms": round(t, 3), "TBps": round(8.0 * n * n / t / 1e9, 3)}), flush=True)
+
+# ---- LDS-DMA loads (round 3): persistent grids, R segments per wave at a time, ring of S slots, nothing consumed
+lib.readbw_lds_launch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+def run_lds(seg, grid, wpb, R, S, blocked=0):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = lib.readbw_lds_launch(A.data_ptr(), seg, n * n // seg, grid, wpb, R, S, blocked, st)
+    assert rc == 0, rc
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+lcfgs = [(n, 256, 2, 4, 4), (n, 256, 4, 4, 4), (n, 256, 2, 4, 8), (n, 256, 4, 2, 8), (n, 256, 2, 8, 4), (n, 512, 1, 4, 4),
+         (n, 512, 2, 4, 4), (n, 256, 4, 1, 16), (n, 256, 4, 4, 2), (n, 256, 8, 4, 2), (n, 256, 1, 4, 8), (n, 256, 1, 8, 4),
+         (8192, 256, 2, 4, 4), (8192, 256, 4, 4, 4), (8192, 256, 2, 4, 8), (32768, 256, 2, 4, 4),
+         (8192, 256, 2, 4, 4, 1), (8192, 256, 4, 4, 4, 1), (8192, 256, 2, 4, 8, 1), (8192, 256, 4, 1, 16, 1), (8192, 256, 4, 1, 8, 1),
+         (8192, 256, 2, 1, 16, 1), (8192, 256, 4, 1, 16, 0), (8192, 256, 4, 2, 8, 1), (8192, 256, 4, 2, 4, 1), (8192, 256, 8, 1, 8, 1),
+         (131072, 256, 2, 4, 4, 1), (32768, 256, 2, 4, 4, 1), (8192, 512, 2, 4, 4, 1), (8192, 512, 1, 4, 4, 1), (8192, 256, 1, 4, 8, 1),
+         (4096, 256, 2, 4, 4, 0), (4096, 256, 2, 4, 4, 1), (4096, 256, 4, 1, 16, 1)]
+lres = {i: [] for i in range(len(lcfgs))}
+for i, c in enumerate(lcfgs): run_lds(*c)
+for rep in range(4):
+    for i, c in enumerate(lcfgs):
+        lres[i].append(run_lds(*c))
+for i, c in enumerate(lcfgs):
+    t = float(np.median(lres[i]))
+    print(json.dumps({"config": "LDS-DMA ring, segments of %d doubles, %d workgroups x %d waves, R %d segments per wave, S %d slots, %s "
+                      "(%d KiB in flight per workgroup)" % (c[0], c[1], c[2], c[3], c[4],
+                                                             "each wave a contiguous run of tasks" if len(c) > 5 and c[5] else "moving band",
+                                                             c[2] * c[3] * (c[4] - 1)),
+                      "ms": round(t, 3), "TBps": round(8.0 * n * n / t / 1e9, 3)}), flush=True)

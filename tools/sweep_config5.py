@@ -29,16 +29,18 @@ def main():
         op, b, _ = problems.random_problem(n, 1234 + p, device=0)
         probs.append((op, b, None, ss.BoxProjOp(n, lb, ub)))
     make = lambda: solvers.CCQPSolverMPRGP(1e-6, 300)       # noqa: E731
-    variants = [("default (two rows x two steps per wave, one run)", dict(halves=False, ahead=4, tune=0)),
+    variants = [("default (one run)", dict(halves=False, ahead=4, tune=0)),
+                ("two halves, matvecs chained on one stream", dict(halves=True, chained=True, ahead=4, tune=0)),
+                ("two halves, free-running streams", dict(halves=True, chained=False, ahead=4, tune=0)),
+                ("two halves, chained, 6 rounds ahead", dict(halves=True, chained=True, ahead=6, tune=0)),
                 ("round 2's matvec (two rows x one step per wave)", dict(halves=False, ahead=4, tune=7 << 4)),
-                ("two alternating halves", dict(halves=True, ahead=4, tune=0)),
                 ("persistent LDS-DMA matvec (R 4, S 4, 2 waves per CU)", dict(halves=False, ahead=4, tune=(3 << 1) | (4 << 4))),
-                ("LDS-DMA matvec, 16 workgroups per problem", dict(halves=False, ahead=4, tune=(3 << 1) | (16 << 8))),
-                ("256 workgroups per problem", dict(halves=False, ahead=4, tune=256 << 8)),
-                ("default (repeat)", dict(halves=False, ahead=4, tune=0))]
+                ("default (repeat)", dict(halves=False, ahead=4, tune=0)),
+                ("two halves, chained (repeat)", dict(halves=True, chained=True, ahead=4, tune=0))]
     ref = None
     for label, kw in variants:
         lockstep._HALVES_DEFAULT = bool(kw["halves"])
+        lockstep._HALVES_CHAINED = bool(kw.get("chained", True))
         best = None
         for rep in range(args.reps + 1):
             torch.cuda.synchronize()
