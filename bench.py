@@ -35,8 +35,11 @@ exchange), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange 
 an `exchange_ab` object: after the timed steps, untimed, 50 exchanges of the n-vector by each of the three forms
 (torch all_gather_into_tensor | the C ABI's in-place RCCL all-gather on the compute stream | zero-padded
 all-reduce), HIP-event timed on the launch stream, with a check that all three leave the same bits in y on every
-rank -- the line decides by itself which exchange should be the default on the box it ran on.
-Any RCCL error ends the run with a non-zero exit code and RCCL's message on stderr: no retry, no other backend.
+rank -- the line decides by itself which exchange should be the default on the box it ran on.  It runs LAST (after
+the CPU baseline), under a watchdog, and a failure or a hang inside it -- it includes a form no multi-rank run has
+exercised yet -- puts an `error` into `exchange_ab` and ends the run with the complete line and exit code 0.
+Any RCCL error in the measured part ends the run with a non-zero exit code and RCCL's message on stderr: no retry, no
+other backend.
 """
 import argparse
 from datetime import timedelta
@@ -227,22 +230,32 @@ def box_id(device_index):
     return out
 
 
-def exchange_ab(op, eng, group, backend, reps=50):
+# watchdog of the untimed exchange A/B (normally a few seconds); the two environment variables are the hooks of
+# tests/test_gpu_bench_multirank.py, which rehearses a failing / hanging form
+AB_LIMIT_S = int(os.environ.get("CCQP_BENCH_AB_LIMIT_S", "180"))
+AB_FAULT = os.environ.get("CCQP_BENCH_AB_FAULT", "")
+
+
+def exchange_ab(n, row0, rows, slab, eng, group, backend, reps=50, state=None):
     """N > 1, untimed: the three forms of the per-matvec vector exchange, `reps` calls each, HIP events on the launch
     stream (first call of each form untimed: communicator / buffer set-up), and a check that all three leave the same
-    bits in y.  The vector exchanged is a real A.x slab (this rank's row block times x*); before every form the rest
-    of y is filled with NaN so that an entry a form failed to deliver cannot pass.  (Zero-padded all-reduce: x + 0 + ...
-    + 0 is exact except that it turns -0.0 into +0.0; the slab of a random matvec holds no zero.)"""
+    bits in y.  The vector exchanged is a real A.x slab (this rank's row block times x*, computed by the caller while
+    the matrix was resident); before every form the rest of y is filled with NaN so that an entry a form failed to
+    deliver cannot pass.  (Zero-padded all-reduce: x + 0 + ... + 0 is exact except that it turns -0.0 into +0.0; the
+    slab of a random matvec holds no zero.)  `state` (a dict) receives the form being run and the results so far, for
+    the caller's watchdog: this A/B is informational and must never cost the timed line above it."""
     import torch.distributed as dist
     from ccqppy_amd.operators import VectorExchange
-    from ccqppy_amd.problems import xstar
-    n, world = op.n, dist.get_world_size(group)
-    x = xstar(n, 99, eng.device)
-    sl = slice(op.row0, op.row0 + op.rows)
-    slab = eng.empty(op.rows)
-    eng.gemv(op.A, x, slab)
-    out, ys = {}, {}
-    for mode in ("allgather", "direct", "allreduce"):
+    world = dist.get_world_size(group)
+    sl = slice(row0, row0 + rows)
+    state = {} if state is None else state
+    out, ys = state.setdefault("out", {}), {}
+    for mode in ("allgather", "allreduce", "direct"):   # (the experimental form last: the other two are kept if it fails)
+        state["mode"] = mode
+        if mode == "allreduce" and AB_FAULT == "raise" and dist.get_rank(group) == world - 1:
+            raise RuntimeError("injected failure (CCQP_BENCH_AB_FAULT)")
+        if mode == "allreduce" and AB_FAULT == "hang":
+            time.sleep(10 ** 6)
         if mode == "direct" and backend != "nccl":
             out[mode] = "unavailable: %s" % backend
             continue
@@ -266,9 +279,10 @@ def exchange_ab(op, eng, group, backend, reps=50):
         torch.cuda.synchronize()
         ys[mode] = y.view(torch.int64).clone()
         out[mode] = {"mean_ms": float(np.mean(ms)), "median_ms": float(np.median(ms)), "min_ms": float(np.min(ms)),
-                     "max_ms": float(np.max(ms)), "calls": reps, "bytes_moved_per_rank": 8 * (n if mode == "allreduce" else op.rows),
+                     "max_ms": float(np.max(ms)), "calls": reps, "bytes_moved_per_rank": 8 * (n if mode == "allreduce" else rows),
                      "launches_besides_the_collective": {"allgather": 1, "direct": 0, "allreduce": 2}[mode] if n % world == 0 else None}
         ex.close()
+    state["mode"] = "comparison"
     names = list(ys)
     same = all(bool(torch.equal(ys[names[0]], ys[m])) for m in names[1:])
     # the same bits on every rank: xor-fold of the words, compared across ranks on the host
@@ -436,10 +450,14 @@ def _main():
         except torch.cuda.OutOfMemoryError:
             sym_info = {"note": "skipped: no room for the n^2/32 workspace"}
 
-    ab = None
+    ab_in = None
     if world > 1 and not args.no_exchange_ab:
-        ab = exchange_ab(op, eng, group, backend)
-        barrier()
+        # the vector the untimed exchange A/B moves: this rank's slab of A.x*, computed while the matrix is resident
+        from ccqppy_amd.problems import xstar
+        slab = eng.empty(op.rows)
+        eng.gemv(op.A, xstar(n, 99, eng.device), slab)
+        torch.cuda.synchronize()
+        ab_in = (n, op.row0, op.rows, slab)
 
     rows_local = op.rows
     holder = [op]
@@ -519,8 +537,6 @@ def _main():
             },
         }
         line["box"] = box_id(local_rank)
-        if ab is not None:
-            line["exchange_ab"] = ab
         cpu_n = args.cpu_n
         if cpu_n < 0:
             need = 8.0 * n * n / 2.0 ** 30 + 24.0
@@ -535,7 +551,47 @@ def _main():
                 import traceback
                 traceback.print_exc()
                 line["cpu_baseline_error"] = "%s: %s" % (type(e).__name__, e)
+    else:
+        line = None
+        holder[0] = None
+    ab_failed = False
+    if ab_in is not None:
+        # LAST, after the line is complete (ranks > 0 wait here while rank 0 times the oracle): the A/B of the three
+        # exchange forms is informational and includes a form no multi-rank run has exercised yet ("direct"), so a
+        # failure or a hang in it costs the `exchange_ab` object, never the measured line -- rank 0 prints the line
+        # with the error in it and every rank leaves without another collective
+        import threading
+        barrier()
+        state = {"out": {}, "mode": None}
+
+        def give_up():
+            if line is not None:
+                line["exchange_ab"] = dict(state["out"], error="no answer within %d s in form %r (untimed A/B; the timed "
+                                           "region above is complete)" % (AB_LIMIT_S, state["mode"]))
+                print(json.dumps(line), flush=True)
+            print("[bench] rank %d: exchange A/B gave no answer in form %r; leaving" % (rank, state["mode"]),
+                  file=sys.stderr, flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(AB_LIMIT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            ab = exchange_ab(*ab_in, eng, group, backend, state=state)
+            barrier()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            ab = dict(state["out"], error="%s in form %r: %s" % (type(e).__name__, state["mode"], e))
+            ab_failed = True
+        watchdog.cancel()
+        if line is not None:
+            line["exchange_ab"] = ab
+    if line is not None:
         print(json.dumps(line), flush=True)
+    if ab_failed:
+        sys.stdout.flush()
+        os._exit(0)                     # (the other ranks may sit in the failed form's collective: their watchdogs end them)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -880,10 +880,13 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=
     `halves=True` (an A/B option, OFF by default) advances the batch as TWO runs on two streams, the host alternating
     between them, so that one half's decision stages and vector update -- small launches, a few tens of microseconds
     each, during which the memory system idles -- go by under the other half's matvec.  Every problem is independent,
-    so the results are those of one run, bit for bit.  Measured on config 5's share (128 x n = 8192, round 3,
-    profiles/r03_sweep_config5_halves.jsonl): 410.8 problems/s against 421.5 for the single run -- two 32 GiB matvec
-    kernels sharing the machine stream worse than one 64 GiB kernel by more than the 0.8 % of a round the small
-    launches take -- so the scheme that pays for SPG (whose host turn-around is 10x longer) is not the default here."""
+    so the results are those of one run, bit for bit.  `_HALVES_CHAINED` (default) sends both halves' matvecs through
+    the device's ONE matvec stream (ccqp_batch_serialize_matvecs), so that they run one after the other at full
+    bandwidth; free-running, two 32 GiB matvec kernels share the machine worse than one 64 GiB kernel.  Measured on
+    config 5's share (128 x n = 8192, round 3, profiles/r03_sweep_config5_{halves,chained,memo}.jsonl): free-running
+    390-411 problems/s, chained 420-422.6, the single run 421-425 -- the small launches are only 1 % of a round, and the
+    second table, the event chaining and twice the launches cost what the overlap gains -- so the scheme that pays for
+    SPG (whose host turn-around is 10x longer) is not the default here."""
     B = len(spec)
     single = plans is None and (n <= _BSOLVE_MAX_N_MPRGP if single_launch is None else bool(single_launch)) and n <= 2048
     if halves is None:

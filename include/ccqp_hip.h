@@ -672,9 +672,10 @@ typedef struct ccqp_bop {
   int32_t reserved;
   ccqp_seg seg;
 } ccqp_bop;
-/* on != 0: the matvec groups of ccqp_batch_run_f64 calls made with this context are issued on one
- * process-wide stream, event-chained to the caller's stream, so that matvecs of different lane groups
- * never overlap each other (they would only split the HBM bandwidth). */
+/* on != 0: the matvec groups of ccqp_batch_run_f64 calls and the batched matvecs of ccqp_bmprgp_* /
+ * ccqp_bsegs_mprgp_* calls made with this context are issued on one stream per device, event-chained to
+ * the caller's stream, so that matvecs of different lane groups / half-batches never overlap each other
+ * (they would only split the HBM bandwidth) while their small launches still do. */
 int ccqp_batch_serialize_matvecs(ccqp_ctx* ctx, int on);
 /* Device addresses of a context's scalar slab and reduction workspace (to fill ccqp_bop). */
 int ccqp_ctx_workspace(ccqp_ctx* ctx, double** slab, double** partials);

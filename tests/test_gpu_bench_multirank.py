@@ -1,0 +1,64 @@
+"""bench.py at N > 1, rehearsed inside the GPU suite: 2 gloo ranks on ONE device (RCCL refuses two ranks on one GPU,
+profiles/r02_rccl_two_ranks_one_gpu_probe.txt), a small matrix.  The line must be complete (cpu_baseline on rank 0,
+exchange_ab with the bitwise checks), and a failing or hanging form of the untimed exchange A/B must cost the
+`exchange_ab` object only -- never the measured line or the exit code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(port, extra_env, timeout=420):
+    env = dict(os.environ, CCQP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env.pop("OMP_NUM_THREADS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--size", "4096", "--cpu-n", "4096"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    return p, lines
+
+
+def _check_measured_part(d):
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "matvecs/s" and d["value"] > 0
+    assert d["scaling"] == "strong" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["solve"]["converged"] and d["solve"]["reported_mv"] == d["solve"]["executed_mv"] > 5
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["exchange_ms_per_mv"] > 0
+    c = d["cpu_baseline"]
+    assert c is not None and c["kind"] == "port" and c["n"] == 4096 and c["value"] > 0 and c["cores"] >= 1
+    # the same problem on both sides: the oracle's count and iterate against the 2-rank GPU solve
+    assert c["reported_mv"] == d["solve"]["reported_mv"]
+    assert c["gpu_vs_oracle"]["mv_equal"] and c["gpu_vs_oracle"]["rel_diff_x"] < 1e-10
+    assert d["box"]["gpu_uuid"]
+
+
+def test_two_rank_line_is_complete():
+    p, lines = _run(29611, {})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_measured_part(d)
+    ab = d["exchange_ab"]
+    assert "error" not in ab
+    assert ab["direct"] == "unavailable: gloo"
+    for form in ("allgather", "allreduce"):
+        assert ab[form]["calls"] == 50 and ab[form]["median_ms"] > 0
+    assert ab["bitwise_equal_forms"] and ab["bitwise_equal_ranks"] and ab["no_nan_left"]
+
+
+@pytest.mark.parametrize("fault", ["raise", "hang"])
+def test_a_failing_exchange_form_costs_only_the_ab_object(fault):
+    p, lines = _run(29613 if fault == "raise" else 29615, {"CCQP_BENCH_AB_FAULT": fault, "CCQP_BENCH_AB_LIMIT_S": "20"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_measured_part(d)
+    ab = d["exchange_ab"]
+    assert "error" in ab and "allreduce" in ab["error"]
+    assert ab["allgather"]["calls"] == 50          # the form that ran before the failing one is kept

@@ -76,8 +76,10 @@ def test_lockstep_mprgp_equals_individual_solves(n, count):
 @pytest.mark.parametrize("n,count,segmented", [(300, 9, False), (1500, 5, False), (384, 7, True)])
 def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
     """The A/B option of lockstep._bmprgp_run: the batch as two runs on two streams, the host alternating between them
-    (a CPU test covers the polling logic; this one the streams, the staging on lane engines and the reassembly).  Same
-    bits as one run -- on elementwise sets and through the segmented form."""
+    (a CPU test covers the polling logic; this one the streams, the staging on lane engines and the reassembly) -- with
+    the halves' matvecs chained through the device's matvec stream (ccqp_batch_serialize_matvecs on the lanes: one after
+    the other, each half's small launches under the other's matvec) and free-running.  Same bits as one run -- on
+    elementwise sets and through the segmented form."""
     from ccqppy_amd import lockstep, solution_spaces as ss
     probs = _problems(n, count, 4100 + n)
     if segmented:
@@ -88,7 +90,8 @@ def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
     monkeypatch.setattr(lockstep, "_HALVES_DEFAULT", True)
     monkeypatch.setattr(lockstep, "_HALF_MIN_PROBLEMS", 2)
     monkeypatch.setattr(lockstep, "_HALF_MIN_BYTES", 0.0)
-    for ahead in (1, 4):
+    for chained, ahead in ((True, 1), (True, 4), (False, 4)):
+        monkeypatch.setattr(lockstep, "_HALVES_CHAINED", chained)
         two = _batch(probs, tols, 3000, single_launch=False, ahead=ahead)
         for a, c in zip(one, two):
             _same(a, c)

@@ -7,6 +7,11 @@ JSON line with a `roofline` object measured LIVE (HIP events on the launch strea
     python3 tools/config_profile_driver.py 5      # 128 x n = 8192 MPRGP + Box through solve_batch_pipelined
                                                   # (the 1-GPU share of the 1024-problem batch)
     options: --reps R (timed repetitions, default 2)  --warm W (default 1)  --ahead K (config 5: rounds queued ahead)
+             --cpu  also time the oracle (oracle/cpu_ref.py: the reference's algorithm on numpy + OpenBLAS) on the host
+                    cores beside it -> a `cpu_baseline` object: config 2 on the SAME problem (and x compared), config 3
+                    on a bounded sample (n = 32768, same generator / solver / set; the full size is compared in
+                    tests/test_gpu_baseline_configs.py), config 5 on the first 8 problems of the batch one after the
+                    other (the reference has no batch form) with x compared.  Not for runs under rocprofv3.
 
 roofline.achieved = algorithmic bytes of all matvecs executed in the timed repetitions / the summed event time of
 their launches (configs 2, 3: Engine.gemv_events, one pair per matvec = `launches_per_matvec` kernel launches;
@@ -73,6 +78,55 @@ def traffic_lookup(kernel_prefix, bytes_per_launch, which, tag_hint):
     return None, None
 
 
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(limits=os.cpu_count(), user_api="blas")
+        return int(max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] + [1]))
+    except Exception:  # noqa: BLE001
+        return int(os.cpu_count())
+
+
+def to_host(A, step=8192):
+    out = np.empty(tuple(A.shape), dtype=np.float64)
+    for r0 in range(0, A.shape[0], step):
+        out[r0:r0 + step] = A[r0:r0 + step].cpu().numpy()
+    return out
+
+
+def cpu_dense(which, op, b, x_gpu, gpu_mv_per_s, n):
+    """The oracle beside configs 2 / 3 (tools may call the oracle; the product never does)."""
+    from ccqppy_amd import problems
+    from oracle import cpu_ref
+    cores = blas_threads()
+    if which == "2":
+        A, bb, same, ns = to_host(op.A), b.cpu().numpy(), True, n
+        run = lambda: cpu_ref.solve_apgd(A, bb, 1e-8, 5000, P=cpu_ref.Box(ns, -0.5, 0.5))       # noqa: E731
+        what = "oracle/cpu_ref.solve_apgd, the SAME n=32768 problem"
+    else:
+        ns, same = 32768, False
+        op2, b2, _ = problems.random_problem(ns, 1234)
+        A, bb = to_host(op2.A), b2.cpu().numpy()
+        del op2
+        torch.cuda.empty_cache()
+        run = lambda: cpu_ref.solve_bbpgd(A, bb, 1e-8, 64, P=cpu_ref.Cone(ns))                  # noqa: E731
+        what = "oracle/cpu_ref.solve_bbpgd + Cone, 64-MV budget, bounded sample n=32768 of the same generator"
+    A[:8192].dot(bb)
+    t0 = time.perf_counter()
+    r = run()
+    dt = time.perf_counter() - t0
+    gbs = r.executed_mv * mv_bytes(ns, ns) / dt / 1e9
+    out = {"value": gbs * 1e9 / mv_bytes(n, n), "unit": "matvecs/s at n=%d%s" % (n, "" if same else " (bytes-equivalent)"),
+           "cores": cores, "kind": "port", "solve_s": dt, "executed_mv": int(r.executed_mv),
+           "reported_mv": int(r.solution_num_matrix_vector_multiplications), "GBps": gbs,
+           "sample": "%s: %d matvecs in %.2f s on %d BLAS threads" % (what, r.executed_mv, dt, cores),
+           "gpu_over_cpu": gpu_mv_per_s / (gbs * 1e9 / mv_bytes(n, n))}
+    if same and x_gpu is not None:
+        xc = r.solution
+        out["gpu_vs_oracle"] = {"rel_dx": float(np.linalg.norm(x_gpu - xc) / max(np.linalg.norm(xc), 1e-300))}
+    return out
+
+
 def dense_config(which, args):
     from bench import box_id, HBM_PEAK_GBS
     from ccqppy_amd import problems, solvers, solution_spaces as ss
@@ -115,7 +169,19 @@ def dense_config(which, args):
     form = eng.gemv_form(n, n)
     achieved = mv_bytes(n, n) / (np.mean(ms) * 1e-3) / 1e9
     traffic, src = traffic_lookup(form, mv_bytes(rpl, n), "dense", "config" + which)
+    cpu = None
+    if args.cpu:
+        xg = r.solution
+        xg = xg.cpu().numpy() if isinstance(xg, torch.Tensor) else np.asarray(xg)
+        if which == "3":
+            del op
+            torch.cuda.empty_cache()
+            op = None
+        cpu = cpu_dense(which, op, b, xg, mv / dt, n)
+        if cpu.get("reported_mv") is not None and which == "2":
+            cpu["gpu_vs_oracle"]["reported_mv"] = [int(r.solution_num_matrix_vector_multiplications), cpu["reported_mv"]]
     return {
+        "cpu_baseline": cpu,
         "config": label, "n": n, "repetitions": args.reps, "wall_s_per_solve": dt / args.reps,
         "executed_mv_per_solve": mv // args.reps, "reported_mv": int(r.solution_num_matrix_vector_multiplications),
         "converged": bool(r.solution_converged), "residual": float(r.solution_residual),
@@ -180,7 +246,33 @@ def config5(args):
     full = ms[ms >= 0.9 * ms.max()]
     full_bytes = B * mv_bytes(n, n)
     traffic, src = traffic_lookup("bmprgp_gemv_kernel", full_bytes, "bmprgp", "config5")
+    cpu = None
+    if args.cpu:
+        from oracle import cpu_ref
+        cores = blas_threads()
+        k = min(8, B)
+        t_cpu, mv_cpu, worst, same_mv = 0.0, 0, 0.0, True
+        for p in range(k):
+            A, bb = to_host(probs[p][0].A), probs[p][1].cpu().numpy()
+            if p == 0:
+                A.dot(bb)
+            t0 = time.perf_counter()
+            rc = cpu_ref.solve_mprgp(A, bb, 1e-6, 300, P=cpu_ref.Box(n, lb, ub))
+            t_cpu += time.perf_counter() - t0
+            mv_cpu += rc.executed_mv
+            xg = res[p].solution
+            xg = xg.cpu().numpy() if isinstance(xg, torch.Tensor) else np.asarray(xg)
+            worst = max(worst, float(np.linalg.norm(xg - rc.solution) / max(np.linalg.norm(rc.solution), 1e-300)))
+            same_mv = same_mv and int(rc.solution_num_matrix_vector_multiplications) == \
+                int(res[p].solution_num_matrix_vector_multiplications)
+        cpu = {"value": k / t_cpu, "unit": "problems/s", "cores": cores, "kind": "port", "problems": k, "solve_s": t_cpu,
+               "executed_mv": int(mv_cpu), "GBps": mv_cpu * mv_bytes(n, n) / t_cpu / 1e9,
+               "sample": "oracle/cpu_ref.solve_mprgp on the first %d problems of the batch, one after the other (the "
+                         "reference has no batch form), %d BLAS threads: %.2f s" % (k, cores, t_cpu),
+               "gpu_over_cpu": (B / best) / (k / t_cpu),
+               "gpu_vs_oracle": {"worst_rel_dx": worst, "same_reported_mv": bool(same_mv)}}
     return {
+        "cpu_baseline": cpu,
         "config": "config 5 (1-GPU share): %d x (n=%d dense random-SPD fp64 + BoxProjOp(array bounds +-0.5), "
                   "CCQPSolverMPRGP(1e-6, 300)), solve_batch_pipelined (lock-step rounds, ahead=%d)" % (B, n, args.ahead),
         "n": n, "problems": B, "wall_s": best, "problems_per_s": B / best, "executed_mv": int(mv),
@@ -213,6 +305,7 @@ def main():
     ap.add_argument("--ahead", type=int, default=4)
     ap.add_argument("--problems", type=int, default=128)
     ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--cpu", action="store_true")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     line = config5(args) if args.which == "5" else dense_config(args.which, args)

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in $WHICH; do
   echo "[configs] config $c: plain line"; date
-  python3 "$ROOT/tools/config_profile_driver.py" $c > "$OUT/${TAG}_config${c}_line.json" 2> "$OUT/${TAG}_config${c}_line.err" || exit 1
+  python3 "$ROOT/tools/config_profile_driver.py" $c --cpu > "$OUT/${TAG}_config${c}_line.json" 2> "$OUT/${TAG}_config${c}_line.err" || exit 1
   echo "[configs] config $c: kernel trace"; date
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_c${c}_trace" -- \
     python3 "$ROOT/tools/config_profile_driver.py" $c --reps 2 > "$OUT/${TAG}_config${c}_under_rocprof.json" 2> "$OUT/${TAG}_c${c}_trace.err" || exit 1
@@ -44,7 +44,8 @@ print(json.dumps({"config": d["config"], "algorithmic_bytes_per_launch": bpl,
 PY
 )
   python3 tools/summarize_prof.py "${TAG}_config${c}" "$OUT/prof_${TAG}_c${c}_trace" "$OUT/prof_${TAG}_c${c}_pmc1" "$OUT/prof_${TAG}_c${c}_pmc2" "$OUT/prof_${TAG}_c${c}_pmc3" > "$OUT/${TAG}_config${c}_summary.log" 2>&1 || exit 1
-  cp profiles/${TAG}_config${c}_* "$OUT/" 2>/dev/null
+  # (summarize_prof.py writes into profiles/: only ITS files travel back -- the line files of this run are already in $OUT)
+  cp profiles/${TAG}_config${c}_kernel_stats* profiles/${TAG}_config${c}_pmc.json "$OUT/" 2>/dev/null
   cd /tmp
 done
 echo "[configs] done"; date
