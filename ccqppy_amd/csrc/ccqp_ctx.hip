@@ -83,7 +83,15 @@ extern "C" int ccqp_mv_timing_begin(int max_pairs) {
   if (max_pairs > g_mvt_cap) {
     hipEvent_t* ev = new hipEvent_t[2 * (size_t)max_pairs];
     for (int i = 0; i < 2 * g_mvt_cap; ++i) ev[i] = g_mvt_ev[i];
-    for (int i = 2 * g_mvt_cap; i < 2 * max_pairs; ++i) CCQP_HIP(hipEventCreate(&ev[i]));
+    for (int i = 2 * g_mvt_cap; i < 2 * max_pairs; ++i) {
+      const hipError_t e = hipEventCreate(&ev[i]);
+      if (e != hipSuccess) {                      // the session does not open; the old table stays as it was
+        for (int j = 2 * g_mvt_cap; j < i; ++j) (void)hipEventDestroy(ev[j]);
+        delete[] ev;
+        ccqp_set_error("%s: hipEventCreate failed: %s", __func__, hipGetErrorString(e));
+        return CCQP_ERR_HIP;
+      }
+    }
     delete[] g_mvt_ev;
     g_mvt_ev = ev;
     g_mvt_cap = max_pairs;

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
                                                               const double* __restrict__ x,
                                                               const double* __restrict__ b, double* __restrict__ y,
                                                               double* __restrict__ g, int64_t rows, int64_t cols,
-                                                              int64_t ntasks, const double* __restrict__ skip) {
+                                                              int64_t ntasks, const double* __restrict__ skip,
+                                                              int stagger) {
 #if defined(__HIP_DEVICE_COMPILE__)             // (the host pass only needs the launch stub)
   if (skip != nullptr && *skip != 0.0) return;
   // dynamic LDS: the four waves' rings, then their parked row sums
@@ -149,6 +150,11 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
   const int64_t wave = (int64_t)blockIdx.x * wpb + w;
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  // staggered start: every wave of the machine walks the SAME x (and, row for row, the same column positions) at the
+  // same pace, so waves launched together ask the same L2 lines and DRAM pages at the same moments; a start delay of
+  // (37 wave mod 64) x stagger x 64 clocks (at most 7.7 us at stagger 4) spreads them: +0.5 ... 1 % on the pure read
+  // with the x stream beside it (tools/readbw.py) and on the matvec, at any size
+  for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
   gemv_lds_body<R, S, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves, ring + w * RING, res);
 #endif
 }
@@ -163,6 +169,7 @@ static bool gemv_lds_applicable(const double* A, int64_t lda, const double* x, i
 // + 1 KiB), at most 160 KiB per CU -- a ring that does not fit (or is not instantiated) is shortened to the next one
 struct gemv_lds_shape {
   int R, S, bpc_max, wpb;      // wpb: waves per workgroup
+  int stagger;                 // start delay unit of the waves (bits 20-22: 0 = by size, 1 = none, 2 .. 6 = 1, 4, 16, 32, 64)
   size_t lds;
 };
 
@@ -171,6 +178,8 @@ static gemv_lds_shape gemv_lds_decode(int variant) {
   static const int rows_of[4] = {2, 4, 1, 8};
   h.R = rows_of[(variant >> 28) & 3];
   h.wpb = ((variant >> 23) & 1) ? 1 : ((variant >> 30) & 1) ? 2 : CCQP_BLOCK / 64;
+  static const int stagger_of[8] = {-1, 0, 1, 4, 16, 32, 64, 64};
+  h.stagger = stagger_of[(variant >> 20) & 7];     // (-1: chosen by the launch from the bytes it reads)
   const int want = 4 * (((variant >> 25) & 7) + 1);
   static const int have[4][3] = {{12, 8, 4}, {8, 4, 4}, {16, 8, 4}, {4, 4, 4}};   // instantiated depths, by R code
   const int* row = have[(variant >> 28) & 3];
@@ -189,10 +198,15 @@ static gemv_lds_shape gemv_lds_decode(int variant) {
 }
 
 template <int R, int S>
-static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, hipStream_t s, const double* A, int64_t lda,
-                         const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, int stagger, hipStream_t s, const double* A,
+                         int64_t lda, const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
                          const double* skip) {
   const int64_t ntasks = (rows + R - 1) / R;
+  if (stagger < 0) {
+    // by size: the longest delay (63 x stagger x 64 clocks ~ 1.9 us x stagger) stays near 0.3 % of the launch's duration
+    const double gib4 = 8.0 * (double)rows * (double)cols / 4294967296.0;
+    stagger = gib4 < 1.0 ? 1 : gib4 > 32.0 ? 32 : (int)(gib4 + 0.5);
+  }
   static bool raised = false;                   // more than 64 KiB of dynamic LDS has to be asked for once per kernel
   if (!raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds_kernel<R, S, true>),
@@ -204,10 +218,10 @@ static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, hipStream
   }
   if (nt)
     hipLaunchKernelGGL((gemv_lds_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
-                       g, rows, cols, ntasks, skip);
+                       g, rows, cols, ntasks, skip, stagger);
   else
     hipLaunchKernelGGL((gemv_lds_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
-                       g, rows, cols, ntasks, skip);
+                       g, rows, cols, ntasks, skip, stagger);
   return 0;
 }
 
@@ -215,7 +229,7 @@ static int launch_lds(const gemv_lds_shape& h, int64_t blocks, bool nt, hipStrea
                       const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
                       const double* skip) {
 #define LDS_CASE(RR, SS) \
-  if (h.R == RR && h.S == SS) return launch_lds_rs<RR, SS>(blocks, nt, h.lds, h.wpb, s, A, lda, x, b, y, g, rows, cols, skip)
+  if (h.R == RR && h.S == SS) return launch_lds_rs<RR, SS>(blocks, nt, h.lds, h.wpb, h.stagger, s, A, lda, x, b, y, g, rows, cols, skip)
   LDS_CASE(1, 4);
   LDS_CASE(1, 8);
   LDS_CASE(1, 16);

@@ -72,3 +72,56 @@ for i, c in enumerate(lcfgs):
                                                              "each wave a contiguous run of tasks" if len(c) > 5 and c[5] else "moving band",
                                                              c[2] * c[3] * (c[4] - 1)),
                       "ms": round(t, 3), "TBps": round(8.0 * n * n / t / 1e9, 3)}), flush=True)
+
+# ---- static against DYNAMIC task assignment (a global counter, drawn one task ahead), on the whole matrix and on the
+# first 65536 / 32768 / 16384 rows (the row slabs one rank holds at 2 / 4 / 8 GPUs)
+lib.readbw_lds_dyn_launch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+counter = torch.zeros(4, dtype=torch.int32, device="cuda")
+def run_pair(rows, dyn, grid=256, wpb=2, R=4, S=4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    if dyn:
+        rc = lib.readbw_lds_dyn_launch(A.data_ptr(), n, rows, grid, wpb, R, S, counter.data_ptr(), st)
+    else:
+        rc = lib.readbw_lds_launch(A.data_ptr(), n, rows, grid, wpb, R, S, 0, st)
+    assert rc == 0, rc
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+for rows in (n, n // 2, n // 4, n // 8):
+    t = {0: [], 1: []}
+    for rep in range(7):
+        for dyn in (0, 1):
+            ms = run_pair(rows, dyn)
+            if rep:
+                t[dyn].append(ms)
+    for dyn in (0, 1):
+        m = float(np.median(t[dyn]))
+        print(json.dumps({"config": "LDS-DMA ring, %d rows of 1 MiB, 256 workgroups x 2 waves, R 4, S 4, %s task assignment"
+                          % (rows, "DYNAMIC" if dyn else "static"), "ms": round(m, 4), "min_ms": round(min(t[dyn]), 4),
+                          "TBps": round(8.0 * rows * n / m / 1e9, 3)}), flush=True)
+
+# ---- the static ring with the matvec's x stream beside it (one shared vector, 1 KiB per step and wave, out of L2), and with
+# the waves' starts staggered by up to 63 * k * 64 clocks
+lib.readbw_lds_x_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_void_p]
+xv = torch.ones(n, dtype=torch.float64, device="cuda")
+def run_x(rows, stagger):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = lib.readbw_lds_x_launch(A.data_ptr(), xv.data_ptr(), n, rows, 256, 2, stagger, st)
+    assert rc == 0, rc
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+for rows in (n, n // 2, n // 4, n // 8):
+    modes = [("no x", None), ("x", 0), ("x, stagger 1", 1), ("x, stagger 4", 4), ("x, stagger 16", 16), ("x, stagger 64", 64)]
+    t = {m[0]: [] for m in modes}
+    for rep in range(7):
+        for name, sg in modes:
+            ms = run_pair(rows, 0) if sg is None else run_x(rows, sg)
+            if rep:
+                t[name].append(ms)
+    for name, sg in modes:
+        m = float(np.median(t[name]))
+        print(json.dumps({"config": "LDS-DMA ring, %d rows of 1 MiB, 256 workgroups x 2 waves, R 4, S 4, static: %s" % (rows, name),
+                          "ms": round(m, 4), "min_ms": round(min(t[name]), 4), "TBps": round(8.0 * rows * n / m / 1e9, 3)}), flush=True)
