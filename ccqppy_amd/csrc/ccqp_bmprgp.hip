@@ -180,7 +180,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_kernel(const ccqp_pmpr
 // (profiles/r03_bmv_sweep_lds.jsonl) -- 64 KiB rows leave the ring little to stream between two row ends.
 template <int R, int S>
 __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_lds_kernel(const ccqp_pmprgp* __restrict__ probs, int init,
-                                                                     int64_t n) {
+                                                                     int64_t n, int64_t ntasks, int64_t rs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const ccqp_pmprgp& q = probs[blockIdx.y];
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_lds_kernel(const ccqp_
   constexpr int RING = S * (R + 1) * 1024;
   const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
-  gemv_lds_body<R, S, true>(q.A, q.lda, m.x, m.b, m.y, m.g, n, n, (n + R - 1) / R, (int64_t)blockIdx.x * wpb + w,
-                            (int64_t)gridDim.x * wpb, ring + w * RING, res);
+  gemv_lds_body<R, S, true>(q.A, q.lda, m.x, m.b, m.y, m.g, n, n, ntasks, (int64_t)blockIdx.x * wpb + w,
+                            (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
 #endif
 }
 
@@ -207,77 +207,46 @@ static int bmprgp_launch_gemv_lds(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, i
   // workgroups per problem: the tuning word's, else one workgroup per CU over the whole batch (at least 1 per problem)
   int64_t per = flags >> 8;
   if (per <= 0) per = ctx->num_cu / count > 0 ? ctx->num_cu / count : 1;
-  const int64_t tasks = (n + R - 1) / R;
+  const int64_t rs = gemv_lds_row_stride(n, n, R);          // (the wave's R rows about 1 MiB apart, ccqp_bodies.h)
+  const int64_t tasks = gemv_lds_tasks(n, R, rs);
   if (per > (tasks + wpb - 1) / wpb) per = (tasks + wpb - 1) / wpb;
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
   hipLaunchKernelGGL((bmprgp_gemv_lds_kernel<R, S>), dim3((unsigned)per, count), dim3(64 * wpb), lds, s, dev_probs, init,
-                     n);
+                     n, tasks, rs);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }
 
-// The PERSISTENT form of the same (tuning word: loads = 3, ring code 4): one 2-wave workgroup per CU for the whole batch;
-// the waves walk the live problems' matrices one after the other (gemv_lds_multi_body) instead of every problem having
-// workgroups of its own -- the single big matvec's best shape (few, long row streams; profiles/r03_gemv_lds_ab.md)
-// carried over to many 512 MiB matrices.  The problems' operands are resolved once, into LDS, before the first DMA.
-#define BMV_PERS_MAX 512                        // problems per launch (48 B of LDS each)
-template <int R, int S>
-__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_pers_kernel(const ccqp_pmprgp* __restrict__ probs, int count,
-                                                                      int init, int64_t n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char ring[];
-  __shared__ int nlive_s;
-  constexpr int RING = S * (R + 1) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
-  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
-  gemv_lds_desc* D = reinterpret_cast<gemv_lds_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
-  // the live problems, in order, compacted by wave 0 (ballot + prefix over 64 problems at a time)
-  if (w == 0) {
-    int base = 0;
-    for (int p0 = 0; p0 < count; p0 += 64) {
-      const int p = p0 + lane;
-      bmprgp_mv m;
-      bool live = false;
-      if (p < count) live = bmprgp_mv_operands(probs[p], init, &m);
-      const unsigned long long mask = __ballot(live);
-      if (live) {
-        const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
-        gemv_lds_desc d = {probs[p].A, probs[p].lda, m.x, m.b, m.y, m.g};
-        D[at] = d;
-      }
-      base += __popcll(mask);
-    }
-    if (lane == 0) nlive_s = base;
+// The PERSISTENT form (bp_gemv_pers_kernel, ccqp_lockstep.h; tuning word: loads = 3, ring codes 4-7; code 5 is the
+// default from n = 4096 on): which operands problem p multiplies in this launch
+struct bmprgp_resolve {
+  const ccqp_pmprgp* probs;
+  int init;
+  __device__ bool operator()(int p, gemv_lds_desc* d) const {
+    bmprgp_mv m;
+    if (!bmprgp_mv_operands(probs[p], init, &m)) return false;
+    d->A = probs[p].A;
+    d->lda = probs[p].lda;
+    d->x = m.x;
+    d->b = m.b;
+    d->y = m.y;
+    d->g = m.g;
+    return true;
   }
-  __syncthreads();                               // (ordinary loads are done; from here on only DMA and LDS)
-  const int nlive = nlive_s;
-  if (nlive == 0) return;
-  gemv_lds_multi_body<R, S, true>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res);
-#endif
-}
+};
 
 template <int R, int S>
 static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int wpb,
                                    int bpc, hipStream_t s) {
-  const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
-                     (size_t)count * sizeof(gemv_lds_desc);
-  static size_t raised = 0;                     // (the kernel also holds a few bytes of static LDS: ask for what is needed)
-  if (lds > raised) {
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bmprgp_gemv_pers_kernel<R, S>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = lds;
-  }
-  if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
-  hipLaunchKernelGGL((bmprgp_gemv_pers_kernel<R, S>), dim3((unsigned)(ctx->num_cu * bpc)), dim3(64 * wpb), lds, s,
-                     dev_probs, count, init, n);
-  if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
-  return CCQP_OK;
+  (void)ctx;
+  const bmprgp_resolve rsv = {dev_probs, init};
+  return bp_launch_gemv_pers<R, S>(rsv, count, n, wpb, bpc, s);
 }
 
-// launches the round's matvec: the LDS-DMA form where the tuning word asks for it (loads = 3) and the shape allows
 static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
                                  hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  if (bp_pers_default(t, flags, count, n)) return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
   if (((flags >> 1) & 3) == 3 && t.aligned && n % 2 == 0 && n >= 128) {
     const int code = (flags >> 4) & 7;
     if (code >= 4 && count <= BMV_PERS_MAX) {   // persistent: 4 = R 4, S 4, 2 waves; 5 = 4 waves; 6 = R 2, S 8, 4 waves; 7 = R 4, S 4, 2 waves, 2 wg/CU

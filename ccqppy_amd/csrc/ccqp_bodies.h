@@ -5,6 +5,7 @@
 #pragma once
 #include "ccqp_internal.h"
 
+#include <stdlib.h>
 #ifdef __HIPCC__
 #define BODY_LOOP(i, n) \
   for (int64_t i = (int64_t)bx * CCQP_BLOCK + threadIdx.x; i < (n); i += (int64_t)nbx * CCQP_BLOCK)
@@ -340,7 +341,7 @@ __device__ __forceinline__ void gemv_body(const double* __restrict__ A, int64_t 
 // LDS (`res`) and stored -- with the `+ b` epilogue -- after the group's last load has landed, so no ordinary load or
 // store is ever in flight beside the DMA (hipcc would answer with vmcnt(0), and stores count on the same counter).
 // No barrier anywhere: a wave reads only what it has loaded itself.  Needs an even cols >= 128 and 16-byte aligned rows / x.
-#define GEMV_LDS_RESCAP 128        // row sums a wave parks before it flushes them (doubles of LDS per wave)
+#define GEMV_LDS_RESCAP 512        // row sums a wave parks before it flushes them (doubles of LDS per wave: 4 KiB)
 struct gemv_lds_desc {             // operands of one matrix of the multi-matrix form (gemv_lds_multi_body)
   const double* A;
   int64_t lda;
@@ -349,12 +350,41 @@ struct gemv_lds_desc {             // operands of one matrix of the multi-matrix
   double* y;
   double* g;
 };
+// Which rows a task takes.  The R row streams a wave reads side by side should lie about 1 MiB apart: the DRAM serves
+// R = 4 streams at 1 MiB spacing at 7.18 TB/s, at 64 KiB spacing at 6.83-6.98, at 4 MiB at 6.7, at 128 MiB again at 7.2
+// (tools/readbw.py, profiles/r03_read_ceiling.jsonl; spacing between DIFFERENT waves' streams does not matter, they
+// drift).  So task T of a matrix with row stride `rs` takes rows first, first + rs, ..., first + (R - 1) rs with
+// first = (T / rs) R rs + T mod rs: groups of R rs consecutive rows, dealt to rs tasks.  rs = 1: R consecutive rows.
+// The bits of y do not depend on it (they are a function of (row, n) only).
+// (CCQP_GEMV_ROW_STRIDE=k in the environment, read at every launch, forces rs = k: the A/B switch of the tools; 1 = R
+// consecutive rows, the only form before round 3's probe)
+static inline int64_t gemv_lds_row_stride(int64_t lda, int64_t rows, int R) {
+  const char* e = getenv("CCQP_GEMV_ROW_STRIDE");
+  if (e && e[0] >= '1' && e[0] <= '9') {
+    int64_t k = atoll(e);
+    while (k > 1 && (int64_t)R * k > rows) k /= 2;
+    return k < 1 ? 1 : k;
+  }
+  const double rowbytes = 8.0 * (double)lda;
+  int64_t rs = rowbytes <= 1.5 * 1048576.0 ? (int64_t)(1048576.0 / rowbytes + 0.5) : (int64_t)(134217728.0 / rowbytes + 0.5);
+  if (rs < 1) rs = 1;
+  while (rs > 1 && (int64_t)R * rs > rows) rs /= 2;        // (a matrix with fewer rows than one group)
+  return rs;
+}
+static inline int64_t gemv_lds_tasks(int64_t rows, int R, int64_t rs) {
+  return (rows + R * rs - 1) / (R * rs) * rs;
+}
 #if defined(__HIP_DEVICE_COMPILE__)
+template <int R>
+__device__ __forceinline__ int64_t gemv_lds_first_row(int64_t T, int64_t rs) {
+  const int64_t q = T / rs;
+  return q * (R * rs) + (T - q * rs);
+}
 template <int R, int S, bool NT>
 __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x,
                                               const double* __restrict__ b, double* __restrict__ y,
                                               double* __restrict__ g, int64_t rows, int64_t cols, int64_t ntasks,
-                                              int64_t wave, int64_t nwaves, char* mine, double* res) {
+                                              int64_t wave, int64_t nwaves, char* mine, double* res, int64_t rs) {
   constexpr int PIECE = 1024;                   // bytes one wave instruction moves: 64 lanes x 16 B
   constexpr int SLOT = (R + 1) * PIECE;
   constexpr int GROUP = GEMV_LDS_RESCAP / R;    // tasks per flush
@@ -375,10 +405,10 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
     int64_t is = 0, issued = 0;
     const double* irp[R];
     auto rows_of = [&](int k) {
-      const int64_t r0 = (wave + (k0 + k) * nwaves) * R;
+      const int64_t r0 = gemv_lds_first_row<R>(wave + (k0 + k) * nwaves, rs);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        int64_t row = r0 + r;
+        int64_t row = r0 + r * rs;
         if (row > rows - 1) row = rows - 1;     // clamp: tail rows re-read a valid row, never stored
         irp[r] = A + row * lda + 2 * lane;
       }
@@ -437,7 +467,7 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
     // ---- flush: every DMA of the group has landed (the last steps waited for vmcnt(0))
     for (int j = lane; j < kn * R; j += 64) {
       const int kk = j / R, r = j - kk * R;
-      const int64_t row = (wave + (k0 + kk) * nwaves) * R + r;
+      const int64_t row = gemv_lds_first_row<R>(wave + (k0 + kk) * nwaves, rs) + r * rs;
       if (row < rows) {
         const double v = res[j];
         y[row] = v;
@@ -453,7 +483,7 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
 // D (in LDS: descriptor reads must not be ordinary loads -- they would drain the ring) holds each matrix's operands.
 template <int R, int S, bool NT>
 __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int nlive, int64_t n, int64_t wave,
-                                                    int64_t nwaves, char* mine, double* res) {
+                                                    int64_t nwaves, char* mine, double* res, int64_t rs) {
   constexpr int PIECE = 1024;
   constexpr int SLOT = (R + 1) * PIECE;
   constexpr int GROUP = GEMV_LDS_RESCAP / R;
@@ -462,7 +492,7 @@ __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int 
   const int tail = (int)(n - nfull * 128);
   const bool mine_in_tail = 2 * lane < tail;
   const int64_t nsteps = nfull + (tail ? 1 : 0);
-  const int64_t tpp = (n + R - 1) / R;         // tasks per matrix
+  const int64_t tpp = (n + R * rs - 1) / (R * rs) * rs;       // tasks per matrix (gemv_lds_tasks)
   const int64_t ntasks = (int64_t)nlive * tpp;
   const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
   for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
@@ -476,10 +506,10 @@ __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int 
       const int64_t T = wave + (k0 + k) * nwaves;
       const int64_t m = T / tpp, t = T - m * tpp;
       const gemv_lds_desc d = D[m];
-      const int64_t r0 = t * R;
+      const int64_t r0 = gemv_lds_first_row<R>(t, rs);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        int64_t row = r0 + r;
+        int64_t row = r0 + r * rs;
         if (row > n - 1) row = n - 1;           // clamp: tail rows re-read a valid row, never stored
         irp[r] = d.A + row * d.lda + 2 * lane;
       }
@@ -539,7 +569,7 @@ __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int 
       const int kk = j / R, r = j - kk * R;
       const int64_t T = wave + (k0 + kk) * nwaves;
       const int64_t m = T / tpp, t = T - m * tpp;
-      const int64_t row = t * R + r;
+      const int64_t row = gemv_lds_first_row<R>(t, rs) + r * rs;
       if (row < n) {
         const gemv_lds_desc d = D[m];
         const double v = res[j];

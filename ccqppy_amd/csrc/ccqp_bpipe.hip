@@ -12,6 +12,7 @@
 // Bits: the bodies are those of the single-problem kernels (proj_elem_body, gemv_task, residual_body, dot_body,
 // bb_tail_body), the reduction geometry is the same function of n and the matvec's bits do not depend on its
 // tiling, so every problem gets exactly the result of its own CCQPSolverBBPGD.solve() (tests/test_gpu_bpipe.py).
+#include <string.h>
 #include "ccqp_lockstep.h"
 
 __global__ void bpipe_begin_kernel(unsigned* batch) {
@@ -227,8 +228,29 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
 }
 
 // (also used by the segmented lock-step form, ccqp_bsegs.hip)
+// (the persistent LDS-DMA form, bp_gemv_pers_kernel of ccqp_lockstep.h: the operands bpipe_gemv_kernel would take)
+struct bpipe_resolve {
+  const ccqp_pprob* probs;
+  int i, mode;
+  __device__ bool operator()(int p, gemv_lds_desc* d) const {
+    const ccqp_pprob& q = probs[p];
+    if (q.slab[BP_DONE] != 0.0) return false;
+    d->A = q.A;
+    d->lda = q.lda;
+    d->y = q.y;
+    d->x = mode == 0 ? q.x[i] : q.g[i];
+    d->b = mode == 0 ? q.b : nullptr;
+    d->g = mode == 0 ? q.g[i] : nullptr;
+    return true;
+  }
+};
+
 void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  if (bp_pers_default(t, flags, count, n)) {
+    const bpipe_resolve rsv = {probs, i, mode};
+    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+  }
   BP_MV_LAUNCH(bpipe_gemv_kernel, probs, i, mode, n);
 }
 
@@ -301,6 +323,20 @@ extern "C" int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   out[0] = m[0];
   out[1] = seq;
+  return CCQP_OK;
+}
+
+// Name of the kernel the batched matvec of the lock-step forms (ccqp_bpipe_* / ccqp_bapgd_* / ccqp_bmprgp_* / ccqp_bspg_*
+// and their segmented forms) runs as for `count` problems of size n under `flags` (bit 0 = aligned operands, the rest
+// the tuning word): "bp_gemv_pers_kernel" (one persistent LDS-DMA launch for the whole batch) or "batched VALU kernel".
+extern "C" int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen) {
+  CCQP_REQUIRE(name != nullptr && buflen > 0 && count >= 1 && n >= 1, "bad argument");
+  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  const bool lds_tuned = ((flags >> 1) & 3) == 3 && ((flags >> 4) & 7) >= 4;          // (MPRGP's explicit ring codes)
+  const char* k = bp_pers_default(t, flags, count, n) || (lds_tuned && t.aligned && n % 2 == 0 && n >= 128 && count <= BMV_PERS_MAX)
+                      ? "bp_gemv_pers_kernel" : "batched VALU kernel";
+  strncpy(name, k, (size_t)buflen - 1);
+  name[buflen - 1] = 0;
   return CCQP_OK;
 }
 
@@ -616,8 +652,38 @@ void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipS
   hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
 }
 
+// (the persistent LDS-DMA form: the operands bapgd_gemv_body would take)
+struct bapgd_resolve {
+  const ccqp_papgd* probs;
+  int init;
+  __device__ bool operator()(int p, gemv_lds_desc* d) const {
+    const ccqp_papgd& q = probs[p];
+    d->A = q.A;
+    d->lda = q.lda;
+    if (init) {
+      d->x = q.X[1];
+      d->b = nullptr;
+      d->y = q.Ax1;
+      d->g = nullptr;
+      return true;
+    }
+    if (q.slab[AP_DONE] != 0.0) return false;
+    const int it = (int)q.slab[AP_IT];
+    const bool trial = q.slab[AP_PHASE] == 0.0;
+    d->x = trial ? q.Y[it & 1] : q.X[(it + 1) & 1];
+    d->b = q.b;
+    d->y = trial ? q.Ayk : q.Ax1;
+    d->g = trial ? q.gk : q.g1;
+    return true;
+  }
+};
+
 void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  if (bp_pers_default(t, flags, count, n)) {
+    const bapgd_resolve rsv = {probs, init};
+    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+  }
   BP_MV_LAUNCH(bapgd_gemv_kernel, probs, init, n);
 }
 
@@ -631,8 +697,7 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 1, n);
+  ccqp_bapgd_launch_gemv(dev_probs, count, n, 1, flags, s);
   hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -647,8 +712,7 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  BP_MV_LAUNCH(bapgd_gemv_kernel, dev_probs, 0, n);
+  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s);
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, (flags & BP_FLAG_CONST_STEP) != 0);
   hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);

@@ -295,9 +295,31 @@ static int bspg_wait(volatile double* flag, double seq, hipStream_t s) {
   return CCQP_OK;
 }
 
+// (the persistent LDS-DMA form, bp_gemv_pers_kernel of ccqp_lockstep.h: the operands bspg_gemv_kernel would take)
+struct bspg_resolve {
+  const ccqp_pspg* probs;
+  const double* ctl;
+  int which;
+  __device__ bool operator()(int p, gemv_lds_desc* d) const {
+    if ((int)ctl[4 * p + SPG_MODE] != 1) return false;
+    const ccqp_pspg& q = probs[p];
+    d->A = q.A;
+    d->lda = q.lda;
+    d->y = q.Ad;
+    d->x = which == 0 ? q.x : which == 1 ? q.g : q.d;
+    d->b = which == 0 ? q.b : nullptr;
+    d->g = which == 0 ? q.g : nullptr;
+    return true;
+  }
+};
+
 static void bspg_gemv(const ccqp_pspg* probs, const double* ctl, int count, int64_t n, int which, int flags,
                       hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  if (bp_pers_default(t, flags, count, n)) {
+    const bspg_resolve rsv = {probs, ctl, which};
+    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+  }
   BP_MV_LAUNCH(bspg_gemv_kernel, probs, ctl, which, n);
 }
 

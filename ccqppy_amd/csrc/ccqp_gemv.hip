@@ -133,14 +133,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_mfma_kernel(const double* __r
 // VALU form.  The guide's rule for GEMV is "load straight to VGPRs; an LDS round trip is pure overhead"; measured here
 // (profiles/r03_gemv_lds_ab.md) the deep ring with ONE workgroup per CU reads the headline matrix FASTER than any
 // VGPR form (fewer, longer row streams), which is why it is selectable and, where it wins, the default.
-// LDS: 4 waves x (S x (R + 1) KiB ring + 1 KiB of parked row sums) per workgroup.
+// LDS: waves x (S x (R + 1) KiB ring + 4 KiB of parked row sums) per workgroup.
 template <int R, int S, bool NT>
 __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __restrict__ A, int64_t lda,
                                                               const double* __restrict__ x,
                                                               const double* __restrict__ b, double* __restrict__ y,
                                                               double* __restrict__ g, int64_t rows, int64_t cols,
                                                               int64_t ntasks, const double* __restrict__ skip,
-                                                              int stagger) {
+                                                              int stagger, int64_t rs) {
 #if defined(__HIP_DEVICE_COMPILE__)             // (the host pass only needs the launch stub)
   if (skip != nullptr && *skip != 0.0) return;
   // dynamic LDS: the four waves' rings, then their parked row sums
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
   // (37 wave mod 64) x stagger x 64 clocks (at most 7.7 us at stagger 4) spreads them: +0.5 ... 1 % on the pure read
   // with the x stream beside it (tools/readbw.py) and on the matvec, at any size
   for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-  gemv_lds_body<R, S, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves, ring + w * RING, res);
+  gemv_lds_body<R, S, NT>(A, lda, x, b, y, g, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs);
 #endif
 }
 
@@ -166,7 +166,7 @@ static bool gemv_lds_applicable(const double* A, int64_t lda, const double* x, i
 
 // ring shapes selectable by the variant word: bits 25-27 slots S = 4 (code + 1), bits 28-29 rows per wave R = 2, 4, 1, 8
 // (codes 0 .. 3), bit 30 / bit 23: 2 / 1 waves per workgroup instead of 4; LDS per workgroup = waves x (S x (R + 1) KiB
-// + 1 KiB), at most 160 KiB per CU -- a ring that does not fit (or is not instantiated) is shortened to the next one
+// + 4 KiB), at most 160 KiB per CU -- a ring that does not fit (or is not instantiated) is shortened to the next one
 struct gemv_lds_shape {
   int R, S, bpc_max, wpb;      // wpb: waves per workgroup
   int stagger;                 // start delay unit of the waves (bits 20-22: 0 = by size, 1 = none, 2 .. 6 = 1, 4, 16, 32, 64)
@@ -201,7 +201,8 @@ template <int R, int S>
 static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, int stagger, hipStream_t s, const double* A,
                          int64_t lda, const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
                          const double* skip) {
-  const int64_t ntasks = (rows + R - 1) / R;
+  const int64_t rs = gemv_lds_row_stride(lda, rows, R);
+  const int64_t ntasks = gemv_lds_tasks(rows, R, rs);
   if (stagger < 0) {
     // by size: the longest delay (63 x stagger x 64 clocks ~ 1.9 us x stagger) stays near 0.3 % of the launch's duration
     const double gib4 = 8.0 * (double)rows * (double)cols / 4294967296.0;
@@ -218,10 +219,10 @@ static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, int stagg
   }
   if (nt)
     hipLaunchKernelGGL((gemv_lds_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
-                       g, rows, cols, ntasks, skip, stagger);
+                       g, rows, cols, ntasks, skip, stagger, rs);
   else
     hipLaunchKernelGGL((gemv_lds_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
-                       g, rows, cols, ntasks, skip, stagger);
+                       g, rows, cols, ntasks, skip, stagger, rs);
   return 0;
 }
 

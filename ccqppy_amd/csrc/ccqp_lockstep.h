@@ -1,6 +1,7 @@
 // Shared pieces of the lock-step batch drivers (ccqp_bpipe.hip: BBPGD and APGD; ccqp_bmprgp.hip: MPRGP): slab slots,
 // the per-problem meeting point, the batch-wide roll-call with its host mirror, the batched matvec's tuning.
 #pragma once
+#include <stdlib.h>
 #include "ccqp_bodies.h"
 
 #define BP_ALPHA 48
@@ -285,6 +286,97 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
       else BP_MV_LAUNCH_U(KERNEL, false, false, __VA_ARGS__);              \
     }                                                                      \
   } while (0)
+
+// ---- the batched matvec as ONE persistent LDS-DMA launch (round 3): one 4-wave workgroup per CU for the whole batch;
+// the waves walk the live problems' matrices one after the other (gemv_lds_multi_body, ccqp_bodies.h: rows through
+// per-wave LDS rings, a wave's 4 rows about 1 MiB apart) instead of every problem having workgroups of its own -- the
+// single big matvec's best shape (few, long row streams) carried over to many matrices.  `Resolve` names a problem's
+// operands: bool operator()(int p, gemv_lds_desc* d) const, false = the problem does not multiply in this launch.  The
+// operands are resolved once per workgroup, into LDS, before the first DMA (an ordinary load beside the DMA stream
+// would make hipcc drain it).  Same bits as the VALU kernels (a function of (row, n) only).
+#define BMV_PERS_MAX 512                        // problems per launch (48 B of LDS each)
+template <int R, int S, class Resolve>
+__global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve rsv, int count, int64_t n, int64_t rs,
+                                                                  float stagger_per_problem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  __shared__ int nlive_s;
+  constexpr int RING = S * (R + 1) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  gemv_lds_desc* D = reinterpret_cast<gemv_lds_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
+  // the live problems, in order, compacted by wave 0 (ballot + prefix over 64 problems at a time)
+  if (w == 0) {
+    int base = 0;
+    for (int p0 = 0; p0 < count; p0 += 64) {
+      const int p = p0 + lane;
+      gemv_lds_desc d;
+      bool live = false;
+      if (p < count) live = rsv(p, &d);
+      const unsigned long long mask = __ballot(live);
+      if (live) D[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+      base += __popcll(mask);
+    }
+    if (lane == 0) nlive_s = base;
+  }
+  __syncthreads();                               // (ordinary loads are done; from here on only DMA and LDS)
+  const int nlive = nlive_s;
+  if (nlive == 0) return;
+  // staggered start (gemv_lds_kernel, ccqp_gemv.hip): the waves walk the same column positions at the same pace; the
+  // delay unit follows the bytes the LIVE problems make this launch read (a round in which one problem of 64 is left
+  // must not wait as the full batch would)
+  float su = stagger_per_problem * (float)nlive;
+  const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
+  for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+  gemv_lds_multi_body<R, S, true>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
+#endif
+}
+
+static inline int bp_num_cu() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int v = 0;
+    cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+  }
+  return cus[dev];
+}
+
+// The tuned default of every lock-step solver (no loads / rows-x-steps / workgroups field in the tuning word; bits 3
+// and 7 are solver variants): from n = 4096 and 1 GiB of matrices on, the persistent form.  Measured against the VALU
+// kernels: the launch alone (tools/bmv_sweep.py, profiles/r03_bmv_sweep_stride.jsonl) 128 x 8192 +1.7 %, 512 x 4096
+// +3.4 %, 16 x 8192 +6.5 %, 4 x 8192 +12 %; whole solves (tools/bench_lockstep_matvec_forms.py,
+// profiles/r03_lockstep_matvec_forms.jsonl) n = 4096 / 8192: APGD, MPRGP, SPG, BBPGD +2 ... +6 %.  At n = 1024 / 2048 the
+// launch gains 1.5-2.7 % with every problem live, but whole solves come out even (-4 ... +5 %, solver by solver), and
+// 512 x 512 loses 5 %: those stay on the VALU kernels, as do batches small enough to be re-read from the MALL.
+static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, int64_t n) {
+  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= 4096 && count <= BMV_PERS_MAX &&
+         8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
+}
+
+template <int R, int S, class Resolve>
+static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
+  const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
+                     (size_t)count * sizeof(gemv_lds_desc);
+  static size_t raised = 0;                     // (the kernel also holds a few bytes of static LDS: ask for what is needed)
+  if (lds > raised) {
+    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
+  }
+  // start delay unit of the waves per live problem: one unit per 4 GiB read, as the single matvec's (ccqp_gemv.hip)
+  static const bool stagger_off = [] {
+    const char* e = getenv("CCQP_BMV_STAGGER");      // (A/B switch of the tools: 0 = none)
+    return e && e[0] == '0';
+  }();
+  const float stagger = stagger_off ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
+  hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(bp_num_cu() * bpc)), dim3(64 * wpb), lds, s, rsv,
+                     count, n, gemv_lds_row_stride(n, n, R), stagger);
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
+  return CCQP_OK;
+}
 
 #define BP_CHECK_BATCH()                                                                          \
   CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument"); \

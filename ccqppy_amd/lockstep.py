@@ -22,7 +22,7 @@ from ._engine import get_engine
 # Problems the device-resident runs handed back to the host-driven loop (matvec budget reached, device budget of a
 # single-launch kernel, MPRGP's unreachable branches).  The fall-back keeps every result right, so a device-side bug
 # can hide behind it: the tests assert that this counter does not move where no fall-back is expected.
-stats = {"fallback_solves": 0, "auto_declined": 0}
+stats = {"fallback_solves": 0, "auto_declined": 0, "halved_runs": 0}
 
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
@@ -866,9 +866,10 @@ class _MprgpRun:
         return status, sols, np.sqrt(res2), mvs, execd
 
 
-_HALVES_DEFAULT = False          # (measured slower for MPRGP: see _bmprgp_run)
-_HALF_MIN_PROBLEMS = 32          # a batch advances as two alternating halves from this many problems on ...
-_HALF_MIN_BYTES = 2.0 ** 30      # ... if one round of matvecs reads at least this much (else launches bind, not HBM)
+_HALVES_DEFAULT = True           # lock-step MPRGP: large batches advance as two alternating halves (see _bmprgp_run)
+_HALF_MIN_PROBLEMS = 96          # ... from this many problems on ...
+_HALF_MIN_BYTES = 2.0 ** 35      # ... if one round of matvecs reads at least this much (32 GiB: 16 GiB per half) ...
+_HALF_MIN_N = 4096               # ... of matrices at least this large (below, the stage launches are already one)
 _HALVES_CHAINED = True           # the halves' matvecs go through ONE stream, one after the other (False: the free-running
                                  # form of the first A/B, whose two matvec kernels share the machine)
 _half_lanes = {}
@@ -877,20 +878,23 @@ _half_lanes = {}
 def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=None, plans=None):
     """Lock-step MPRGP over `spec`; returns (status, (B, n) final iterates, residuals, reported matvecs, executed
     matvecs); status 1 = converged, anything else = not finished here (rows meaningless).
-    `halves=True` (an A/B option, OFF by default) advances the batch as TWO runs on two streams, the host alternating
-    between them, so that one half's decision stages and vector update -- small launches, a few tens of microseconds
-    each, during which the memory system idles -- go by under the other half's matvec.  Every problem is independent,
-    so the results are those of one run, bit for bit.  `_HALVES_CHAINED` (default) sends both halves' matvecs through
-    the device's ONE matvec stream (ccqp_batch_serialize_matvecs), so that they run one after the other at full
-    bandwidth; free-running, two 32 GiB matvec kernels share the machine worse than one 64 GiB kernel.  Measured on
-    config 5's share (128 x n = 8192, round 3, profiles/r03_sweep_config5_{halves,chained,memo}.jsonl): free-running
-    390-411 problems/s, chained 420-422.6, the single run 421-425 -- the small launches are only 1 % of a round, and the
-    second table, the event chaining and twice the launches cost what the overlap gains -- so the scheme that pays for
-    SPG (whose host turn-around is 10x longer) is not the default here."""
+    Large batches (`halves`: by default from 96 problems of n >= 4096 reading 32 GiB per round, with the default matvec)
+    advance as TWO runs on two streams, the host alternating between them, so that one half's decision stages and
+    vector update -- small launches, a few tens of microseconds each, during which the memory system idles -- go by
+    under the other half's matvec.  Every problem is independent, so the results are those of one run, bit for bit.
+    `_HALVES_CHAINED` (default) sends both halves' matvecs through the device's ONE matvec stream
+    (ccqp_batch_serialize_matvecs), so that they run one after the other at full bandwidth; free-running, two 32 GiB
+    matvec kernels share the machine worse than one 64 GiB kernel.  Measured on config 5's share (128 x n = 8192, round
+    3, profiles/r03_sweep_config5_{halves,chained,memo,lds}.jsonl): free-running 390-411 problems/s against 421-425 for
+    one run; chained, with the VALU matvec a tie (the second table, the event chaining and twice the launches cost what
+    the overlap gains), with the persistent LDS-DMA matvec -- whose half-batch launch is as efficient as the full one
+    -- 434-435 against 430-431 (+1.1 %; 256 x 4096: +0.5 %; 64 x 8192 and 256 x 2048: nothing or a loss, hence the
+    thresholds)."""
     B = len(spec)
     single = plans is None and (n <= _BSOLVE_MAX_N_MPRGP if single_launch is None else bool(single_launch)) and n <= 2048
     if halves is None:
-        halves = _HALVES_DEFAULT and (not single) and B >= _HALF_MIN_PROBLEMS and 8.0 * n * n * B >= _HALF_MIN_BYTES
+        halves = _HALVES_DEFAULT and (not single) and tune == 0 and n >= _HALF_MIN_N and B >= _HALF_MIN_PROBLEMS \
+            and 8.0 * n * n * B >= _HALF_MIN_BYTES
     if not halves or B < 2:
         run = _MprgpRun(eng, spec, n, max_mv, tune, single_launch, plans)
         if run.last >= 1:
@@ -898,6 +902,7 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=
         return run.finish()
     from . import _lib
     from ._engine import make_lanes
+    stats["halved_runs"] += 1
     lanes = _half_lanes.get(eng.index)
     if lanes is None:
         lanes = _half_lanes[eng.index] = make_lanes(eng.index, 2)

@@ -385,6 +385,11 @@ typedef struct ccqp_pprob {
   double* gmin;      /* (solvers.py:762-763 -- sic, gmin starts as a copy of x0); NULL otherwise */
 } ccqp_pprob;
 int64_t ccqp_bpipe_partials_doubles(int64_t n);
+/* Name of the kernel the batched matvec of ALL lock-step forms runs as for `count` problems of size n under `flags`
+ * (bit 0 = aligned operands, the rest the tuning word): "bp_gemv_pers_kernel" -- ONE persistent LDS-DMA launch whose
+ * waves walk the live problems' matrices (rows through per-wave LDS rings, a wave's 4 rows about 1 MiB apart); the
+ * tuned default from n = 4096 and 1 GiB of matrices on -- or "batched VALU kernel".  Same bits either way. */
+int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
  * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_lockstep.h).  Bit 3 (8)

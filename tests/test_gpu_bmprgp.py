@@ -90,11 +90,14 @@ def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
     monkeypatch.setattr(lockstep, "_HALVES_DEFAULT", True)
     monkeypatch.setattr(lockstep, "_HALF_MIN_PROBLEMS", 2)
     monkeypatch.setattr(lockstep, "_HALF_MIN_BYTES", 0.0)
+    monkeypatch.setattr(lockstep, "_HALF_MIN_N", 0)
+    halved0 = lockstep.stats["halved_runs"]
     for chained, ahead in ((True, 1), (True, 4), (False, 4)):
         monkeypatch.setattr(lockstep, "_HALVES_CHAINED", chained)
         two = _batch(probs, tols, 3000, single_launch=False, ahead=ahead)
         for a, c in zip(one, two):
             _same(a, c)
+    assert lockstep.stats["halved_runs"] == halved0 + 3
     ref = _reference(probs[:2], tols[:2], 3000)
     for a, c in zip(ref, one[:2]):
         _same(a, c)
@@ -334,3 +337,34 @@ def test_rejects_scalar_bounds_and_tiny_problems():
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8),
                                     [(op, b, None, ss.BoxProjOp(48, -0.5 * np.ones(48), 0.5 * np.ones(48)))])
+
+
+@pytest.mark.parametrize("n,count", [(4096, 9), (4098, 8), (6000, 4)])
+def test_default_batched_matvec_is_the_persistent_lds_form_and_changes_no_bit(n, count):
+    """From n = 4096 and 1 GiB of matrices on, the batched matvec of lock-step MPRGP is ONE persistent LDS-DMA launch whose
+    waves walk the live problems' matrices and read their 4 rows about 1 MiB apart (bmprgp_gemv_pers_kernel,
+    gemv_lds_row_stride); an explicit rows-x-steps field in the tuning word keeps the VALU form.  Same bits (the matvec's
+    bits are a function of (row, n) only), and those of each problem's own solve()."""
+    from ccqppy_amd._engine import get_engine
+    probs = _problems(n, count, 6100 + n)
+    tols = [1e-6] * count
+    eng = get_engine(0)
+    import ctypes
+    lib = eng.lib
+
+    def timed(**kw):
+        lib.ccqp_mv_timing_begin(4096)
+        out = _batch(probs, tols, 3000, single_launch=False, **kw)
+        buf, cnt = (ctypes.c_double * 4096)(), ctypes.c_int()
+        lib.ccqp_mv_timing_end(buf, 4096, ctypes.byref(cnt))
+        return out, cnt.value
+
+    lds, launches_lds = timed()
+    valu, launches_valu = timed(tune=3 << 4)
+    assert launches_lds == launches_valu > 5
+    for a, c in zip(valu, lds):
+        assert c.solution_converged
+        _same(a, c)
+    ref = _reference(probs[:2], tols[:2], 3000)
+    for a, c in zip(ref, lds[:2]):
+        _same(a, c)

@@ -1,0 +1,92 @@
+"""The batched matvec of every lock-step solver as ONE persistent LDS-DMA launch (bp_gemv_pers_kernel, the tuned default
+from n = 4096 and 1 GiB of matrices on) against the batched VALU kernels (an explicit rows-x-steps field in the tuning
+word keeps them): the same bits, MV counts and residuals per problem, and those of each problem's own solve()."""
+import contextlib
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, c):
+    assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+    assert bool(a.solution_converged) == bool(c.solution_converged)
+    assert float(a.solution_residual) == float(c.solution_residual)
+    xa, xc = a.solution, c.solution
+    xa = xa.cpu().numpy() if hasattr(xa, "cpu") else xa
+    xc = xc.cpu().numpy() if hasattr(xc, "cpu") else xc
+    assert np.array_equal(xa.view(np.uint64), xc.view(np.uint64))
+
+
+def _form(count, n, flags):
+    from ccqppy_amd._engine import get_engine
+    buf = ctypes.create_string_buffer(64)
+    assert get_engine(0).lib.ccqp_bpipe_matvec_form(count, n, flags, buf, 64) == 0
+    return buf.value.decode()
+
+
+def test_which_batches_take_the_persistent_form():
+    assert _form(8, 4096, 1) == "bp_gemv_pers_kernel"
+    assert _form(128, 8192, 1) == "bp_gemv_pers_kernel"
+    assert _form(128, 8192, 1 | 8) == "bp_gemv_pers_kernel"          # (bits 3 / 7: solver variants, not tuning)
+    assert _form(128, 8192, 1 | (3 << 4)) == "batched VALU kernel"    # an explicit rows-x-steps field
+    assert _form(128, 8192, 0) == "batched VALU kernel"               # unaligned operands
+    assert _form(7, 4096, 1) == "batched VALU kernel"                 # below 1 GiB
+    assert _form(512, 2048, 1) == "batched VALU kernel"               # n < 4096
+    assert _form(8, 4097, 1) == "batched VALU kernel"                 # odd n
+    assert _form(600, 4096, 1) == "batched VALU kernel"               # more problems than one launch takes
+    assert _form(8, 8192, 1 | (3 << 1) | (4 << 4)) == "bp_gemv_pers_kernel"     # MPRGP's explicit ring codes
+
+
+@pytest.mark.parametrize("kind,segmented", [("BBPGD", False), ("BBPGDf", False), ("PGD", False), ("APGD", False),
+                                            ("APGDAntiRelaxation", False), ("MPRGP", False), ("SPG", False),
+                                            ("BBPGD", True), ("APGD", True), ("MPRGP", True), ("SPG", True)])
+def test_persistent_batched_matvec_changes_no_bit(kind, segmented):
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    n, count = 4096, 8                                    # 8 n^2 count = 1 GiB: the smallest batch that takes the form
+    assert _form(count, n, 1) == "bp_gemv_pers_kernel"
+    probs = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, 7300 + p)
+        if segmented:
+            h = n // 2
+            first = ss.SphereProjOp(h, 0.8 + 0.01 * p)
+            P = ss.DisjointProjOp(first, ss.BoxProjOp(n - h, -0.4 * np.ones(n - h), 0.5 * np.ones(n - h)))
+        else:
+            P = ss.BoxProjOp(n, -0.5 * np.ones(n), (0.4 + 0.005 * p) * np.ones(n))
+        probs.append((op, b, None, P))
+    cls = getattr(solvers, "CCQPSolver" + kind)
+    budget = 400 if kind in ("APGD", "APGDAntiRelaxation", "MPRGP") else 2000
+    tol = 1e-6
+
+    def new_solver(p):
+        if kind == "PGD":
+            return cls(1e-4, 600, 0.3)
+        s = cls(tol, budget)
+        if kind == "SPG":
+            s.rng = np.random.RandomState(900 + p)        # (lock-step SPG: one generator per solver)
+        return s
+
+    def run(tune):
+        order = iter(range(count))
+        fb0 = lockstep.stats["fallback_solves"]
+        out = lockstep.solve_batch_pipelined(lambda: new_solver(next(order)), probs, device=0, tune=tune)
+        assert lockstep.stats["fallback_solves"] == fb0
+        return out
+
+    pers = run(0)
+    valu = run(1 << 4)
+    for a, c in zip(valu, pers):
+        _same(a, c)
+    assert max(r.solution_num_matrix_vector_multiplications for r in pers) > 5
+    # and the plain per-problem solve of the first two
+    for p in range(2):
+        A, b, x0, P = probs[p]
+        s = new_solver(p)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.solve(A, b, x0=x0, convex_proj_op=P)
+        _same(s, pers[p])

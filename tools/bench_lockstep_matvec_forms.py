@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Lock-step batches of every solver with the persistent LDS-DMA batched matvec (the default from n = 1024 and 1 GiB on)
+against the batched VALU kernels it replaced (the same tuning the default had: an explicit rows-x-steps field keeps
+them) -- problems/s of whole solves, best of a few repetitions, same bits asserted.
+    python tools/bench_lockstep_matvec_forms.py [--shapes 2048:256,4096:128,8192:64] [--solvers BBPGD,APGD,MPRGP,SPG]"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="1024:512,2048:256,4096:128,8192:64")
+    ap.add_argument("--solvers", default="BBPGD,APGD,MPRGP,SPG")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    lib = get_engine(0).lib
+    for shape in args.shapes.split(","):
+        n, B = (int(v) for v in shape.split(":"))
+        probs = []
+        for p in range(B):
+            op, b, _ = problems.random_problem(n, 1234 + p, device=0)
+            probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+        valu_tune = (3 if n >= 4096 else 1) << 4
+        for kind in args.solvers.split(","):
+            cls = getattr(solvers, "CCQPSolver" + kind)
+
+            def new_solver(p):
+                s = cls(1e-6, 300) if kind == "MPRGP" else cls(1e-8, 5000)
+                if kind == "SPG":
+                    s.rng = np.random.RandomState(1000 + p)
+                return s
+
+            out = {}
+            for label, tune in (("persistent_lds", 0), ("valu", valu_tune)):
+                best, res = None, None
+                for rep in range(args.reps + 1):
+                    order = iter(range(B))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    res = lockstep.solve_batch_pipelined(lambda: new_solver(next(order)), probs, device=0, tune=tune)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    if rep and (best is None or dt < best):
+                        best = dt
+                # one more repetition under the C ABI's event hook: the batched matvec launches alone
+                lib.ccqp_mv_timing_begin(8192)
+                order = iter(range(B))
+                lockstep.solve_batch_pipelined(lambda: new_solver(next(order)), probs, device=0, tune=tune)
+                torch.cuda.synchronize()
+                buf, cnt = (ctypes.c_double * 8192)(), ctypes.c_int()
+                lib.ccqp_mv_timing_end(buf, 8192, ctypes.byref(cnt))
+                ms = np.array(buf[:min(cnt.value, 8192)])
+                out[label] = (best, torch.stack([r.solution for r in res]),
+                              sum(r.executed_matrix_vector_multiplications for r in res), float(ms.sum()), int(len(ms)))
+            same = bool(torch.equal(out["persistent_lds"][1].view(torch.int64), out["valu"][1].view(torch.int64)))
+            mv = out["valu"][2]
+            print(json.dumps({"solver": kind, "n": n, "problems": B, "executed_mv": int(mv),
+                              "problems_per_s_persistent_lds": B / out["persistent_lds"][0],
+                              "problems_per_s_valu": B / out["valu"][0],
+                              "gain": out["valu"][0] / out["persistent_lds"][0] - 1.0,
+                              "matvec_launch_ms_persistent_lds": out["persistent_lds"][3], "matvec_launch_ms_valu": out["valu"][3],
+                              "matvec_launches": [out["persistent_lds"][4], out["valu"][4]],
+                              "wall_ms": [1e3 * out["persistent_lds"][0], 1e3 * out["valu"][0]],
+                              "solve_level_hbm_frac_persistent_lds": mv * 8.0 * n * (n + 2) / out["persistent_lds"][0] / 8e12,
+                              "same_bits": same}), flush=True)
+        del probs
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

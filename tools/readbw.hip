@@ -184,3 +184,52 @@ extern "C" int readbw_lds_x_launch(const double* a, const double* x, int64_t seg
   hipLaunchKernelGGL((read_lds_x_kernel<R, S>), dim3(grid), dim3(64 * wpb), bytes, s, a, x, seg, nseg, stagger);
   return hipGetLastError() != hipSuccess;
 }
+
+// ---- does the SPACING of the R segments a wave reads side by side matter?  Task t of the static ring takes segments
+// {(t / rstride) * R * rstride + t % rstride + r * rstride : r < R}: rstride = 1 is R adjacent segments (the matvec's
+// R consecutive rows), rstride = 16 with 64 KiB segments puts them 1 MiB apart, as adjacent rows of the headline matrix are
+template <int R, int S>
+__global__ void read_lds_rs_kernel(const double* __restrict__ a, int64_t seg, int64_t nseg, int64_t rstride) {
+  extern __shared__ char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  char* mine = lds + (threadIdx.x >> 6) * (S * R * 1024);
+  const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * wpb;
+  const int64_t ntasks = nseg / R, steps = seg / 128;
+  const int64_t mytasks = wave < ntasks ? (ntasks - wave + nw - 1) / nw : 0;
+  const int64_t total = mytasks * steps;
+  int64_t task = wave, k = 0;
+  int slot = 0;
+  for (int64_t i = 0; i < total; ++i) {
+    const int64_t first = (task / rstride) * R * rstride + task % rstride;
+    const double* p = a + first * seg + k * 128 + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      __builtin_amdgcn_global_load_lds(p + r * rstride * seg, (__attribute__((address_space(3))) void*)(mine + (slot * R + r) * 1024), 16, 0, 2);
+    slot = slot + 1 == S ? 0 : slot + 1;
+    if (++k == steps) {
+      k = 0;
+      task += nw;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * R) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int R, int S>
+static int launch_lds_rs(const double* a, int64_t seg, int64_t nseg, int grid, int wpb, int64_t rstride, hipStream_t s) {
+  const size_t bytes = (size_t)wpb * S * R * 1024;
+  nseg -= nseg % (R * rstride);                 // (whole groups only: the caller counts the bytes the same way)
+  if (hipFuncSetAttribute((const void*)read_lds_rs_kernel<R, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 2;
+  hipLaunchKernelGGL((read_lds_rs_kernel<R, S>), dim3(grid), dim3(64 * wpb), bytes, s, a, seg, nseg, rstride);
+  return hipGetLastError() != hipSuccess;
+}
+extern "C" int readbw_lds_rs_launch(const double* a, int64_t seg, int64_t nseg, int grid, int wpb, int R, int S, int64_t rstride,
+                                    void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (seg % 128 || rstride < 1 || (size_t)wpb * S * R * 1024 > 160 * 1024) return 3;
+  if (R == 4 && S == 4) return launch_lds_rs<4, 4>(a, seg, nseg, grid, wpb, rstride, s);
+  if (R == 2 && S == 8) return launch_lds_rs<2, 8>(a, seg, nseg, grid, wpb, rstride, s);
+  if (R == 2 && S == 4) return launch_lds_rs<2, 4>(a, seg, nseg, grid, wpb, rstride, s);
+  return 1;
+}

@@ -125,3 +125,33 @@ for rows in (n, n // 2, n // 4, n // 8):
         m = float(np.median(t[name]))
         print(json.dumps({"config": "LDS-DMA ring, %d rows of 1 MiB, 256 workgroups x 2 waves, R 4, S 4, static: %s" % (rows, name),
                           "ms": round(m, 4), "min_ms": round(min(t[name]), 4), "TBps": round(8.0 * rows * n / m / 1e9, 3)}), flush=True)
+
+# ---- spacing of the R segments a wave reads side by side (64 KiB and 32 KiB segments: config 5's rows and n = 4096)
+lib.readbw_lds_rs_launch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]
+def run_rs(seg, wpb, R, S, rstride):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = lib.readbw_lds_rs_launch(A.data_ptr(), seg, n * n // seg, 256, wpb, R, S, rstride, st)
+    assert rc == 0, rc
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+rcfgs = [(8192, 2, 4, 4, rs) for rs in (1, 2, 4, 8, 16, 32, 64, 256, 2048)] + [(8192, 4, 2, 8, rs) for rs in (1, 16, 64)] + \
+        [(4096, 2, 4, 4, rs) for rs in (1, 8, 32, 128)] + \
+        [(131072, 2, 4, 4, rs) for rs in (1, 2, 3, 4, 5, 8, 16, 32, 64, 128, 256, 512, 1024)] + \
+        [(262144, 2, 4, 4, rs) for rs in (1, 2, 4, 8, 16, 32, 64, 128, 256)] + \
+        [(32768, 2, 4, 4, rs) for rs in (1, 4, 8)] + [(65536, 2, 4, 4, rs) for rs in (1, 2, 4)] + \
+        [(16384, 2, 4, 4, rs) for rs in (1, 8, 16)] + [(8192, 2, 4, 4, rs) for rs in (12, 20, 24)]
+rres = {i: [] for i in range(len(rcfgs))}
+for rep in range(5):
+    for i, c in enumerate(rcfgs):
+        ms = run_rs(*c)
+        if rep:
+            rres[i].append(ms)
+for i, c in enumerate(rcfgs):
+    t = float(np.median(rres[i]))
+    nseg = n * n // c[0]
+    nseg -= nseg % (c[2] * c[4])
+    print(json.dumps({"config": "LDS-DMA ring, segments of %d doubles, 256 workgroups x %d waves, R %d, S %d, side-by-side segments "
+                      "%d apart (%d KiB)" % (c[0], c[1], c[2], c[3], c[4], c[4] * c[0] * 8 // 1024),
+                      "ms": round(t, 4), "TBps": round(8.0 * nseg * c[0] / t / 1e9, 3)}), flush=True)

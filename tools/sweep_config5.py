@@ -29,14 +29,14 @@ def main():
         op, b, _ = problems.random_problem(n, 1234 + p, device=0)
         probs.append((op, b, None, ss.BoxProjOp(n, lb, ub)))
     make = lambda: solvers.CCQPSolverMPRGP(1e-6, 300)       # noqa: E731
-    variants = [("default (one run)", dict(halves=False, ahead=4, tune=0)),
-                ("two halves, matvecs chained on one stream", dict(halves=True, chained=True, ahead=4, tune=0)),
-                ("two halves, free-running streams", dict(halves=True, chained=False, ahead=4, tune=0)),
-                ("two halves, chained, 6 rounds ahead", dict(halves=True, chained=True, ahead=6, tune=0)),
+    variants = [("default (persistent LDS-DMA matvec, 4 waves per CU, rows 1 MiB apart; two chained halves)", dict(halves=True, ahead=4, tune=0)),
+                ("VALU matvec, two rows x two steps per wave (the default until the row-spacing probe)", dict(halves=False, ahead=4, tune=3 << 4)),
                 ("round 2's matvec (two rows x one step per wave)", dict(halves=False, ahead=4, tune=7 << 4)),
-                ("persistent LDS-DMA matvec (R 4, S 4, 2 waves per CU)", dict(halves=False, ahead=4, tune=(3 << 1) | (4 << 4))),
-                ("default (repeat)", dict(halves=False, ahead=4, tune=0)),
-                ("two halves, chained (repeat)", dict(halves=True, chained=True, ahead=4, tune=0))]
+                ("persistent LDS-DMA matvec, 2 waves per CU", dict(halves=False, ahead=4, tune=(3 << 1) | (4 << 4))),
+                ("persistent LDS-DMA matvec, R 2, S 8, 4 waves per CU", dict(halves=False, ahead=4, tune=(3 << 1) | (6 << 4))),
+                ("one run instead of two chained halves", dict(halves=False, ahead=4, tune=0)),
+                ("default (repeat)", dict(halves=True, ahead=4, tune=0)),
+                ("VALU matvec (repeat)", dict(halves=False, ahead=4, tune=3 << 4))]
     ref = None
     for label, kw in variants:
         lockstep._HALVES_DEFAULT = bool(kw["halves"])
