@@ -315,15 +315,17 @@ static int gemv_lds_variant(int variant) {
   return (variant & ~0xFF00F) | h.R | (bpc << 12);
 }
 
-// ---- which form a matvec takes.  variant == 0 (the tuned default): matrices of 2^31 elements (16 GiB) or more whose
-// shape the LDS-staged form covers take IT -- one persistent launch, one 2-wave workgroup per CU, GEMV_AUTO_LDS below
-// (measured +1.5 ... +3 % over the VALU form in launch rounds from 16 GiB slabs to the 128 GiB headline matrix,
-// profiles/r03_gemv_lds_ab.md; below that size the VALU form wins); (variant & 0xF) == 0xF forces the VALU form with its
-// shape defaults (the A/B switch).  Same bits whichever form runs.
+// ---- which form a matvec takes.  variant == 0 (the tuned default): matrices of 2^30 elements (8 GiB) or more whose
+// shape the LDS-staged form covers take IT -- one persistent launch, one 2-wave workgroup per CU, GEMV_AUTO_LDS below,
+// a wave's rows about 1 MiB apart.  Measured against the VALU form on the same box (profiles/r03_gemv_lds_ab.md,
+// r03_gemv_threshold.jsonl): +1.4 ... +4.5 % from 16 GiB slabs to the 128 GiB headline matrix; at 8 GiB (with the row
+// spacing) 32768^2 +1.3 %, 65536 x 16384 +1 %, 16384 x 65536 +2.6 %; at 4.5 GiB (24576^2) -5 % and at 2 GiB -3 %: the
+// persistent grid's ramp.  (variant & 0xF) == 0xF forces the VALU form with its shape defaults (the A/B switch).  Same
+// bits whichever form runs.
 #define GEMV_AUTO_LDS ((1 << 24) | (1 << 28) | (0 << 25) | (1 << 12) | (2 << 10) | (1 << 30))   // R = 4, S = 4, 2 waves, 1 wg/CU
 static int gemv_resolve(int variant, int64_t rows, int64_t cols, bool lds_ok) {
   if ((variant & 0xF) == 0xF) return variant & ~0xF;
-  if (variant == 0 && lds_ok && (double)rows * (double)cols >= 2147483648.0) return GEMV_AUTO_LDS;
+  if (variant == 0 && lds_ok && (double)rows * (double)cols >= 1073741824.0) return GEMV_AUTO_LDS;
   return variant;
 }
 

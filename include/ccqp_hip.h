@@ -72,7 +72,7 @@ int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
  * variant: 0 = tuned default; other values select tuning variants and the A/B forms (MFMA: bit 9; rows staged through
  * LDS rings by LDS-DMA loads: bit 24, with bits 20-22 its waves' start stagger -- 0 = by size, 1 = none, 2 .. 6 = 1, 4,
  * 16, 32, 64 units; (variant & 0xF) == 0xF: the VALU form even where the default would not take it)
- * -- see DESIGN.md 3.1 and ccqp_gemv.hip.  Default by size: from 16 GiB on (an even number of columns, 16-byte aligned rows and x) the
+ * -- see DESIGN.md 3.1 and ccqp_gemv.hip.  Default by size: from 8 GiB on (an even number of columns, 16-byte aligned rows and x) the
  * LDS-staged form as ONE persistent launch; below, the VALU form -- as several launches over row blocks that fill the
  * machine once ("rounds") where the LDS form does not apply to a >= 32 GiB matrix.  Same bits whichever runs.
  */

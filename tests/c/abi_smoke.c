@@ -405,6 +405,11 @@ int main(void) {
     if (strcmp(form, "gemv_stream_kernel")) bad++;
     printf("matvec plan: %lld x %lld -> 1 launch; 131072 x 131072 -> 1 launch (LDS-staged), VALU form: %lld launches of "
            "%lld rows\n", (long long)n, (long long)n, (long long)launches, (long long)per);
+    /* the batched matvec of the lock-step forms: one persistent LDS-DMA launch from n = 4096 and 1 GiB on */
+    CHECK(ccqp_bpipe_matvec_form(128, 8192, 1, form, 64));
+    if (strcmp(form, "bp_gemv_pers_kernel")) bad++;
+    CHECK(ccqp_bpipe_matvec_form(8, 512, 1, form, 64));
+    if (strcmp(form, "batched VALU kernel")) bad++;
   }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;

@@ -244,7 +244,8 @@ def test_gemv_bits_do_not_depend_on_tiling_alignment_or_sharding(eng):
     # form (where it applies: columns a multiple of 128); the VALU form (forced: 0xF) cuts the headline matrix into rounds
     assert eng.gemv_plan(4096, 4096)[1] == 1 and eng.gemv_form(4096, 4096) == "gemv_stream_kernel"
     assert eng.gemv_plan(131072, 131072) == (131072, 1) and eng.gemv_form(131072, 131072) == "gemv_lds_kernel"
-    assert eng.gemv_form(16384, 131072) == "gemv_lds_kernel" and eng.gemv_form(32768, 32768) == "gemv_stream_kernel"
+    assert eng.gemv_form(16384, 131072) == "gemv_lds_kernel" and eng.gemv_form(32768, 32768) == "gemv_lds_kernel"
+    assert eng.gemv_form(24576, 24576) == "gemv_stream_kernel" and eng.gemv_form(32768, 32768, 0xF) == "gemv_stream_kernel"
     assert eng.gemv_form(131072, 131000) == "gemv_lds_kernel" and eng.gemv_form(131072, 131001) == "gemv_stream_kernel"
     per, launches = eng.gemv_plan(131072, 131072, 0xF)
     assert launches > 1 and per * launches >= 131072 and eng.gemv_form(131072, 131072, 0xF) == "gemv_stream_kernel"
