@@ -249,7 +249,7 @@ static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, in
   if (bp_pers_default(t, flags, count, n)) return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
   if (((flags >> 1) & 3) == 3 && t.aligned && n % 2 == 0 && n >= 128) {
     const int code = (flags >> 4) & 7;
-    if (code >= 4 && count <= BMV_PERS_MAX) {   // persistent: 4 = R 4, S 4, 2 waves; 5 = 4 waves; 6 = R 2, S 8, 4 waves; 7 = R 4, S 4, 2 waves, 2 wg/CU
+    if (code >= 4) {   // persistent: 4 = R 4, S 4, 2 waves; 5 = 4 waves; 6 = R 2, S 8, 4 waves; 7 = R 4, S 4, 2 waves, 2 wg/CU
       if (code == 5) return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
       if (code == 6) return bmprgp_launch_gemv_pers<2, 8>(ctx, dev_probs, count, n, init, 4, 1, s);
       if (code == 7) return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 2, 2, s);

@@ -333,7 +333,7 @@ extern "C" int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* nam
   CCQP_REQUIRE(name != nullptr && buflen > 0 && count >= 1 && n >= 1, "bad argument");
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool lds_tuned = ((flags >> 1) & 3) == 3 && ((flags >> 4) & 7) >= 4;          // (MPRGP's explicit ring codes)
-  const char* k = bp_pers_default(t, flags, count, n) || (lds_tuned && t.aligned && n % 2 == 0 && n >= 128 && count <= BMV_PERS_MAX)
+  const char* k = bp_pers_default(t, flags, count, n) || (lds_tuned && t.aligned && n % 2 == 0 && n >= 128)
                       ? "bp_gemv_pers_kernel" : "batched VALU kernel";
   strncpy(name, k, (size_t)buflen - 1);
   name[buflen - 1] = 0;

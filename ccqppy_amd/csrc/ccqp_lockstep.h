@@ -294,10 +294,10 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 // operands: bool operator()(int p, gemv_lds_desc* d) const, false = the problem does not multiply in this launch.  The
 // operands are resolved once per workgroup, into LDS, before the first DMA (an ordinary load beside the DMA stream
 // would make hipcc drain it).  Same bits as the VALU kernels (a function of (row, n) only).
-#define BMV_PERS_MAX 512                        // problems per launch (48 B of LDS each)
+#define BMV_PERS_MAX 512                        // problems per launch (48 B of LDS each); larger batches: several launches
 template <int R, int S, class Resolve>
-__global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve rsv, int count, int64_t n, int64_t rs,
-                                                                  float stagger_per_problem) {
+__global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve rsv, int first, int count, int64_t n,
+                                                                  int64_t rs, float stagger_per_problem) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   __shared__ int nlive_s;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
       const int p = p0 + lane;
       gemv_lds_desc d;
       bool live = false;
-      if (p < count) live = rsv(p, &d);
+      if (p < count) live = rsv(first + p, &d);
       const unsigned long long mask = __ballot(live);
       if (live) D[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
       base += __popcll(mask);
@@ -351,14 +351,15 @@ static inline int bp_num_cu() {
 // launch gains 1.5-2.7 % with every problem live, but whole solves come out even (-4 ... +5 %, solver by solver), and
 // 512 x 512 loses 5 %: those stay on the VALU kernels, as do batches small enough to be re-read from the MALL.
 static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, int64_t n) {
-  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= 4096 && count <= BMV_PERS_MAX &&
+  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= 4096 &&
          8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
 }
 
 template <int R, int S, class Resolve>
 static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
+  const int chunk = count < BMV_PERS_MAX ? count : BMV_PERS_MAX;
   const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
-                     (size_t)count * sizeof(gemv_lds_desc);
+                     (size_t)chunk * sizeof(gemv_lds_desc);
   static size_t raised = 0;                     // (the kernel also holds a few bytes of static LDS: ask for what is needed)
   if (lds > raised) {
     CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve>),
@@ -372,8 +373,10 @@ static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb
   }();
   const float stagger = stagger_off ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
-  hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(bp_num_cu() * bpc)), dim3(64 * wpb), lds, s, rsv,
-                     count, n, gemv_lds_row_stride(n, n, R), stagger);
+  for (int first = 0; first < count; first += BMV_PERS_MAX)      // (more than BMV_PERS_MAX problems: one launch per group)
+    hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(bp_num_cu() * bpc)), dim3(64 * wpb), lds, s, rsv,
+                       first, count - first < BMV_PERS_MAX ? count - first : BMV_PERS_MAX, n, gemv_lds_row_stride(n, n, R),
+                       stagger);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }

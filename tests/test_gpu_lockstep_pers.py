@@ -38,7 +38,7 @@ def test_which_batches_take_the_persistent_form():
     assert _form(7, 4096, 1) == "batched VALU kernel"                 # below 1 GiB
     assert _form(512, 2048, 1) == "batched VALU kernel"               # n < 4096
     assert _form(8, 4097, 1) == "batched VALU kernel"                 # odd n
-    assert _form(600, 4096, 1) == "batched VALU kernel"               # more problems than one launch takes
+    assert _form(600, 4096, 1) == "bp_gemv_pers_kernel"               # (more than 512 problems: one launch per 512)
     assert _form(8, 8192, 1 | (3 << 1) | (4 << 4)) == "bp_gemv_pers_kernel"     # MPRGP's explicit ring codes
 
 
@@ -89,4 +89,31 @@ def test_persistent_batched_matvec_changes_no_bit(kind, segmented):
         s = new_solver(p)
         with contextlib.redirect_stdout(io.StringIO()):
             s.solve(A, b, x0=x0, convex_proj_op=P)
+        _same(s, pers[p])
+
+
+def test_more_problems_than_one_persistent_launch_takes():
+    """The persistent launch holds the operands of at most 512 problems in LDS; a larger batch is multiplied by one launch
+    per 512 problems.  520 problems of n = 4096 (65 GiB): the bits of the VALU kernels, and of the first / last
+    problem's own solve()."""
+    import torch
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    if torch.cuda.mem_get_info(0)[0] < 90 * 2 ** 30:
+        pytest.skip("needs 90 GiB of free device memory")
+    n, count = 4096, 520
+    P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    probs = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, 8800 + p)
+        probs.append((op, b, None, P))
+    make = lambda: solvers.CCQPSolverBBPGD(1e-8, 2000)        # noqa: E731
+    pers = lockstep.solve_batch_pipelined(make, probs, device=0)
+    valu = lockstep.solve_batch_pipelined(make, probs, device=0, tune=3 << 4)
+    for a, c in zip(valu, pers):
+        assert c.solution_converged
+        _same(a, c)
+    for p in (0, 511, 512, count - 1):
+        A, b, x0, Pp = probs[p]
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = make().solve(A, b, x0=x0, convex_proj_op=Pp)
         _same(s, pers[p])
