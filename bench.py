@@ -9,13 +9,21 @@ Workload (BASELINE.json `metric`): n = 131072 dense random-SPD fp64 box-constrai
 (tol 1e-8, max 5000 MVs), synthetic inputs generated on the GPU.  One STEP = one complete APGD solve
 from x0 = 0 (about 44 matvecs + all vector work + every host<->device scalar sync).
 `value` = matvecs executed per second over the whole job; `ms_per_step` = solve wall-clock.
+The solver is the package's default CCQPSolverAPGD: the two matvecs of an iteration (A.x_{k+1} and A.y_{k+1}; the second
+does not depend on the line search) are computed by ONE two-vector launch, ccqp_gemv2_f64 -- one pass over the matrix
+for both, each product with the bits of its own matvec, the reference's MV counts (35 = 35 against the oracle in this
+very line, `cpu_baseline.gpu_vs_oracle`).  Every matvec is computed; what is saved is reading A twice.  `--no-pair` runs
+one launch per matvec (the A/B).
 For N > 1 the matrix is row-block sharded (one process per GPU, RCCL all-gather of the n-vector per
 matvec) and the SAME problem is solved: strong scaling.
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel (fp64 streaming GEMV; `kernel` names the form this shape runs as, ccqp_gemv_form):
                   algorithmic bytes / duration measured with HIP events on the launch stream inside the timed region,
-                  against the 8 TB/s HBM3E peak.  A matvec is `launches_per_matvec` launches of the kernel, each over
+                  against the 8 TB/s HBM3E peak.  Paired launches (`matvecs_per_launch` = 2): the algorithmic bytes of a
+                  launch are A once + two vectors in + two out, `solve_level_frac` prices the launches' bytes over the
+                  wall-clock, and `solve_level_frac_at_one_pass_per_matvec` is the figure comparable with unpaired
+                  runs (> 1 = passes shared).  Unpaired: a matvec is `launches_per_matvec` launches of the kernel, each over
                   `rows_per_launch` rows (ccqp_gemv_plan; the headline size: ONE persistent launch of the LDS-staged
                   form): `achieved` = bytes of a MATVEC / the events' time around all of its launches (gaps between
                   them included); `bytes_per_launch`, `avg_launch_ms` (= that time / launches) and `traffic` are per
@@ -329,6 +337,8 @@ def _main():
                          "in-place RCCL all-gather of the C ABI on the compute stream (ccqp_comm_allgather_f64)")
     ap.add_argument("--variant", type=lambda v: int(v, 0), default=0, help="GEMV tuning variant word")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the untimed A/B of the three exchanges")
+    ap.add_argument("--no-pair", action="store_true",
+                    help="one launch (one pass over A) per matvec instead of one per pair of matvecs (A/B; same bits and counts)")
     ap.add_argument("--cpu-n", type=int, default=-1,
                     help="size of the CPU-baseline problem (0 = skip); default: the metric's own n when the host has "
                          ">= 160 GiB of free RAM (~30 s copy + ~60 s oracle solve), else 65536")
@@ -375,10 +385,15 @@ def _main():
 
     def step():
         np.random.seed(args.seed)
-        s = solvers.CCQPSolverAPGD(args.tol, args.max_mv)
+        s = solvers.CCQPSolverAPGD(args.tol, args.max_mv, pair_matvecs=False if args.no_pair else None)
         with contextlib.redirect_stdout(io.StringIO()):
             s.solve(op, b, convex_proj_op=P)
         return s
+
+    # Do the two matvecs of an APGD iteration share ONE pass over the matrix?  (CCQPSolverAPGD's default wherever the
+    # dense matvec is the LDS-staged form: A.x_{k+1} and A.y_{k+1} from one ccqp_gemv2_f64 launch, each product with the
+    # bits of its own matvec, same MV counts; --no-pair: one launch per matvec, the A/B.)
+    paired = (not args.no_pair) and hasattr(op, "pair_in_one_pass") and op.pair_in_one_pass(eng)
 
     for _ in range(args.warmup):
         step()
@@ -464,10 +479,17 @@ def _main():
     del op                      # from here on `holder` owns the matrix (cpu_baseline releases it)
     if rank == 0:
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
-        achieved = mv_bytes(rows_local, n) / (avg_ms * 1e-3) / 1e9
         rows_per_launch, launches = eng.gemv_plan(rows_local, n)
         form = eng.gemv_form(rows_local, n)              # the kernel this shape runs as: its name in a rocprofv3 table
-        traffic, traffic_src = pmc_traffic(mv_bytes(rows_per_launch, n), form)
+        per_launch = 1
+        launch_bytes = mv_bytes(rows_per_launch, n)
+        if paired:
+            # one launch = TWO products in one pass: A once, two vectors in, two out -- the algorithmic bytes of the pair
+            form, per_launch, launches = eng.gemv2_form(rows_local, n), 2, 1
+            rows_per_launch = rows_local
+            launch_bytes = 8.0 * (rows_local * n + 2 * n + 2 * rows_local)
+        achieved = launch_bytes * launches / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(launch_bytes, form)
         steps = max(args.steps, 1)
         line = {
             "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
@@ -507,9 +529,12 @@ def _main():
             "extension_symmetric": sym_info,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "%s (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64%s)" % (
-                    form, "; rows through per-wave LDS rings by LDS-DMA loads, one persistent launch"
-                    if form == "gemv_lds_kernel" else ""),
+                "kernel": "%s (%s%s)" % (
+                    form, "ccqp_gemv2_f64: the two matvecs of an APGD iteration in ONE pass over A" if paired
+                    else "ccqp_gemv_f64 / ccqp_gemv_epilogue_f64",
+                    "; rows through per-wave LDS rings by LDS-DMA loads, one persistent launch"
+                    if form in ("gemv_lds_kernel", "gemv_lds2_kernel") else ""),
+                "matvecs_per_launch": per_launch,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -517,14 +542,18 @@ def _main():
                 "traffic": traffic if (traffic_src or {}).get("verified_same_source") else None,
                 "traffic_from_profile": traffic,
                 "traffic_source": traffic_src,
-                "bytes_per_launch": mv_bytes(rows_per_launch, n),
+                "bytes_per_launch": launch_bytes,
                 "avg_launch_ms": avg_ms / launches,
                 "launches_per_matvec": launches,
                 "rows_per_launch": rows_per_launch,
                 "bytes_per_matvec": mv_bytes(rows_local, n),
-                "avg_matvec_ms": avg_ms,
-                "matvecs_timed": len(gemv_ms),
-                "solve_level_frac": mv_exec * mv_bytes(rows_local, n) / elapsed / 1e9 / HBM_PEAK_GBS,
+                "avg_matvec_ms": avg_ms / per_launch,       # (a paired launch delivers two products)
+                "matvecs_timed": len(gemv_ms) * per_launch,
+                # the bytes the solve's matvec launches have to read, over the whole wall-clock of the timed region
+                "solve_level_frac": len(gemv_ms) * launch_bytes * launches / elapsed / 1e9 / HBM_PEAK_GBS,
+                # for comparison with unpaired runs: every matvec priced at a full pass over A (> 1 means passes shared)
+                "solve_level_frac_at_one_pass_per_matvec": mv_exec * mv_bytes(rows_local, n) / elapsed / 1e9 / HBM_PEAK_GBS,
+                "launches_timed": len(gemv_ms),
                 "gemv_ms_per_step": float(np.sum(gemv_ms)) / steps if gemv_ms else None,
                 # N > 1: where the rest of a step goes (rank 0's own clock; the exchange includes waiting for the
                 # slowest rank's slab)

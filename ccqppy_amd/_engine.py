@@ -146,6 +146,32 @@ class Engine:
         _lib.check(self.lib.ccqp_gemv_plan(self.ctx, rows, cols, v, ctypes.byref(rpl), ctypes.byref(nl)))
         return rpl.value, nl.value
 
+    def gemv2(self, A, x1, x2, y1, y2, b=None, g1=None, g2=None, variant=None):
+        """y1 = A.x1 and y2 = A.x2 (g_i = y_i + b where given) in ONE pass over A where the LDS-staged form applies
+        (ccqp_gemv2_f64), each with the bits of its own gemv(); otherwise two single matvecs.  Counts as TWO executed
+        matvecs; one (start, end) event pair when profiling is on."""
+        rows, cols = A.shape
+        assert A.stride(1) == 1 and x1.numel() >= cols and x2.numel() >= cols and y1.numel() >= rows and y2.numel() >= rows
+        ev = None
+        if self.gemv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.torch_stream)
+        _lib.check(self.lib.ccqp_gemv2_f64(self.ctx, A.data_ptr(), A.stride(0), x1.data_ptr(), x2.data_ptr(),
+                                          0 if b is None else b.data_ptr(), y1.data_ptr(),
+                                          0 if g1 is None else g1.data_ptr(), y2.data_ptr(),
+                                          0 if g2 is None else g2.data_ptr(), rows, cols,
+                                          self.gemv_variant if variant is None else variant, self.stream))
+        if ev is not None:
+            ev[1].record(self.torch_stream)
+            self.gemv_events.append(ev)
+        self.mv_executed += 2
+
+    def gemv2_form(self, rows, cols, variant=None):
+        """"gemv_lds2_kernel" (one pass for two products) or "two single matvecs"."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self.lib.ccqp_gemv2_form(self.ctx, rows, cols, self.gemv_variant if variant is None else variant, buf, 64))
+        return buf.value.decode()
+
     def gemv_form(self, rows, cols, variant=None):
         """Name of the kernel a rows x cols matvec runs as (aligned operands assumed)."""
         buf = ctypes.create_string_buffer(64)

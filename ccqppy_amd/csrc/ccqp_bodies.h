@@ -477,6 +477,118 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stores count on the DMA's counter)
   }
 }
+// ---- TWO right-hand sides in one pass over A (y1 = A x1, y2 = A x2; g_i = y_i + b where asked): the ring's slot holds
+// R row pieces and BOTH x pieces, every row piece is read back once and multiplied into two accumulators.  Each product
+// has the bits of its own gemv_lds_body / gemv_task pass (same lane -> column map, same fma chain per accumulator); the
+// matrix is read from HBM once instead of twice.  (APGD's trial point and its momentum point: solvers.py:275,290.)
+template <int R, int S, bool NT>
+__device__ __forceinline__ void gemv_lds2_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x1,
+                                               const double* __restrict__ x2, const double* __restrict__ b,
+                                               double* __restrict__ y1, double* __restrict__ g1, double* __restrict__ y2,
+                                               double* __restrict__ g2, int64_t rows, int64_t cols, int64_t ntasks,
+                                               int64_t wave, int64_t nwaves, char* mine, double* res, int64_t rs) {
+  constexpr int PIECE = 1024;
+  constexpr int SLOT = (R + 2) * PIECE;
+  constexpr int GROUP = GEMV_LDS_RESCAP / (2 * R);     // tasks per flush (two sums per row)
+  const int lane = threadIdx.x & 63;
+  const int64_t nfull = cols / 128;
+  const int tail = (int)(cols - nfull * 128);
+  const bool mine_in_tail = 2 * lane < tail;
+  const int64_t nsteps = nfull + (tail ? 1 : 0);
+  const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
+  const double* xp1 = x1 + 2 * lane;
+  const double* xp2 = x2 + 2 * lane;
+  for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
+    const int kn = (int)(mytasks - k0 < GROUP ? mytasks - k0 : GROUP);
+    const int64_t total = (int64_t)kn * nsteps;
+    int ik = 0, islot = 0;
+    int64_t is = 0, issued = 0;
+    const double* irp[R];
+    auto rows_of = [&](int k) {
+      const int64_t r0 = gemv_lds_first_row<R>(wave + (k0 + k) * nwaves, rs);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r * rs;
+        if (row > rows - 1) row = rows - 1;     // clamp: tail rows re-read a valid row, never stored
+        irp[r] = A + row * lda + 2 * lane;
+      }
+    };
+    rows_of(0);
+    auto issue_next = [&]() {
+      char* slot = mine + islot * SLOT;
+      if (is < nfull || mine_in_tail) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
+                                           16, 0, NT ? 2 : 0);
+        __builtin_amdgcn_global_load_lds(xp1 + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
+                                         0);
+        __builtin_amdgcn_global_load_lds(xp2 + is * 128, (__attribute__((address_space(3))) void*)(slot + (R + 1) * PIECE),
+                                         16, 0, 0);
+      }
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++issued;
+      if (++is == nsteps) {
+        is = 0;
+        if (++ik < kn) rows_of(ik);
+      }
+    };
+    for (int p = 0; p < S - 1 && issued < total; ++p) issue_next();
+    int cslot = 0;
+    for (int kk = 0; kk < kn; ++kk) {
+      double acc1[R], acc2[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc1[r] = acc2[r] = 0.0;
+      for (int64_t s = 0; s < nsteps; ++s) {
+        if (issued < total) {
+          issue_next();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 2)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = mine + cslot * SLOT;
+        if (s < nfull || mine_in_tail) {
+          const ccqp_d2 xv1 = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+          const ccqp_d2 xv2 = *reinterpret_cast<const ccqp_d2*>(slot + (R + 1) * PIECE + lane * 16);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+            acc1[r] = fma(av.x, xv1.x, acc1[r]);
+            acc1[r] = fma(av.y, xv1.y, acc1[r]);
+            acc2[r] = fma(av.x, xv2.x, acc2[r]);
+            acc2[r] = fma(av.y, xv2.y, acc2[r]);
+          }
+        }
+        cslot = cslot + 1 == S ? 0 : cslot + 1;
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        acc1[r] = ccqp_wave_sum(acc1[r]);
+        acc2[r] = ccqp_wave_sum(acc2[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lane == r) {
+          res[(kk * R + r) * 2] = acc1[r];
+          res[(kk * R + r) * 2 + 1] = acc2[r];
+        }
+    }
+    // ---- flush: every DMA of the group has landed (the last steps waited for vmcnt(0))
+    for (int j = lane; j < kn * R; j += 64) {
+      const int kk = j / R, r = j - kk * R;
+      const int64_t row = gemv_lds_first_row<R>(wave + (k0 + kk) * nwaves, rs) + r * rs;
+      if (row < rows) {
+        const double v1 = res[2 * j], v2 = res[2 * j + 1];
+        y1[row] = v1;
+        y2[row] = v2;
+        if (g1) g1[row] = v1 + b[row];          // `A.dot(x) + b`: one more rounding, as numpy
+        if (g2) g2[row] = v2 + b[row];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
 // ---- the same ring over MANY matrices of one size (the batched matvec of the lock-step forms): the wave's tasks are
 // T = wave, wave + nwaves, ... over the concatenation of `nlive` matrices (task T = rows [R t, R t + R) of matrix T / tpp,
 // t = T % tpp), so the 2 x 256 waves of a persistent grid work through ONE matrix after the other, close together.

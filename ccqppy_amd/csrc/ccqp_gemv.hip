@@ -425,6 +425,126 @@ extern "C" int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const 
   return CCQP_OK;
 }
 
+// ---- two right-hand sides in one pass over A (gemv_lds2_body, ccqp_bodies.h): the LDS-staged form with both x pieces in
+// the ring's slot.  R = 4, S = 4; waves per workgroup, workgroups per CU, stagger and row stride as the single form's.
+template <int R, int S, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds2_kernel(const double* __restrict__ A, int64_t lda,
+                                                               const double* __restrict__ x1,
+                                                               const double* __restrict__ x2,
+                                                               const double* __restrict__ b, double* __restrict__ y1,
+                                                               double* __restrict__ g1, double* __restrict__ y2,
+                                                               double* __restrict__ g2, int64_t rows, int64_t cols,
+                                                               int64_t ntasks, int stagger, int64_t rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int RING = S * (R + 2) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * wpb + w;
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (staggered start)
+  gemv_lds2_body<R, S, NT>(A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs);
+#endif
+}
+
+template <int R, int S>
+static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, hipStream_t s, const double* A, int64_t lda,
+                       const double* x1, const double* x2, const double* b, double* y1, double* g1, double* y2, double* g2,
+                       int64_t rows, int64_t cols) {
+  size_t lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  while (wpb > 1 && lds > 160 * 1024) {           // (a ring that does not fit: fewer waves per workgroup)
+    wpb -= 1;
+    lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  }
+  if (bpc < 1 || (size_t)bpc * lds > 160 * 1024) bpc = 1;
+  const int64_t rs = gemv_lds_row_stride(lda, rows, R);
+  const int64_t ntasks = gemv_lds_tasks(rows, R, rs);
+  int64_t blocks = (ntasks + wpb - 1) / wpb;
+  if (blocks > (int64_t)ctx->num_cu * bpc) blocks = (int64_t)ctx->num_cu * bpc;
+  if (blocks < 1) blocks = 1;
+  static bool raised = false;
+  if (!raised) {
+    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds2_kernel<R, S, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds2_kernel<R, S, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  if (nt)
+    hipLaunchKernelGGL((gemv_lds2_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x1, x2, b, y1, g1,
+                       y2, g2, rows, cols, ntasks, stagger, rs);
+  else
+    hipLaunchKernelGGL((gemv_lds2_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x1, x2, b, y1,
+                       g1, y2, g2, rows, cols, ntasks, stagger, rs);
+  return CCQP_OK;
+}
+
+// Which form a pair of matvecs takes: true = ONE pass (gemv_lds2_kernel), wherever the single matvec would take the
+// LDS-staged form; false = two passes of the single matvec.
+static bool gemv2_fused(int variant, const double* A, int64_t lda, const double* x1, const double* x2, int64_t rows,
+                        int64_t cols) {
+  const bool ok = gemv_lds_applicable(A, lda, x1, cols) && (reinterpret_cast<uintptr_t>(x2) & 15) == 0;
+  variant = gemv_resolve(variant, rows, cols, ok);
+  return ok && ((variant >> 24) & 1) && !((variant >> 9) & 1);
+}
+
+extern "C" int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen) {
+  CCQP_REQUIRE(ctx != nullptr && name != nullptr && buflen > 0, "NULL argument");
+  const bool lds_ok = cols >= 128 && cols % 2 == 0;             // (16-byte aligned operands assumed)
+  variant = gemv_resolve(variant, rows, cols, lds_ok);
+  const char* k = lds_ok && ((variant >> 24) & 1) && !((variant >> 9) & 1) ? "gemv_lds2_kernel" : "two single matvecs";
+  strncpy(name, k, (size_t)buflen - 1);
+  name[buflen - 1] = 0;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x1, const double* x2,
+                              const double* b, double* y1, double* g1, double* y2, double* g2, int64_t rows,
+                              int64_t cols, int variant, void* stream) {
+  int rc = gemv_check(ctx, A, lda, x1, y1, rows, cols);
+  if (rc) return rc;
+  rc = gemv_check(ctx, A, lda, x2, y2, rows, cols);
+  if (rc) return rc;
+  CCQP_REQUIRE((g1 == nullptr && g2 == nullptr) || b != nullptr, "g requested but b is NULL");
+  CCQP_REQUIRE(y1 != x2 && y2 != x1 && (g1 == nullptr || (g1 != y1 && g1 != y2)) && (g2 == nullptr || (g2 != y1 && g2 != y2)),
+               "outputs must not alias each other or the inputs");
+  CCQP_REQUIRE(y1 != y2 && (g1 == nullptr || (g1 != g2 && g1 != x1 && g1 != x2)) && (g2 == nullptr || (g2 != x1 && g2 != x2)),
+               "outputs must not alias each other or the inputs");
+  if (rows == 0) return CCQP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!gemv2_fused(variant, A, lda, x1, x2, rows, cols)) {
+    rc = ccqp_gemv_launch(ctx, A, lda, x1, b, y1, g1, rows, cols, variant, s, nullptr);
+    if (rc) return rc;
+    rc = ccqp_gemv_launch(ctx, A, lda, x2, b, y2, g2, rows, cols, variant, s, nullptr);
+    if (rc) return rc;
+    CCQP_LAUNCH_CHECK();
+    return CCQP_OK;
+  }
+  const int v = gemv_lds_variant(gemv_resolve(variant, rows, cols, true));
+  const gemv_lds_shape h = gemv_lds_decode(v);
+  int bpc = (v >> 12) & 0xFF;
+  int stagger = h.stagger;
+  if (stagger < 0) {
+    const double gib4 = 8.0 * (double)rows * (double)cols / 4294967296.0;
+    stagger = gib4 < 1.0 ? 1 : gib4 > 32.0 ? 32 : (int)(gib4 + 0.5);
+  }
+  const bool nt = !((v >> 8) & 1) && (double)rows * (double)cols * 8.0 > 192.0 * 1048576.0;
+  // waves per workgroup: FOUR by default (twice the single matvec's: a wave's step now feeds two fma chains per row and
+  // reads two x pieces, and two waves per CU no longer hide it -- 19.36 against 22.06 ms on the headline matrix,
+  // profiles/r03_gemv2_sweep.jsonl); an explicit variant word keeps its own count; CCQP_GEMV2_WPB: the tools' A/B switch
+  int wpb = variant == 0 ? CCQP_BLOCK / 64 : h.wpb;
+  {
+    const char* e = getenv("CCQP_GEMV2_WPB");
+    if (e && e[0] >= '1' && e[0] <= '4') wpb = e[0] - '0';
+  }
+  // rows per wave: 4 (the single matvec's shape) or 8 (variant bits 28-29 = 3: half the x traffic per byte of A)
+  if (h.R == 8) rc = launch_lds2<8, 4>(ctx, wpb, bpc, nt, stagger, s, A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols);
+  else rc = launch_lds2<4, 4>(ctx, wpb, bpc, nt, stagger, s, A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols);
+  if (rc) return rc;
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 extern "C" int ccqp_gemv_epilogue_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x,
                                       const double* b, double* y, double* g, int64_t rows, int64_t cols,
                                       int variant, void* stream) {

@@ -51,6 +51,16 @@ class DenseOperator:
     def apply(self, eng, x, y, b=None, g=None):
         eng.gemv(self.A, x, y, b, g)
 
+    def matvec2(self, x1, y1, g1, x2, y2, g2, b=None, engine=None):
+        """y1 = A.x1, y2 = A.x2 (g_i = y_i + b where g_i is given) -- ONE pass over A where the LDS-staged form applies
+        (Engine.gemv2), each product with the bits of its own matvec()."""
+        (engine or self.engine).gemv2(self.A, x1, x2, y1, y2, b, g1, g2)
+
+    def pair_in_one_pass(self, engine=None):
+        """True if matvec2 reads the matrix once (what makes speculating on the second product worth it)."""
+        eng = engine or self.engine                     # (a recording engine of the fused batch scheduler has no pair form)
+        return hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
+
     def pipe_apply(self, eng, x, y, b=None, g=None):
         """apply() behind the pipeline's "converged" word (solvers.CCQPSolverBBPGD(pipeline=True))."""
         A = self.A
@@ -488,6 +498,26 @@ class RowShardedOperator:
         self.exchange(y, eng)
         if g is not None:
             eng.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
+
+    def matvec2(self, x1, y1, g1, x2, y2, g2, b=None, engine=None):
+        """Two products in one pass over the local row block (Engine.gemv2), then the two exchanges."""
+        eng = engine or self.engine
+        if self.sparse:
+            self.matvec(x1, y1, b, g1, eng)
+            self.matvec(x2, y2, b, g2, eng)
+            return
+        sl = slice(self.row0, self.row0 + self.rows)
+        eng.gemv2(self.A, x1, x2, y1[sl], y2[sl])
+        self.exchange(y1, eng)
+        self.exchange(y2, eng)
+        if g1 is not None:
+            eng.axpby(1.0, y1, 1.0, b, g1)
+        if g2 is not None:
+            eng.axpby(1.0, y2, 1.0, b, g2)
+
+    def pair_in_one_pass(self, engine=None):
+        eng = engine or self.engine
+        return (not self.sparse) and hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
 
 
 def as_operator(A, engine=None):

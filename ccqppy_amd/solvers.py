@@ -77,6 +77,14 @@ class _Run:
         self.op.matvec(v, y, None, None, self.eng)
         return y
 
+    def mv2(self, v1, with_g1, v2, with_g2):
+        """(A.v1[, A.v1 + b]), (A.v2[, A.v2 + b]) from ONE call of the operator's matvec2 (one pass over a dense A)."""
+        y1, y2 = self.new(), self.new()
+        g1 = self.new() if with_g1 else None
+        g2 = self.new() if with_g2 else None
+        self.op.matvec2(v1, y1, g1, v2, y2, g2, self.b, self.eng)
+        return (y1, g1), (y2, g2)
+
     def lin(self, a, x, b, y):
         out = self.new()
         self.eng.axpby(a, x, b, y, out)
@@ -252,8 +260,16 @@ class _APGDCore(CCQPSolverBase):
     _anti_relaxation = False
 
     def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, reuse_matvec=False,
-                 pipeline=False):
+                 pipeline=False, pair_matvecs=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        # SAME results bit for bit, same MV counts: the two products of an iteration share ONE pass over A.
+        # y_{k+1} = (1 + beta) x_{k+1} - beta x_k (solvers.py:313-316) depends on x_{k+1}, x_k and theta only -- not on
+        # the line search -- so it is formed as soon as x_{k+1} is, and A.x_{k+1} (:290) and A.y_{k+1} (:275 of the NEXT
+        # iteration) come from one two-vector matvec (operator.matvec2 -> ccqp_gemv2_f64: each product with the bits of
+        # its own matvec).  If the line search rejects x_{k+1} (:306-310) the second product is discarded and the retry
+        # is again one pass -- never more passes than the reference has matvecs.  None (default): wherever the operator
+        # reads its matrix once for the pair (dense, LDS-staged form: >= 8 GiB); True / False force it (plain APGD only).
+        self.pair_matvecs = pair_matvecs
         # Extension, OFF by default, SAME results bit for bit (plain APGD, dense operator with n <= 2048, elementwise
         # set): line search, momentum and exit test run on the device and rounds are queued ahead (ccqp_bapgd_*, the
         # lock-step batch scheduler with a batch of one): 1.2-1.9x lower latency.  Beyond n = 2048 the matvec hides the
@@ -276,6 +292,13 @@ class _APGDCore(CCQPSolverBase):
                 return out
         Ay_next = None                                  # A.yk obtained without a matvec (reuse mode)
         Axk = None                                      # A.xk
+        # pair mode: A.yk (and A.yk + b) computed ahead, in the pass that computed the previous A.x
+        pair = self.pair_matvecs
+        if pair is None:
+            pair = hasattr(run.op, "pair_in_one_pass") and run.op.pair_in_one_pass(eng)
+        from ._record import RecordingEngine            # (the fused batch scheduler records launches: no pair form there)
+        pair = bool(pair) and not reuse and not AR and hasattr(run.op, "matvec2") and not isinstance(eng, RecordingEngine)
+        Ay_ahead = None
         mv_count = 0
         xk = run.copy(run.x0)
         yk = run.copy(run.x0)
@@ -285,7 +308,11 @@ class _APGDCore(CCQPSolverBase):
         thk = 1.0
         thk1 = 1.0
         d = run.lin(1.0, xk, -1.0, ones)                # xk - ones
-        Ad = run.mv(d)
+        if pair:
+            (Ad, _), Ay_ahead = run.mv2(d, False, yk, True)
+            eng.mv_executed -= 1                        # (the second product counts where the reference computes it)
+        else:
+            Ad = run.mv(d)
         s = yield from run.dots_now([(Ad, Ad), (d, d)])
         mv_count += 1
         L = np.sqrt(s[0]) / np.sqrt(s[1])               # :264-268
@@ -298,17 +325,30 @@ class _APGDCore(CCQPSolverBase):
                 Ayk = Ay_next
                 gk = run.lin(1.0, Ayk, 1.0, b)
             else:
-                Ayk, gk = run.mv(yk, True)
+                if Ay_ahead is not None:
+                    Ayk, gk = Ay_ahead                  # computed in the previous pass: counted here, as :275-278
+                    Ay_ahead = None
+                    eng.mv_executed += 1
+                else:
+                    Ayk, gk = run.mv(yk, True)
                 mv_count += 1
                 if mv_count >= max_mv:
                     break
                 if reuse:
                     Axk = Ayk                           # first iteration: xk == yk == x0
             xkp1 = run.step_project(yk, t, gk)
+            if pair:                                    # (scalars of :313-314: functions of theta_k alone)
+                thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
+                beta = thk * (1 - thk) / (thk * thk + thk1)
             first = True
             nback = 0
             while True:
-                Ax1, g1 = run.mv(xkp1, True)
+                if pair:
+                    ykp1 = run.lin(1 + beta, xkp1, -beta, xk)          # :316, ahead of the line search
+                    (Ax1, g1), Ay_ahead = run.mv2(xkp1, True, ykp1, True)
+                    eng.mv_executed -= 1                # (counted when the next iteration takes it, or never)
+                else:
+                    Ax1, g1 = run.mv(xkp1, True)
                 mv_count += 1
                 if mv_count >= max_mv:
                     # the reference leaves the inner loop only; the tail below still runs
@@ -349,9 +389,10 @@ class _APGDCore(CCQPSolverBase):
                 t = 1.0 / L
                 xkp1 = run.step_project(yk, t, gk)
                 nback += 1
-            thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
-            beta = thk * (1 - thk) / (thk * thk + thk1)
-            ykp1 = run.lin(1 + beta, xkp1, -beta, xk)   # (1+beta)*xkp1 - beta*xk
+            if not pair:
+                thk1 = 0.5 * (-thk * thk + thk * np.sqrt(4 + thk * thk))
+                beta = thk * (1 - thk) / (thk * thk + thk1)
+                ykp1 = run.lin(1 + beta, xkp1, -beta, xk)   # (1+beta)*xkp1 - beta*xk
             if reuse:
                 Ay_next = run.lin(1 + beta, Ax1, -beta, Axk)
             res = np.sqrt(res2[1])

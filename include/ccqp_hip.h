@@ -85,6 +85,15 @@ int ccqp_gemv_plan(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, int64
 /* Name of the kernel a rows x cols matvec runs as ("gemv_stream_kernel" | "gemv_lds_kernel" | "gemv_mfma_kernel";
  * 16-byte aligned operands assumed): the key of its rows in a rocprofv3 table. */
 int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen);
+/* TWO matvecs with the same matrix in ONE pass over it: y1 = A x1, y2 = A x2 (g_i = y_i + b where g_i != NULL).
+ * Replaces the two `A.dot(...)` of an APGD iteration (solvers.py:275 A.dot(yk) of the NEXT iteration and :290
+ * A.dot(xkp1): y_{k+1} = (1 + beta) x_{k+1} - beta x_k is known as soon as x_{k+1} is, :313-316).  Each product has
+ * the bits ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 give it; the matrix is read from HBM once wherever the single matvec
+ * would take the LDS-staged form (ccqp_gemv2_form says "gemv_lds2_kernel"), otherwise the call is two single matvecs.
+ * y1, y2, g1, g2 must not alias each other or the inputs. */
+int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x1, const double* x2, const double* b,
+                   double* y1, double* g1, double* y2, double* g2, int64_t rows, int64_t cols, int variant, void* stream);
+int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen);
 /* Measurement hook (kernel-level roofline figures measured live, not only under a profiler): between
  * begin and end every BATCHED matvec launch of the lock-step drivers (ccqp_bpipe_*, ccqp_bapgd_*, ccqp_bmprgp_*,
  * ccqp_bsegs_*, ccqp_bspg_*) is bracketed by a pair of HIP events on its own stream, up to `max_pairs` of them (later

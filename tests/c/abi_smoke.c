@@ -386,6 +386,34 @@ int main(void) {
   } else {
     printf("rccl: not available, communicator section skipped\n");
   }
+  /* two matvecs in one pass over A (the LDS-staged form forced for this small matrix: variant 0x51001800) against two
+     single matvecs: the same bits */
+  {
+    double *y1, *y2, *g2, *r1, *r2;
+    double *h1 = (double*)malloc(n * sizeof(double)), *h2 = (double*)malloc(n * sizeof(double));
+    char form[64];
+    if (hipMalloc((void**)&y1, n * sizeof(double)) || hipMalloc((void**)&y2, n * sizeof(double)) ||
+        hipMalloc((void**)&g2, n * sizeof(double)) || hipMalloc((void**)&r1, n * sizeof(double)) ||
+        hipMalloc((void**)&r2, n * sizeof(double)))
+      return 1;
+    CHECK(ccqp_gemv_f64(ctx, A, n, x, r1, n, n, 0, NULL));
+    CHECK(ccqp_gemv_epilogue_f64(ctx, A, n, b, b, y2, r2, n, n, 0, NULL));      /* A.b and A.b + b */
+    CHECK(ccqp_gemv2_f64(ctx, A, n, x, b, b, y1, NULL, y2, g2, n, n, 0x51001800, NULL));
+    CHECK(ccqp_gemv2_form(ctx, n, n, 0x51001800, form, 64));
+    if (strcmp(form, "gemv_lds2_kernel")) bad++;
+    CHECK(ccqp_gemv2_form(ctx, n, n, 0, form, 64));
+    if (strcmp(form, "two single matvecs")) bad++;
+    hipDeviceSynchronize();
+    hipMemcpy(h1, r1, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipMemcpy(h2, y1, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (memcmp(h1, h2, n * sizeof(double))) bad++;
+    hipMemcpy(h1, r2, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipMemcpy(h2, g2, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (memcmp(h1, h2, n * sizeof(double))) bad++;
+    printf("two-vector matvec: A.x and A.b + b in one pass, bits of the single matvecs: %s\n", bad ? "NO" : "yes");
+    free(h1); free(h2);
+    hipFree(y1); hipFree(y2); hipFree(g2); hipFree(r1); hipFree(r2);
+  }
   /* how a shape will be launched: the small matrix in one launch of the VALU form; the headline matrix as ONE
      persistent launch of the LDS-staged form by default, in launch rounds when the VALU form is forced (0xF) */
   {

@@ -28,7 +28,12 @@ def _solve_all(op, b, n):
     out = {}
     box = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
     mixed = ss.DisjointProjOp(ss.BoxProjOp(n // 2, -0.5, 0.5), ss.ConeProjOp(n - n // 2))
+    # ("APGD paired": the two matvecs of an iteration from one two-vector matvec -- on a row-sharded operator one pass
+    # over the local row block and two exchanges; single GPU: no pair form asked for, so the comparison is with the
+    # plain solve)
+    paired = (lambda *a: solvers.CCQPSolverAPGD(*a, pair_matvecs=hasattr(op, "exchange")))
     for name, cls, args, P in (("APGD", solvers.CCQPSolverAPGD, (1e-8, 5000), box),
+                               ("APGD paired", paired, (1e-8, 5000), box),
                                ("BBPGD", solvers.CCQPSolverBBPGD, (1e-8, 5000), box),
                                ("SPG", solvers.CCQPSolverSPG, (1e-8, 64), mixed),
                                ("MPRGP", solvers.CCQPSolverMPRGP, (1e-6, 300), box)):

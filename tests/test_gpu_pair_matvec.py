@@ -1,0 +1,134 @@
+"""Two matvecs in one pass over A (ccqp_gemv2_f64 / gemv_lds2_kernel) and the APGD loop built on it: the second product
+of an iteration, A.y_{k+1}, is formed in the pass that computes A.x_{k+1} (y_{k+1} does not depend on the line search,
+solvers.py:313-316).  Everything must come out bit for bit as from single matvecs: products, iterates, residuals, reported
+and executed MV counts -- also when the line search rejects a step or the matvec budget ends the solve."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+LDS = 0x51001800          # the LDS-staged form forced (the default only from 8 GiB on)
+
+
+def _bits(t):
+    return t.view(torch.int64)
+
+
+@pytest.mark.parametrize("rows,cols", [(512, 512), (300, 1000), (1030, 258), (64, 130), (2048, 4096), (777, 2050)])
+@pytest.mark.parametrize("with_g", [(True, True), (False, True), (True, False), (False, False)])
+def test_pair_product_has_the_bits_of_two_single_products(rows, cols, with_g):
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    torch.manual_seed(rows * 7 + cols)
+    A = torch.randn(rows, cols, dtype=torch.float64, device="cuda")
+    x1, x2 = (torch.randn(cols, dtype=torch.float64, device="cuda") for _ in range(2))
+    b = torch.randn(rows, dtype=torch.float64, device="cuda")
+    ref = []
+    for x, wg in ((x1, with_g[0]), (x2, with_g[1])):
+        y, g = torch.empty_like(b), torch.empty_like(b)
+        eng.gemv(A, x, y, b if wg else None, g if wg else None, variant=0xF)       # the VALU form
+        ref.append((y, g if wg else None))
+    for variant in (LDS, 0x11001800, 0):
+        assert eng.gemv2_form(rows, cols, variant) == ("two single matvecs" if variant == 0 else "gemv_lds2_kernel")
+        y1, y2 = torch.full_like(b, float("nan")), torch.full_like(b, float("nan"))
+        g1 = torch.full_like(b, float("nan")) if with_g[0] else None
+        g2 = torch.full_like(b, float("nan")) if with_g[1] else None
+        mv0 = eng.mv_executed
+        eng.gemv2(A, x1, x2, y1, y2, b if (with_g[0] or with_g[1]) else None, g1, g2, variant=variant)
+        assert eng.mv_executed == mv0 + 2
+        assert torch.equal(_bits(y1), _bits(ref[0][0])) and torch.equal(_bits(y2), _bits(ref[1][0]))
+        if g1 is not None:
+            assert torch.equal(_bits(g1), _bits(ref[0][1]))
+        if g2 is not None:
+            assert torch.equal(_bits(g2), _bits(ref[1][1]))
+
+
+def test_pair_product_on_a_row_block_of_a_larger_matrix():
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    big = torch.randn(900, 1536, dtype=torch.float64, device="cuda")
+    A = big[100:700, :1400]                     # lda 1536 > cols 1400, rows 600
+    x1, x2 = (torch.randn(1400, dtype=torch.float64, device="cuda") for _ in range(2))
+    y = [torch.empty(600, dtype=torch.float64, device="cuda") for _ in range(4)]
+    eng.gemv(A, x1, y[0], variant=0xF)
+    eng.gemv(A, x2, y[1], variant=0xF)
+    eng.gemv2(A, x1, x2, y[2], y[3], variant=LDS)
+    assert torch.equal(_bits(y[0]), _bits(y[2])) and torch.equal(_bits(y[1]), _bits(y[3]))
+
+
+def _solve(n, seed, pair, tol=1e-8, max_mv=5000, width=0.5, variant=LDS, x0=None):
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    op, b, _ = problems.random_problem(n, seed)
+    old = eng.gemv_variant
+    eng.gemv_variant = variant
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            return solvers.CCQPSolverAPGD(tol, max_mv, pair_matvecs=pair).solve(
+                op, b, x0=x0, convex_proj_op=ss.BoxProjOp(n, -width * np.ones(n), width * np.ones(n)))
+    finally:
+        eng.gemv_variant = old
+
+
+def _same(a, c):
+    assert a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
+    assert a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
+    assert bool(a.solution_converged) == bool(c.solution_converged)
+    assert float(a.solution_residual) == float(c.solution_residual)
+    assert torch.equal(_bits(a.solution), _bits(c.solution))
+
+
+@pytest.mark.parametrize("n", [256, 1000, 2050, 4096])
+def test_apgd_with_paired_matvecs_equals_apgd(n):
+    for seed in (11, 12):
+        one = _solve(n, seed, False)
+        two = _solve(n, seed, True)
+        auto = _solve(n, seed, None)            # (below 8 GiB the default stays on single matvecs)
+        assert one.solution_converged and one.solution_num_matrix_vector_multiplications > 20
+        _same(one, two)
+        _same(one, auto)
+
+
+@pytest.mark.parametrize("max_mv", [3, 4, 5, 6, 7, 12, 13])
+def test_paired_matvecs_keep_the_budget_semantics(max_mv):
+    """The matvec budget is checked where the reference checks it (:277, :292): the product computed ahead is counted when
+    the next iteration takes it, not when the pass computes it."""
+    one = _solve(777, 5, False, max_mv=max_mv)
+    two = _solve(777, 5, True, max_mv=max_mv)
+    assert not one.solution_converged
+    _same(one, two)
+
+
+def test_paired_matvecs_when_the_line_search_rejects_steps():
+    """A start far outside the box and a tiny first Lipschitz estimate make the line search double L several times
+    (:306-310): every rejected trial discards the product computed ahead."""
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    n = 1500
+    op, b, _ = problems.random_problem(n, 77)
+    A = op.A.clone()
+    A[0, 0] += 400.0                             # one stiff direction the |A d| / |d| estimate at x0 - 1 underrates
+    x0 = torch.ones(n, dtype=torch.float64, device="cuda")
+    x0[0] = 1.0 + 1e-9
+    P = ss.BoxProjOp(n, -5.0 * np.ones(n), 5.0 * np.ones(n))
+    out = []
+    old = eng.gemv_variant
+    eng.gemv_variant = LDS
+    try:
+        for pair in (False, True):
+            s = solvers.CCQPSolverAPGD(1e-8, 5000, pair_matvecs=pair)
+            s.trace = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.solve(A, b, x0=x0, convex_proj_op=P)
+            out.append(s)
+    finally:
+        eng.gemv_variant = old
+    assert sum(t["nback"] for t in out[0].trace) >= 2, "the case is meant to backtrack"
+    assert [t["nback"] for t in out[0].trace] == [t["nback"] for t in out[1].trace]
+    _same(out[0], out[1])

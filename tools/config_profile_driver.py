@@ -167,8 +167,15 @@ def dense_config(which, args):
     eng.gemv_events = None
     rpl, launches = eng.gemv_plan(n, n)
     form = eng.gemv_form(n, n)
-    achieved = mv_bytes(n, n) / (np.mean(ms) * 1e-3) / 1e9
-    traffic, src = traffic_lookup(form, mv_bytes(rpl, n), "dense", "config" + which)
+    # APGD (config 2) computes the two matvecs of an iteration with ONE two-vector launch wherever the dense matvec is
+    # the LDS-staged form (CCQPSolverAPGD's default: ccqp_gemv2_f64, one pass over A, same bits and counts)
+    paired = which == "2" and op.pair_in_one_pass(eng)
+    per_launch, launch_bytes = 1, mv_bytes(rpl, n)
+    if paired:
+        form, per_launch, launches, rpl = eng.gemv2_form(n, n), 2, 1, n
+        launch_bytes = 8.0 * (n * n + 4 * n)
+    achieved = launch_bytes * launches / (np.mean(ms) * 1e-3) / 1e9
+    traffic, src = traffic_lookup(form, launch_bytes, "dense", "config" + which)
     cpu = None
     if args.cpu:
         xg = r.solution
@@ -187,13 +194,19 @@ def dense_config(which, args):
         "converged": bool(r.solution_converged), "residual": float(r.solution_residual),
         "mv_per_s": mv / dt,
         "roofline": {
-            "bound": "hbm", "kernel": "%s (ccqp_gemv_f64 / ccqp_gemv_epilogue_f64)" % form,
+            "bound": "hbm", "kernel": "%s (%s)" % (form, "ccqp_gemv2_f64: two matvecs per pass over A" if paired
+                                                   else "ccqp_gemv_f64 / ccqp_gemv_epilogue_f64"),
+            "matvecs_per_launch": per_launch,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src,
-            "bytes_per_matvec": mv_bytes(n, n), "avg_matvec_ms": float(np.mean(ms)), "matvecs_timed": len(ms),
-            "launches_per_matvec": launches, "rows_per_launch": rpl, "bytes_per_launch": mv_bytes(rpl, n),
+            "bytes_per_matvec": mv_bytes(n, n), "avg_matvec_ms": float(np.mean(ms)) / per_launch,
+            "matvecs_timed": len(ms) * per_launch,
+            "launches_per_matvec": launches, "rows_per_launch": rpl, "bytes_per_launch": launch_bytes,
             "avg_launch_ms": float(np.mean(ms)) / launches,
-            "solve_level_frac": mv * mv_bytes(n, n) / dt / 1e9 / HBM_PEAK_GBS,
+            # the bytes the matvec launches have to read over the wall-clock (events and wall-clock are taken in
+            # separate repetitions of the same solve: same number of launches)
+            "solve_level_frac": (len(ms) / args.reps) * launch_bytes * launches / (dt / args.reps) / 1e9 / HBM_PEAK_GBS,
+            "solve_level_frac_at_one_pass_per_matvec": mv * mv_bytes(n, n) / dt / 1e9 / HBM_PEAK_GBS,
             "gemv_ms_per_solve": float(np.sum(ms)) / args.reps,
             "other_ms_per_solve": 1e3 * dt / args.reps - float(np.sum(ms)) / args.reps,
             "wall_s_per_solve_with_event_pairs": dt_events / args.reps,
