@@ -268,7 +268,9 @@ class _APGDCore(CCQPSolverBase):
         # iteration) come from one two-vector matvec (operator.matvec2 -> ccqp_gemv2_f64: each product with the bits of
         # its own matvec).  If the line search rejects x_{k+1} (:306-310) the second product is discarded and the retry
         # is again one pass -- never more passes than the reference has matvecs.  None (default): wherever the operator
-        # reads its matrix once for the pair (dense, LDS-staged form: >= 8 GiB); True / False force it (plain APGD only).
+        # reads its matrix once for the pair (dense, LDS-staged form: >= 8 GiB); True / False force it.  The
+        # anti-relaxation variant's restart (:510-512) makes y_{k+1} = x_{k+1}: then the product computed ahead is dropped
+        # and A.x_{k+1}, which the same pass computed, is the next iteration's A.y_k.
         self.pair_matvecs = pair_matvecs
         # Extension, OFF by default, SAME results bit for bit (plain APGD, dense operator with n <= 2048, elementwise
         # set): line search, momentum and exit test run on the device and rounds are queued ahead (ccqp_bapgd_*, the
@@ -297,7 +299,7 @@ class _APGDCore(CCQPSolverBase):
         if pair is None:
             pair = hasattr(run.op, "pair_in_one_pass") and run.op.pair_in_one_pass(eng)
         from ._record import RecordingEngine            # (the fused batch scheduler records launches: no pair form there)
-        pair = bool(pair) and not reuse and not AR and hasattr(run.op, "matvec2") and not isinstance(eng, RecordingEngine)
+        pair = bool(pair) and not reuse and hasattr(run.op, "matvec2") and not isinstance(eng, RecordingEngine)
         Ay_ahead = None
         mv_count = 0
         xk = run.copy(run.x0)
@@ -408,6 +410,8 @@ class _APGDCore(CCQPSolverBase):
                 thk1 = 1
                 if reuse:
                     Ay_next = Ax1
+                if pair:                                # y_{k+1} is x_{k+1} itself: its product is the pass's FIRST one
+                    Ay_ahead = (Ax1, g1)
             L *= 0.9
             t = 1.0 / L
             yk, ykp1 = ykp1, yk

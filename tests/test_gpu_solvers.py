@@ -100,7 +100,7 @@ def test_solver_golden(case):
     assert s.solution_time > 0
 
 
-_PAIR_CASES = [c for c in SOLV if c["solver"] == "APGD" and c["err"] is None and not c["kwargs"]
+_PAIR_CASES = [c for c in SOLV if c["solver"] in ("APGD", "APGDAntiRelaxation") and c["err"] is None and not c["kwargs"]
                and c["mv_band"][0] == c["mv_band"][1]]
 
 
