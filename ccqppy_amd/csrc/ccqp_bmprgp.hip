@@ -40,6 +40,16 @@
 #define MP_ACT 39
 #define MP_IT 40         // outer iterations finished (parity addresses x_k / g_k)
 #define MP_EXEC 52       // matvecs executed (the reference's count skips A dx)
+// Look-ahead (round 3, the persistent LDS-DMA matvec only): at the A.dx launch of an iteration x_{k+1} and p_{k+1} are
+// final, so that launch also computes A.x_{k+1} + b and A.p_{k+1} -- ONE pass over A with three right-hand sides
+// (bp_gemv3_pers_kernel) instead of three passes per CG step.  MP_LOOK: this run looks ahead; MP_AHEAD: what the next
+// rounds find computed -- bit 0: A.x_k + b, parked in the OTHER gradient buffer (the recurrence gradient, still needed
+// by the residual of the A.dx round, sits where it belongs: the M1 round copies instead of multiplying), bit 1: A.p in
+// Ap, bit 2: A.x_k + b already in place (after an expansion step, whose :1152 matvec is the loop top's :1086 again;
+// likewise the start's :1065).  Every product has the bits of its own pass; the counters advance where the reference
+// computes the product (the stage of the M1 / AP round).
+#define MP_AHEAD 53
+#define MP_LOOK 54
 #define MP_DONE BP_DONE  // 49: 1 converged, 2 the feasibility search cannot terminate (:1113-1118), 3 proportioning step
 #define MP_MV BP_ITERS   // 50: the reference's mv_count
 #define MP_RES2 BP_RES2  // 51
@@ -56,7 +66,7 @@ enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 
 // entry snapshot of a problem's steering words (ccqp_lockstep.h: the meeting-point invariant)
 struct mp_words {
-  double done, state, it, mv, exec, dist2, ng, af, tried, acg, s0, s1;
+  double done, state, it, mv, exec, dist2, ng, af, tried, acg, s0, s1, ahead, look;
 };
 __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   mp_words z;
@@ -72,6 +82,8 @@ __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   z.acg = slab[MP_ACG];
   z.s0 = slab[MP_S0];
   z.s1 = slab[MP_S1];
+  z.ahead = slab[MP_AHEAD];
+  z.look = slab[MP_LOOK];
   __syncthreads();
   return z;
 }
@@ -131,14 +143,17 @@ __device__ __forceinline__ bool bmprgp_mv_operands(const ccqp_pmprgp& q, int ini
     return true;
   }
   const int it = (int)q.slab[MP_IT];
+  const int ahead = (int)q.slab[MP_AHEAD];
   switch ((int)q.slab[MP_STATE]) {
     case ST_M1:
+      if (ahead & 5) return false;            // computed ahead (bmprgp_resolve3, bmprgp_take_ahead_kernel)
       m->x = q.X[it & 1];
       m->b = q.b;
       m->y = q.ytmp;
       m->g = q.G[it & 1];
       return true;
     case ST_AP:
+      if (ahead & 2) return false;
       m->x = q.p;
       m->y = q.Ap;
       return true;
@@ -150,6 +165,7 @@ __device__ __forceinline__ bool bmprgp_mv_operands(const ccqp_pmprgp& q, int ini
       return true;
     case ST_ADXC:
     case ST_ADXH:
+      if (q.slab[MP_LOOK] != 0.0) return false;   // the three-vector launch of this round (bmprgp_resolve3)
       m->x = q.dx;
       m->y = q.Adx;
       return true;
@@ -235,6 +251,80 @@ struct bmprgp_resolve {
   }
 };
 
+// The three-vector launch of a look-ahead run (MP_LOOK): a problem in its A.dx round multiplies dx, p_{k+1} and -- after a
+// CG step -- x_{k+1} (+ b, into the gradient buffer the recurrence gradient is NOT in) in one pass over its matrix.
+struct bmprgp_resolve3 {
+  const ccqp_pmprgp* probs;
+  __device__ bool operator()(int p, gemv_lds3_desc* d) const {
+    const ccqp_pmprgp& q = probs[p];
+    const double* s = q.slab;
+    if (s[MP_DONE] != 0.0 || s[MP_LOOK] == 0.0) return false;
+    const int st = (int)s[MP_STATE];
+    if (st != ST_ADXC && st != ST_ADXH) return false;
+    const int it = (int)s[MP_IT];
+    d->A = q.A;
+    d->lda = q.lda;
+    d->b = q.b;
+    d->x[0] = q.dx;                           // :1129 / :1163
+    d->y[0] = q.Adx;
+    d->g[0] = nullptr;
+    d->x[1] = q.p;                            // :1100 of the next iteration (p_{k+1}: bmprgp_apply_body has formed it)
+    d->y[1] = q.Ap;
+    d->g[1] = nullptr;
+    if (st == ST_ADXC) {                      // :1086 of the next iteration
+      d->x[2] = q.X[(it + 1) & 1];
+      d->y[2] = q.ytmp;
+      d->g[2] = q.G[it & 1];
+    } else {                                  // (after an expansion step A.x_{k+1} + b is in place: :1152)
+      d->x[2] = q.dx;
+      d->y[2] = nullptr;
+      d->g[2] = nullptr;
+    }
+    return true;
+  }
+};
+
+// the start of a look-ahead run: A.g_0 (:1077) and A.p_0 (:1100 of the first iteration; p_0 depends on x_0 and g_0 only)
+struct bmprgp_resolve3_start {
+  const ccqp_pmprgp* probs;
+  __device__ bool operator()(int p, gemv_lds3_desc* d) const {
+    const ccqp_pmprgp& q = probs[p];
+    if (q.slab[MP_DONE] != 0.0) return false;
+    d->A = q.A;
+    d->lda = q.lda;
+    d->b = q.b;
+    d->x[0] = q.G[0];
+    d->y[0] = q.Adx;
+    d->x[1] = q.p;
+    d->y[1] = q.Ap;
+    d->x[2] = q.G[0];
+    d->y[2] = nullptr;
+    d->g[0] = d->g[1] = d->g[2] = nullptr;
+    return true;
+  }
+};
+
+// the M1 round of a problem whose A.x_k + b was computed ahead into the other gradient buffer: take it
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_take_ahead_kernel(const ccqp_pmprgp* __restrict__ probs, int64_t n) {
+  const ccqp_pmprgp& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[MP_DONE] != 0.0 || (int)s[MP_STATE] != ST_M1 || !((int)s[MP_AHEAD] & 1)) return;
+  const int it = (int)s[MP_IT];
+  const double* __restrict__ from = q.G[(it + 1) & 1];
+  double* __restrict__ to = q.G[it & 1];
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) to[i] = from[i];
+}
+
+// whether a run looks ahead: the persistent matvec is its default form (CCQP_MPRGP_LOOKAHEAD=0 in the environment: off,
+// the A/B switch of the tools)
+static bool bmprgp_looks_ahead(int count, int64_t n, int flags) {
+  static const bool off = [] {
+    const char* e = getenv("CCQP_MPRGP_LOOKAHEAD");
+    return e && e[0] == '0';
+  }();
+  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
+}
+
 template <int R, int S>
 static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int wpb,
                                    int bpc, hipStream_t s) {
@@ -244,9 +334,17 @@ static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, 
 }
 
 static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
-                                 hipStream_t s) {
+                                 hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n)) return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
+  if (bp_pers_default(t, flags, count, n)) {
+    if (init == 0 && elementwise && bmprgp_looks_ahead(count, n, flags)) {   // (the segmented form does not look ahead)
+      hipLaunchKernelGGL(bmprgp_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
+      const bmprgp_resolve3 rsv3 = {dev_probs};
+      const int rc3 = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+      if (rc3) return rc3;
+    }
+    return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
+  }
   if (((flags >> 1) & 3) == 3 && t.aligned && n % 2 == 0 && n >= 128) {
     const int code = (flags >> 4) & 7;
     if (code >= 4) {   // persistent: 4 = R 4, S 4, 2 waves; 5 = 4 waves; 6 = R 2, S 8, 4 waves; 7 = R 4, S 4, 2 waves, 2 wg/CU
@@ -270,11 +368,11 @@ static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, in
 // -- two half-batches on two streams then multiply one after the other while each one's decision stages and vector
 // update go by under the other's matvec)
 static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
-                              hipStream_t s) {
+                              hipStream_t s, bool elementwise = true) {
   hipStream_t ms = s;
   int rc = ccqp_mv_stream_enter(ctx, s, &ms);
   if (rc) return rc;
-  rc = bmprgp_launch_gemv_on(ctx, dev_probs, count, n, init, flags, ms);
+  rc = bmprgp_launch_gemv_on(ctx, dev_probs, count, n, init, flags, ms, elementwise);
   if (rc) return rc;
   return ccqp_mv_stream_leave(ctx, s, ms);
 }
@@ -282,7 +380,7 @@ static int bmprgp_launch_gemv(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int c
 // residual of the start (exit test :1070-1073)
 template <bool LOCKSTEP>
 __device__ __forceinline__ void bmprgp_init_res_body(const ccqp_pmprgp& q, double gd, int64_t chunk, int nblk, int bx,
-                                                     unsigned* batch, double* lds4, int* is_last_p) {
+                                                     unsigned* batch, double* lds4, int* is_last_p, double look = 0.0) {
   double v[1];
   v[0] = residual_body(bp_segk_of(q), q.X[0], q.G[0], q.c, gd, chunk, bx, lds4);
   if (!bp_meet(q.partials, q.counter, nblk, 1, v, lds4, is_last_p)) return;
@@ -295,6 +393,9 @@ __device__ __forceinline__ void bmprgp_init_res_body(const ccqp_pmprgp& q, doubl
     s[MP_IT] = 0.0;
     s[MP_STATE] = (double)ST_M1;
     s[MP_ACT] = (double)ACT_NONE;
+    s[MP_LOOK] = look;
+    // (the loop top's A.x_0 + b, :1086, is the start's :1065 again: in place; A.p_0 comes with the start's A.g_0)
+    s[MP_AHEAD] = look != 0.0 ? 6.0 : 0.0;
     if (sqrt(v[0]) >= q.tol) {               // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
       s[MP_DONE] = 0.0;
     } else {
@@ -306,10 +407,10 @@ __device__ __forceinline__ void bmprgp_init_res_body(const ccqp_pmprgp& q, doubl
 
 __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_res_kernel(const ccqp_pmprgp* __restrict__ probs, double gd,
                                                                      int64_t chunk, int nblk,
-                                                                     unsigned* __restrict__ batch) {
+                                                                     unsigned* __restrict__ batch, double look) {
   __shared__ double lds4[4];
   __shared__ int is_last;
-  bmprgp_init_res_body<true>(probs[blockIdx.y], gd, chunk, nblk, blockIdx.x, batch, lds4, &is_last);
+  bmprgp_init_res_body<true>(probs[blockIdx.y], gd, chunk, nblk, blockIdx.x, batch, lds4, &is_last, look);
 }
 
 // alpha_bb = g.g / g.Ag (:1077), then g_{k+1} = copy(g_k) and p = phi(x_k, g_k) (:1066, :1081)
@@ -368,6 +469,8 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, const mp_words& z,
   } else {
     s[MP_IT] = z.it + 1.0;
     s[MP_STATE] = (double)ST_M1;
+    // (what this round's three-vector launch computed ahead, bmprgp_resolve3)
+    if (z.look != 0.0) s[MP_AHEAD] = (int)z.state == ST_ADXC ? 3.0 : 6.0;
   }
 }
 
@@ -409,6 +512,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           s[MP_MV] = z.mv + 1.0;
           s[MP_EXEC] = z.exec + 1.0;
           s[MP_STATE] = (double)ST_M1_N;
+          s[MP_AHEAD] = (double)((int)z.ahead & 2);       // (A.x_k + b taken, whichever way it came)
         }
         return;
       }
@@ -428,6 +532,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           s[MP_MV] = z.mv + 1.0;
           s[MP_EXEC] = z.exec + 1.0;
           s[MP_STATE] = (double)ST_FEAS_NOW;
+          s[MP_AHEAD] = (double)((int)z.ahead & ~2);
         }
         return;
       }
@@ -705,11 +810,26 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   hipLaunchKernelGGL(bmprgp_init_x_kernel, vgrid, blk, 0, s, dev_probs);
   int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch);
-  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bmprgp_init_alpha_kernel, rgrid, blk, 0, s, dev_probs, n, chunk, nblk);
-  hipLaunchKernelGGL(bmprgp_init_p_kernel, vgrid, blk, 0, s, dev_probs);
+  const bool look = bmprgp_looks_ahead(count, n, flags);
+  hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch, look ? 1.0 : 0.0);
+  if (look) {
+    // p_0 first (it needs x_0 and g_0 only), then A.g_0 and A.p_0 in one pass over every matrix
+    hipLaunchKernelGGL(bmprgp_init_p_kernel, vgrid, blk, 0, s, dev_probs);
+    hipStream_t ms = s;
+    rc = ccqp_mv_stream_enter(ctx, s, &ms);
+    if (rc) return rc;
+    const bmprgp_resolve3_start rsv3 = {dev_probs};
+    rc = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, ms);
+    if (rc) return rc;
+    rc = ccqp_mv_stream_leave(ctx, s, ms);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmprgp_init_alpha_kernel, rgrid, blk, 0, s, dev_probs, n, chunk, nblk);
+  } else {
+    rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmprgp_init_alpha_kernel, rgrid, blk, 0, s, dev_probs, n, chunk, nblk);
+    hipLaunchKernelGGL(bmprgp_init_p_kernel, vgrid, blk, 0, s, dev_probs);
+  }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -1360,12 +1480,12 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   ccqp_lockstep_begin(ctx, dev_batch, s);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_X, gd);
-  int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
+  int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s, false);
   if (rc) return rc;
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch);
-  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s);
+  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s, false);
   if (rc) return rc;
   hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
@@ -1387,7 +1507,7 @@ extern "C" int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
   const dim3 gwk((unsigned)max_nwork, count, MPS_STEPS), gnk((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count, MPS_STEPS);
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s);
+  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s, false);
   if (rc) return rc;
   hipLaunchKernelGGL(mps_reduce_a_kernel, rgrid, blk, 0, s, dev_probs, n, eps10, chunk, nblk);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gnk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);

@@ -374,6 +374,14 @@ static inline int64_t gemv_lds_row_stride(int64_t lda, int64_t rows, int R) {
 static inline int64_t gemv_lds_tasks(int64_t rows, int R, int64_t rs) {
   return (rows + R * rs - 1) / (R * rs) * rs;
 }
+struct gemv_lds3_desc {            // operands of one matrix of the three-vector multi-matrix form (gemv_lds3_multi_body)
+  const double* A;
+  int64_t lda;
+  const double* x[3];              // (a matrix with fewer products repeats a vector and leaves y / g of it NULL)
+  const double* b;
+  double* y[3];
+  double* g[3];
+};
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int R>
 __device__ __forceinline__ int64_t gemv_lds_first_row(int64_t T, int64_t rs) {
@@ -687,6 +695,129 @@ __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int 
         const double v = res[j];
         d.y[row] = v;
         if (d.g) d.g[row] = v + d.b[row];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+// ---- up to THREE right-hand sides per matrix in one pass, over MANY matrices (gemv_lds_multi_body with the slot of
+// gemv_lds2_body widened to three x pieces): y_j = A x_j for j < 3 (g_j = y_j + b where g_j != NULL).  A matrix with fewer
+// products repeats a vector (its outputs NULL): the number of DMA loads per step is fixed (the waits are counted).
+// Each product has the bits of its own single pass.  (Lock-step MPRGP: A dx, A x_{k+1} and A p_{k+1} of a CG step.)
+template <int R, int S, bool NT>
+__device__ __forceinline__ void gemv_lds3_multi_body(const gemv_lds3_desc* D, int nlive, int64_t n, int64_t wave,
+                                                     int64_t nwaves, char* mine, double* res, int64_t rs) {
+  constexpr int PIECE = 1024;
+  constexpr int SLOT = (R + 3) * PIECE;
+  constexpr int GROUP = GEMV_LDS_RESCAP / (3 * R);
+  const int lane = threadIdx.x & 63;
+  const int64_t nfull = n / 128;
+  const int tail = (int)(n - nfull * 128);
+  const bool mine_in_tail = 2 * lane < tail;
+  const int64_t nsteps = nfull + (tail ? 1 : 0);
+  const int64_t tpp = (n + R * rs - 1) / (R * rs) * rs;       // tasks per matrix (gemv_lds_tasks)
+  const int64_t ntasks = (int64_t)nlive * tpp;
+  const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
+  for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
+    const int kn = (int)(mytasks - k0 < GROUP ? mytasks - k0 : GROUP);
+    const int64_t total = (int64_t)kn * nsteps;
+    int ik = 0, islot = 0;
+    int64_t is = 0, issued = 0;
+    const double* irp[R];
+    const double* ixp[3];
+    auto rows_of = [&](int k) {
+      const int64_t T = wave + (k0 + k) * nwaves;
+      const int64_t m = T / tpp, t = T - m * tpp;
+      const gemv_lds3_desc& d = D[m];
+      const int64_t r0 = gemv_lds_first_row<R>(t, rs);
+      const double* A = d.A;
+      const int64_t lda = d.lda;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r * rs;
+        if (row > n - 1) row = n - 1;           // clamp: tail rows re-read a valid row, never stored
+        irp[r] = A + row * lda + 2 * lane;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ixp[j] = d.x[j] + 2 * lane;
+    };
+    rows_of(0);
+    auto issue_next = [&]() {
+      char* slot = mine + islot * SLOT;
+      if (is < nfull || mine_in_tail) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
+                                           16, 0, NT ? 2 : 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __builtin_amdgcn_global_load_lds(ixp[j] + is * 128,
+                                           (__attribute__((address_space(3))) void*)(slot + (R + j) * PIECE), 16, 0, 0);
+      }
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++issued;
+      if (++is == nsteps) {
+        is = 0;
+        if (++ik < kn) rows_of(ik);
+      }
+    };
+    for (int p = 0; p < S - 1 && issued < total; ++p) issue_next();
+    int cslot = 0;
+    for (int kk = 0; kk < kn; ++kk) {
+      double acc[3][R];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[j][r] = 0.0;
+      for (int64_t s = 0; s < nsteps; ++s) {
+        if (issued < total) {
+          issue_next();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 3)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = mine + cslot * SLOT;
+        if (s < nfull || mine_in_tail) {
+          ccqp_d2 xv[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) xv[j] = *reinterpret_cast<const ccqp_d2*>(slot + (R + j) * PIECE + lane * 16);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              acc[j][r] = fma(av.x, xv[j].x, acc[j][r]);
+              acc[j][r] = fma(av.y, xv[j].y, acc[j][r]);
+            }
+          }
+        }
+        cslot = cslot + 1 == S ? 0 : cslot + 1;
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[j][r] = ccqp_wave_sum(acc[j][r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lane == r) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) res[(kk * R + r) * 3 + j] = acc[j][r];
+        }
+    }
+    for (int i = lane; i < kn * R; i += 64) {
+      const int kk = i / R, r = i - kk * R;
+      const int64_t T = wave + (k0 + kk) * nwaves;
+      const int64_t m = T / tpp, t = T - m * tpp;
+      const int64_t row = gemv_lds_first_row<R>(t, rs) + r * rs;
+      if (row < n) {
+        const gemv_lds3_desc& d = D[m];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double v = res[3 * i + j];
+          if (d.y[j]) d.y[j][row] = v;
+          if (d.g[j]) d.g[j][row] = v + d.b[row];
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -381,6 +381,72 @@ static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb
   return CCQP_OK;
 }
 
+// ---- the same persistent launch with up to THREE products per problem in one pass over its matrix (gemv_lds3_multi_body):
+// `Resolve3` fills a gemv_lds3_desc, false = the problem takes no part.  At most BMV3_PERS_MAX problems per launch
+// (96 B of LDS each), more in several launches.
+#define BMV3_PERS_MAX 256
+template <int R, int S, class Resolve3>
+__global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve3 rsv, int first, int count, int64_t n,
+                                                                   int64_t rs, float stagger_per_problem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  __shared__ int nlive_s;
+  constexpr int RING = S * (R + 3) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  gemv_lds3_desc* D = reinterpret_cast<gemv_lds3_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
+  if (w == 0) {
+    int base = 0;
+    for (int p0 = 0; p0 < count; p0 += 64) {
+      const int p = p0 + lane;
+      gemv_lds3_desc d;
+      bool live = false;
+      if (p < count) live = rsv(first + p, &d);
+      const unsigned long long mask = __ballot(live);
+      if (live) D[base + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+      base += __popcll(mask);
+    }
+    if (lane == 0) nlive_s = base;
+  }
+  __syncthreads();
+  const int nlive = nlive_s;
+  if (nlive == 0) return;
+  float su = stagger_per_problem * (float)nlive;
+  const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
+  for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+  gemv_lds3_multi_body<R, S, true>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
+#endif
+}
+
+template <int R, int S, class Resolve3>
+static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int wpb, hipStream_t s) {
+  const int chunk = count < BMV3_PERS_MAX ? count : BMV3_PERS_MAX;
+  const size_t lds = (size_t)wpb * ((size_t)S * (R + 3) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
+                     (size_t)chunk * sizeof(gemv_lds3_desc);
+  if (lds > 160 * 1024) {
+    ccqp_set_error("%s: ring does not fit", __func__);
+    return CCQP_ERR_UNSUPPORTED;
+  }
+  static size_t raised = 0;
+  if (lds > raised) {
+    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
+  }
+  static const bool stagger_off = [] {
+    const char* e = getenv("CCQP_BMV_STAGGER");
+    return e && e[0] == '0';
+  }();
+  const float stagger = stagger_off ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
+  for (int first = 0; first < count; first += BMV3_PERS_MAX)
+    hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3>), dim3((unsigned)bp_num_cu()), dim3(64 * wpb), lds, s, rsv, first,
+                       count - first < BMV3_PERS_MAX ? count - first : BMV3_PERS_MAX, n, gemv_lds_row_stride(n, n, R),
+                       stagger);
+  if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
+  return CCQP_OK;
+}
+
 #define BP_CHECK_BATCH()                                                                          \
   CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument"); \
   CCQP_REQUIRE(count >= 1 && count <= 65535 && n >= 1, "bad batch shape")

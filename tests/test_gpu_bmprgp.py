@@ -343,8 +343,10 @@ def test_rejects_scalar_bounds_and_tiny_problems():
 def test_default_batched_matvec_is_the_persistent_lds_form_and_changes_no_bit(n, count):
     """From n = 4096 and 1 GiB of matrices on, the batched matvec of lock-step MPRGP is ONE persistent LDS-DMA launch whose
     waves walk the live problems' matrices and read their 4 rows about 1 MiB apart (bmprgp_gemv_pers_kernel,
-    gemv_lds_row_stride); an explicit rows-x-steps field in the tuning word keeps the VALU form.  Same bits (the matvec's
-    bits are a function of (row, n) only), and those of each problem's own solve()."""
+    gemv_lds_row_stride) -- and the run LOOKS AHEAD: the A.dx launch of an iteration also computes A.x_{k+1} + b and
+    A.p_{k+1} (one pass over A with three right-hand sides instead of three passes per CG step; the start's A.x_0 + b
+    serves the first loop top).  An explicit rows-x-steps field in the tuning word keeps the VALU form, one matvec per
+    launch.  Same bits, same reported and executed MV counts, and those of each problem's own solve()."""
     from ccqppy_amd._engine import get_engine
     probs = _problems(n, count, 6100 + n)
     tols = [1e-6] * count
@@ -361,7 +363,7 @@ def test_default_batched_matvec_is_the_persistent_lds_form_and_changes_no_bit(n,
 
     lds, launches_lds = timed()
     valu, launches_valu = timed(tune=3 << 4)
-    assert launches_lds == launches_valu > 5
+    assert launches_lds > 5 and launches_valu > 5
     for a, c in zip(valu, lds):
         assert c.solution_converged
         _same(a, c)

@@ -26,7 +26,7 @@ for c in $WHICH; do
   done
   cd "$ROOT"
   if [ "$c" = "5" ]; then
-    export PROF_FULL_ONLY=1 PROF_KERNEL_FILTER="bp_gemv_pers" PROF_SOURCES="ccqppy_amd/csrc/ccqp_bmprgp.hip,ccqppy_amd/csrc/ccqp_lockstep.h,ccqppy_amd/csrc/ccqp_bodies.h,ccqppy_amd/csrc/ccqp_internal.h"
+    export PROF_FULL_ONLY=1 PROF_KERNEL_FILTER="bp_gemv" PROF_SOURCES="ccqppy_amd/csrc/ccqp_bmprgp.hip,ccqppy_amd/csrc/ccqp_lockstep.h,ccqppy_amd/csrc/ccqp_bodies.h,ccqppy_amd/csrc/ccqp_internal.h"
   else
     unset PROF_FULL_ONLY; export PROF_KERNEL_FILTER="gemv_" PROF_SOURCES=""
   fi
