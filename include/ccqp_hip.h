@@ -535,6 +535,12 @@ int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, cons
 int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, const struct ccqp_psegs* dev_segs, int count,
                                int64_t n, int64_t round, int64_t max_nwork, int64_t max_nnorm, double gd, double eps10,
                                int flags, uint32_t* dev_batch, void* stream);
+/* (ccqp_bmprgp_*: a run whose batched matvec is the persistent form -- ccqp_bpipe_matvec_form, default tuning word --
+ * LOOKS AHEAD: the A.dx launch of an iteration (solvers.py:1129 / :1163) also computes A.p_{k+1} (:1100 of the next
+ * iteration) and, after a CG step, A.x_{k+1} + b (:1086), three right-hand sides in one pass over each matrix; the
+ * start's A.x_0 + b (:1065) serves the first :1086 and A.g_0 (:1077) carries A.p_0.  Slab words 53 / 54 hold what is
+ * computed ahead.  Every product has the bits of its own pass and the two counters advance where the reference computes
+ * the product, so results and counts are unchanged; CCQP_MPRGP_LOOKAHEAD=0 in the environment turns it off.) */
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,
