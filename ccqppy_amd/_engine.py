@@ -166,6 +166,33 @@ class Engine:
             self.gemv_events.append(ev)
         self.mv_executed += 2
 
+    def gemv3(self, A, xs, ys, b=None, gs=(None, None, None), variant=None):
+        """ys[j] = A.xs[j] (gs[j] = ys[j] + b where given) for the j with ys[j] not None -- up to three products of a
+        SQUARE matrix in ONE pass over it where the LDS-staged form applies (ccqp_gemv3_f64), each with the bits of its
+        own gemv().  Counts one executed matvec per product; one (start, end) event pair when profiling is on."""
+        n = A.shape[0]
+        assert A.shape[1] == n and A.stride(1) == 1
+        arr = ctypes.c_void_p * 3
+        px = arr(*[None if x is None else x.data_ptr() for x in xs])
+        py = arr(*[None if y is None else y.data_ptr() for y in ys])
+        pg = arr(*[None if g is None else g.data_ptr() for g in gs])
+        ev = None
+        if self.gemv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.torch_stream)
+        _lib.check(self.lib.ccqp_gemv3_f64(self.ctx, A.data_ptr(), A.stride(0), px, 0 if b is None else b.data_ptr(), py, pg,
+                                          n, self.gemv_variant if variant is None else variant, self.stream))
+        if ev is not None:
+            ev[1].record(self.torch_stream)
+            self.gemv_events.append(ev)
+        self.mv_executed += sum(y is not None for y in ys)
+
+    def gemv3_form(self, n, variant=None):
+        """"bp_gemv3_pers_kernel" (one pass for up to three products of an n x n matrix) or "single matvecs"."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self.lib.ccqp_gemv3_form(self.ctx, n, self.gemv_variant if variant is None else variant, buf, 64))
+        return buf.value.decode()
+
     def gemv2_form(self, rows, cols, variant=None):
         """"gemv_lds2_kernel" (one pass for two products) or "two single matvecs"."""
         buf = ctypes.create_string_buffer(64)

@@ -130,6 +130,8 @@ SIGNATURES = {
     "ccqp_gemv_form": [_P, _I64, _I64, _I, _c.c_char_p, _I],
     "ccqp_gemv2_f64": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P],
     "ccqp_gemv2_form": [_P, _I64, _I64, _I, _c.c_char_p, _I],
+    "ccqp_gemv3_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I, _P],
+    "ccqp_gemv3_form": [_P, _I64, _I, _c.c_char_p, _I],
     "ccqp_mv_timing_begin": [_I],
     "ccqp_mv_timing_end": [_c.POINTER(_c.c_double), _I, _c.POINTER(_I)],
     "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],

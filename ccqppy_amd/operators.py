@@ -56,6 +56,15 @@ class DenseOperator:
         (Engine.gemv2), each product with the bits of its own matvec()."""
         (engine or self.engine).gemv2(self.A, x1, x2, y1, y2, b, g1, g2)
 
+    def matvec3(self, xs, ys, gs, b=None, engine=None):
+        """ys[j] = A.xs[j] (gs[j] = ys[j] + b where given) for the j with ys[j] not None: up to three products in ONE pass
+        over a square A where the LDS-staged form applies (Engine.gemv3), each with the bits of its own matvec()."""
+        (engine or self.engine).gemv3(self.A, xs, ys, b, gs)
+
+    def triple_in_one_pass(self, engine=None):
+        eng = engine or self.engine
+        return self.rows == self.n and hasattr(eng, "gemv3_form") and eng.gemv3_form(self.n) == "bp_gemv3_pers_kernel"
+
     def pair_in_one_pass(self, engine=None):
         """True if matvec2 reads the matrix once (what makes speculating on the second product worth it)."""
         eng = engine or self.engine                     # (a recording engine of the fused batch scheduler has no pair form)

@@ -85,6 +85,14 @@ class _Run:
         self.op.matvec2(v1, y1, g1, v2, y2, g2, self.b, self.eng)
         return (y1, g1), (y2, g2)
 
+    def mv3(self, vs, with_g):
+        """[(A.v, A.v + b | None) | None for v in vs] from ONE call of the operator's matvec3 (None entries of vs: no
+        product): one pass over a square dense A."""
+        ys = [None if v is None else self.new() for v in vs]
+        gs = [self.new() if (v is not None and wg) else None for v, wg in zip(vs, with_g)]
+        self.op.matvec3(list(vs), ys, gs, self.b, self.eng)
+        return [None if y is None else (y, g) for y, g in zip(ys, gs)]
+
     def lin(self, a, x, b, y):
         out = self.new()
         self.eng.axpby(a, x, b, y, out)
@@ -814,8 +822,16 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     """MPRGP with BB proportioning/expansion steps (solvers.py:1002-1224); README's "MPRGP-BB"."""
     _label = "MPRGP"
 
-    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=False):
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=False, look_ahead=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
+        # SAME results bit for bit, same reported and executed MV counts: at the A.dx matvec of an iteration (:1129 after
+        # a CG step, :1163 after an expansion step) x_{k+1} and p_{k+1} are known, so A.x_{k+1} + b (:1086 of the next
+        # iteration) and A.p_{k+1} (:1100) are computed by the SAME call (operator.matvec3 -> ccqp_gemv3_f64: one pass over
+        # A, each product with the bits of its own matvec); after an expansion step A.x_{k+1} + b is the :1152 product
+        # again, and the start's :1065 is the first :1086.  A CG step then costs one pass over A instead of three, an
+        # expansion step two instead of four.  None (default): wherever the operator reads its matrix once for the three
+        # (square dense, LDS-staged form: >= 8 GiB); True / False force it.
+        self.look_ahead = look_ahead
         # Extension, OFF by default, SAME results bit for bit (dense operator, elementwise set with array bounds):
         # every branch decision on the device, rounds queued ahead (ccqp_bmprgp_*, the lock-step batch scheduler with a
         # batch of one); a solve that would reach the matvec budget falls back to the loop below
@@ -870,6 +886,14 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 and run.n > ss._lib.SMALL_SEG_MAX:
             self._seg = P._seg(eng, 0, run.n)
         seg = self._seg
+        from ._record import RecordingEngine
+        look = self.look_ahead
+        if look is None:
+            look = hasattr(run.op, "triple_in_one_pass") and run.op.triple_in_one_pass(eng)
+        look = bool(look) and hasattr(run.op, "matvec3") and getattr(run.op, "rows", None) == run.n \
+            and not isinstance(eng, RecordingEngine)
+        g_ahead = None                                  # A.x_k + b of the NEXT loop top, computed ahead (or in place)
+        Ap_ahead = None                                 # A.p of the next :1100
         mv_count = 0
         xk = run.project(run.x0)                        # :1063
         xkp1 = run.copy(xk)
@@ -878,13 +902,25 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         mv_count += 1
         res = yield from run.residual_now(xk, gk)
         if res >= tol:
-            Agk = run.mv(gk)
+            if look:
+                p = self._free_mask_mul(run, xk, gk)    # (p_0 needs x_0 and g_0 only: A.g_0 and A.p_0 in one pass)
+                (Agk, _), Ap_ahead, _ = run.mv3([gk, p, None], [False, False, False])
+                eng.mv_executed -= 1                    # (A.p_0 counts where the reference computes it)
+                g_ahead = (None, gk)                    # the first :1086 is the :1065 product again
+            else:
+                Agk = run.mv(gk)
             s = yield from run.dots_now([(gk, gk), (gk, Agk)])
             alpha_bb = s[0] / s[1]
             mv_count += 1
-            p = self._free_mask_mul(run, xk, gk)
+            if not look:
+                p = self._free_mask_mul(run, xk, gk)
             while True:
-                _, gnew = run.mv(xk, True)
+                if g_ahead is not None:
+                    gnew = g_ahead[1]
+                    g_ahead = None
+                    eng.mv_executed += 1
+                else:
+                    _, gnew = run.mv(xk, True)
                 mv_count += 1
                 if mv_count >= max_mv:
                     break
@@ -909,7 +945,12 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                     bb, pp = yield from run.dots_now([(beta_x, beta_x), (psi, psi)])
                 self._nhalve = 0
                 if bb < pp:
-                    Ap = run.mv(p)
+                    if Ap_ahead is not None:
+                        Ap = Ap_ahead[0]
+                        Ap_ahead = None
+                        eng.mv_executed += 1
+                    else:
+                        Ap = run.mv(p)
                     mv_count += 1
                     if mv_count >= max_mv:
                         break
@@ -922,11 +963,15 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                         xkp1 = y                                         # np.copy(y): nothing writes in place
                         gkp1 = run.lin(1.0, gk, -alpha_cg, Ap)
                         dx = run.lin(1.0, xkp1, -1.0, xk)
-                        Adx = run.mv(dx)                                 # executed, not counted (:1129)
-                        eng.dots([(dx, dx), (dx, Adx)], 0)               # alpha_bb: read in the tail
                         psi_y = self._free_mask_mul(run, y, gkp1)
                         pn = run.new()
                         eng.cg_direction(psi_y, Ap, pAp, p, pn)          # psi_y - (psi_y*Ap/pAp)*p, :1134-1135
+                        if look:                                         # A.dx, A.p_{k+1}, A.x_{k+1} + b: one pass
+                            (Adx, _), Ap_ahead, g_ahead = run.mv3([dx, pn, xkp1], [False, False, True])
+                            eng.mv_executed -= 2
+                        else:
+                            Adx = run.mv(dx)                             # executed, not counted (:1129)
+                        eng.dots([(dx, dx), (dx, Adx)], 0)               # alpha_bb: read in the tail
                         p = pn
                     else:
                         xh = run.lin(1.0, xk, -alpha_f, p)
@@ -942,10 +987,16 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                             break
                         p = self._free_mask_mul(run, xkp1, gkp1)
                         dx = run.lin(1.0, xkp1, -1.0, xk)
-                        Adx = run.mv(dx)                                 # executed, not counted (:1163)
+                        if look:                                         # A.dx and A.p_{k+1}: one pass; the next :1086
+                            (Adx, _), Ap_ahead, _ = run.mv3([dx, p, None], [False, False, False])   # is :1152 again
+                            eng.mv_executed -= 1
+                            g_ahead = (None, gkp1)
+                        else:
+                            Adx = run.mv(dx)                             # executed, not counted (:1163)
                         eng.dots([(dx, dx), (dx, Adx)], 0)
                 else:
                     branch = "prop"
+                    Ap_ahead = None                                      # (p is re-formed below: nothing to take over)
                     xkp1 = run.step_project(xk, alpha_bb, gk)
                     dx = run.lin(1.0, xkp1, -1.0, xk)
                     Adx = run.mv(dx)                                     # executed, not counted (:1172)

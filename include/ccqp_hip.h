@@ -94,6 +94,15 @@ int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char*
 int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x1, const double* x2, const double* b,
                    double* y1, double* g1, double* y2, double* g2, int64_t rows, int64_t cols, int variant, void* stream);
 int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen);
+/* Up to THREE matvecs with one SQUARE matrix in ONE pass over it: y[j] = A x[j] (g[j] = y[j] + b where g[j] != NULL) for
+ * every j < 3 with y[j] != NULL.  Replaces the A.dot(dx), A.dot(xk) and A.dot(p) that follow each other across the end
+ * of an MPRGP iteration (solvers.py:1129 | :1163, then :1086 and :1100 of the next iteration: at the A.dx call x_{k+1}
+ * and p_{k+1} are known).  Each product has the bits of its own ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 call; one pass
+ * wherever the single matvec would take the LDS-staged form (ccqp_gemv3_form: "bp_gemv3_pers_kernel"), otherwise
+ * single matvecs.  Outputs must not alias inputs. */
+int ccqp_gemv3_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* const* x, const double* b,
+                   double* const* y, double* const* g, int64_t n, int variant, void* stream);
+int ccqp_gemv3_form(ccqp_ctx* ctx, int64_t n, int variant, char* name, int buflen);
 /* Measurement hook (kernel-level roofline figures measured live, not only under a profiler): between
  * begin and end every BATCHED matvec launch of the lock-step drivers (ccqp_bpipe_*, ccqp_bapgd_*, ccqp_bmprgp_*,
  * ccqp_bsegs_*, ccqp_bspg_*) is bracketed by a pair of HIP events on its own stream, up to `max_pairs` of them (later

@@ -411,6 +411,27 @@ int main(void) {
     hipMemcpy(h2, g2, n * sizeof(double), hipMemcpyDeviceToHost);
     if (memcmp(h1, h2, n * sizeof(double))) bad++;
     printf("two-vector matvec: A.x and A.b + b in one pass, bits of the single matvecs: %s\n", bad ? "NO" : "yes");
+    /* three products of the square matrix in one pass (ccqp_gemv3_f64): slot 1 unused */
+    {
+      const double* xs[3] = {x, NULL, b};
+      double* ys[3] = {y1, NULL, y2};
+      double* gs[3] = {NULL, NULL, g2};
+      hipMemset(y1, 0xff, n * sizeof(double));
+      hipMemset(g2, 0xff, n * sizeof(double));
+      CHECK(ccqp_gemv3_f64(ctx, A, n, xs, b, ys, gs, n, 0x51001800, NULL));
+      CHECK(ccqp_gemv3_form(ctx, n, 0x51001800, form, 64));
+      if (strcmp(form, "bp_gemv3_pers_kernel")) bad++;
+      CHECK(ccqp_gemv3_form(ctx, n, 0, form, 64));
+      if (strcmp(form, "single matvecs")) bad++;
+      hipDeviceSynchronize();
+      hipMemcpy(h1, r1, n * sizeof(double), hipMemcpyDeviceToHost);
+      hipMemcpy(h2, y1, n * sizeof(double), hipMemcpyDeviceToHost);
+      if (memcmp(h1, h2, n * sizeof(double))) bad++;
+      hipMemcpy(h1, r2, n * sizeof(double), hipMemcpyDeviceToHost);
+      hipMemcpy(h2, g2, n * sizeof(double), hipMemcpyDeviceToHost);
+      if (memcmp(h1, h2, n * sizeof(double))) bad++;
+      printf("three-vector matvec: bits of the single matvecs: %s\n", bad ? "NO" : "yes");
+    }
     free(h1); free(h2);
     hipFree(y1); hipFree(y2); hipFree(g2); hipFree(r1); hipFree(r2);
   }

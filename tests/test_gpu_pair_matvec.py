@@ -132,3 +132,74 @@ def test_paired_matvecs_when_the_line_search_rejects_steps():
     assert sum(t["nback"] for t in out[0].trace) >= 2, "the case is meant to backtrack"
     assert [t["nback"] for t in out[0].trace] == [t["nback"] for t in out[1].trace]
     _same(out[0], out[1])
+
+
+# ------------------------------------------------------------------ three products in one pass (ccqp_gemv3_f64)
+@pytest.mark.parametrize("n", [128, 130, 1000, 1502, 4096])
+@pytest.mark.parametrize("mask", [(1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 0)])
+def test_triple_product_has_the_bits_of_single_products(n, mask):
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    torch.manual_seed(n)
+    A = torch.randn(n, n, dtype=torch.float64, device="cuda")
+    xs = [torch.randn(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    b = torch.randn(n, dtype=torch.float64, device="cuda")
+    want_g = (False, False, True)
+    ref = []
+    for j in range(3):
+        y, g = torch.empty_like(b), torch.empty_like(b)
+        eng.gemv(A, xs[j], y, b if want_g[j] else None, g if want_g[j] else None, variant=0xF)
+        ref.append((y, g))
+    for variant in (LDS, 0):
+        assert eng.gemv3_form(n, variant) == ("single matvecs" if variant == 0 else "bp_gemv3_pers_kernel")
+        ys = [torch.full_like(b, float("nan")) if mask[j] else None for j in range(3)]
+        gs = [torch.full_like(b, float("nan")) if (mask[j] and want_g[j]) else None for j in range(3)]
+        mv0 = eng.mv_executed
+        eng.gemv3(A, [xs[j] if mask[j] else None for j in range(3)], ys, b, gs, variant=variant)
+        assert eng.mv_executed == mv0 + sum(mask)
+        for j in range(3):
+            if mask[j]:
+                assert torch.equal(_bits(ys[j]), _bits(ref[j][0]))
+                if gs[j] is not None:
+                    assert torch.equal(_bits(gs[j]), _bits(ref[j][1]))
+
+
+def _solve_mprgp(n, seed, look, tol=1e-6, max_mv=300, width=0.5, variant=LDS):
+    from ccqppy_amd import problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    op, b, _ = problems.random_problem(n, seed)
+    old = eng.gemv_variant
+    eng.gemv_variant = variant
+    try:
+        s = solvers.CCQPSolverMPRGP(tol, max_mv, look_ahead=look)
+        s.trace = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.solve(op, b, convex_proj_op=ss.BoxProjOp(n, -width * np.ones(n), width * np.ones(n)))
+        return s
+    finally:
+        eng.gemv_variant = old
+
+
+@pytest.mark.parametrize("n,width", [(256, 0.5), (1000, 0.5), (2050, 0.3), (4096, 0.5), (1500, 5.0)])
+def test_mprgp_with_look_ahead_equals_mprgp(n, width):
+    """CG steps (wide box: few active bounds) and expansion steps (narrow box) both occur over these cases."""
+    branches = set()
+    for seed in (21, 22):
+        one = _solve_mprgp(n, seed, False, width=width)
+        two = _solve_mprgp(n, seed, True, width=width)
+        auto = _solve_mprgp(n, seed, None, width=width)
+        assert one.solution_converged
+        _same(one, two)
+        _same(one, auto)
+        assert [t["branch"] for t in one.trace] == [t["branch"] for t in two.trace]
+        branches |= {t["branch"] for t in one.trace}
+    assert branches & {"cg", "expand"}
+
+
+@pytest.mark.parametrize("max_mv", [2, 3, 4, 5, 6, 7, 8, 9, 11, 14])
+def test_look_ahead_keeps_the_budget_semantics(max_mv):
+    for width in (0.5, 5.0):
+        one = _solve_mprgp(900, 3, False, max_mv=max_mv, width=width)
+        two = _solve_mprgp(900, 3, True, max_mv=max_mv, width=width)
+        _same(one, two)

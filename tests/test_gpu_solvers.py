@@ -133,6 +133,37 @@ def test_apgd_golden_with_paired_matvecs(case, forced_lds):
     assert np.linalg.norm((s.solution - want)[~nan]) <= RTOL * max(np.linalg.norm(want[~nan]), 1e-300) + 1e-14
 
 
+_LOOK_CASES = [c for c in SOLV if c["solver"] == "MPRGP" and c["err"] is None and not c["kwargs"]
+               and c["mv_band"][0] == c["mv_band"][1] and not c["problem"].startswith("suite") and c["problem"] != "readme"]
+
+
+@pytest.mark.parametrize("forced_lds", [False, True])
+@pytest.mark.parametrize("case", _LOOK_CASES, ids=[c["id"] for c in _LOOK_CASES])
+def test_mprgp_golden_with_look_ahead(case, forced_lds):
+    """CCQPSolverMPRGP(look_ahead=True): the A.dx matvec of an iteration also computes A.x_{k+1} + b and A.p_{k+1} (one
+    three-vector call, ccqp_gemv3_f64: one pass over A where the LDS-staged form runs -- forced here for the small golden
+    matrices -- else single launches).  The reference's MV counts, executed counts, x and per-iteration scalars."""
+    from ccqppy_amd._engine import get_engine
+    A = _device_matrix(case["problem"])
+    b = SOLV_ARR[case["problem"] + ".b"]
+    n = b.shape[0]
+    x0 = C.case_x0(case, n)
+    eng = get_engine(0)
+    old = eng.gemv_variant
+    eng.gemv_variant = 0x51001800 if forced_lds else 0
+    try:
+        case2 = dict(case, kwargs=dict(look_ahead=True))
+        s, out = _solve(case2, A, b, x0)
+    finally:
+        eng.gemv_variant = old
+    assert s.solution_num_matrix_vector_multiplications == case["mv"]
+    assert s.executed_matrix_vector_multiplications == case["executed_mv"]
+    H.check_trace(case, s, SOLV_ARR, n)
+    want = SOLV_ARR[case["id"] + ".x"]
+    assert bool(s.solution_converged) == case["converged"]
+    assert np.linalg.norm(s.solution - want) <= RTOL * max(np.linalg.norm(want), 1e-300) + 1e-14
+
+
 _LOCKSTEP_CASES = [c for c in SOLV if c["err"] is None and not c["problem"].startswith("suite")
                    and c["problem"] != "readme" and c["mv_band"][0] == c["mv_band"][1]]
 
