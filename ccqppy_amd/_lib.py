@@ -74,7 +74,8 @@ class PApgd(ctypes.Structure):
                 ("X", ctypes.c_void_p * 2), ("Y", ctypes.c_void_p * 2), ("gk", ctypes.c_void_p),
                 ("g1", ctypes.c_void_p), ("Ayk", ctypes.c_void_p), ("Ax1", ctypes.c_void_p),
                 ("xhat", ctypes.c_void_p), ("seg", Seg), ("slab", ctypes.c_void_p), ("partials", ctypes.c_void_p),
-                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double)]
+                ("counter", ctypes.c_void_p), ("c", ctypes.c_double), ("tol", ctypes.c_double),
+                ("ga", ctypes.c_void_p), ("Aya", ctypes.c_void_p)]
 
 
 class PMprgp(ctypes.Structure):

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd
 
 // L = |A d| / |d|, t = 1 / L (solvers.py:264-268) and the initial state
 __device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n, int64_t chunk, int nblk, int bx,
-                                                  double* lds4, int* is_last_p) {
+                                                  double* lds4, int* is_last_p, double look = 0.0) {
   double v[2];
   v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, bx, lds4);
   v[1] = dot_body(q.X[1], q.X[1], n, chunk, bx, lds4);
@@ -427,14 +427,18 @@ __device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n
     s[AP_RESMIN] = INFINITY;
     s[AP_COPYHAT] = 0.0;
     s[AP_SOLHAT] = 1.0;
+    const double looks = (look != 0.0 && q.ga != nullptr && q.Aya != nullptr) ? 1.0 : 0.0;   // (opt-in: the two buffers)
+    s[AP_LOOK] = looks;
+    s[AP_AHEAD] = looks;                       // (a look-ahead run's start multiplies y_0 beside x_0 - 1: bapgd_resolve3_start)
+    s[AP_BETAS] = 0.0;
   }
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
-                                                                  int64_t chunk, int nblk) {
+                                                                  int64_t chunk, int nblk, double look = 0.0) {
   __shared__ double lds4[4];
   __shared__ int is_last;
-  bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last);
+  bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last, look);
 }
 
 // LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call, converged counter); otherwise the problem
@@ -458,6 +462,19 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
       s[AP_ACT] = 1.0;
       s[AP_FIRST] = 1.0;
       s[AP_MV] = z.mv + 1.0;
+      if (z.look != 0.0) {
+        // look-ahead: beta of :313 is a function of theta_k alone -- the apply launch forms y_{k+1} beside the trial
+        // point, the next matvec launch multiplies both.  (The expressions of the accepting branch below, so the bits.)
+        const double thk = z.thk;
+        const double tt = thk * thk;
+        const double root = sqrt(4.0 + tt);
+        const double m1 = (-thk) * thk;
+        const double m2 = thk * root;
+        const double thk1 = 0.5 * (m1 + m2);
+        const double num = thk * (1.0 - thk);
+        s[AP_BETAS] = num / (tt + thk1);
+        s[AP_AHEAD] = 0.0;                                 // (A.y_k + b computed ahead has been taken: bapgd_take_ahead_kernel)
+      }
       if (LOCKSTEP) bp_report(batch, host, count, seq);
     }
     return;
@@ -578,6 +595,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
         s[AP_PHASE] = 0.0;
         s[AP_ACT] = restart ? 3.0 : 2.0;
         s[AP_COPYHAT] = improved ? 1.0 : 0.0;
+        if (z.look != 0.0) s[AP_AHEAD] = 1.0;            // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3)
       }
     } else {
       L = L * 2.0;
@@ -620,6 +638,12 @@ __device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, in
     if (n_segs > 0) return;
     const double mt = -s[AP_T];
     proj_elem_body(bp_segk_of(q), 1.0, q.Y[it & 1], mt, q.gk, q.X[(it + 1) & 1], bx, nbx);
+    if (s[AP_LOOK] != 0.0) {
+      // y_{k+1} = (1 + beta) x_{k+1} - beta x_k (:316) of the trial point just formed, into the OTHER y buffer (y_{k-1},
+      // dead): every thread reads back the elements it wrote itself (the same element partition in both bodies)
+      const double beta = s[AP_BETAS];
+      axpby_body(1.0 + beta, q.X[(it + 1) & 1], -beta, q.X[it & 1], q.Y[(it + 1) & 1], n, bx, nbx);
+    }
   } else {
     if (s[AP_ACT] == 3.0) {                   // anti-relaxation restart: y_{k+1} = copy(x_{k+1})
       copy_body(q.X[it & 1], q.Y[it & 1], n, bx, nbx);
@@ -638,7 +662,6 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papg
 }
 
 // the three launches of an APGD round, for the segmented form's driver (ccqp_bsegs.hip)
-void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s);
 void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
                               double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s) {
   int64_t chunk;
@@ -661,6 +684,7 @@ struct bapgd_resolve {
     d->A = q.A;
     d->lda = q.lda;
     if (init) {
+      if (init == 2 && q.ga != nullptr && q.Aya != nullptr) return false;   // (multiplied by bapgd_resolve3_start)
       d->x = q.X[1];
       d->b = nullptr;
       d->y = q.Ax1;
@@ -670,6 +694,7 @@ struct bapgd_resolve {
     if (q.slab[AP_DONE] != 0.0) return false;
     const int it = (int)q.slab[AP_IT];
     const bool trial = q.slab[AP_PHASE] == 0.0;
+    if (q.slab[AP_LOOK] != 0.0 && (!trial || q.slab[AP_AHEAD] != 0.0)) return false;   // (bapgd_resolve3 / taken over)
     d->x = trial ? q.Y[it & 1] : q.X[(it + 1) & 1];
     d->b = q.b;
     d->y = trial ? q.Ayk : q.Ax1;
@@ -678,9 +703,83 @@ struct bapgd_resolve {
   }
 };
 
-void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s) {
+// Look-ahead (plain APGD, elementwise sets, the persistent matvec): the launch that multiplies the trial point x_{k+1} (:290)
+// also multiplies y_{k+1} (:275 of the next iteration), which bapgd_apply_body has formed beside it -- one pass over each
+// matrix for both.  If the line search rejects the trial point the product is dropped and the retry pairs again.
+struct bapgd_resolve3 {
+  const ccqp_papgd* probs;
+  __device__ bool operator()(int p, gemv_lds3_desc* d) const {
+    const ccqp_papgd& q = probs[p];
+    const double* s = q.slab;
+    if (s[AP_DONE] != 0.0 || s[AP_LOOK] == 0.0 || s[AP_PHASE] == 0.0) return false;
+    const int it = (int)s[AP_IT];
+    d->A = q.A;
+    d->lda = q.lda;
+    d->b = q.b;
+    d->x[0] = q.X[(it + 1) & 1];
+    d->y[0] = q.Ax1;
+    d->g[0] = q.g1;
+    d->x[1] = q.Y[(it + 1) & 1];
+    d->y[1] = q.Aya;
+    d->g[1] = q.ga;
+    d->x[2] = q.X[(it + 1) & 1];
+    d->y[2] = nullptr;
+    d->g[2] = nullptr;
+    return true;
+  }
+};
+
+// the start of a look-ahead run: A.(x_0 - 1) (:264) and A.y_0 + b (:275 of the first iteration; y_0 = x_0) in one pass
+struct bapgd_resolve3_start {
+  const ccqp_papgd* probs;
+  __device__ bool operator()(int p, gemv_lds3_desc* d) const {
+    const ccqp_papgd& q = probs[p];
+    d->A = q.A;
+    d->lda = q.lda;
+    d->b = q.b;
+    d->x[0] = q.X[1];
+    d->y[0] = q.Ax1;
+    d->g[0] = nullptr;
+    d->x[1] = q.Y[0];
+    d->y[1] = q.Aya;
+    d->g[1] = q.ga;
+    d->x[2] = q.X[1];
+    d->y[2] = nullptr;
+    d->g[2] = nullptr;
+    return q.ga != nullptr && q.Aya != nullptr;
+  }
+};
+
+// the phase-0 round of a problem whose A.y_k + b was computed ahead: take it
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_take_ahead_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[AP_DONE] != 0.0 || s[AP_PHASE] != 0.0 || s[AP_AHEAD] == 0.0) return;
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    q.gk[i] = q.ga[i];
+    q.Ayk[i] = q.Aya[i];
+  }
+}
+
+// (CCQP_APGD_LOOKAHEAD=0 in the environment: off -- the A/B switch of the tools; flags bit 3: the anti-relaxation variant,
+// whose restart decides y_{k+1}, does not look ahead)
+static bool bapgd_looks_ahead(int count, int64_t n, int flags) {
+  static const bool off = [] {
+    const char* e = getenv("CCQP_APGD_LOOKAHEAD");
+    return e && e[0] == '0';
+  }();
+  return !off && !(flags & BP_FLAG_CONST_STEP) && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
+}
+
+void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,
+                            bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   if (bp_pers_default(t, flags, count, n)) {
+    if (init == 0 && elementwise && bapgd_looks_ahead(count, n, flags)) {
+      hipLaunchKernelGGL(bapgd_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
+      const bapgd_resolve3 rsv3 = {probs};
+      (void)bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+    }
     const bapgd_resolve rsv = {probs, init};
     if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
   }
@@ -697,8 +796,19 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
-  ccqp_bapgd_launch_gemv(dev_probs, count, n, 1, flags, s);
-  hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
+  if (bapgd_looks_ahead(count, n, flags)) {
+    // (problems without the two buffers -- the segmented form, the anti-relaxation variant -- take no part here and
+    // are multiplied by the single launch below; with them the three-vector launch finds nothing to do below)
+    const bapgd_resolve3_start rsv3 = {dev_probs};
+    (void)bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+    ccqp_bapgd_launch_gemv(dev_probs, count, n, 2, flags, s);       // init = 2: the problems the launch above left out
+  } else {
+    ccqp_bapgd_launch_gemv(dev_probs, count, n, 1, flags, s);
+  }
+  // (a run looks ahead if the caller gave it the two buffers for the products computed ahead: probs[p].ga / .Aya; the
+  // flag travels in the problems' slabs, set here)
+  hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk,
+                     bapgd_looks_ahead(count, n, flags) ? 1.0 : 0.0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

@@ -395,7 +395,7 @@ extern "C" int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_pr
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
   hipStream_t s = (hipStream_t)stream;
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s);
+  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s, false);
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
   hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);

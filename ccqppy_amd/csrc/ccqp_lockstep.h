@@ -30,6 +30,11 @@
 #define AP_COPYHAT 42     // ... "apply: xhat = x_{k+1}" ...
 #define AP_SOLHAT 43      // ... and, at convergence, whether the solution is xhat (1) or x_{k+1} itself (0)
 #define AP_FIRST 44
+// look-ahead of a lock-step APGD run (ccqp_bpipe.hip): this run pairs A.x_{k+1} with A.y_{k+1} | the next phase-0 round finds
+// A.y_k + b computed (in `ga` / `Aya`) | beta of :313, computed when the trial step is (it depends on theta_k only)
+#define AP_LOOK 45
+#define AP_AHEAD 46
+#define AP_BETAS 47
 #define AP_DONE BP_DONE   // 49
 #define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
 #define AP_RES2 BP_RES2   // 51
@@ -37,7 +42,7 @@
 
 // the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
 // tests/test_lockstep_host_cpu.py pins the same numbers)
-static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 192 && sizeof(ccqp_papgd) == 192 &&
+static_assert(sizeof(ccqp_seg) == 56 && sizeof(ccqp_pprob) == 192 && sizeof(ccqp_papgd) == 208 &&
                   sizeof(ccqp_pmprgp) == 224,
               "descriptor layout changed: update ccqppy_amd/_lib.py and the tests");
 
@@ -69,7 +74,7 @@ __device__ __forceinline__ bp_words bp_enter(const double* __restrict__ slab) {
 }
 
 struct ap_words {                            // APGD / anti-relaxation APGD
-  double done, phase, mv, it, first, r1, r2, L, thk, resmin;
+  double done, phase, mv, it, first, r1, r2, L, thk, resmin, look;
 };
 __device__ __forceinline__ ap_words ap_enter(const double* __restrict__ slab) {
   ap_words z;
@@ -83,6 +88,7 @@ __device__ __forceinline__ ap_words ap_enter(const double* __restrict__ slab) {
   z.L = slab[AP_L];
   z.thk = slab[AP_THK];
   z.resmin = slab[AP_RESMIN];
+  z.look = slab[AP_LOOK];
   __syncthreads();
   return z;
 }
@@ -460,7 +466,8 @@ void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode
 void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s);
 // the launches of a lock-step APGD round (ccqp_bpipe.hip), shared with the segmented form: `segs` != NULL takes the
 // residual from the segmented residual launch and leaves the trial step to the segmented step launch
-void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s);
+void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,
+                            bool elementwise = true);
 void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
                               double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s);
 void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s);

@@ -711,14 +711,16 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(spec)
-    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat
-    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 9, 8)
+    # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat ga Aya (the last two: products computed ahead, ccqp_bpipe.hip)
+    vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 11, 8)
     spec.stage_x0(vec[0])
     vec[8].fill_(1.0)                                                   # xhat = ones (solvers.py:432)
     vec[2].copy_(vec[0])                                                # yk = x0 (solvers.py:257-258)
     tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
     tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
     tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"], tab["xhat"] = planes[4], planes[5], planes[6], planes[7], planes[8]
+    if plans is None and not ar:                       # (the segmented form and the anti-relaxation variant do not look ahead)
+        tab["ga"], tab["Aya"] = planes[9], planes[10]
     flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0)  # bit 3: the anti-relaxation variant
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B

@@ -105,7 +105,7 @@ def test_spec_part_slices_every_array():
 
 def test_descriptor_dtypes_match_the_c_structs():
     from ccqppy_amd import _lib
-    for struct, size in ((_lib.Seg, 56), (_lib.PProb, 192), (_lib.PApgd, 192), (_lib.PMprgp, 224)):
+    for struct, size in ((_lib.Seg, 56), (_lib.PProb, 192), (_lib.PApgd, 208), (_lib.PMprgp, 224)):
         dt = np.dtype(struct)
         assert dt.itemsize == ctypes.sizeof(struct) == size
         for name, _ in struct._fields_:
