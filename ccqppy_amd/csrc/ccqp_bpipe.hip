@@ -595,7 +595,9 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
         s[AP_PHASE] = 0.0;
         s[AP_ACT] = restart ? 3.0 : 2.0;
         s[AP_COPYHAT] = improved ? 1.0 : 0.0;
-        if (z.look != 0.0) s[AP_AHEAD] = 1.0;            // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3)
+        // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3); after an anti-relaxation restart y_{k+1} is
+        // x_{k+1} itself (:510-512) and its product the launch's FIRST one (2: taken from g1 / Ax1)
+        if (z.look != 0.0) s[AP_AHEAD] = restart ? 2.0 : 1.0;
       }
     } else {
       L = L * 2.0;
@@ -755,20 +757,21 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_take_ahead_kernel(const ccqp
   const ccqp_papgd& q = probs[blockIdx.y];
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0 || s[AP_PHASE] != 0.0 || s[AP_AHEAD] == 0.0) return;
+  const double* __restrict__ gfrom = s[AP_AHEAD] == 2.0 ? q.g1 : q.ga;
+  const double* __restrict__ yfrom = s[AP_AHEAD] == 2.0 ? q.Ax1 : q.Aya;
   for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
-    q.gk[i] = q.ga[i];
-    q.Ayk[i] = q.Aya[i];
+    q.gk[i] = gfrom[i];
+    q.Ayk[i] = yfrom[i];
   }
 }
 
-// (CCQP_APGD_LOOKAHEAD=0 in the environment: off -- the A/B switch of the tools; flags bit 3: the anti-relaxation variant,
-// whose restart decides y_{k+1}, does not look ahead)
+// (CCQP_APGD_LOOKAHEAD=0 in the environment: off -- the A/B switch of the tools)
 static bool bapgd_looks_ahead(int count, int64_t n, int flags) {
   static const bool off = [] {
     const char* e = getenv("CCQP_APGD_LOOKAHEAD");
     return e && e[0] == '0';
   }();
-  return !off && !(flags & BP_FLAG_CONST_STEP) && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
+  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
 }
 
 void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,

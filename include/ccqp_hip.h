@@ -481,7 +481,7 @@ typedef struct ccqp_papgd {
   uint32_t* counter; /* one word, zero on entry */
   double c;
   double tol;
-  double* ga;        /* look-ahead (plain APGD on elementwise sets, persistent batched matvec): A y_{k+1} + b and A y_{k+1}, */
+  double* ga;        /* look-ahead (elementwise sets, persistent batched matvec): A y_{k+1} + b and A y_{k+1},                */
   double* Aya;       /* computed in the pass that computes A x_{k+1}; NULL: the run does not look ahead */
 } ccqp_papgd;
 int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
