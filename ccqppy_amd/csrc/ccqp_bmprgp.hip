@@ -470,7 +470,8 @@ __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, const mp_words& z,
     s[MP_IT] = z.it + 1.0;
     s[MP_STATE] = (double)ST_M1;
     // (what this round's three-vector launch computed ahead, bmprgp_resolve3)
-    if (z.look != 0.0) s[MP_AHEAD] = (int)z.state == ST_ADXC ? 3.0 : 6.0;
+    // (the segmented form passes through ST_TAIL and has set the word in its A.dx round, mps_reduce_a_kernel)
+    if (z.look != 0.0 && ((int)z.state == ST_ADXC || (int)z.state == ST_ADXH)) s[MP_AHEAD] = (int)z.state == ST_ADXC ? 3.0 : 6.0;
   }
 }
 
@@ -1197,7 +1198,7 @@ __device__ __forceinline__ double mps_item_sum(const double* part, int nwork, do
 // start-up decision: residual of (x_k, g_k), exit test (:1070-1073).  One block per problem.
 __global__ __launch_bounds__(CCQP_BLOCK) void mps_init_res_kernel(const ccqp_pmprgp* __restrict__ probs,
                                                                   const ccqp_psegs* __restrict__ segs,
-                                                                  unsigned* __restrict__ batch) {
+                                                                  unsigned* __restrict__ batch, double look) {
   __shared__ double lds4[4];
   const ccqp_pmprgp& q = probs[blockIdx.x];
   const ccqp_psegs& ps = segs[blockIdx.x];
@@ -1211,6 +1212,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void mps_init_res_kernel(const ccqp_pmp
   s[MP_IT] = 0.0;
   s[MP_STATE] = (double)ST_M1;
   s[MP_ACT] = (double)ACT_NONE;
+  s[MP_LOOK] = look;                           // (look-ahead: as the elementwise form, bmprgp_init_res_body)
+  s[MP_AHEAD] = look != 0.0 ? 6.0 : 0.0;
   if (sqrt(r) >= q.tol) {                      // `if res >= tol:` -- a NaN residual skips the loop, as in the reference
     s[MP_DONE] = 0.0;
   } else {
@@ -1231,13 +1234,14 @@ __global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_a_kernel(const ccqp_pmp
   const int bx = blockIdx.x;
   double v[2];
   switch ((int)z.state) {
-    case ST_M1:                                // g_k = A x_k + b has run (:1086)
+    case ST_M1:                                // g_k = A x_k + b has run (:1086) -- or was computed ahead
       if (!bp_meet(q.partials, q.counter, nblk, 0, v, lds4, &is_last)) return;
       if (threadIdx.x == 0) {
         s[MP_ACT] = (double)ACT_NONE;
         s[MP_MV] = z.mv + 1.0;
         s[MP_EXEC] = z.exec + 1.0;
         s[MP_STATE] = (double)ST_M1_N;
+        s[MP_AHEAD] = (double)((int)z.ahead & 2);
       }
       return;
     case ST_AP:                                // :1100-1111
@@ -1256,6 +1260,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_a_kernel(const ccqp_pmp
         s[MP_MV] = z.mv + 1.0;
         s[MP_EXEC] = z.exec + 1.0;
         s[MP_STATE] = (double)ST_FEAS_NOW;
+        s[MP_AHEAD] = (double)((int)z.ahead & ~2);
       }
       return;
     case ST_G1:                                // g_{k+1} = A x_{k+1} + b has run (:1152)
@@ -1284,6 +1289,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void mps_reduce_a_kernel(const ccqp_pmp
         s[MP_ACT] = (double)ACT_NONE;
         s[MP_EXEC] = z.exec + 1.0;
         s[MP_STATE] = (double)ST_TAIL;
+        // (what this round's three-vector launch computed ahead, bmprgp_resolve3; harmless if the tail finds convergence)
+        if (z.look != 0.0) s[MP_AHEAD] = (int)z.state == ST_ADXC ? 3.0 : 6.0;
       }
       return;
     default:
@@ -1484,12 +1491,28 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   if (rc) return rc;
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
-  hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch);
-  rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s, false);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
-  if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
-  hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+  const bool look = bmprgp_looks_ahead(count, n, flags);
+  hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch, look ? 1.0 : 0.0);
+  if (look) {
+    // p_0 first (it needs x_0 and g_0 only), then A.g_0 and A.p_0 in one pass over every matrix (as ccqp_bmprgp_start_f64)
+    if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+    hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+    hipStream_t ms = s;
+    rc = ccqp_mv_stream_enter(ctx, s, &ms);
+    if (rc) return rc;
+    const bmprgp_resolve3_start rsv3 = {dev_probs};
+    rc = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, ms);
+    if (rc) return rc;
+    rc = ccqp_mv_stream_leave(ctx, s, ms);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
+  } else {
+    rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 2, flags, s, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmprgp_init_alpha_kernel, dim3(nblk, count), blk, 0, s, dev_probs, n, chunk, nblk);
+    if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+    hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_P, gd);
+  }
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -1507,7 +1530,7 @@ extern "C" int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
   const dim3 gwk((unsigned)max_nwork, count, MPS_STEPS), gnk((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count, MPS_STEPS);
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s, false);
+  const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s, true);    // (looks ahead like the elementwise form)
   if (rc) return rc;
   hipLaunchKernelGGL(mps_reduce_a_kernel, rgrid, blk, 0, s, dev_probs, n, eps10, chunk, nblk);
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gnk, blk, 0, s, dev_probs, dev_segs, (int)MPS_BY_STATE, gd);

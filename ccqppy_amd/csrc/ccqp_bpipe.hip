@@ -663,6 +663,20 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_apply_kernel(const ccqp_papg
   bapgd_apply_body(probs[blockIdx.y], blockIdx.x, gridDim.x, n_segs);
 }
 
+// look-ahead of the SEGMENTED form (ccqp_bsegs.hip takes the trial step itself): y_{k+1} beside the trial point just formed
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_spec_kernel(const ccqp_papgd* __restrict__ probs, int64_t n) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const double* s = q.slab;
+  if (s[AP_DONE] != 0.0 || s[AP_LOOK] == 0.0 || s[AP_ACT] != 1.0) return;
+  const int it = (int)s[AP_IT];
+  const double beta = s[AP_BETAS];
+  axpby_body(1.0 + beta, q.X[(it + 1) & 1], -beta, q.X[it & 1], q.Y[(it + 1) & 1], n, blockIdx.x, gridDim.x);
+}
+
+void ccqp_bapgd_launch_spec(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(bapgd_spec_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
+}
+
 // the three launches of an APGD round, for the segmented form's driver (ccqp_bsegs.hip)
 void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
                               double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s) {

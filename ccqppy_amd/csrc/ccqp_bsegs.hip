@@ -395,7 +395,7 @@ extern "C" int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_pr
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
   hipStream_t s = (hipStream_t)stream;
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s, false);
+  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s, true);     // (looks ahead like the elementwise form)
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
   hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
@@ -404,6 +404,7 @@ extern "C" int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_pr
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 1, gd);
   hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 1, gd);
+  ccqp_bapgd_launch_spec(dev_probs, count, n, s);                      // (look-ahead runs: y_{k+1} of the trial point)
   ccqp_bapgd_launch_apply(dev_probs, count, n, s);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

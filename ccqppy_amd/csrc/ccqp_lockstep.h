@@ -471,3 +471,4 @@ void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int i
 void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
                               double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s);
 void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s);
+void ccqp_bapgd_launch_spec(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s);   // (look-ahead: y_{k+1} of a trial point)

@@ -719,8 +719,7 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     tab["X"][:, 0], tab["X"][:, 1] = planes[0], planes[1]
     tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
     tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"], tab["xhat"] = planes[4], planes[5], planes[6], planes[7], planes[8]
-    if plans is None:                                  # (the segmented form does not look ahead)
-        tab["ga"], tab["Aya"] = planes[9], planes[10]
+    tab["ga"], tab["Aya"] = planes[9], planes[10]
     flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0)  # bit 3: the anti-relaxation variant
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B

@@ -551,7 +551,8 @@ int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, cons
  * iteration) and, after a CG step, A.x_{k+1} + b (:1086), three right-hand sides in one pass over each matrix; the
  * start's A.x_0 + b (:1065) serves the first :1086 and A.g_0 (:1077) carries A.p_0.  Slab words 53 / 54 hold what is
  * computed ahead.  Every product has the bits of its own pass and the two counters advance where the reference computes
- * the product, so results and counts are unchanged; CCQP_MPRGP_LOOKAHEAD=0 in the environment turns it off.) */
+ * the product, so results and counts are unchanged; CCQP_MPRGP_LOOKAHEAD=0 in the environment turns it off.  The
+ * segmented form ccqp_bsegs_mprgp_* looks ahead in the same way.) */
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,

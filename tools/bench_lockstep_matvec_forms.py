@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--shapes", default="1024:512,2048:256,4096:128,8192:64")
     ap.add_argument("--solvers", default="BBPGD,APGD,MPRGP,SPG")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--set", default="box", help="box | union (a Sphere block and a Box block: the segmented lock-step forms)")
     args = ap.parse_args()
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     from ccqppy_amd._engine import get_engine
@@ -30,7 +31,12 @@ def main():
         probs = []
         for p in range(B):
             op, b, _ = problems.random_problem(n, 1234 + p, device=0)
-            probs.append((op, b, None, ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))))
+            if args.set == "union":
+                h = n // 2
+                P = ss.DisjointProjOp(ss.SphereProjOp(h, 0.8), ss.BoxProjOp(n - h, -0.5 * np.ones(n - h), 0.5 * np.ones(n - h)))
+            else:
+                P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+            probs.append((op, b, None, P))
         valu_tune = (3 if n >= 4096 else 1) << 4
         for kind in args.solvers.split(","):
             cls = getattr(solvers, "CCQPSolver" + kind)
@@ -65,7 +71,7 @@ def main():
                               sum(r.executed_matrix_vector_multiplications for r in res), float(ms.sum()), int(len(ms)))
             same = bool(torch.equal(out["persistent_lds"][1].view(torch.int64), out["valu"][1].view(torch.int64)))
             mv = out["valu"][2]
-            print(json.dumps({"solver": kind, "n": n, "problems": B, "executed_mv": int(mv),
+            print(json.dumps({"solver": kind, "set": args.set, "n": n, "problems": B, "executed_mv": int(mv),
                               "problems_per_s_persistent_lds": B / out["persistent_lds"][0],
                               "problems_per_s_valu": B / out["valu"][0],
                               "gain": out["valu"][0] / out["persistent_lds"][0] - 1.0,
