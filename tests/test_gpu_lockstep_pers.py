@@ -117,3 +117,42 @@ def test_more_problems_than_one_persistent_launch_takes():
         with contextlib.redirect_stdout(io.StringIO()):
             s = make().solve(A, b, x0=x0, convex_proj_op=Pp)
         _same(s, pers[p])
+
+
+@pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation", "MPRGP"])
+@pytest.mark.parametrize("segmented", [False, True])
+def test_look_ahead_with_problems_far_out_of_step(kind, segmented):
+    """Twelve problems of n = 4096 whose boxes are 0.02 ... 8 wide (and start points partly outside them): they take very
+    different numbers of iterations, CG and expansion steps, line-search rejections -- so in most rounds some problems
+    find their product computed ahead, some multiply, some have finished.  The look-ahead run (default) against one
+    matvec per launch (the VALU kernels), bit for bit, and against each problem's own solve()."""
+    import torch
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    n, count = 4096, 12
+    widths = np.geomspace(0.02, 8.0, count)
+    probs = []
+    for p in range(count):
+        op, b, _ = problems.random_problem(n, 9100 + p)
+        w = float(widths[p])
+        if segmented:
+            h = n // 2
+            P = ss.DisjointProjOp(ss.SphereProjOp(h, 4.0 * w), ss.BoxProjOp(n - h, -w * np.ones(n - h), 1.5 * w * np.ones(n - h)))
+        else:
+            P = ss.BoxProjOp(n, -w * np.ones(n), 1.5 * w * np.ones(n))
+        x0 = None if p % 3 else torch.full((n,), 0.7, dtype=torch.float64, device="cuda")
+        probs.append((op, b, x0, P))
+    cls = getattr(solvers, "CCQPSolver" + kind)
+    make = (lambda: cls(1e-6, 400)) if kind == "MPRGP" else (lambda: cls(1e-8, 600))
+    fb0 = lockstep.stats["fallback_solves"]
+    look = lockstep.solve_batch_pipelined(make, probs, device=0)
+    plain = lockstep.solve_batch_pipelined(make, probs, device=0, tune=3 << 4)
+    assert lockstep.stats["fallback_solves"] == fb0
+    for a, c in zip(plain, look):
+        _same(a, c)
+    counts = [r.solution_num_matrix_vector_multiplications for r in look]
+    assert max(counts) - min(counts) >= 4, counts                      # (the case is meant to be heterogeneous)
+    for p in (0, count // 2, count - 1):
+        A, b, x0, P = probs[p]
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = make().solve(A, b, x0=x0, convex_proj_op=P)
+        _same(s, look[p])
