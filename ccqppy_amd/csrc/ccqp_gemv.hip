@@ -481,9 +481,15 @@ static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, hi
 
 // Which form a pair of matvecs takes: true = ONE pass (gemv_lds2_kernel), wherever the single matvec would take the
 // LDS-staged form; false = two passes of the single matvec.
+// (the default, variant == 0, from 2^24 elements -- 4096^2 -- on: there ONE pass of the LDS-staged pair kernel beats two
+// passes of whichever single form is the default, 27 against 46 us at 4096^2, 89 against 168 us at 8192^2, 0.33 against
+// 0.64 ms at 16384^2; at 2048^2 a tie -- profiles/r03_gemv2_small.jsonl)
+static bool gemv2_default_fused(int64_t rows, int64_t cols) { return (double)rows * (double)cols >= 16777216.0; }
+
 static bool gemv2_fused(int variant, const double* A, int64_t lda, const double* x1, const double* x2, int64_t rows,
                         int64_t cols) {
   const bool ok = gemv_lds_applicable(A, lda, x1, cols) && (reinterpret_cast<uintptr_t>(x2) & 15) == 0;
+  if (variant == 0) return ok && gemv2_default_fused(rows, cols);
   variant = gemv_resolve(variant, rows, cols, ok);
   return ok && ((variant >> 24) & 1) && !((variant >> 9) & 1);
 }
@@ -491,8 +497,10 @@ static bool gemv2_fused(int variant, const double* A, int64_t lda, const double*
 extern "C" int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char* name, int buflen) {
   CCQP_REQUIRE(ctx != nullptr && name != nullptr && buflen > 0, "NULL argument");
   const bool lds_ok = cols >= 128 && cols % 2 == 0;             // (16-byte aligned operands assumed)
-  variant = gemv_resolve(variant, rows, cols, lds_ok);
-  const char* k = lds_ok && ((variant >> 24) & 1) && !((variant >> 9) & 1) ? "gemv_lds2_kernel" : "two single matvecs";
+  const bool fused = variant == 0 ? lds_ok && gemv2_default_fused(rows, cols)
+                                  : lds_ok && ((gemv_resolve(variant, rows, cols, lds_ok) >> 24) & 1) &&
+                                        !((gemv_resolve(variant, rows, cols, lds_ok) >> 9) & 1);
+  const char* k = fused ? "gemv_lds2_kernel" : "two single matvecs";
   strncpy(name, k, (size_t)buflen - 1);
   name[buflen - 1] = 0;
   return CCQP_OK;
@@ -520,7 +528,7 @@ extern "C" int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const
     CCQP_LAUNCH_CHECK();
     return CCQP_OK;
   }
-  const int v = gemv_lds_variant(gemv_resolve(variant, rows, cols, true));
+  const int v = gemv_lds_variant(variant == 0 ? GEMV_AUTO_LDS : gemv_resolve(variant, rows, cols, true));
   const gemv_lds_shape h = gemv_lds_decode(v);
   int bpc = (v >> 12) & 0xFF;
   int stagger = h.stagger;

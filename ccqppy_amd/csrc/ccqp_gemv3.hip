@@ -24,12 +24,14 @@ struct gemv3_one {                 // "resolver" of a batch of one
   }
 };
 
-// the single matvec's rule (ccqp_gemv.hip: gemv_resolve) for aligned operands: LDS-staged from 2^30 elements on, or where
-// the variant word asks for it (bit 24), never under (variant & 0xF) == 0xF or the MFMA bit
+// one pass: by default from 2^24 elements on (below), or where the variant word asks for the LDS-staged form (bit 24);
+// never under (variant & 0xF) == 0xF or the MFMA bit, nor for unaligned operands / odd or tiny n
 static bool gemv3_one_pass(int variant, int64_t n, bool aligned) {
   if (!aligned || n < 128 || n % 2) return false;
   if ((variant & 0xF) == 0xF || ((variant >> 9) & 1)) return false;
-  if (variant == 0) return (double)n * (double)n >= 1073741824.0;
+  // (the default from 4096^2 on: one pass for three products 31 against 71 us at 4096^2, 94 against 244 us at 8192^2,
+  // 0.34 against 0.91 ms at 16384^2; at 2048^2 a tie -- profiles/r03_gemv2_small.jsonl)
+  if (variant == 0) return (double)n * (double)n >= 16777216.0;
   return (variant >> 24) & 1;
 }
 

@@ -276,7 +276,7 @@ class _APGDCore(CCQPSolverBase):
         # iteration) come from one two-vector matvec (operator.matvec2 -> ccqp_gemv2_f64: each product with the bits of
         # its own matvec).  If the line search rejects x_{k+1} (:306-310) the second product is discarded and the retry
         # is again one pass -- never more passes than the reference has matvecs.  None (default): wherever the operator
-        # reads its matrix once for the pair (dense, LDS-staged form: >= 8 GiB); True / False force it.  The
+        # reads its matrix once for the pair (dense, aligned, an even n >= 4096); True / False force it.  The
         # anti-relaxation variant's restart (:510-512) makes y_{k+1} = x_{k+1}: then the product computed ahead is dropped
         # and A.x_{k+1}, which the same pass computed, is the next iteration's A.y_k.
         self.pair_matvecs = pair_matvecs
@@ -830,7 +830,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         # A, each product with the bits of its own matvec); after an expansion step A.x_{k+1} + b is the :1152 product
         # again, and the start's :1065 is the first :1086.  A CG step then costs one pass over A instead of three, an
         # expansion step two instead of four.  None (default): wherever the operator reads its matrix once for the three
-        # (square dense, LDS-staged form: >= 8 GiB); True / False force it.
+        # (square dense, aligned, an even n >= 4096); True / False force it.
         self.look_ahead = look_ahead
         # Extension, OFF by default, SAME results bit for bit (dense operator, elementwise set with array bounds):
         # every branch decision on the device, rounds queued ahead (ccqp_bmprgp_*, the lock-step batch scheduler with a

@@ -88,8 +88,9 @@ int ccqp_gemv_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char*
 /* TWO matvecs with the same matrix in ONE pass over it: y1 = A x1, y2 = A x2 (g_i = y_i + b where g_i != NULL).
  * Replaces the two `A.dot(...)` of an APGD iteration (solvers.py:275 A.dot(yk) of the NEXT iteration and :290
  * A.dot(xkp1): y_{k+1} = (1 + beta) x_{k+1} - beta x_k is known as soon as x_{k+1} is, :313-316).  Each product has
- * the bits ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 give it; the matrix is read from HBM once wherever the single matvec
- * would take the LDS-staged form (ccqp_gemv2_form says "gemv_lds2_kernel"), otherwise the call is two single matvecs.
+ * the bits ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 give it; the matrix is read from HBM once (ccqp_gemv2_form says
+ * "gemv_lds2_kernel": aligned operands, an even number of columns, by default from 2^24 elements on -- or where the
+ * variant word asks for the LDS-staged form), otherwise the call is two single matvecs.
  * y1, y2, g1, g2 must not alias each other or the inputs. */
 int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x1, const double* x2, const double* b,
                    double* y1, double* g1, double* y2, double* g2, int64_t rows, int64_t cols, int variant, void* stream);
@@ -98,8 +99,8 @@ int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char
  * every j < 3 with y[j] != NULL.  Replaces the A.dot(dx), A.dot(xk) and A.dot(p) that follow each other across the end
  * of an MPRGP iteration (solvers.py:1129 | :1163, then :1086 and :1100 of the next iteration: at the A.dx call x_{k+1}
  * and p_{k+1} are known).  Each product has the bits of its own ccqp_gemv_f64 / ccqp_gemv_epilogue_f64 call; one pass
- * wherever the single matvec would take the LDS-staged form (ccqp_gemv3_form: "bp_gemv3_pers_kernel"), otherwise
- * single matvecs.  Outputs must not alias inputs. */
+ * (ccqp_gemv3_form: "bp_gemv3_pers_kernel") for aligned operands and an even n, by default from n = 4096 on,
+ * otherwise single matvecs.  Outputs must not alias inputs. */
 int ccqp_gemv3_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* const* x, const double* b,
                    double* const* y, double* const* g, int64_t n, int variant, void* stream);
 int ccqp_gemv3_form(ccqp_ctx* ctx, int64_t n, int variant, char* name, int buflen);

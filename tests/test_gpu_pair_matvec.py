@@ -18,7 +18,7 @@ def _bits(t):
     return t.view(torch.int64)
 
 
-@pytest.mark.parametrize("rows,cols", [(512, 512), (300, 1000), (1030, 258), (64, 130), (2048, 4096), (777, 2050)])
+@pytest.mark.parametrize("rows,cols", [(512, 512), (300, 1000), (1030, 258), (64, 130), (2048, 4096), (777, 2050), (4096, 4098)])
 @pytest.mark.parametrize("with_g", [(True, True), (False, True), (True, False), (False, False)])
 def test_pair_product_has_the_bits_of_two_single_products(rows, cols, with_g):
     from ccqppy_amd._engine import get_engine
@@ -33,7 +33,8 @@ def test_pair_product_has_the_bits_of_two_single_products(rows, cols, with_g):
         eng.gemv(A, x, y, b if wg else None, g if wg else None, variant=0xF)       # the VALU form
         ref.append((y, g if wg else None))
     for variant in (LDS, 0x11001800, 0):
-        assert eng.gemv2_form(rows, cols, variant) == ("two single matvecs" if variant == 0 else "gemv_lds2_kernel")
+        one_pass = variant != 0 or rows * cols >= 2 ** 24       # (the default: from 2^24 elements on)
+        assert eng.gemv2_form(rows, cols, variant) == ("gemv_lds2_kernel" if one_pass else "two single matvecs")
         y1, y2 = torch.full_like(b, float("nan")), torch.full_like(b, float("nan"))
         g1 = torch.full_like(b, float("nan")) if with_g[0] else None
         g2 = torch.full_like(b, float("nan")) if with_g[1] else None
@@ -88,7 +89,7 @@ def test_apgd_with_paired_matvecs_equals_apgd(n):
     for seed in (11, 12):
         one = _solve(n, seed, False)
         two = _solve(n, seed, True)
-        auto = _solve(n, seed, None)            # (below 8 GiB the default stays on single matvecs)
+        auto = _solve(n, seed, None)            # (the default pairs from n = 4096 on)
         assert one.solution_converged and one.solution_num_matrix_vector_multiplications > 20
         _same(one, two)
         _same(one, auto)
@@ -151,7 +152,8 @@ def test_triple_product_has_the_bits_of_single_products(n, mask):
         eng.gemv(A, xs[j], y, b if want_g[j] else None, g if want_g[j] else None, variant=0xF)
         ref.append((y, g))
     for variant in (LDS, 0):
-        assert eng.gemv3_form(n, variant) == ("single matvecs" if variant == 0 else "bp_gemv3_pers_kernel")
+        one_pass = variant != 0 or n * n >= 2 ** 24            # (the default: from 4096^2 on)
+        assert eng.gemv3_form(n, variant) == ("bp_gemv3_pers_kernel" if one_pass else "single matvecs")
         ys = [torch.full_like(b, float("nan")) if mask[j] else None for j in range(3)]
         gs = [torch.full_like(b, float("nan")) if (mask[j] and want_g[j]) else None for j in range(3)]
         mv0 = eng.mv_executed

@@ -41,6 +41,13 @@ def main():
         runs = {"two single matvecs (default form)": lambda: (eng.gemv(A, x1, y[0], b, y[1]), eng.gemv(A, x2, y[2], b, y[3]))}
         for v in variants:
             runs["pair, variant %s" % hex(v)] = (lambda v=v: eng.gemv2(A, x1, x2, y[0], y[2], b, y[1], y[3], variant=v))
+        if rows == cols:                                    # three products of a square matrix (ccqp_gemv3_f64)
+            x3 = torch.randn(cols, dtype=torch.float64, device="cuda")
+            y3 = [torch.empty(rows, dtype=torch.float64, device="cuda") for _ in range(2)]
+            runs["three single matvecs (default form)"] = lambda: (eng.gemv(A, x1, y[0]), eng.gemv(A, x2, y[2]), eng.gemv(A, x3, y3[0], b, y3[1]))
+            runs["triple, default"] = lambda: eng.gemv3(A, [x1, x2, x3], [y[0], y[2], y3[0]], b, [None, None, y3[1]])
+            runs["triple, one pass forced"] = lambda: eng.gemv3(A, [x1, x2, x3], [y[0], y[2], y3[0]], b, [None, None, y3[1]], variant=0x11001800)
+        runs["pair, default"] = lambda: eng.gemv2(A, x1, x2, y[0], y[2], b, y[1], y[3])
         t = {k: [] for k in runs}
         for k, fn in runs.items():
             timed(fn)
