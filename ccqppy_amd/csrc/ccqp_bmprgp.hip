@@ -322,7 +322,7 @@ static bool bmprgp_looks_ahead(int count, int64_t n, int flags) {
     const char* e = getenv("CCQP_MPRGP_LOOKAHEAD");
     return e && e[0] == '0';
   }();
-  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
+  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n, BP_LOOKAHEAD_MIN_N);
 }
 
 template <int R, int S>
@@ -336,7 +336,7 @@ static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, 
 static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
                                  hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n)) {
+  if (bp_pers_default(t, flags, count, n, elementwise && bmprgp_looks_ahead(count, n, flags) ? BP_LOOKAHEAD_MIN_N : 4096)) {
     if (init == 0 && elementwise && bmprgp_looks_ahead(count, n, flags)) {   // (the segmented form does not look ahead)
       hipLaunchKernelGGL(bmprgp_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
       const bmprgp_resolve3 rsv3 = {dev_probs};

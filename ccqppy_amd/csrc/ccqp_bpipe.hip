@@ -785,13 +785,13 @@ static bool bapgd_looks_ahead(int count, int64_t n, int flags) {
     const char* e = getenv("CCQP_APGD_LOOKAHEAD");
     return e && e[0] == '0';
   }();
-  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n);
+  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n, BP_LOOKAHEAD_MIN_N);
 }
 
 void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,
                             bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n)) {
+  if (bp_pers_default(t, flags, count, n, elementwise && bapgd_looks_ahead(count, n, flags) ? BP_LOOKAHEAD_MIN_N : 4096)) {
     if (init == 0 && elementwise && bapgd_looks_ahead(count, n, flags)) {
       hipLaunchKernelGGL(bapgd_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
       const bapgd_resolve3 rsv3 = {probs};

@@ -356,10 +356,14 @@ static inline int bp_num_cu() {
 // profiles/r03_lockstep_matvec_forms.jsonl) n = 4096 / 8192: APGD, MPRGP, SPG, BBPGD +2 ... +6 %.  At n = 1024 / 2048 the
 // launch gains 1.5-2.7 % with every problem live, but whole solves come out even (-4 ... +5 %, solver by solver), and
 // 512 x 512 loses 5 %: those stay on the VALU kernels, as do batches small enough to be re-read from the MALL.
-static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, int64_t n) {
-  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= 4096 &&
+// `min_n`: solvers that LOOK AHEAD (APGD, MPRGP: two or three products per pass over a matrix) take the persistent form
+// from n = 1024 on -- there its single-product launch ties with the VALU kernels, and a shared pass replaces two or
+// three of them (profiles/r03_lockstep_matvec_forms_small.jsonl).
+static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, int64_t n, int64_t min_n = 4096) {
+  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= min_n &&
          8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
 }
+#define BP_LOOKAHEAD_MIN_N 1024
 
 template <int R, int S, class Resolve>
 static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
