@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in $WHICH; do
-  echo "[configs] config $c: plain line"; date
-  python3 "$ROOT/tools/config_profile_driver.py" $c --cpu > "$OUT/${TAG}_config${c}_line.json" 2> "$OUT/${TAG}_config${c}_line.err" || exit 1
+  echo "[configs] config $c: sizes of the launch (a first plain run; the line that is kept is taken LAST, below)"; date
+  python3 "$ROOT/tools/config_profile_driver.py" $c > "$OUT/${TAG}_config${c}_meta.json" 2> "$OUT/${TAG}_config${c}_meta.err" || exit 1
   echo "[configs] config $c: kernel trace"; date
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_c${c}_trace" -- \
     python3 "$ROOT/tools/config_profile_driver.py" $c --reps 2 > "$OUT/${TAG}_config${c}_under_rocprof.json" 2> "$OUT/${TAG}_c${c}_trace.err" || exit 1
@@ -30,7 +30,7 @@ for c in $WHICH; do
   else
     unset PROF_FULL_ONLY; export PROF_KERNEL_FILTER="gemv_" PROF_SOURCES=""
   fi
-  export PROF_META=$(python3 - "$OUT/${TAG}_config${c}_line.json" "$c" <<'PY'
+  export PROF_META=$(python3 - "$OUT/${TAG}_config${c}_meta.json" "$c" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
@@ -47,5 +47,8 @@ PY
   # (summarize_prof.py writes into profiles/: only ITS files travel back -- the line files of this run are already in $OUT)
   cp profiles/${TAG}_config${c}_kernel_stats* profiles/${TAG}_config${c}_pmc.json "$OUT/" 2>/dev/null
   cd /tmp
+  # the plain line last: its "traffic" is read from the PMC summary just written -- same sources (sha1), same box, same call
+  echo "[configs] config $c: plain line"; date
+  python3 "$ROOT/tools/config_profile_driver.py" $c --cpu > "$OUT/${TAG}_config${c}_line.json" 2> "$OUT/${TAG}_config${c}_line.err" || exit 1
 done
 echo "[configs] done"; date
