@@ -329,11 +329,16 @@ extern "C" int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out) {
 // Name of the kernel the batched matvec of the lock-step forms (ccqp_bpipe_* / ccqp_bapgd_* / ccqp_bmprgp_* / ccqp_bspg_*
 // and their segmented forms) runs as for `count` problems of size n under `flags` (bit 0 = aligned operands, the rest
 // the tuning word): "bp_gemv_pers_kernel" (one persistent LDS-DMA launch for the whole batch) or "batched VALU kernel".
+// Bit 16 of `flags` asks for the runs that share passes between products (ccqp_bapgd_* / ccqp_bmprgp_* with their
+// look-ahead on): those take the persistent form from n = 1024 on.
 extern "C" int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen) {
   CCQP_REQUIRE(name != nullptr && buflen > 0 && count >= 1 && n >= 1, "bad argument");
+  const bool shares = (flags >> 16) & 1;
+  flags &= 0xFFFF;
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool lds_tuned = ((flags >> 1) & 3) == 3 && ((flags >> 4) & 7) >= 4;          // (MPRGP's explicit ring codes)
-  const char* k = bp_pers_default(t, flags, count, n) || (lds_tuned && t.aligned && n % 2 == 0 && n >= 128)
+  const char* k = bp_pers_default(t, flags, count, n, shares ? BP_LOOKAHEAD_MIN_N : 4096) ||
+                          (lds_tuned && t.aligned && n % 2 == 0 && n >= 128)
                       ? "bp_gemv_pers_kernel" : "batched VALU kernel";
   strncpy(name, k, (size_t)buflen - 1);
   name[buflen - 1] = 0;

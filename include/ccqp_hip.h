@@ -408,8 +408,8 @@ int64_t ccqp_bpipe_partials_doubles(int64_t n);
  * (bit 0 = aligned operands, the rest the tuning word): "bp_gemv_pers_kernel" -- ONE persistent LDS-DMA launch whose
  * waves walk the live problems' matrices (rows through per-wave LDS rings, a wave's 4 rows about 1 MiB apart); the
  * tuned default from n = 4096 and 1 GiB of matrices on (the runs that look ahead -- ccqp_bapgd_*, ccqp_bmprgp_* and their
- * segmented forms -- already from n = 1024: this query answers for the others) -- or "batched VALU kernel".  Same bits
- * either way. */
+ * segmented forms -- already from n = 1024: set bit 16 of `flags` to ask for those) -- or "batched VALU kernel".  Same
+ * bits either way. */
 int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a

@@ -67,3 +67,25 @@ def test_product_fails_loudly_without_gpu():
         ss.BoxProjOp(3)(np.zeros(3))
     with pytest.raises(CCQPHipUnavailable):
         solvers.CCQPSolverBBPGD(1e-8, 10).solve(np.eye(3), np.ones(3))
+
+
+def test_which_form_the_batched_matvec_takes_is_host_arithmetic(built_lib):
+    """ccqp_bpipe_matvec_form is a pure host query (no device call): the persistent LDS-DMA launch from n = 4096 and
+    1 GiB of matrices on, for the runs that share passes between products (bit 16) from n = 1024 on."""
+    from ccqppy_amd import _lib
+    lib = _lib.load()
+
+    def form(count, n, flags):
+        buf = ctypes.create_string_buffer(64)
+        assert lib.ccqp_bpipe_matvec_form(count, n, flags, buf, 64) == 0
+        return buf.value.decode()
+
+    assert form(128, 8192, 1) == "bp_gemv_pers_kernel"
+    assert form(512, 2048, 1) == "batched VALU kernel"
+    assert form(512, 2048, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert form(128, 1024, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert form(127, 1024, 1 | (1 << 16)) == "batched VALU kernel"
+    assert form(4096, 512, 1 | (1 << 16)) == "batched VALU kernel"
+    assert form(128, 1024, 1 << 16) == "batched VALU kernel"              # unaligned operands
+    assert form(128, 1026, 1 | (1 << 16)) == "bp_gemv_pers_kernel" and form(128, 1025, 1 | (1 << 16)) == "batched VALU kernel"
+    assert lib.ccqp_bpipe_matvec_form(0, 1024, 1, ctypes.create_string_buffer(8), 8) != 0

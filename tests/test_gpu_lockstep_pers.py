@@ -40,6 +40,12 @@ def test_which_batches_take_the_persistent_form():
     assert _form(8, 4097, 1) == "batched VALU kernel"                 # odd n
     assert _form(600, 4096, 1) == "bp_gemv_pers_kernel"               # (more than 512 problems: one launch per 512)
     assert _form(8, 8192, 1 | (3 << 1) | (4 << 4)) == "bp_gemv_pers_kernel"     # MPRGP's explicit ring codes
+    # the runs that share passes between products (lock-step APGD / MPRGP, bit 16 of the query): from n = 1024 on
+    assert _form(512, 2048, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert _form(128, 1024, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert _form(127, 1024, 1 | (1 << 16)) == "batched VALU kernel"   # below 1 GiB
+    assert _form(2048, 512, 1 | (1 << 16)) == "batched VALU kernel"   # n < 1024
+    assert _form(128, 1024, 1 | (1 << 16) | (3 << 4)) == "batched VALU kernel"
 
 
 @pytest.mark.parametrize("kind,segmented", [("BBPGD", False), ("BBPGDf", False), ("PGD", False), ("APGD", False),
@@ -121,14 +127,15 @@ def test_more_problems_than_one_persistent_launch_takes():
 
 @pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation", "MPRGP"])
 @pytest.mark.parametrize("segmented", [False, True])
-def test_look_ahead_with_problems_far_out_of_step(kind, segmented):
-    """Twelve problems of n = 4096 whose boxes are 0.02 ... 8 wide (and start points partly outside them): they take very
-    different numbers of iterations, CG and expansion steps, line-search rejections -- so in most rounds some problems
-    find their product computed ahead, some multiply, some have finished.  The look-ahead run (default) against one
-    matvec per launch (the VALU kernels), bit for bit, and against each problem's own solve()."""
+@pytest.mark.parametrize("n,count", [(4096, 12), (2048, 36), (1024, 130)])
+def test_look_ahead_with_problems_far_out_of_step(kind, segmented, n, count):
+    """Problems whose boxes are 0.02 ... 8 wide (and start points partly outside them): they take very different numbers
+    of iterations, CG and expansion steps, line-search rejections -- so in most rounds some problems find their product
+    computed ahead, some multiply, some have finished.  The look-ahead run (default from n = 1024 and 1 GiB of matrices
+    on) against one matvec per launch (the VALU kernels), bit for bit, and against each problem's own solve()."""
     import torch
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
-    n, count = 4096, 12
+    assert _form(count, n, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
     widths = np.geomspace(0.02, 8.0, count)
     probs = []
     for p in range(count):
