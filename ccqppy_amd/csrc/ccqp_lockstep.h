@@ -363,7 +363,15 @@ static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, 
   return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= min_n &&
          8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
 }
-#define BP_LOOKAHEAD_MIN_N 1024
+static inline int64_t bp_lookahead_min_n() {
+  static const int64_t v = [] {
+    const char* e = getenv("CCQP_LOOKAHEAD_MIN_N");      // (A/B switch of the tools)
+    const long long x = e ? atoll(e) : 0;
+    return (int64_t)(x >= 128 ? x : 1024);
+  }();
+  return v;
+}
+#define BP_LOOKAHEAD_MIN_N bp_lookahead_min_n()
 
 template <int R, int S, class Resolve>
 static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {

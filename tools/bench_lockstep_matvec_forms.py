@@ -37,7 +37,7 @@ def main():
             else:
                 P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
             probs.append((op, b, None, P))
-        valu_tune = (3 if n >= 4096 else 1) << 4
+        valu_tune = (3 if n >= 4096 else 6 if n <= 256 else 7 if n <= 512 else 1) << 4      # (the VALU default's own choice)
         for kind in args.solvers.split(","):
             cls = getattr(solvers, "CCQPSolver" + kind)
 
