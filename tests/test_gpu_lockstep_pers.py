@@ -127,7 +127,7 @@ def test_more_problems_than_one_persistent_launch_takes():
 
 @pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation", "MPRGP"])
 @pytest.mark.parametrize("segmented", [False, True])
-@pytest.mark.parametrize("n,count", [(4096, 12), (2048, 36), (1024, 130)])
+@pytest.mark.parametrize("n,count", [(4096, 12), (2048, 36), (1024, 130), (1024, 300)])     # (300: two three-vector launches)
 def test_look_ahead_with_problems_far_out_of_step(kind, segmented, n, count):
     """Problems whose boxes are 0.02 ... 8 wide (and start points partly outside them): they take very different numbers
     of iterations, CG and expansion steps, line-search rejections -- so in most rounds some problems find their product
@@ -137,6 +137,8 @@ def test_look_ahead_with_problems_far_out_of_step(kind, segmented, n, count):
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     assert _form(count, n, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
     widths = np.geomspace(0.02, 8.0, count)
+    if count > 256:
+        widths = widths[(np.arange(count) * 7) % count]       # (fast and slow problems on both sides of the launch split)
     probs = []
     for p in range(count):
         op, b, _ = problems.random_problem(n, 9100 + p)
