@@ -340,7 +340,7 @@ static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, in
     if (init == 0 && elementwise && bmprgp_looks_ahead(count, n, flags)) {   // (the segmented form does not look ahead)
       hipLaunchKernelGGL(bmprgp_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
       const bmprgp_resolve3 rsv3 = {dev_probs};
-      const int rc3 = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+      const int rc3 = bp_launch_gemv3(rsv3, count, n, s);
       if (rc3) return rc3;
     }
     return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
@@ -820,7 +820,7 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
     rc = ccqp_mv_stream_enter(ctx, s, &ms);
     if (rc) return rc;
     const bmprgp_resolve3_start rsv3 = {dev_probs};
-    rc = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, ms);
+    rc = bp_launch_gemv3(rsv3, count, n, ms);
     if (rc) return rc;
     rc = ccqp_mv_stream_leave(ctx, s, ms);
     if (rc) return rc;
@@ -1501,7 +1501,7 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
     rc = ccqp_mv_stream_enter(ctx, s, &ms);
     if (rc) return rc;
     const bmprgp_resolve3_start rsv3 = {dev_probs};
-    rc = bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, ms);
+    rc = bp_launch_gemv3(rsv3, count, n, ms);
     if (rc) return rc;
     rc = ccqp_mv_stream_leave(ctx, s, ms);
     if (rc) return rc;

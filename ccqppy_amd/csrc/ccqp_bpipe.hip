@@ -800,7 +800,7 @@ void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int i
     if (init == 0 && elementwise && bapgd_looks_ahead(count, n, flags)) {
       hipLaunchKernelGGL(bapgd_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
       const bapgd_resolve3 rsv3 = {probs};
-      (void)bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+      (void)bp_launch_gemv3(rsv3, count, n, s);
     }
     const bapgd_resolve rsv = {probs, init};
     if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
@@ -822,7 +822,7 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
     // (problems without the two buffers -- the segmented form, the anti-relaxation variant -- take no part here and
     // are multiplied by the single launch below; with them the three-vector launch finds nothing to do below)
     const bapgd_resolve3_start rsv3 = {dev_probs};
-    (void)bp_launch_gemv3_pers<4, 4>(rsv3, count, n, 4, s);
+    (void)bp_launch_gemv3(rsv3, count, n, s);
     ccqp_bapgd_launch_gemv(dev_probs, count, n, 2, flags, s);       // init = 2: the problems the launch above left out
   } else {
     ccqp_bapgd_launch_gemv(dev_probs, count, n, 1, flags, s);

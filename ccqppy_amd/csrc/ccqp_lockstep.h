@@ -465,6 +465,29 @@ static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int w
   return CCQP_OK;
 }
 
+// ring shape of the three-vector launch: rows per wave, slots, waves per workgroup.  EIGHT rows per wave, two slots, four
+// waves: a step brings 8 KiB of matrix with 3 KiB of vectors instead of 4 + 3 -- against <4, 4> x 4 waves +1.5 % on
+// config 5's share (788 -> 800 problems/s), +2...+4 % on lock-step MPRGP / APGD batches of n = 1024 ... 8192, nine cases
+// of nine (profiles/r03_bmv3_shapes.jsonl; <8, 3> x 3 waves loses 1-7 %, <4, 3> x 4 is within +-1 %).  The bits do not
+// depend on the shape.  CCQP_BMV3_SHAPE=<R><S><W> in the environment is the A/B switch of the tools.
+static inline int bp_gemv3_shape() {
+  static const int v = [] {
+    const char* e = getenv("CCQP_BMV3_SHAPE");
+    const int x = e ? atoi(e) : 0;
+    return (x == 833 || x == 824 || x == 444 || x == 434) ? x : 824;
+  }();
+  return v;
+}
+template <class Resolve3>
+static int bp_launch_gemv3(const Resolve3& rsv, int count, int64_t n, hipStream_t s) {
+  switch (bp_gemv3_shape()) {
+    case 833: return bp_launch_gemv3_pers<8, 3>(rsv, count, n, 3, s);
+    case 444: return bp_launch_gemv3_pers<4, 4>(rsv, count, n, 4, s);
+    case 434: return bp_launch_gemv3_pers<4, 3>(rsv, count, n, 4, s);
+    default: return bp_launch_gemv3_pers<8, 2>(rsv, count, n, 4, s);
+  }
+}
+
 #define BP_CHECK_BATCH()                                                                          \
   CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument"); \
   CCQP_REQUIRE(count >= 1 && count <= 65535 && n >= 1, "bad batch shape")
