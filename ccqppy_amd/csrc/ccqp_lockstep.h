@@ -469,18 +469,21 @@ static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int w
 // waves: a step brings 8 KiB of matrix with 3 KiB of vectors instead of 4 + 3 -- against <4, 4> x 4 waves +1.5 % on
 // config 5's share (788 -> 800 problems/s), +2...+4 % on lock-step MPRGP / APGD batches of n = 1024 ... 8192, nine cases
 // of nine (profiles/r03_bmv3_shapes.jsonl; <8, 3> x 3 waves loses 1-7 %, <4, 3> x 4 is within +-1 %).  The bits do not
-// depend on the shape.  CCQP_BMV3_SHAPE=<R><S><W> in the environment is the A/B switch of the tools.
-static inline int bp_gemv3_shape() {
-  static const int v = [] {
+// depend on the shape.  With FEW matrices per launch the waves crowd on one matrix at a time and the bytes a wave keeps
+// in flight count for more: <4, 4> x 4 waves (12 KiB per wave against 8) is 2-5 % ahead for a single problem of
+// n <= 16384 and level at n = 32768 (ccqp_gemv3_f64), level to +1 % for 2 ... 16 problems -- kept below 32 problems.
+// CCQP_BMV3_SHAPE=<R><S><W> in the environment is the A/B switch of the tools.
+static inline int bp_gemv3_shape(int count) {
+  static const int forced = [] {
     const char* e = getenv("CCQP_BMV3_SHAPE");
     const int x = e ? atoi(e) : 0;
-    return (x == 833 || x == 824 || x == 444 || x == 434) ? x : 824;
+    return (x == 833 || x == 824 || x == 444 || x == 434) ? x : 0;
   }();
-  return v;
+  return forced ? forced : count >= 32 ? 824 : 444;
 }
 template <class Resolve3>
 static int bp_launch_gemv3(const Resolve3& rsv, int count, int64_t n, hipStream_t s) {
-  switch (bp_gemv3_shape()) {
+  switch (bp_gemv3_shape(count)) {
     case 833: return bp_launch_gemv3_pers<8, 3>(rsv, count, n, 3, s);
     case 444: return bp_launch_gemv3_pers<4, 4>(rsv, count, n, 4, s);
     case 434: return bp_launch_gemv3_pers<4, 3>(rsv, count, n, 4, s);
