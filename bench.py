@@ -2,6 +2,7 @@
 """Headline benchmark of the CCQP hot path on MI355X (contract: see the task's bench.py section).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W       (N > 1: starts its own N ranks, launch_ranks_if_asked below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -17,6 +18,9 @@ one launch per matvec (the A/B).
 For N > 1 the matrix is row-block sharded (one process per GPU, RCCL all-gather of the n-vector per
 matvec) and the SAME problem is solved: strong scaling.
 
+What a step launched is in the line itself: `matvec_launches_per_step`, `pair_launches_per_step`,
+`products_computed_per_step` and `products_discarded_per_step` (headline: 19 pair launches = 1 start + 16 iterations + 2
+rejected line-search trials; 38 products computed, 3 never taken over, 35 executed = the reference's count).
 Extra objects on the JSON line:
   roofline     -- dominant kernel (fp64 streaming GEMV; `kernel` names the form this shape runs as, ccqp_gemv_form):
                   algorithmic bytes / duration measured with HIP events on the launch stream inside the timed region,
@@ -45,7 +49,8 @@ an `exchange_ab` object: after the timed steps, untimed, 50 exchanges of the n-v
 all-reduce), HIP-event timed on the launch stream, with a check that all three leave the same bits in y on every
 rank -- the line decides by itself which exchange should be the default on the box it ran on.  It runs LAST (after
 the CPU baseline), under a watchdog, and a failure or a hang inside it -- it includes a form no multi-rank run has
-exercised yet -- puts an `error` into `exchange_ab` and ends the run with the complete line and exit code 0.
+exercised yet -- puts an `error` into `exchange_ab`, sets the top-level `exchange_ab_ok` to false and ends the run with
+the complete line and exit code 0.
 Any RCCL error in the measured part ends the run with a non-zero exit code and RCCL's message on stderr: no retry, no
 other backend.
 """
@@ -58,8 +63,50 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def launch_ranks_if_asked(argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the LAUNCHER.  It
+    starts ONE child -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free port> bench.py <the same arguments>` -- lets the child's stdout / stderr through, and leaves with
+    the child's exit code.  It runs before numpy / torch are imported: the launcher never touches a GPU, never retries and
+    has no other backend to fall back to.  Returns only if there is nothing to launch."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1:
+        return
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launcher: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env)
+
+    def forward(signum, _frame):                        # a signal for the launcher is a signal for the job
+        try:
+            child.send_signal(signum)
+        except OSError:
+            pass
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    rc = child.wait()
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_asked(sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -307,6 +354,14 @@ def exchange_ab(n, row0, rows, slab, eng, group, backend, reps=50, state=None):
     return out
 
 
+def exchange_ab_ok(ab):
+    """The top-level verdict on the untimed exchange A/B: every form answered, same bits across forms and ranks, no NaN
+    left.  The process still ends with exit code 0 when this is False (the timed line is complete by then) -- so the
+    failure has a field of its own that nothing reading the line can miss."""
+    return bool(ab) and "error" not in ab and bool(ab.get("bitwise_equal_forms")) and \
+        bool(ab.get("bitwise_equal_ranks")) and bool(ab.get("no_nan_left"))
+
+
 def main():
     try:
         _main()
@@ -348,9 +403,9 @@ def _main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        # (`python bench.py --gpus N` without a launcher never gets here: launch_ranks_if_asked started the ranks)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: one rank per GPU, started by bench.py itself or by "
+                 "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     # CCQP_DIST_BACKEND=gloo lets two ranks share one GPU for a rehearsal on a 1-GPU box
     backend = os.environ.get("CCQP_DIST_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
@@ -404,6 +459,7 @@ def _main():
         exch.events = []
         exch.calls = 0
     mv0 = eng.mv_executed
+    prod0 = eng.products_launched
     t0 = time.perf_counter()
     last = None
     step_end = []                                       # host clock after each step's solve() returned (its last scalar
@@ -413,6 +469,7 @@ def _main():
     barrier()
     elapsed = time.perf_counter() - t0
     mv_exec = eng.mv_executed - mv0
+    products = eng.products_launched - prod0            # every A.v a launch of the timed region computed, taken over or not
     events = eng.gemv_events
     eng.gemv_events = None
     gemv_ms = [a.elapsed_time(b_) for a, b_ in events]
@@ -479,6 +536,7 @@ def _main():
     del op                      # from here on `holder` owns the matrix (cpu_baseline releases it)
     if rank == 0:
         avg_ms = float(np.mean(gemv_ms)) if gemv_ms else float("nan")
+        steps = max(args.steps, 1)
         rows_per_launch, launches = eng.gemv_plan(rows_local, n)
         form = eng.gemv_form(rows_local, n)              # the kernel this shape runs as: its name in a rocprofv3 table
         per_launch = 1
@@ -490,7 +548,6 @@ def _main():
             launch_bytes = 8.0 * (rows_local * n + 2 * n + 2 * rows_local)
         achieved = launch_bytes * launches / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(launch_bytes, form)
-        steps = max(args.steps, 1)
         line = {
             "metric": "A.x matvecs/sec (+ solve wall-clock), n=%d random-SPD box-CCQP, APGD" % n,
             "value": mv_exec / elapsed,
@@ -500,6 +557,13 @@ def _main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "step_ms": [round(1e3 * (b_ - a), 3) for a, b_ in zip([t0] + step_end[:-1], step_end)],
+            # what a step launched: matvec launches (paired: two products each), the products they computed, and those
+            # of them the solver never took over (the product computed ahead of a REJECTED line-search trial; they cost
+            # no extra pass over A).  `value` counts the reference's executed matvecs: computed - discarded.
+            "matvec_launches_per_step": len(gemv_ms) / steps,
+            "pair_launches_per_step": len(gemv_ms) / steps if paired else 0,
+            "products_computed_per_step": products / steps,
+            "products_discarded_per_step": (products - mv_exec) / steps,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -597,6 +661,7 @@ def _main():
             if line is not None:
                 line["exchange_ab"] = dict(state["out"], error="no answer within %d s in form %r (untimed A/B; the timed "
                                            "region above is complete)" % (AB_LIMIT_S, state["mode"]))
+                line["exchange_ab_ok"] = False
                 print(json.dumps(line), flush=True)
             print("[bench] rank %d: exchange A/B gave no answer in form %r; leaving" % (rank, state["mode"]),
                   file=sys.stderr, flush=True)
@@ -616,6 +681,7 @@ def _main():
         watchdog.cancel()
         if line is not None:
             line["exchange_ab"] = ab
+            line["exchange_ab_ok"] = exchange_ab_ok(ab)
     if line is not None:
         print(json.dumps(line), flush=True)
     if ab_failed:

@@ -75,6 +75,7 @@ class Engine:
         self._scratch = {}
         self.gemv_variant = 0
         self.mv_executed = 0      # every matvec launched through this engine (counted or not)
+        self.products_launched = 0  # every A.v a launch computed (never corrected: a product computed ahead and dropped stays)
         self.gemv_events = None   # list of (start, end) HIP events per matvec when profiling is on
         self.own_stream = stream  # torch.cuda.Stream of a lane engine, None for the default engine
         self.torch_stream = stream
@@ -165,6 +166,7 @@ class Engine:
             ev[1].record(self.torch_stream)
             self.gemv_events.append(ev)
         self.mv_executed += 2
+        self.products_launched += 2
 
     def gemv3(self, A, xs, ys, b=None, gs=(None, None, None), variant=None):
         """ys[j] = A.xs[j] (gs[j] = ys[j] + b where given) for the j with ys[j] not None -- up to three products of a
@@ -186,6 +188,7 @@ class Engine:
             ev[1].record(self.torch_stream)
             self.gemv_events.append(ev)
         self.mv_executed += sum(y is not None for y in ys)
+        self.products_launched += sum(y is not None for y in ys)
 
     def gemv3_form(self, n, variant=None):
         """"bp_gemv3_pers_kernel" (one pass for up to three products of an n x n matrix) or "single matvecs"."""
@@ -212,6 +215,7 @@ class Engine:
         assert A.stride(1) == 1 and x.numel() >= cols and y.numel() >= rows
         v = self.gemv_variant if variant is None else variant
         self.mv_executed += 1
+        self.products_launched += 1
         ev = None
         if self.gemv_events is not None:
             # HIP events on the stream the kernel is launched on
@@ -247,6 +251,7 @@ class Engine:
         rows = rowptr.numel() - 1
         assert x.numel() >= cols and y.numel() >= rows
         self.mv_executed += 1
+        self.products_launched += 1
         ev = None
         if self.gemv_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
