@@ -18,6 +18,7 @@ import torch
 from . import _lib
 
 _engines = {}
+_default_options = {}      # device index -> {option name: value}: what every NEW engine (lane engines too) of the device starts with
 
 
 def _require_gpu():
@@ -49,6 +50,18 @@ def get_engine(device=None):
     return eng
 
 
+def set_default_option(name, value, device=None):
+    """Tuning option `name` (ccqppy_amd._lib.OPTIONS; 0 = the tuned default) for the default engine of `device` and for
+    every engine created on that device afterwards (the lanes of the batch schedulers).  The A/B switches of tools/ and
+    tests/: no option changes a result bit, and nothing in the library reads the environment."""
+    _require_gpu()
+    idx = _index_of(device)
+    if name not in _lib.OPTIONS:
+        raise KeyError("no such option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
+    _default_options.setdefault(idx, {})[name] = int(value)
+    get_engine(idx).set_option(name, value)
+
+
 def make_lanes(device, count):
     """`count` engines on `device`, each with its own context and its own HIP stream."""
     _require_gpu()
@@ -77,6 +90,8 @@ class Engine:
         self.mv_executed = 0      # every matvec launched through this engine (counted or not)
         self.products_launched = 0  # every A.v a launch computed (never corrected: a product computed ahead and dropped stays)
         self.gemv_events = None   # list of (start, end) HIP events per matvec when profiling is on
+        for name, value in _default_options.get(index, {}).items():
+            self.set_option(name, value)
         self.own_stream = stream  # torch.cuda.Stream of a lane engine, None for the default engine
         self.torch_stream = stream
         self.stream = None        # raw hipStream_t (int) every launch goes to
@@ -87,6 +102,19 @@ class Engine:
             self.lib.ccqp_ctx_destroy(self.ctx)
         except Exception:  # noqa: BLE001
             pass
+
+    # ------------------------------------------------------------------ tuning options (per context, never the environment)
+    def set_option(self, name, value):
+        _lib.check(self.lib.ccqp_ctx_set_option(self.ctx, _lib.OPTIONS[name], int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int64()
+        _lib.check(self.lib.ccqp_ctx_get_option(self.ctx, _lib.OPTIONS[name], ctypes.byref(v)))
+        return v.value
+
+    def options(self):
+        """{name: value} of the options that are not at their default -- what makes a measurement self-describing."""
+        return {name: v for name in _lib.OPTIONS for v in [self.get_option(name)] if v}
 
     # ------------------------------------------------------------------ stream / memory plumbing
     def bind(self):

@@ -17,6 +17,13 @@ MAX_DOTS = 8
 SMALL_SEG_MAX = 64
 MAX_STEPS = 16
 
+ABI_VERSION = 2          # CCQP_ABI_VERSION of include/ccqp_hip.h this binding was written against
+LOCKSTEP_LOOKAHEAD = 1 << 17   # CCQP_LOCKSTEP_LOOKAHEAD: flags bit of ccqp_bapgd_* (every problem carries ga / Aya)
+# per-context tuning options (ccqp_ctx_set_option): name -> key
+OPTIONS = {name: key for key, name in enumerate((
+    "GEMV_ROW_STRIDE", "GEMV2_WPB", "GEMV2_SHAPE", "GEMV2_GROUP", "BMV3_SHAPE", "LOOKAHEAD_MIN_N", "MPRGP_LOOKAHEAD_MIN_N",
+    "MPRGP_LOOKAHEAD", "APGD_LOOKAHEAD", "BMV_STAGGER", "MPRGP_FUSED_TAIL", "PERS1_MIN_N"))}
+
 OP_IDENTITY, OP_LOWER, OP_UPPER, OP_BOX, OP_SPHERE, OP_CONE = range(6)
 SEG_LB_INT, SEG_UB_INT, SEG_P0_INT = 1, 2, 4
 
@@ -122,6 +129,8 @@ SIGNATURES = {
     "ccqp_ctx_create": [_I, _c.POINTER(_P)],
     "ccqp_ctx_destroy": [_P],
     "ccqp_ctx_info": [_P, _c.POINTER(_I), _c.POINTER(_I), _c.c_char_p, _I],
+    "ccqp_ctx_set_option": [_P, _I, _I64],
+    "ccqp_ctx_get_option": [_P, _I, _c.POINTER(_I64)],
     "ccqp_scalars_read": [_P, _I, _I, _c.POINTER(_D), _P],
     "ccqp_scalars_read_async": [_P, _I, _I, _P],
     "ccqp_scalars_host": [_P, _I, _I, _c.POINTER(_D)],
@@ -179,7 +188,7 @@ SIGNATURES = {
     "ccqp_pipe_graph_launch": [_P, _P, _P],
     "ccqp_pipe_graph_destroy": [_P],
     "ccqp_bpipe_partials_doubles": [_I64],
-    "ccqp_bpipe_matvec_form": [_I, _I64, _I, _c.c_char_p, _I],
+    "ccqp_bpipe_matvec_form": [_P, _I, _I64, _I, _c.c_char_p, _I],
     "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],
@@ -255,8 +264,9 @@ def load():
                       ctypes.c_int64 if name in ("ccqp_symv_workspace_doubles", "ccqp_spmv_plan_words",
                                                  "ccqp_bpipe_partials_doubles", "ccqp_segs_workspace_doubles")
                       else ctypes.c_int)
-    if lib.ccqp_abi_version() != 1:
-        raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s" % LIB_PATH)
+    if lib.ccqp_abi_version() != ABI_VERSION:
+        raise CCQPHipUnavailable("ccqppy_amd: ABI version mismatch in %s (library %d, binding %d): rebuild with `make`"
+                                 % (LIB_PATH, lib.ccqp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

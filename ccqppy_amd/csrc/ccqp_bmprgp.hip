@@ -213,17 +213,13 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_lds_kernel(const ccqp_
 template <int R, int S>
 static int bmprgp_launch_gemv_lds(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
                                   int wpb, hipStream_t s) {
-  static bool raised = false;
-  if (!raised) {
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bmprgp_gemv_lds_kernel<R, S>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised = true;
-  }
   const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  const int rcl = ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bmprgp_gemv_lds_kernel<R, S>), lds);
+  if (rcl) return rcl;
   // workgroups per problem: the tuning word's, else one workgroup per CU over the whole batch (at least 1 per problem)
   int64_t per = flags >> 8;
   if (per <= 0) per = ctx->num_cu / count > 0 ? ctx->num_cu / count : 1;
-  const int64_t rs = gemv_lds_row_stride(n, n, R);          // (the wave's R rows about 1 MiB apart, ccqp_bodies.h)
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);   // (the wave's R rows about 1 MiB apart, ccqp_bodies.h)
   const int64_t tasks = gemv_lds_tasks(n, R, rs);
   if (per > (tasks + wpb - 1) / wpb) per = (tasks + wpb - 1) / wpb;
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
@@ -315,32 +311,28 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_take_ahead_kernel(const ccq
   for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) to[i] = from[i];
 }
 
-// whether a run looks ahead: the persistent matvec is its default form (CCQP_MPRGP_LOOKAHEAD=0 in the environment: off,
-// the A/B switch of the tools)
-static bool bmprgp_looks_ahead(int count, int64_t n, int flags) {
-  static const bool off = [] {
-    const char* e = getenv("CCQP_MPRGP_LOOKAHEAD");
-    return e && e[0] == '0';
-  }();
-  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n, BP_LOOKAHEAD_MIN_N);
+// whether a run looks ahead: the persistent matvec is its form (the context's option MPRGP_LOOKAHEAD = 1: off, the A/B
+// switch of the tools)
+static bool bmprgp_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int flags) {
+  return !ccqp_opt(ctx, CCQP_OPT_MPRGP_LOOKAHEAD) && bp_pers_sharing(ctx, bp_mv_tune(count, n, flags), flags, count, n, true);
 }
 
 template <int R, int S>
 static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int wpb,
                                    int bpc, hipStream_t s) {
-  (void)ctx;
   const bmprgp_resolve rsv = {dev_probs, init};
-  return bp_launch_gemv_pers<R, S>(rsv, count, n, wpb, bpc, s);
+  return bp_launch_gemv_pers<R, S>(ctx, rsv, count, n, wpb, bpc, s);
 }
 
 static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int flags,
                                  hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n, elementwise && bmprgp_looks_ahead(count, n, flags) ? BP_LOOKAHEAD_MIN_N : 4096)) {
-    if (init == 0 && elementwise && bmprgp_looks_ahead(count, n, flags)) {   // (the segmented form does not look ahead)
+  const bool ahead = elementwise && bmprgp_looks_ahead(ctx, count, n, flags);
+  if (ahead || bp_pers_default(t, flags, count, n)) {
+    if (init == 0 && ahead) {
       hipLaunchKernelGGL(bmprgp_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
       const bmprgp_resolve3 rsv3 = {dev_probs};
-      const int rc3 = bp_launch_gemv3(rsv3, count, n, s);
+      const int rc3 = bp_launch_gemv3(ctx, rsv3, count, n, s);
       if (rc3) return rc3;
     }
     return bmprgp_launch_gemv_pers<4, 4>(ctx, dev_probs, count, n, init, 4, 1, s);
@@ -811,7 +803,7 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   hipLaunchKernelGGL(bmprgp_init_x_kernel, vgrid, blk, 0, s, dev_probs);
   int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
   if (rc) return rc;
-  const bool look = bmprgp_looks_ahead(count, n, flags);
+  const bool look = bmprgp_looks_ahead(ctx, count, n, flags);
   hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch, look ? 1.0 : 0.0);
   if (look) {
     // p_0 first (it needs x_0 and g_0 only), then A.g_0 and A.p_0 in one pass over every matrix
@@ -820,7 +812,7 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
     rc = ccqp_mv_stream_enter(ctx, s, &ms);
     if (rc) return rc;
     const bmprgp_resolve3_start rsv3 = {dev_probs};
-    rc = bp_launch_gemv3(rsv3, count, n, ms);
+    rc = bp_launch_gemv3(ctx, rsv3, count, n, ms);
     if (rc) return rc;
     rc = ccqp_mv_stream_leave(ctx, s, ms);
     if (rc) return rc;
@@ -847,15 +839,10 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
   const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s);
   if (rc) return rc;
-  // (by shape; CCQP_MPRGP_FUSED_TAIL=0 in the environment keeps the four launches: the A/B switch of the tools)
-  static const bool allow_fused = [] {
-    const char* e = getenv("CCQP_MPRGP_FUSED_TAIL");
-    return !(e && e[0] == '0');
-  }();
-  static const bool force_fused = [] {
-    const char* e = getenv("CCQP_MPRGP_FUSED_TAIL");
-    return e && e[0] == '2';                    // (2: wherever the kernel can run -- the A/B of the rule above)
-  }();
+  // (by shape; the context's option MPRGP_FUSED_TAIL: 1 keeps the four launches, 2 fuses wherever the kernel can run --
+  // the A/B switches of the tools and of tests/test_gpu_bmprgp.py)
+  const bool allow_fused = ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) != 1;
+  const bool force_fused = ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) == 2;
   const bool fuse = allow_fused && count >= 64 && nblk <= (force_fused ? MP_FUSED_MAX_BLK : MP_FUSED_USE_BLK);
   if (fuse) {
     hipLaunchKernelGGL(bmprgp_tail_fused_kernel, dim3(count), blk, 0, s, dev_probs, gd, eps10, chunk, nblk, dev_batch,
@@ -1491,7 +1478,7 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
   if (rc) return rc;
   if (max_nnorm > 0) hipLaunchKernelGGL(mps_norm_kernel, gn, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
   hipLaunchKernelGGL(mps_apply_kernel, gw, blk, 0, s, dev_probs, dev_segs, (int)MPS_START_RES, gd);
-  const bool look = bmprgp_looks_ahead(count, n, flags);
+  const bool look = bmprgp_looks_ahead(ctx, count, n, flags);
   hipLaunchKernelGGL(mps_init_res_kernel, dim3(count), blk, 0, s, dev_probs, dev_segs, dev_batch, look ? 1.0 : 0.0);
   if (look) {
     // p_0 first (it needs x_0 and g_0 only), then A.g_0 and A.p_0 in one pass over every matrix (as ccqp_bmprgp_start_f64)
@@ -1501,7 +1488,7 @@ extern "C" int ccqp_bsegs_mprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_
     rc = ccqp_mv_stream_enter(ctx, s, &ms);
     if (rc) return rc;
     const bmprgp_resolve3_start rsv3 = {dev_probs};
-    rc = bp_launch_gemv3(rsv3, count, n, ms);
+    rc = bp_launch_gemv3(ctx, rsv3, count, n, ms);
     if (rc) return rc;
     rc = ccqp_mv_stream_leave(ctx, s, ms);
     if (rc) return rc;

@@ -356,12 +356,11 @@ struct gemv_lds_desc {             // operands of one matrix of the multi-matrix
 // drift).  So task T of a matrix with row stride `rs` takes rows first, first + rs, ..., first + (R - 1) rs with
 // first = (T / rs) R rs + T mod rs: groups of R rs consecutive rows, dealt to rs tasks.  rs = 1: R consecutive rows.
 // The bits of y do not depend on it (they are a function of (row, n) only).
-// (CCQP_GEMV_ROW_STRIDE=k in the environment, read at every launch, forces rs = k: the A/B switch of the tools; 1 = R
+// (`forced` = the context's CCQP_OPT_GEMV_ROW_STRIDE, 0 = by shape: k forces rs = k -- the A/B switch of the tools; 1 = R
 // consecutive rows, the only form before round 3's probe)
-static inline int64_t gemv_lds_row_stride(int64_t lda, int64_t rows, int R) {
-  const char* e = getenv("CCQP_GEMV_ROW_STRIDE");
-  if (e && e[0] >= '1' && e[0] <= '9') {
-    int64_t k = atoll(e);
+static inline int64_t gemv_lds_row_stride(int64_t forced, int64_t lda, int64_t rows, int R) {
+  if (forced >= 1) {
+    int64_t k = forced;
     while (k > 1 && (int64_t)R * k > rows) k /= 2;
     return k < 1 ? 1 : k;
   }
@@ -494,10 +493,11 @@ __device__ __forceinline__ void gemv_lds2_body(const double* __restrict__ A, int
                                                const double* __restrict__ x2, const double* __restrict__ b,
                                                double* __restrict__ y1, double* __restrict__ g1, double* __restrict__ y2,
                                                double* __restrict__ g2, int64_t rows, int64_t cols, int64_t ntasks,
-                                               int64_t wave, int64_t nwaves, char* mine, double* res, int64_t rs) {
+                                               int64_t wave, int64_t nwaves, char* mine, double* res, int64_t rs,
+                                               int rescap = GEMV_LDS_RESCAP) {
   constexpr int PIECE = 1024;
   constexpr int SLOT = (R + 2) * PIECE;
-  constexpr int GROUP = GEMV_LDS_RESCAP / (2 * R);     // tasks per flush (two sums per row)
+  const int GROUP = rescap / (2 * R);           // tasks per flush (two sums per row; rescap <= GEMV_LDS_RESCAP)
   const int lane = threadIdx.x & 63;
   const int64_t nfull = cols / 128;
   const int tail = (int)(cols - nfull * 128);

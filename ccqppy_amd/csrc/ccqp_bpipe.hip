@@ -245,21 +245,22 @@ struct bpipe_resolve {
   }
 };
 
-void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+int ccqp_bp_gemv(ccqp_ctx* ctx, const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   if (bp_pers_default(t, flags, count, n)) {
     const bpipe_resolve rsv = {probs, i, mode};
-    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+    return bp_launch_gemv_pers<4, 4>(ctx, rsv, count, n, 4, 1, s);
   }
   BP_MV_LAUNCH(bpipe_gemv_kernel, probs, i, mode, n);
+  return CCQP_OK;
 }
 
 void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s) {
   hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, probs, n, chunk, nblk);
 }
 
-static void bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
-  ccqp_bp_gemv(probs, count, n, i, mode, flags, s);
+static int bp_gemv(ccqp_ctx* ctx, const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
+  return ccqp_bp_gemv(ctx, probs, count, n, i, mode, flags, s);
 }
 
 // Start-up of all solves (solvers.py:626-636): g0 = A x0 + b, residual, A g0, alpha0.  Expects x[0] staged, the
@@ -273,12 +274,14 @@ extern "C" int ccqp_bpipe_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   // (DONE is read by the matvec: the caller zeroes the slabs before this call)
-  bp_gemv(dev_probs, count, n, 0, 0, flags, s);
+  int rc = bp_gemv(ctx, dev_probs, count, n, 0, 0, flags, s);
+  if (rc) return rc;
   const int const_step = (flags & BP_FLAG_CONST_STEP) != 0;
   hipLaunchKernelGGL(bpipe_init_res_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, 0.0, const_step);
   if (!const_step) {                          // PGD (solvers.py:94-170) has no A.g0 / alpha0
-    bp_gemv(dev_probs, count, n, 0, 1, flags, s);
+    rc = bp_gemv(ctx, dev_probs, count, n, 0, 1, flags, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(bpipe_init_alpha_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk);
   }
   CCQP_LAUNCH_CHECK();
@@ -295,7 +298,8 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   hipStream_t s = (hipStream_t)stream;
   const int inew = (int)(iteration % 3), icur = (int)((iteration - 1) % 3);
   hipLaunchKernelGGL(bpipe_step_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur);
-  bp_gemv(dev_probs, count, n, inew, 0, flags, s);
+  const int rc = bp_gemv(ctx, dev_probs, count, n, inew, 0, flags, s);
+  if (rc) return rc;
   if (with_tail) {
     int64_t chunk;
     int nblk;
@@ -331,13 +335,14 @@ extern "C" int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out) {
 // the tuning word): "bp_gemv_pers_kernel" (one persistent LDS-DMA launch for the whole batch) or "batched VALU kernel".
 // Bit 16 of `flags` asks for the runs that share passes between products (ccqp_bapgd_* / ccqp_bmprgp_* with their
 // look-ahead on): those take the persistent form from n = 1024 on.
-extern "C" int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen) {
+// (bit 18 beside bit 16: the sharing run is MPRGP -- it shares passes from a smaller n on than APGD, bp_lookahead_min_n)
+extern "C" int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int flags, char* name, int buflen) {
   CCQP_REQUIRE(name != nullptr && buflen > 0 && count >= 1 && n >= 1, "bad argument");
-  const bool shares = (flags >> 16) & 1;
+  const bool shares = (flags >> 16) & 1, mprgp = (flags >> 18) & 1;
   flags &= 0xFFFF;
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool lds_tuned = ((flags >> 1) & 3) == 3 && ((flags >> 4) & 7) >= 4;          // (MPRGP's explicit ring codes)
-  const char* k = bp_pers_default(t, flags, count, n, shares ? BP_LOOKAHEAD_MIN_N : 4096) ||
+  const char* k = (shares ? bp_pers_sharing(ctx, t, flags, count, n, mprgp) : bp_pers_default(t, flags, count, n)) ||
                           (lds_tuned && t.aligned && n % 2 == 0 && n >= 128)
                       ? "bp_gemv_pers_kernel" : "batched VALU kernel";
   strncpy(name, k, (size_t)buflen - 1);
@@ -705,7 +710,9 @@ struct bapgd_resolve {
     d->A = q.A;
     d->lda = q.lda;
     if (init) {
-      if (init == 2 && q.ga != nullptr && q.Aya != nullptr) return false;   // (multiplied by bapgd_resolve3_start)
+      // (init == 2: the start of a run that looks ahead -- only then are `ga` / `Aya` read; a problem WITH the two
+      // buffers was multiplied by bapgd_resolve3_start)
+      if (init == 2 && q.ga != nullptr && q.Aya != nullptr) return false;
       d->x = q.X[1];
       d->b = nullptr;
       d->y = q.Ax1;
@@ -784,53 +791,60 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_take_ahead_kernel(const ccqp
   }
 }
 
-// (CCQP_APGD_LOOKAHEAD=0 in the environment: off -- the A/B switch of the tools)
-static bool bapgd_looks_ahead(int count, int64_t n, int flags) {
-  static const bool off = [] {
-    const char* e = getenv("CCQP_APGD_LOOKAHEAD");
-    return e && e[0] == '0';
-  }();
-  return !off && bp_pers_default(bp_mv_tune(count, n, flags), flags, count, n, BP_LOOKAHEAD_MIN_N);
+// whether a run looks ahead: the caller asked for it (CCQP_LOCKSTEP_LOOKAHEAD: every problem has its two buffers) and the
+// persistent matvec is the run's form (the context's option APGD_LOOKAHEAD = 1: off -- the A/B switch of the tools)
+static bool bapgd_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int flags, bool asked) {
+  return asked && !ccqp_opt(ctx, CCQP_OPT_APGD_LOOKAHEAD) &&
+         bp_pers_sharing(ctx, bp_mv_tune(count, n, flags), flags, count, n, false);
 }
 
-void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,
-                            bool elementwise) {
+int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, int64_t n, int init, int flags, bool look,
+                           hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n, elementwise && bapgd_looks_ahead(count, n, flags) ? BP_LOOKAHEAD_MIN_N : 4096)) {
-    if (init == 0 && elementwise && bapgd_looks_ahead(count, n, flags)) {
+  const bool ahead = elementwise && bapgd_looks_ahead(ctx, count, n, flags, look);
+  if (ahead || bp_pers_default(t, flags, count, n)) {
+    if (init == 0 && ahead) {
       hipLaunchKernelGGL(bapgd_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
       const bapgd_resolve3 rsv3 = {probs};
-      (void)bp_launch_gemv3(rsv3, count, n, s);
+      // (a three-vector launch that cannot be queued fails the round: the slabs already say "computed ahead")
+      const int rc3 = bp_launch_gemv3(ctx, rsv3, count, n, s);
+      if (rc3) return rc3;
     }
     const bapgd_resolve rsv = {probs, init};
-    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+    return bp_launch_gemv_pers<4, 4>(ctx, rsv, count, n, 4, 1, s);
   }
   BP_MV_LAUNCH(bapgd_gemv_kernel, probs, init, n);
+  return CCQP_OK;
 }
 
 // Start-up of all solves: d = x0 - 1, A d, L, t.  Expects X[0] = Y[0] = x0, slabs and counters zero.
 extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
                                     uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
+  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0;
+  flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
-  if (bapgd_looks_ahead(count, n, flags)) {
-    // (problems without the two buffers -- the segmented form, the anti-relaxation variant -- take no part here and
-    // are multiplied by the single launch below; with them the three-vector launch finds nothing to do below)
+  const bool look = bapgd_looks_ahead(ctx, count, n, flags, asked);
+  int rc;
+  if (look) {
+    // (a problem whose two buffers are NULL takes no part here and is multiplied by the single launch below; with every
+    // problem looking ahead that launch finds nothing to do)
     const bapgd_resolve3_start rsv3 = {dev_probs};
-    (void)bp_launch_gemv3(rsv3, count, n, s);
-    ccqp_bapgd_launch_gemv(dev_probs, count, n, 2, flags, s);       // init = 2: the problems the launch above left out
+    rc = bp_launch_gemv3(ctx, rsv3, count, n, s);
+    if (rc) return rc;
+    rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 2, flags, look, s);   // init = 2: the problems the launch above left out
   } else {
-    ccqp_bapgd_launch_gemv(dev_probs, count, n, 1, flags, s);
+    rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 1, flags, look, s);
   }
-  // (a run looks ahead if the caller gave it the two buffers for the products computed ahead: probs[p].ga / .Aya; the
-  // flag travels in the problems' slabs, set here)
+  if (rc) return rc;
+  // (the flag travels in the problems' slabs, set here: AP_LOOK)
   hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk,
-                     bapgd_looks_ahead(count, n, flags) ? 1.0 : 0.0);
+                     look ? 1.0 : 0.0);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -840,11 +854,14 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
                                     double gd, int flags, uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0;
+  flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s);
+  const int rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 0, flags, asked, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, (flags & BP_FLAG_CONST_STEP) != 0);
   hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);

@@ -257,7 +257,8 @@ extern "C" int ccqp_bsegs_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
-  ccqp_bp_gemv(dev_probs, count, n, 0, 0, flags, s);
+  int rc = ccqp_bp_gemv(ctx, dev_probs, count, n, 0, 0, flags, s);
+  if (rc) return rc;
   const int const_step = (flags & BP_FLAG_CONST_STEP) != 0;
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_norm_kernel, dim3((unsigned)max_nnorm, count), dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs,
@@ -267,7 +268,8 @@ extern "C" int ccqp_bsegs_start_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, 
   hipLaunchKernelGGL(bsegs_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, 0, 0.0, n,
                      chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, 0.0, const_step, 1);
   if (!const_step) {
-    ccqp_bp_gemv(dev_probs, count, n, 0, 1, flags, s);
+    rc = ccqp_bp_gemv(ctx, dev_probs, count, n, 0, 1, flags, s);
+    if (rc) return rc;
     ccqp_bp_init_alpha(dev_probs, count, n, chunk, nblk, s);
   }
   CCQP_LAUNCH_CHECK();
@@ -287,7 +289,8 @@ extern "C" int ccqp_bsegs_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, icur, gd);
   hipLaunchKernelGGL(bsegs_step_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, inew, icur, 0, gd);
-  ccqp_bp_gemv(dev_probs, count, n, inew, 0, flags, s);
+  const int rc = ccqp_bp_gemv(ctx, dev_probs, count, n, inew, 0, flags, s);
+  if (rc) return rc;
   if (with_tail) {
     int64_t chunk;
     int nblk;
@@ -393,9 +396,12 @@ extern "C" int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_pr
                                          double gd, int flags, uint32_t* dev_batch, void* stream) {
   BSEGS_CHECK();
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0;
+  flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gw((unsigned)max_nwork, count), gn((unsigned)(max_nnorm > 0 ? max_nnorm : 1), count);
-  ccqp_bapgd_launch_gemv(dev_probs, count, n, 0, flags, s, true);     // (looks ahead like the elementwise form)
+  const int rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 0, flags, asked, s, true);   // (looks ahead like the elementwise form)
+  if (rc) return rc;
   if (max_nnorm > 0)
     hipLaunchKernelGGL(bsegs_apgd_norm_kernel, gn, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);
   hipLaunchKernelGGL(bsegs_apgd_apply_kernel, gw, dim3(CCQP_BLOCK), 0, s, dev_probs, dev_segs, 0, gd);

@@ -313,14 +313,15 @@ struct bspg_resolve {
   }
 };
 
-static void bspg_gemv(const ccqp_pspg* probs, const double* ctl, int count, int64_t n, int which, int flags,
-                      hipStream_t s) {
+static int bspg_gemv(ccqp_ctx* ctx, const ccqp_pspg* probs, const double* ctl, int count, int64_t n, int which, int flags,
+                     hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   if (bp_pers_default(t, flags, count, n)) {
     const bspg_resolve rsv = {probs, ctl, which};
-    if (bp_launch_gemv_pers<4, 4>(rsv, count, n, 4, 1, s) == CCQP_OK) return;
+    return bp_launch_gemv_pers<4, 4>(ctx, rsv, count, n, 4, 1, s);
   }
   BP_MV_LAUNCH(bspg_gemv_kernel, probs, ctl, which, n);
+  return CCQP_OK;
 }
 
 // One group of consecutive problems of the batch: its rounds are queued and awaited on their own, so that while the
@@ -391,8 +392,9 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
       __atomic_thread_fence(__ATOMIC_RELEASE);
       hipLaunchKernelGGL(bspg_ctl_kernel, dim3((4 * count + CCQP_BLOCK - 1) / CCQP_BLOCK), blk, 0, s, hctl_dev, dev_ctl,
                          4 * count);
-      bspg_gemv(dev_probs, dev_ctl, count, n, 0, mvflags, s);
-      bspg_gemv(dev_probs, dev_ctl, count, n, 1, mvflags, s);
+      rc = bspg_gemv(ctx, dev_probs, dev_ctl, count, n, 0, mvflags, s);
+      if (!rc) rc = bspg_gemv(ctx, dev_probs, dev_ctl, count, n, 1, mvflags, s);
+      if (rc) return rc;
       hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, count), blk, 0, s, dev_probs, dev_ctl, dev_out, hout_dev, 1, n,
                          chunk, nblk, grp[0].batch, grp[0].flag_dev, nlive, count, 1.0);
       CCQP_LAUNCH_CHECK();
@@ -461,7 +463,7 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
     }
     if (!nlive) return 2;                                // only final updates: nothing will be reported
     G.seq += 1.0;
-    bspg_gemv(probs, ctl, cnt, n, 2, mvflags, s);
+    if (bspg_gemv(ctx, probs, ctl, cnt, n, 2, mvflags, s)) return -1;      // (the message is set)
     hipLaunchKernelGGL(bspg_dots_kernel, dim3(nblk, cnt), blk, 0, s, probs, ctl, dev_out + 4 * p0, hout_dev + 4 * p0, 0,
                        n, chunk, nblk, G.batch, G.flag_dev, nlive, cnt, G.seq);
     G.inflight = true;
@@ -491,6 +493,7 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
       }
       if (stop) continue;
       const int what = launch_round(G);
+      if (what < 0) return CCQP_ERR_HIP;
       CCQP_LAUNCH_CHECK();
       if (what == 2) {
         // the control words of this group must not be overwritten while the copy kernel may still be reading them

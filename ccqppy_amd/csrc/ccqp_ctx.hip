@@ -150,6 +150,8 @@ extern "C" int ccqp_ctx_create(int device, ccqp_ctx** out) {
   c->xchg_host = nullptr;
   c->xchg_host_dev = nullptr;
   c->xchg_doubles = 0;
+  for (int k = 0; k < CCQP_OPT_COUNT; ++k) c->opt[k] = 0;
+  c->lds_nraised = 0;
   hipError_t e = hipMalloc(&c->slots, CCQP_NUM_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&c->partials, CCQP_PARTIALS_DOUBLES * sizeof(double));
   if (e == hipSuccess) e = hipMemset(c->partials, 0, CCQP_PARTIALS_DOUBLES * sizeof(double));
@@ -187,6 +189,67 @@ extern "C" int ccqp_ctx_destroy(ccqp_ctx* c) {
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->xchg_host) (void)hipHostFree(c->xchg_host);
   delete c;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
+  CCQP_REQUIRE(c != nullptr, "ctx is NULL");
+  CCQP_REQUIRE(key >= 0 && key < CCQP_OPT_COUNT, "no such option");
+  bool ok = value >= 0;
+  switch (key) {
+    case CCQP_OPT_GEMV2_WPB: ok = value >= 0 && value <= 4; break;
+    case CCQP_OPT_GEMV2_SHAPE: ok = value == 0 || value == 44 || value == 43 || value == 82 || value == 83 || value == 84; break;
+    case CCQP_OPT_GEMV2_GROUP: ok = value == 0 || (value >= 64 && value <= 512 && value % 16 == 0); break;
+    case CCQP_OPT_BMV3_SHAPE: ok = value == 0 || value == 824 || value == 833 || value == 444 || value == 434; break;
+    case CCQP_OPT_LOOKAHEAD_MIN_N:
+    case CCQP_OPT_MPRGP_LOOKAHEAD_MIN_N:
+    case CCQP_OPT_PERS1_MIN_N: ok = value == 0 || value >= 128; break;
+    case CCQP_OPT_MPRGP_LOOKAHEAD:
+    case CCQP_OPT_APGD_LOOKAHEAD:
+    case CCQP_OPT_BMV_STAGGER: ok = value == 0 || value == 1; break;
+    case CCQP_OPT_MPRGP_FUSED_TAIL: ok = value >= 0 && value <= 2; break;
+    default: break;
+  }
+  CCQP_REQUIRE(ok, "value outside the option's range");
+  c->opt[key] = value;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_ctx_get_option(ccqp_ctx* c, int key, int64_t* value) {
+  CCQP_REQUIRE(c != nullptr && value != nullptr, "NULL argument");
+  CCQP_REQUIRE(key >= 0 && key < CCQP_OPT_COUNT, "no such option");
+  *value = c->opt[key];
+  return CCQP_OK;
+}
+
+int ccqp_lds_raise(ccqp_ctx* c, const void* fn, size_t bytes) {
+  CCQP_REQUIRE(c != nullptr && fn != nullptr, "NULL argument");
+  if (bytes > 160 * 1024) {
+    ccqp_set_error("ccqp_lds_raise: %zu bytes of LDS asked for, a compute unit has 160 KiB", bytes);
+    return CCQP_ERR_UNSUPPORTED;
+  }
+  int at = -1;
+  for (int i = 0; i < c->lds_nraised; ++i)
+    if (c->lds_raised[i].fn == fn) {
+      if (c->lds_raised[i].bytes >= bytes) return CCQP_OK;
+      at = i;
+      break;
+    }
+  if (bytes <= 64 * 1024 && at < 0) return CCQP_OK;       // (within the default limit: nothing to ask for)
+  // the attribute belongs to the device that is current: the caller keeps the context's device current (ccqp_hip.h)
+  int dev = -1;
+  CCQP_HIP(hipGetDevice(&dev));
+  if (dev != c->device) {
+    ccqp_set_error("ccqp_lds_raise: device %d is current, the context belongs to device %d", dev, c->device);
+    return CCQP_ERR_INVALID;
+  }
+  CCQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (at < 0) {
+    if (c->lds_nraised == CCQP_LDS_KERNELS) return CCQP_OK;   // (table full: the attribute is set, only not remembered)
+    at = c->lds_nraised++;
+    c->lds_raised[at].fn = fn;
+  }
+  c->lds_raised[at].bytes = bytes;
   return CCQP_OK;
 }
 

@@ -198,25 +198,19 @@ static gemv_lds_shape gemv_lds_decode(int variant) {
 }
 
 template <int R, int S>
-static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, int stagger, hipStream_t s, const double* A,
-                         int64_t lda, const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
-                         const double* skip) {
-  const int64_t rs = gemv_lds_row_stride(lda, rows, R);
+static int launch_lds_rs(ccqp_ctx* ctx, int64_t blocks, bool nt, size_t lds, int wpb, int stagger, hipStream_t s,
+                         const double* A, int64_t lda, const double* x, const double* b, double* y, double* g, int64_t rows,
+                         int64_t cols, const double* skip) {
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), lda, rows, R);
   const int64_t ntasks = gemv_lds_tasks(rows, R, rs);
   if (stagger < 0) {
     // by size: the longest delay (63 x stagger x 64 clocks ~ 1.9 us x stagger) stays near 0.3 % of the launch's duration
     const double gib4 = 8.0 * (double)rows * (double)cols / 4294967296.0;
     stagger = gib4 < 1.0 ? 1 : gib4 > 32.0 ? 32 : (int)(gib4 + 0.5);
   }
-  static bool raised = false;                   // more than 64 KiB of dynamic LDS has to be asked for once per kernel
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds_kernel<R, S, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds_kernel<R, S, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return 1;
-    raised = true;
-  }
+  // (more than 64 KiB of dynamic LDS has to be asked for, per kernel and device: ccqp_lds_raise)
+  if (ccqp_lds_raise(ctx, reinterpret_cast<const void*>(nt ? gemv_lds_kernel<R, S, true> : gemv_lds_kernel<R, S, false>), lds))
+    return 1;
   if (nt)
     hipLaunchKernelGGL((gemv_lds_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x, b, y,
                        g, rows, cols, ntasks, skip, stagger, rs);
@@ -226,11 +220,12 @@ static int launch_lds_rs(int64_t blocks, bool nt, size_t lds, int wpb, int stagg
   return 0;
 }
 
-static int launch_lds(const gemv_lds_shape& h, int64_t blocks, bool nt, hipStream_t s, const double* A, int64_t lda,
-                      const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
+static int launch_lds(ccqp_ctx* ctx, const gemv_lds_shape& h, int64_t blocks, bool nt, hipStream_t s, const double* A,
+                      int64_t lda, const double* x, const double* b, double* y, double* g, int64_t rows, int64_t cols,
                       const double* skip) {
 #define LDS_CASE(RR, SS) \
-  if (h.R == RR && h.S == SS) return launch_lds_rs<RR, SS>(blocks, nt, h.lds, h.wpb, h.stagger, s, A, lda, x, b, y, g, rows, cols, skip)
+  if (h.R == RR && h.S == SS)   \
+  return launch_lds_rs<RR, SS>(ctx, blocks, nt, h.lds, h.wpb, h.stagger, s, A, lda, x, b, y, g, rows, cols, skip)
   LDS_CASE(1, 4);
   LDS_CASE(1, 8);
   LDS_CASE(1, 16);
@@ -385,7 +380,7 @@ int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* 
       int64_t lb = (ntasks + h.wpb - 1) / h.wpb;
       if (lb > cap) lb = cap;
       if (lb < 1) lb = 1;
-      bad = launch_lds(h, lb, nt, s, Ar, lda, x, br, yr, gr, nr, cols, skip);
+      bad = launch_lds(ctx, h, lb, nt, s, Ar, lda, x, br, yr, gr, nr, cols, skip);
       continue;
     }
     switch (R) {
@@ -434,7 +429,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds2_kernel(const double* __r
                                                                const double* __restrict__ b, double* __restrict__ y1,
                                                                double* __restrict__ g1, double* __restrict__ y2,
                                                                double* __restrict__ g2, int64_t rows, int64_t cols,
-                                                               int64_t ntasks, int stagger, int64_t rs) {
+                                                               int64_t ntasks, int stagger, int64_t rs, int rescap) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int RING = S * (R + 2) * 1024;
@@ -443,39 +438,35 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds2_kernel(const double* __r
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (staggered start)
-  gemv_lds2_body<R, S, NT>(A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs);
+  gemv_lds2_body<R, S, NT>(A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs,
+                           rescap);
 #endif
 }
 
 template <int R, int S>
-static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, hipStream_t s, const double* A, int64_t lda,
-                       const double* x1, const double* x2, const double* b, double* y1, double* g1, double* y2, double* g2,
-                       int64_t rows, int64_t cols) {
+static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, int rescap, hipStream_t s, const double* A,
+                       int64_t lda, const double* x1, const double* x2, const double* b, double* y1, double* g1, double* y2,
+                       double* g2, int64_t rows, int64_t cols) {
   size_t lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
   while (wpb > 1 && lds > 160 * 1024) {           // (a ring that does not fit: fewer waves per workgroup)
     wpb -= 1;
     lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
   }
   if (bpc < 1 || (size_t)bpc * lds > 160 * 1024) bpc = 1;
-  const int64_t rs = gemv_lds_row_stride(lda, rows, R);
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), lda, rows, R);
   const int64_t ntasks = gemv_lds_tasks(rows, R, rs);
   int64_t blocks = (ntasks + wpb - 1) / wpb;
   if (blocks > (int64_t)ctx->num_cu * bpc) blocks = (int64_t)ctx->num_cu * bpc;
   if (blocks < 1) blocks = 1;
-  static bool raised = false;
-  if (!raised) {
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds2_kernel<R, S, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_lds2_kernel<R, S, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised = true;
-  }
+  const int rc = ccqp_lds_raise(
+      ctx, reinterpret_cast<const void*>(nt ? gemv_lds2_kernel<R, S, true> : gemv_lds2_kernel<R, S, false>), lds);
+  if (rc) return rc;
   if (nt)
     hipLaunchKernelGGL((gemv_lds2_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x1, x2, b, y1, g1,
-                       y2, g2, rows, cols, ntasks, stagger, rs);
+                       y2, g2, rows, cols, ntasks, stagger, rs, rescap);
   else
     hipLaunchKernelGGL((gemv_lds2_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, x1, x2, b, y1,
-                       g1, y2, g2, rows, cols, ntasks, stagger, rs);
+                       g1, y2, g2, rows, cols, ntasks, stagger, rs, rescap);
   return CCQP_OK;
 }
 
@@ -484,6 +475,7 @@ static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, hi
 // (the default, variant == 0, from 2^24 elements -- 4096^2 -- on: there ONE pass of the LDS-staged pair kernel beats two
 // passes of whichever single form is the default, 27 against 46 us at 4096^2, 89 against 168 us at 8192^2, 0.33 against
 // 0.64 ms at 16384^2; at 2048^2 a tie -- profiles/r03_gemv2_small.jsonl)
+#define GEMV2_DEFAULT_SHAPE 44
 static bool gemv2_default_fused(int64_t rows, int64_t cols) { return (double)rows * (double)cols >= 16777216.0; }
 
 static bool gemv2_fused(int variant, const double* A, int64_t lda, const double* x1, const double* x2, int64_t rows,
@@ -539,15 +531,28 @@ extern "C" int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const
   const bool nt = !((v >> 8) & 1) && (double)rows * (double)cols * 8.0 > 192.0 * 1048576.0;
   // waves per workgroup: FOUR by default (twice the single matvec's: a wave's step now feeds two fma chains per row and
   // reads two x pieces, and two waves per CU no longer hide it -- 19.36 against 22.06 ms on the headline matrix,
-  // profiles/r03_gemv2_sweep.jsonl); an explicit variant word keeps its own count; CCQP_GEMV2_WPB: the tools' A/B switch
+  // profiles/r03_gemv2_sweep.jsonl); an explicit variant word keeps its own count; the context's options GEMV2_WPB /
+  // GEMV2_SHAPE / GEMV2_GROUP are the tools' A/B switches (same bits whatever the shape)
   int wpb = variant == 0 ? CCQP_BLOCK / 64 : h.wpb;
-  {
-    const char* e = getenv("CCQP_GEMV2_WPB");
-    if (e && e[0] >= '1' && e[0] <= '4') wpb = e[0] - '0';
+  if (ccqp_opt(ctx, CCQP_OPT_GEMV2_WPB)) wpb = (int)ccqp_opt(ctx, CCQP_OPT_GEMV2_WPB);
+  // ring shape <rows per wave><slots>: 44 = the single matvec's (variant bits 28-29 = 3 ask for eight rows: 84)
+  int shape = (int)ccqp_opt(ctx, CCQP_OPT_GEMV2_SHAPE);
+  if (shape == 0) shape = h.R == 8 ? 84 : GEMV2_DEFAULT_SHAPE;
+  int rescap = (int)ccqp_opt(ctx, CCQP_OPT_GEMV2_GROUP);
+  if (rescap == 0) rescap = GEMV_LDS_RESCAP;
+#define LDS2_CASE(RR, SS) \
+  case RR * 10 + SS:      \
+    rc = launch_lds2<RR, SS>(ctx, wpb, bpc, nt, stagger, rescap, s, A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols); \
+    break
+  switch (shape) {
+    LDS2_CASE(4, 3);
+    LDS2_CASE(8, 2);
+    LDS2_CASE(8, 3);
+    LDS2_CASE(8, 4);
+    default:
+      LDS2_CASE(4, 4);
   }
-  // rows per wave: 4 (the single matvec's shape) or 8 (variant bits 28-29 = 3: half the x traffic per byte of A)
-  if (h.R == 8) rc = launch_lds2<8, 4>(ctx, wpb, bpc, nt, stagger, s, A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols);
-  else rc = launch_lds2<4, 4>(ctx, wpb, bpc, nt, stagger, s, A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols);
+#undef LDS2_CASE
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

@@ -82,7 +82,7 @@ extern "C" int ccqp_gemv3_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const
     rsv.d.y[j] = on ? y[j] : nullptr;
     rsv.d.g[j] = on ? g[j] : nullptr;
   }
-  const int rc = bp_launch_gemv3(rsv, 1, n, s);
+  const int rc = bp_launch_gemv3(ctx, rsv, 1, n, s);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

@@ -14,6 +14,8 @@
 #define CCQP_RED_ROWS (CCQP_MAX_STEPS + 1)   // rows of CCQP_RED_MAXBLK partials: up to 16 sums per launch + 1
 #define CCQP_PARTIALS_DOUBLES ((size_t)CCQP_RED_ROWS * CCQP_RED_MAXBLK + CCQP_RED_COUNTERS / 2)
 
+#define CCQP_LDS_KERNELS 128       // distinct kernels with more than 64 KiB of dynamic LDS a context can keep track of
+
 struct ccqp_batch;                 // descriptor ring of the batched launch form (ccqp_batch.hip)
 void ccqp_batch_free(struct ccqp_ctx* ctx);
 
@@ -35,7 +37,23 @@ struct ccqp_ctx {
   double* xchg_host;      // pinned, coherent exchange area of the host-in-the-loop lock-step driver (ccqp_bspg.hip),
   double* xchg_host_dev;  // grown on demand; the same memory as the device sees it
   size_t xchg_doubles;
+  int64_t opt[CCQP_OPT_COUNT];  // tuning options (ccqp_ctx_set_option); 0 = the tuned default
+  // kernels whose dynamic-LDS limit this context has raised on ITS device (hipFuncAttributeMaxDynamicSharedMemorySize is
+  // kept per device by the runtime; a context belongs to one device and is driven by one host thread)
+  struct {
+    const void* fn;
+    size_t bytes;
+  } lds_raised[CCQP_LDS_KERNELS];
+  int lds_nraised;
 };
+
+// tuning option `key` of a context (0 = default; a NULL context has only defaults)
+static inline int64_t ccqp_opt(const struct ccqp_ctx* ctx, int key) { return ctx ? ctx->opt[key] : 0; }
+
+// Makes sure kernel `fn` may be launched with `bytes` of dynamic LDS on the context's device: the first launch of a
+// kernel that needs more than 64 KiB (and any later one that needs more than was asked for) raises the function's
+// attribute, once per context -- never per process (ccqp_ctx.hip).
+int ccqp_lds_raise(struct ccqp_ctx* ctx, const void* fn, size_t bytes);
 
 void ccqp_set_error(const char* fmt, ...);
 

@@ -1,7 +1,6 @@
 // Shared pieces of the lock-step batch drivers (ccqp_bpipe.hip: BBPGD and APGD; ccqp_bmprgp.hip: MPRGP): slab slots,
 // the per-problem meeting point, the batch-wide roll-call with its host mirror, the batched matvec's tuning.
 #pragma once
-#include <stdlib.h>
 #include "ccqp_bodies.h"
 
 #define BP_ALPHA 48
@@ -338,17 +337,6 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
 #endif
 }
 
-static inline int bp_num_cu() {
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cus[dev] == 0) {
-    int v = 0;
-    cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
-  }
-  return cus[dev];
-}
-
 // The tuned default of every lock-step solver (no loads / rows-x-steps / workgroups field in the tuning word; bits 3
 // and 7 are solver variants): from n = 4096 and 1 GiB of matrices on, the persistent form.  Measured against the VALU
 // kernels: the launch alone (tools/bmv_sweep.py, profiles/r03_bmv_sweep_stride.jsonl) 128 x 8192 +1.7 %, 512 x 4096
@@ -363,38 +351,41 @@ static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, 
   return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= min_n &&
          8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
 }
-static inline int64_t bp_lookahead_min_n() {
-  static const int64_t v = [] {
-    const char* e = getenv("CCQP_LOOKAHEAD_MIN_N");      // (A/B switch of the tools)
-    const long long x = e ? atoll(e) : 0;
-    return (int64_t)(x >= 128 ? x : 1024);
-  }();
-  return v;
+// smallest n at which a lock-step run that shares passes takes the persistent form (the context's options LOOKAHEAD_MIN_N
+// for APGD, MPRGP_LOOKAHEAD_MIN_N for MPRGP are the tools' A/B switches).  MPRGP shares up to three products per pass and
+// gains from n = 512 on (+5 ... +6 % there, profiles/r03_lockstep_matvec_forms_tiny.jsonl); APGD shares two and loses
+// 3-8 % at n = 512, so its threshold stays at 1024.
+static inline int64_t bp_lookahead_min_n(const ccqp_ctx* ctx, bool mprgp = false) {
+  const int64_t x = ccqp_opt(ctx, mprgp ? CCQP_OPT_MPRGP_LOOKAHEAD_MIN_N : CCQP_OPT_LOOKAHEAD_MIN_N);
+  return x >= 128 ? x : (mprgp ? 512 : 1024);
 }
-#define BP_LOOKAHEAD_MIN_N bp_lookahead_min_n()
+
+// Runs that SHARE passes between products (lock-step APGD / MPRGP with their look-ahead): the persistent form where
+// bp_pers_default says so from the run's own threshold on, and -- whatever the bytes, down to a batch of ONE problem --
+// from n = 4096 on (the context's option PERS1_MIN_N moves that): one pass of the multi-vector launch replaces two or
+// three single ones there (4096^2: 27 against 46 us for a pair, 31 against 71 us for a triple, profiles/r03_gemv2_small.jsonl),
+// which is what makes a device-resident single solve of 2048 < n <= 16384 faster than the host-driven loop.
+static inline bool bp_pers_sharing(const ccqp_ctx* ctx, const bp_mv_tuning& t, int flags, int count, int64_t n, bool mprgp) {
+  if (bp_pers_default(t, flags, count, n, bp_lookahead_min_n(ctx, mprgp))) return true;
+  const int64_t m = ccqp_opt(ctx, CCQP_OPT_PERS1_MIN_N) ? ccqp_opt(ctx, CCQP_OPT_PERS1_MIN_N) : 4096;
+  return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= m;
+}
 
 template <int R, int S, class Resolve>
-static int bp_launch_gemv_pers(const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
+static int bp_launch_gemv_pers(ccqp_ctx* ctx, const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
   const int chunk = count < BMV_PERS_MAX ? count : BMV_PERS_MAX;
   const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
                      (size_t)chunk * sizeof(gemv_lds_desc);
-  static size_t raised = 0;                     // (the kernel also holds a few bytes of static LDS: ask for what is needed)
-  if (lds > raised) {
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = lds;
-  }
+  // (the kernel also holds a few bytes of static LDS: ask for what is needed)
+  const int rcl = ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve>), lds);
+  if (rcl) return rcl;
   // start delay unit of the waves per live problem: one unit per 4 GiB read, as the single matvec's (ccqp_gemv.hip)
-  static const bool stagger_off = [] {
-    const char* e = getenv("CCQP_BMV_STAGGER");      // (A/B switch of the tools: 0 = none)
-    return e && e[0] == '0';
-  }();
-  const float stagger = stagger_off ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  const float stagger = ccqp_opt(ctx, CCQP_OPT_BMV_STAGGER) ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
   for (int first = 0; first < count; first += BMV_PERS_MAX)      // (more than BMV_PERS_MAX problems: one launch per group)
-    hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(bp_num_cu() * bpc)), dim3(64 * wpb), lds, s, rsv,
-                       first, count - first < BMV_PERS_MAX ? count - first : BMV_PERS_MAX, n, gemv_lds_row_stride(n, n, R),
-                       stagger);
+    hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(ctx->num_cu * bpc)), dim3(64 * wpb), lds, s, rsv,
+                       first, count - first < BMV_PERS_MAX ? count - first : BMV_PERS_MAX, n, rs, stagger);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }
@@ -437,7 +428,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve
 }
 
 template <int R, int S, class Resolve3>
-static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int wpb, hipStream_t s) {
+static int bp_launch_gemv3_pers(ccqp_ctx* ctx, const Resolve3& rsv, int count, int64_t n, int wpb, hipStream_t s) {
   const int chunk = count < BMV3_PERS_MAX ? count : BMV3_PERS_MAX;
   const size_t lds = (size_t)wpb * ((size_t)S * (R + 3) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
                      (size_t)chunk * sizeof(gemv_lds3_desc);
@@ -445,22 +436,14 @@ static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int w
     ccqp_set_error("%s: ring does not fit", __func__);
     return CCQP_ERR_UNSUPPORTED;
   }
-  static size_t raised = 0;
-  if (lds > raised) {
-    CCQP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = lds;
-  }
-  static const bool stagger_off = [] {
-    const char* e = getenv("CCQP_BMV_STAGGER");
-    return e && e[0] == '0';
-  }();
-  const float stagger = stagger_off ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  const int rcl = ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3>), lds);
+  if (rcl) return rcl;
+  const float stagger = ccqp_opt(ctx, CCQP_OPT_BMV_STAGGER) ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
   for (int first = 0; first < count; first += BMV3_PERS_MAX)
-    hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3>), dim3((unsigned)bp_num_cu()), dim3(64 * wpb), lds, s, rsv, first,
-                       count - first < BMV3_PERS_MAX ? count - first : BMV3_PERS_MAX, n, gemv_lds_row_stride(n, n, R),
-                       stagger);
+    hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3>), dim3((unsigned)ctx->num_cu), dim3(64 * wpb), lds, s, rsv, first,
+                       count - first < BMV3_PERS_MAX ? count - first : BMV3_PERS_MAX, n, rs, stagger);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }
@@ -472,22 +455,18 @@ static int bp_launch_gemv3_pers(const Resolve3& rsv, int count, int64_t n, int w
 // depend on the shape.  With FEW matrices per launch the waves crowd on one matrix at a time and the bytes a wave keeps
 // in flight count for more: <4, 4> x 4 waves (12 KiB per wave against 8) is 2-5 % ahead for a single problem of
 // n <= 16384 and level at n = 32768 (ccqp_gemv3_f64), level to +1 % for 2 ... 16 problems -- kept below 32 problems.
-// CCQP_BMV3_SHAPE=<R><S><W> in the environment is the A/B switch of the tools.
-static inline int bp_gemv3_shape(int count) {
-  static const int forced = [] {
-    const char* e = getenv("CCQP_BMV3_SHAPE");
-    const int x = e ? atoi(e) : 0;
-    return (x == 833 || x == 824 || x == 444 || x == 434) ? x : 0;
-  }();
+// The context's option BMV3_SHAPE = <R><S><W> is the A/B switch of the tools.
+static inline int bp_gemv3_shape(const ccqp_ctx* ctx, int count) {
+  const int forced = (int)ccqp_opt(ctx, CCQP_OPT_BMV3_SHAPE);
   return forced ? forced : count >= 32 ? 824 : 444;
 }
 template <class Resolve3>
-static int bp_launch_gemv3(const Resolve3& rsv, int count, int64_t n, hipStream_t s) {
-  switch (bp_gemv3_shape(count)) {
-    case 833: return bp_launch_gemv3_pers<8, 3>(rsv, count, n, 3, s);
-    case 444: return bp_launch_gemv3_pers<4, 4>(rsv, count, n, 4, s);
-    case 434: return bp_launch_gemv3_pers<4, 3>(rsv, count, n, 4, s);
-    default: return bp_launch_gemv3_pers<8, 2>(rsv, count, n, 4, s);
+static int bp_launch_gemv3(ccqp_ctx* ctx, const Resolve3& rsv, int count, int64_t n, hipStream_t s) {
+  switch (bp_gemv3_shape(ctx, count)) {
+    case 833: return bp_launch_gemv3_pers<8, 3>(ctx, rsv, count, n, 3, s);
+    case 444: return bp_launch_gemv3_pers<4, 4>(ctx, rsv, count, n, 4, s);
+    case 434: return bp_launch_gemv3_pers<4, 3>(ctx, rsv, count, n, 4, s);
+    default: return bp_launch_gemv3_pers<8, 2>(ctx, rsv, count, n, 4, s);
   }
 }
 
@@ -500,12 +479,13 @@ static int bp_launch_gemv3(const Resolve3& rsv, int count, int64_t n, hipStream_
 void ccqp_lockstep_begin(ccqp_ctx* ctx, uint32_t* dev_batch, hipStream_t s);
 // the batched matvec (mode 0: y = A x[i], g[i] = y + b; mode 1: y = A g[i]) and the alpha0 reduction of the BBPGD
 // start-up, as launched by ccqp_bpipe_*: shared with the segmented form (ccqp_bsegs.hip)
-void ccqp_bp_gemv(const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s);
+int ccqp_bp_gemv(ccqp_ctx* ctx, const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s);
 void ccqp_bp_init_alpha(const ccqp_pprob* probs, int count, int64_t n, int64_t chunk, int nblk, hipStream_t s);
 // the launches of a lock-step APGD round (ccqp_bpipe.hip), shared with the segmented form: `segs` != NULL takes the
 // residual from the segmented residual launch and leaves the trial step to the segmented step launch
-void ccqp_bapgd_launch_gemv(const ccqp_papgd* probs, int count, int64_t n, int init, int flags, hipStream_t s,
-                            bool elementwise = true);
+// (`look`: the caller asked for the look-ahead -- CCQP_LOCKSTEP_LOOKAHEAD -- and gave every problem its two buffers)
+int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, int64_t n, int init, int flags, bool look,
+                           hipStream_t s, bool elementwise = true);
 void ccqp_bapgd_launch_decide(ccqp_ctx* ctx, const ccqp_papgd* probs, const ccqp_psegs* segs, int count, int64_t n,
                               double gd, double seq, int ar, uint32_t* dev_batch, hipStream_t s);
 void ccqp_bapgd_launch_apply(const ccqp_papgd* probs, int count, int64_t n, hipStream_t s);

@@ -400,7 +400,7 @@ def _bpipe_table(eng, spec, n, struct, nvec, partial_rows):
 def _bpipe_flags(tab, n, tune):
     # bit 0: 16-byte aligned rows and vectors; `tune` = the matvec's tuning word (never changes a result bit)
     # (bits 3 and 7 select solver variants -- PGD / anti-relaxation, BBPGDf -- and are not the caller's to set)
-    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & ~(1 | 8 | 128))
+    return int(n % 2 == 0 and not np.any(tab["A"] % 16) and not np.any(tab["lda"] % 2)) | (int(tune) & 0xFFFF & ~(1 | 8 | 128))
 
 
 def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
@@ -720,7 +720,8 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     tab["Y"][:, 0], tab["Y"][:, 1] = planes[2], planes[3]
     tab["gk"], tab["g1"], tab["Ayk"], tab["Ax1"], tab["xhat"] = planes[4], planes[5], planes[6], planes[7], planes[8]
     tab["ga"], tab["Aya"] = planes[9], planes[10]
-    flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0)  # bit 3: the anti-relaxation variant
+    # bit 3: the anti-relaxation variant; bit 17: every problem carries the two look-ahead buffers (ga / Aya above)
+    flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0) | _lib.LOCKSTEP_LOOKAHEAD
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check

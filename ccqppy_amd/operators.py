@@ -61,14 +61,21 @@ class DenseOperator:
         over a square A where the LDS-staged form applies (Engine.gemv3), each with the bits of its own matvec()."""
         (engine or self.engine).gemv3(self.A, xs, ys, b, gs)
 
+    def _rows_aligned(self):
+        """What the form queries assume and the launches check: 16-byte aligned rows (the solvers' vectors are fresh
+        allocations, always aligned).  A view with an odd leading dimension or an 8-byte offset runs its pairs / triples
+        as single passes -- then speculating on a product costs a whole pass, so the solvers must not."""
+        return self.A.data_ptr() % 16 == 0 and self.A.stride(0) % 2 == 0
+
     def triple_in_one_pass(self, engine=None):
         eng = engine or self.engine
-        return self.rows == self.n and hasattr(eng, "gemv3_form") and eng.gemv3_form(self.n) == "bp_gemv3_pers_kernel"
+        return self.rows == self.n and self._rows_aligned() and hasattr(eng, "gemv3_form") and \
+            eng.gemv3_form(self.n) == "bp_gemv3_pers_kernel"
 
     def pair_in_one_pass(self, engine=None):
         """True if matvec2 reads the matrix once (what makes speculating on the second product worth it)."""
         eng = engine or self.engine                     # (a recording engine of the fused batch scheduler has no pair form)
-        return hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
+        return self._rows_aligned() and hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
 
     def pipe_apply(self, eng, x, y, b=None, g=None):
         """apply() behind the pipeline's "converged" word (solvers.CCQPSolverBBPGD(pipeline=True))."""

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define CCQP_ABI_VERSION 1
+/* 2: struct ccqp_papgd grew `ga` / `Aya` and the look-ahead of the lock-step forms became an explicit request (flags
+ *    bit 17, CCQP_LOCKSTEP_LOOKAHEAD) instead of "ga != NULL"; ccqp_bpipe_matvec_form takes the context; tuning / A-B
+ *    switches are per-context options (ccqp_ctx_set_option) instead of environment variables. */
+#define CCQP_ABI_VERSION 2
 
 enum {
   CCQP_OK = 0,
@@ -52,6 +55,37 @@ int ccqp_ctx_create(int device, ccqp_ctx** out);
 int ccqp_ctx_destroy(ccqp_ctx* ctx);
 /* num_cu: compute units of the device; arch: e.g. "gfx950" copied into buf (<= buflen). */
 int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int buflen);
+/* Per-context tuning options -- the A/B switches of tools/ and tests/.  None of them changes a result bit; value 0 is
+ * always "the tuned default".  They are read by the launches made with THIS context only (nothing in the library reads
+ * the environment); not thread-safe against launches in flight on the same context (one host thread per context).
+ *   GEMV_ROW_STRIDE        k >= 1: a wave's R row streams lie k rows apart (LDS-staged matvecs; default: ~1 MiB apart)
+ *   GEMV2_WPB              1..4 waves per workgroup of the two-vector launch ccqp_gemv2_f64 (default by shape)
+ *   GEMV2_SHAPE            <R><S> of its ring as a two-digit number: 44, 43, 82, 83, 84 (rows per wave, ring slots)
+ *   GEMV2_GROUP            row sums a wave parks before it stores them: 64 .. 512 (default 512)
+ *   BMV3_SHAPE             <R><S><W> of the three-vector persistent launch: 824, 833, 444, 434
+ *   LOOKAHEAD_MIN_N        smallest n at which lock-step APGD looks ahead (>= 128; default 1024)
+ *   MPRGP_LOOKAHEAD_MIN_N  the same for lock-step MPRGP (default 512)
+ *   MPRGP_LOOKAHEAD, APGD_LOOKAHEAD   1 = the lock-step form does not look ahead (A/B of the shared passes)
+ *   BMV_STAGGER            1 = no staggered start of the persistent batched matvec's waves
+ *   MPRGP_FUSED_TAIL       1 = never the fused stage launch, 2 = wherever it can run (default: by shape)
+ *   PERS1_MIN_N            smallest n at which a lock-step batch of ONE problem takes the persistent multi-vector matvec */
+enum {
+  CCQP_OPT_GEMV_ROW_STRIDE = 0,
+  CCQP_OPT_GEMV2_WPB = 1,
+  CCQP_OPT_GEMV2_SHAPE = 2,
+  CCQP_OPT_GEMV2_GROUP = 3,
+  CCQP_OPT_BMV3_SHAPE = 4,
+  CCQP_OPT_LOOKAHEAD_MIN_N = 5,
+  CCQP_OPT_MPRGP_LOOKAHEAD_MIN_N = 6,
+  CCQP_OPT_MPRGP_LOOKAHEAD = 7,
+  CCQP_OPT_APGD_LOOKAHEAD = 8,
+  CCQP_OPT_BMV_STAGGER = 9,
+  CCQP_OPT_MPRGP_FUSED_TAIL = 10,
+  CCQP_OPT_PERS1_MIN_N = 11,
+  CCQP_OPT_COUNT = 12
+};
+int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
+int ccqp_ctx_get_option(ccqp_ctx* ctx, int key, int64_t* value);
 /* Copy slots [slot0, slot0+count) to host_out and wait for `stream` (the only sync point). */
 int ccqp_scalars_read(ccqp_ctx* ctx, int slot0, int count, double* host_out, void* stream);
 /* Split form for callers that interleave several solves on several streams (batch-sharded mode):
@@ -410,7 +444,7 @@ int64_t ccqp_bpipe_partials_doubles(int64_t n);
  * tuned default from n = 4096 and 1 GiB of matrices on (the runs that look ahead -- ccqp_bapgd_*, ccqp_bmprgp_* and their
  * segmented forms -- already from n = 1024: set bit 16 of `flags` to ask for those) -- or "batched VALU kernel".  Same
  * bits either way. */
-int ccqp_bpipe_matvec_form(int count, int64_t n, int flags, char* name, int buflen);
+int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int flags, char* name, int buflen);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
  * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_lockstep.h).  Bit 3 (8)
@@ -484,9 +518,14 @@ typedef struct ccqp_papgd {
   uint32_t* counter; /* one word, zero on entry */
   double c;
   double tol;
-  double* ga;        /* look-ahead (elementwise sets, persistent batched matvec): A y_{k+1} + b and A y_{k+1},                */
-  double* Aya;       /* computed in the pass that computes A x_{k+1}; NULL: the run does not look ahead */
+  double* ga;        /* look-ahead (flags bit 17 of start / round, CCQP_LOCKSTEP_LOOKAHEAD): A y_{k+1} + b and A y_{k+1}, */
+  double* Aya;       /* computed in the pass that computes A x_{k+1}.  Read ONLY when the flag is set -- then both must be
+                        valid n-vectors for every problem (the argument check refuses NULL); ignored otherwise */
 } ccqp_papgd;
+/* flags bit 17 of ccqp_bapgd_start_f64 / ccqp_bapgd_round_f64 / ccqp_bsegs_apgd_round_f64 / ccqp_bsolve_apgd_f64: the
+ * caller has given every problem the two look-ahead buffers and asks the run to share passes where the persistent
+ * batched matvec is its form.  The same value must be passed to every call of a run. */
+#define CCQP_LOCKSTEP_LOOKAHEAD (1 << 17)
 int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
                          uint32_t* dev_batch, void* stream);
 int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
@@ -554,7 +593,7 @@ int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, cons
  * iteration) and, after a CG step, A.x_{k+1} + b (:1086), three right-hand sides in one pass over each matrix; the
  * start's A.x_0 + b (:1065) serves the first :1086 and A.g_0 (:1077) carries A.p_0.  Slab words 53 / 54 hold what is
  * computed ahead.  Every product has the bits of its own pass and the two counters advance where the reference computes
- * the product, so results and counts are unchanged; CCQP_MPRGP_LOOKAHEAD=0 in the environment turns it off.  The
+ * the product, so results and counts are unchanged; ccqp_ctx_set_option(ctx, CCQP_OPT_MPRGP_LOOKAHEAD, 1) turns it off.  The
  * segmented form ccqp_bsegs_mprgp_* looks ahead in the same way.) */
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);

@@ -29,14 +29,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in _declared_symbols():
         assert hasattr(lib, name), "missing export: " + name
     lib.ccqp_abi_version.restype = ctypes.c_int
-    assert lib.ccqp_abi_version() == 1
+    assert lib.ccqp_abi_version() == 2
 
 
 def test_python_binding_covers_the_header(built_lib):
     from ccqppy_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
     handle = _lib.load()
-    assert handle.ccqp_abi_version() == 1
+    assert handle.ccqp_abi_version() == 2
     assert ctypes.sizeof(_lib.Seg) == 56            # struct ccqp_seg layout
 
 
@@ -70,14 +70,16 @@ def test_product_fails_loudly_without_gpu():
 
 
 def test_which_form_the_batched_matvec_takes_is_host_arithmetic(built_lib):
-    """ccqp_bpipe_matvec_form is a pure host query (no device call): the persistent LDS-DMA launch from n = 4096 and
-    1 GiB of matrices on, for the runs that share passes between products (bit 16) from n = 1024 on."""
+    """ccqp_bpipe_matvec_form is a pure host query (no device call; a NULL context = no tuning options set): the persistent
+    LDS-DMA launch from n = 4096 and 1 GiB of matrices on; for the runs that share passes between products (bit 16) from
+    n = 1024 (APGD) / n = 512 (MPRGP, bit 18) on with 1 GiB of matrices, and from n = 4096 on whatever the bytes -- down to
+    a batch of one problem."""
     from ccqppy_amd import _lib
     lib = _lib.load()
 
     def form(count, n, flags):
         buf = ctypes.create_string_buffer(64)
-        assert lib.ccqp_bpipe_matvec_form(count, n, flags, buf, 64) == 0
+        assert lib.ccqp_bpipe_matvec_form(None, count, n, flags, buf, 64) == 0
         return buf.value.decode()
 
     assert form(128, 8192, 1) == "bp_gemv_pers_kernel"
@@ -88,4 +90,7 @@ def test_which_form_the_batched_matvec_takes_is_host_arithmetic(built_lib):
     assert form(4096, 512, 1 | (1 << 16)) == "batched VALU kernel"
     assert form(128, 1024, 1 << 16) == "batched VALU kernel"              # unaligned operands
     assert form(128, 1026, 1 | (1 << 16)) == "bp_gemv_pers_kernel" and form(128, 1025, 1 | (1 << 16)) == "batched VALU kernel"
-    assert lib.ccqp_bpipe_matvec_form(0, 1024, 1, ctypes.create_string_buffer(8), 8) != 0
+    assert form(4096, 512, 1 | (1 << 16) | (1 << 18)) == "bp_gemv_pers_kernel" and form(511, 512, 1 | (1 << 16) | (1 << 18)) == "batched VALU kernel"
+    assert form(1, 4096, 1 | (1 << 16)) == "bp_gemv_pers_kernel" and form(1, 4096, 1) == "batched VALU kernel"
+    assert form(1, 2048, 1 | (1 << 16)) == "batched VALU kernel" and form(3, 8192, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert lib.ccqp_bpipe_matvec_form(None, 0, 1024, 1, ctypes.create_string_buffer(8), 8) != 0

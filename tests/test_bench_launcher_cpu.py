@@ -1,7 +1,7 @@
 """bench.py as its own launcher (`python bench.py --gpus N`, the form of the driver's command), on a box without a GPU:
 the parent must start ONE torch.distributed.run child with N ranks, never touch the GPU itself, and pass the child's exit
-code on.  Without a GPU every rank ends in bench.py's FATAL path -- which is exactly what shows that both ranks were
-started with their own RANK and that the code came back through the launcher."""
+code on.  Without a GPU the ranks end in bench.py's FATAL path -- which is exactly what shows that ranks were started
+with their own RANK and that the code came back through the launcher."""
 import os
 import subprocess
 import sys
@@ -23,7 +23,8 @@ def test_gpus_2_starts_two_ranks_and_passes_their_exit_code_on():
                         "--size", "1024", "--cpu-n", "0"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
     assert "must be launched with" not in p.stderr
     assert "[bench] launcher:" in p.stderr and "--nproc-per-node 2" in p.stderr and "--master-addr 127.0.0.1" in p.stderr
-    assert "[bench] rank 0: FATAL" in p.stderr and "[bench] rank 1: FATAL" in p.stderr
+    # (torch.distributed.run ends the other rank as soon as one has failed: at least one of them got to say why)
+    assert "[bench] rank 0: FATAL" in p.stderr or "[bench] rank 1: FATAL" in p.stderr
     assert p.returncode != 0                    # the ranks failed (no GPU): the launcher says so
     assert not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
 

@@ -124,8 +124,9 @@ def test_fused_stage_launch_of_wide_batches_changes_no_bit(n, count):
 
 def test_fused_stage_launch_forced_on_longer_problems_in_a_child_process():
     """The fused launch walks up to 8 chunks per problem (bp_meet_seq); by default it is used for one-chunk problems only
-    (it measured slower at config 5's shape).  CCQP_MPRGP_FUSED_TAIL=2 forces it wherever it can run -- read once per
-    process, hence a child process: 64 problems of n = 2049 (2 chunks) and n = 4500 (3 chunks) against their own solve()."""
+    (it measured slower at config 5's shape).  The context option MPRGP_FUSED_TAIL = 2 forces it wherever it can run (a
+    child process, so that no other test sees the option): 64 problems of n = 2049 (2 chunks) and n = 4500 (3 chunks)
+    against their own solve()."""
     import os
     import subprocess
     import sys
@@ -134,6 +135,9 @@ import contextlib, io, sys
 import numpy as np, torch
 sys.path.insert(0, %r)
 from ccqppy_amd import batch, lockstep, problems, solvers, solution_spaces as ss
+from ccqppy_amd._engine import get_engine, set_default_option
+set_default_option("MPRGP_FUSED_TAIL", 2)
+assert get_engine(0).options() == {"MPRGP_FUSED_TAIL": 2}
 for n in (2049, 4500):
     probs = []
     for p in range(64):
@@ -152,8 +156,7 @@ for n in (2049, 4500):
         assert float(one.solution_residual) == float(c.solution_residual)
 print("FUSED-OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CCQP_MPRGP_FUSED_TAIL="2")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "FUSED-OK" in out.stdout, out.stderr[-2000:]
 
 

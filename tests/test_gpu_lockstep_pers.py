@@ -25,7 +25,7 @@ def _same(a, c):
 def _form(count, n, flags):
     from ccqppy_amd._engine import get_engine
     buf = ctypes.create_string_buffer(64)
-    assert get_engine(0).lib.ccqp_bpipe_matvec_form(count, n, flags, buf, 64) == 0
+    assert get_engine(0).lib.ccqp_bpipe_matvec_form(get_engine(0).ctx, count, n, flags, buf, 64) == 0
     return buf.value.decode()
 
 
