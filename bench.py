@@ -42,8 +42,8 @@ Extra objects on the JSON line:
                   `cpu_baseline_error` says why.
   box          -- host name, GPU name / unique id of rank 0's device: ties the line to the rocprofv3 tables taken
                   on the same box (profiles/*: `box`).
-For N > 1 the roofline object also carries `exchange_ms_per_mv` (HIP events around the per-matvec vector
-exchange), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange time) and `rccl_ranks`, and the line
+For N > 1 the roofline object also carries `exchange_ms_per_mv` (HIP events around each vector exchange: one per matvec
+LAUNCH -- a pair launch ships both slabs in one collective -- `exchanges_per_step` of them), `vector_work_ms_per_step` (step wall-clock minus matvec and exchange time) and `rccl_ranks`, and the line
 an `exchange_ab` object: after the timed steps, untimed, 50 exchanges of the n-vector by each of the three forms
 (torch all_gather_into_tensor | the C ABI's in-place RCCL all-gather on the compute stream | zero-padded
 all-reduce), HIP-event timed on the launch stream, with a check that all three leave the same bits in y on every
@@ -337,6 +337,58 @@ def exchange_ab(n, row0, rows, slab, eng, group, backend, reps=50, state=None):
                      "max_ms": float(np.max(ms)), "calls": reps, "bytes_moved_per_rank": 8 * (n if mode == "allreduce" else rows),
                      "launches_besides_the_collective": {"allgather": 1, "direct": 0, "allreduce": 2}[mode] if n % world == 0 else None}
         ex.close()
+    # the exchange of a PAIR of products (APGD's two matvecs per pass): round 3's two exchanges + two `+ b` launches against
+    # round 4's one exchange of both slabs + one unpack launch that forms g = y + b (RowShardedOperator.matvec2)
+    state["mode"] = "pair"
+    pair = {}
+    bvec = torch.ones(n, dtype=torch.float64, device=eng.device)
+    for mode in ("allgather", "direct"):
+        if mode == "direct" and backend != "nccl":
+            continue
+        state["mode"] = "pair/" + mode
+        ex = VectorExchange(n, group, mode)
+        ex.open(eng)
+        y1, y2, g1, g2 = (torch.full((n,), float("nan"), dtype=torch.float64, device=eng.device) for _ in range(4))
+
+        def unfused():
+            y1[sl] = slab
+            y2[sl] = slab
+            ex(y1, eng)
+            ex(y2, eng)
+            eng.axpby(1.0, y1, 1.0, bvec, g1)
+            eng.axpby(1.0, y2, 1.0, bvec, g2)
+
+        def fused():
+            s1, s2 = ex.slabs(2, y1)
+            s1.copy_(slab)
+            s2.copy_(slab)
+            ex.exchange_many([y1, y2], bvec, [g1, g2], eng)
+
+        res = {}
+        for name, fn in (("two_exchanges_two_axpby", unfused), ("one_exchange_one_unpack", fused)):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            ms = []
+            for _ in range(reps):
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(eng.torch_stream)
+                fn()
+                b_.record(eng.torch_stream)
+                ms.append((a, b_))
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b_) for a, b_ in ms]
+            res[name] = {"median_ms": float(np.median(ms)), "min_ms": float(np.min(ms)), "calls": reps}
+            if name == "two_exchanges_two_axpby":
+                keep = (y1.clone(), g2.clone())
+                for t in (y1, y2, g1, g2):
+                    t.fill_(float("nan"))
+        res["bitwise_equal"] = bool(torch.equal(keep[0].view(torch.int64), y1.view(torch.int64)) and
+                                    torch.equal(keep[1].view(torch.int64), g2.view(torch.int64)) and
+                                    torch.equal(y1.view(torch.int64), ys["allgather"]))
+        pair[mode] = res
+        ex.close()
+    out["pair_of_products"] = pair
     state["mode"] = "comparison"
     names = list(ys)
     same = all(bool(torch.equal(ys[names[0]], ys[m])) for m in names[1:])
@@ -359,7 +411,8 @@ def exchange_ab_ok(ab):
     left.  The process still ends with exit code 0 when this is False (the timed line is complete by then) -- so the
     failure has a field of its own that nothing reading the line can miss."""
     return bool(ab) and "error" not in ab and bool(ab.get("bitwise_equal_forms")) and \
-        bool(ab.get("bitwise_equal_ranks")) and bool(ab.get("no_nan_left"))
+        bool(ab.get("bitwise_equal_ranks")) and bool(ab.get("no_nan_left")) and \
+        all(v.get("bitwise_equal") for v in ab.get("pair_of_products", {}).values())
 
 
 def main():
@@ -623,6 +676,8 @@ def _main():
                 # slowest rank's slab)
                 "exchange_ms_per_mv": float(np.mean(exch_ms)) if exch_ms else None,
                 "exchange_ms_per_step": float(np.sum(exch_ms)) / steps if exch_ms else None,
+                # (one exchange per matvec LAUNCH: a pair launch ships both slabs in one collective + one unpack launch)
+                "exchanges_per_step": len(exch_ms) / steps if exch_ms else None,
                 "vector_work_ms_per_step": (1e3 * elapsed - float(np.sum(gemv_ms)) - float(np.sum(exch_ms))) / steps
                                            if gemv_ms else None,
                 "rccl_ranks": rccl_ranks,
@@ -630,6 +685,9 @@ def _main():
             },
         }
         line["box"] = box_id(local_rank)
+        # tuning options of the engine that are not at their default (bench.py sets none: {} -- a measurement says so itself)
+        line["box"]["options"] = eng.options()
+        line["box"]["gemv_variant"] = hex(args.variant)
         cpu_n = args.cpu_n
         if cpu_n < 0:
             need = 8.0 * n * n / 2.0 ** 30 + 24.0

@@ -218,6 +218,47 @@ class Engine:
         self.mv_executed += sum(y is not None for y in ys)
         self.products_launched += sum(y is not None for y in ys)
 
+    def gemvk(self, A, xs, ys, b=None, gs=None, variant=None):
+        """ys[j] = A.xs[j] (gs[j] = ys[j] + b where given) for k = len(xs) <= 3 products of a rows x cols BLOCK in one
+        pass where the pair kernel would take one (ccqp_gemvk_f64), each with the bits of its own gemv().  Counts k
+        executed matvecs; one (start, end) event pair when profiling is on."""
+        k = len(xs)
+        rows, cols = A.shape
+        gs = [None] * k if gs is None else gs
+        assert 1 <= k <= 3 and len(ys) == k and len(gs) == k and A.stride(1) == 1
+        assert all(x.numel() >= cols for x in xs) and all(y.numel() >= rows for y in ys)
+        arr = ctypes.c_void_p * 3
+        px = arr(*[x.data_ptr() for x in xs])
+        py = arr(*[y.data_ptr() for y in ys])
+        pg = arr(*[None if g is None else g.data_ptr() for g in gs])
+        ev = None
+        if self.gemv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.torch_stream)
+        _lib.check(self.lib.ccqp_gemvk_f64(self.ctx, A.data_ptr(), A.stride(0), k, px, 0 if b is None else b.data_ptr(), py,
+                                          pg, rows, cols, self.gemv_variant if variant is None else variant, self.stream))
+        if ev is not None:
+            ev[1].record(self.torch_stream)
+            self.gemv_events.append(ev)
+        self.mv_executed += k
+        self.products_launched += k
+
+    def gemvk_form(self, k, rows, cols, variant=None):
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self.lib.ccqp_gemvk_form(self.ctx, k, rows, cols, self.gemv_variant if variant is None else variant, buf, 64))
+        return buf.value.decode()
+
+    def unpack_gathered(self, gathered, k, per, ys, b=None, gs=None):
+        """ys[j][i] = gathered[(r k + j) per + i - r per], r = i // per (the slabs of k row-sharded products after their
+        ONE all-gather), gs[j] = ys[j] + b where given -- one launch (ccqp_unpack_gathered_f64)."""
+        n = ys[0].numel()
+        gs = [None] * k if gs is None else gs
+        arr = ctypes.c_void_p * 3
+        py = arr(*[y.data_ptr() for y in ys])
+        pg = arr(*[None if g is None else g.data_ptr() for g in gs])
+        _lib.check(self.lib.ccqp_unpack_gathered_f64(self.ctx, gathered.data_ptr(), k, per, n, py,
+                                                    0 if b is None else b.data_ptr(), pg, self.stream))
+
     def gemv3_form(self, n, variant=None):
         """"bp_gemv3_pers_kernel" (one pass for up to three products of an n x n matrix) or "single matvecs"."""
         buf = ctypes.create_string_buffer(64)

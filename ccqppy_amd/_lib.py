@@ -142,6 +142,8 @@ SIGNATURES = {
     "ccqp_gemv2_form": [_P, _I64, _I64, _I, _c.c_char_p, _I],
     "ccqp_gemv3_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I, _P],
     "ccqp_gemv3_form": [_P, _I64, _I, _c.c_char_p, _I],
+    "ccqp_gemvk_f64": [_P, _P, _I64, _I, _P, _P, _P, _P, _I64, _I64, _I, _P],
+    "ccqp_gemvk_form": [_P, _I, _I64, _I64, _I, _c.c_char_p, _I],
     "ccqp_mv_timing_begin": [_I],
     "ccqp_mv_timing_end": [_c.POINTER(_c.c_double), _I, _c.POINTER(_I)],
     "ccqp_gemv_epilogue_f64": [_P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I, _P],
@@ -166,6 +168,9 @@ SIGNATURES = {
     "ccqp_comm_allgather_f64": [_P, _P, _I64, _P],
     "ccqp_comm_allreduce_sum_f64": [_P, _P, _I64, _P],
     "ccqp_shard_gemv_allgather_f64": [_P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _I, _P],
+    "ccqp_shard_gemvk_allgather_f64": [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P],
+    "ccqp_shard_gemv2_allgather_f64": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P],
+    "ccqp_unpack_gathered_f64": [_P, _P, _I, _I64, _I64, _P, _P, _P, _P],
     "ccqp_segs_plan": [_P, _I64, _P, _I64, _c.POINTER(_I64), _P, _I64, _c.POINTER(_I64), _c.POINTER(_I64)],
     "ccqp_segs_workspace_doubles": [_I64, _I64],
     "ccqp_segs_project_f64": [_P, _P, _P, _I64, _P, _I64, _I64, _P, _D, _P, _D, _P, _P, _P, _P],

@@ -381,6 +381,12 @@ struct gemv_lds3_desc {            // operands of one matrix of the three-vector
   double* y[3];
   double* g[3];
 };
+template <int K>
+struct gemv_ldsk_io {              // by-value kernel argument: the K vectors and their outputs (g[j] may be NULL)
+  const double* x[K];
+  double* y[K];
+  double* g[K];
+};
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int R>
 __device__ __forceinline__ int64_t gemv_lds_first_row(int64_t T, int64_t rs) {
@@ -484,28 +490,29 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stores count on the DMA's counter)
   }
 }
-// ---- TWO right-hand sides in one pass over A (y1 = A x1, y2 = A x2; g_i = y_i + b where asked): the ring's slot holds
-// R row pieces and BOTH x pieces, every row piece is read back once and multiplied into two accumulators.  Each product
+// ---- K right-hand sides in one pass over A (y_j = A x_j; g_j = y_j + b where asked; K = 2, 3): the ring's slot holds
+// R row pieces and ALL K x pieces, every row piece is read back once and multiplied into K accumulators.  Each product
 // has the bits of its own gemv_lds_body / gemv_task pass (same lane -> column map, same fma chain per accumulator); the
-// matrix is read from HBM once instead of twice.  (APGD's trial point and its momentum point: solvers.py:275,290.)
-template <int R, int S, bool NT>
-__device__ __forceinline__ void gemv_lds2_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ x1,
-                                               const double* __restrict__ x2, const double* __restrict__ b,
-                                               double* __restrict__ y1, double* __restrict__ g1, double* __restrict__ y2,
-                                               double* __restrict__ g2, int64_t rows, int64_t cols, int64_t ntasks,
+// matrix is read from HBM once instead of K times.  (K = 2: APGD's trial point and its momentum point, solvers.py:275,290;
+// K = 3: MPRGP's A.dx, A.x_{k+1} + b, A.p_{k+1} on a rank's row block, solvers.py:1129|1163, 1086, 1100.)
+// `rescap` <= GEMV_LDS_RESCAP: row sums a wave parks before it stores them (the flush group: rescap / (K R) tasks).
+template <int R, int S, int K, bool NT>
+__device__ __forceinline__ void gemv_ldsk_body(const double* __restrict__ A, int64_t lda, const gemv_ldsk_io<K>& io,
+                                               const double* __restrict__ b, int64_t rows, int64_t cols, int64_t ntasks,
                                                int64_t wave, int64_t nwaves, char* mine, double* res, int64_t rs,
-                                               int rescap = GEMV_LDS_RESCAP) {
+                                               int rescap) {
   constexpr int PIECE = 1024;
-  constexpr int SLOT = (R + 2) * PIECE;
-  const int GROUP = rescap / (2 * R);           // tasks per flush (two sums per row; rescap <= GEMV_LDS_RESCAP)
+  constexpr int SLOT = (R + K) * PIECE;
+  const int GROUP = rescap / (K * R);           // tasks per flush (K sums per row)
   const int lane = threadIdx.x & 63;
   const int64_t nfull = cols / 128;
   const int tail = (int)(cols - nfull * 128);
   const bool mine_in_tail = 2 * lane < tail;
   const int64_t nsteps = nfull + (tail ? 1 : 0);
   const int64_t mytasks = wave < ntasks ? (ntasks - wave + nwaves - 1) / nwaves : 0;
-  const double* xp1 = x1 + 2 * lane;
-  const double* xp2 = x2 + 2 * lane;
+  const double* xp[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) xp[j] = io.x[j] + 2 * lane;
   for (int64_t k0 = 0; k0 < mytasks; k0 += GROUP) {
     const int kn = (int)(mytasks - k0 < GROUP ? mytasks - k0 : GROUP);
     const int64_t total = (int64_t)kn * nsteps;
@@ -529,10 +536,10 @@ __device__ __forceinline__ void gemv_lds2_body(const double* __restrict__ A, int
         for (int r = 0; r < R; ++r)
           __builtin_amdgcn_global_load_lds(irp[r] + is * 128, (__attribute__((address_space(3))) void*)(slot + r * PIECE),
                                            16, 0, NT ? 2 : 0);
-        __builtin_amdgcn_global_load_lds(xp1 + is * 128, (__attribute__((address_space(3))) void*)(slot + R * PIECE), 16, 0,
-                                         0);
-        __builtin_amdgcn_global_load_lds(xp2 + is * 128, (__attribute__((address_space(3))) void*)(slot + (R + 1) * PIECE),
-                                         16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          __builtin_amdgcn_global_load_lds(xp[j] + is * 128,
+                                           (__attribute__((address_space(3))) void*)(slot + (R + j) * PIECE), 16, 0, 0);
       }
       islot = islot + 1 == S ? 0 : islot + 1;
       ++issued;
@@ -544,54 +551,58 @@ __device__ __forceinline__ void gemv_lds2_body(const double* __restrict__ A, int
     for (int p = 0; p < S - 1 && issued < total; ++p) issue_next();
     int cslot = 0;
     for (int kk = 0; kk < kn; ++kk) {
-      double acc1[R], acc2[R];
+      double acc[K][R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc1[r] = acc2[r] = 0.0;
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[j][r] = 0.0;
       for (int64_t s = 0; s < nsteps; ++s) {
         if (issued < total) {
           issue_next();
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + 2)) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (R + K)) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const char* slot = mine + cslot * SLOT;
         if (s < nfull || mine_in_tail) {
-          const ccqp_d2 xv1 = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
-          const ccqp_d2 xv2 = *reinterpret_cast<const ccqp_d2*>(slot + (R + 1) * PIECE + lane * 16);
+          ccqp_d2 xv[K];
+#pragma unroll
+          for (int j = 0; j < K; ++j) xv[j] = *reinterpret_cast<const ccqp_d2*>(slot + (R + j) * PIECE + lane * 16);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
-            acc1[r] = fma(av.x, xv1.x, acc1[r]);
-            acc1[r] = fma(av.y, xv1.y, acc1[r]);
-            acc2[r] = fma(av.x, xv2.x, acc2[r]);
-            acc2[r] = fma(av.y, xv2.y, acc2[r]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+              acc[j][r] = fma(av.x, xv[j].x, acc[j][r]);
+              acc[j][r] = fma(av.y, xv[j].y, acc[j][r]);
+            }
           }
         }
         cslot = cslot + 1 == S ? 0 : cslot + 1;
         asm volatile("" ::: "memory");
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        acc1[r] = ccqp_wave_sum(acc1[r]);
-        acc2[r] = ccqp_wave_sum(acc2[r]);
-      }
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j][r] = ccqp_wave_sum(acc[j][r]);
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (lane == r) {
-          res[(kk * R + r) * 2] = acc1[r];
-          res[(kk * R + r) * 2 + 1] = acc2[r];
+#pragma unroll
+          for (int j = 0; j < K; ++j) res[(kk * R + r) * K + j] = acc[j][r];
         }
     }
     // ---- flush: every DMA of the group has landed (the last steps waited for vmcnt(0))
-    for (int j = lane; j < kn * R; j += 64) {
-      const int kk = j / R, r = j - kk * R;
+    for (int i = lane; i < kn * R; i += 64) {
+      const int kk = i / R, r = i - kk * R;
       const int64_t row = gemv_lds_first_row<R>(wave + (k0 + kk) * nwaves, rs) + r * rs;
       if (row < rows) {
-        const double v1 = res[2 * j], v2 = res[2 * j + 1];
-        y1[row] = v1;
-        y2[row] = v2;
-        if (g1) g1[row] = v1 + b[row];          // `A.dot(x) + b`: one more rounding, as numpy
-        if (g2) g2[row] = v2 + b[row];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const double v = res[K * i + j];
+          io.y[j][row] = v;
+          if (io.g[j]) io.g[j][row] = v + b[row];     // `A.dot(x) + b`: one more rounding, as numpy
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

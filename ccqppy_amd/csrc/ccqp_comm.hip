@@ -20,6 +20,27 @@
 int ccqp_gemv_launch(ccqp_ctx* ctx, const double* A, int64_t lda, const double* x, const double* b, double* y,
                      double* g, int64_t rows, int64_t cols, int variant, hipStream_t s, const double* skip);
 
+// ---- k products per exchange: rank r's slab of product j sits at gathered[(r k + j) per ...) (rows_r <= per valid words).
+// One launch scatters the gathered slabs into the k replicated vectors and forms g_j = y_j + b where asked -- the same single
+// add as the matvec's fused epilogue / the axpby it replaces, hence the same bits.
+struct unpack_io {
+  double* y[3];
+  double* g[3];
+};
+__global__ __launch_bounds__(CCQP_BLOCK) void unpack_gathered_kernel(const double* __restrict__ gathered, int k, int64_t per,
+                                                                     int64_t n, const unpack_io io,
+                                                                     const double* __restrict__ b) {
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    const int64_t r = i / per, off = i - r * per;
+    const double bi = b ? b[i] : 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double v = gathered[(r * k + j) * per + off];
+      io.y[j][i] = v;
+      if (io.g[j]) io.g[j][i] = v + bi;
+    }
+  }
+}
+
 struct ccqp_comm {
   ncclComm_t nccl;
   int nranks, rank, device;
@@ -191,4 +212,59 @@ extern "C" int ccqp_shard_gemv_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, con
   if (lo > 0) CCQP_HIP(hipMemsetAsync(y, 0, (size_t)lo * sizeof(double), s));
   if (hi < total) CCQP_HIP(hipMemsetAsync(y + hi, 0, (size_t)(total - hi) * sizeof(double), s));
   return ccqp_comm_allreduce_sum_f64(comm, y, total, stream);
+}
+
+extern "C" int ccqp_unpack_gathered_f64(ccqp_ctx* ctx, const double* gathered, int k, int64_t per, int64_t n,
+                                        double* const* y, const double* b, double* const* g, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && gathered != nullptr && y != nullptr, "NULL argument");
+  CCQP_REQUIRE(k >= 1 && k <= 3 && per >= 1 && n >= 0, "bad shape");
+  unpack_io io;
+  for (int j = 0; j < 3; ++j) {
+    io.y[j] = j < k ? y[j] : nullptr;
+    io.g[j] = j < k && g ? g[j] : nullptr;
+    CCQP_REQUIRE(j >= k || y[j] != nullptr, "NULL output vector");
+    CCQP_REQUIRE(io.g[j] == nullptr || b != nullptr, "g requested but b is NULL");
+  }
+  if (n == 0) return CCQP_OK;
+  int64_t grid = (n + CCQP_BLOCK - 1) / CCQP_BLOCK;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(unpack_gathered_kernel, dim3((unsigned)grid), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, gathered, k, per, n,
+                     io, b);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// k <= 3 row-sharded products with ONE exchange: the local k-vector pass (ccqp_gemvk_f64: one pass over the row block
+// where the pair kernel applies) writes its slabs straight into this rank's part of `work`, one in-place all-gather of
+// k * per doubles per rank, one unpack launch that also forms g_j = y_j + b.
+extern "C" int ccqp_shard_gemvk_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda, int k,
+                                              const double* const* x, const double* b, double* const* y, double* const* g,
+                                              int64_t rows_local, int64_t per, int64_t cols, int variant, double* work,
+                                              void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && comm != nullptr && x != nullptr && y != nullptr && work != nullptr, "NULL argument");
+  CCQP_REQUIRE(k >= 1 && k <= 3, "k outside [1, 3]");
+  CCQP_REQUIRE(rows_local >= 0 && per >= rows_local && per >= 1 && cols >= 0 && lda >= cols, "bad shape");
+  CCQP_REQUIRE(cols <= per * comm->nranks, "the row blocks do not cover the vector");
+  double* mine = work + (int64_t)comm->rank * k * per;
+  double* slab[3] = {mine, mine + per, mine + 2 * per};
+  double* none[3] = {nullptr, nullptr, nullptr};
+  if (rows_local > 0) {
+    const int rc = ccqp_gemvk_f64(ctx, A_local, lda, k, x, nullptr, slab, none, rows_local, cols, variant, stream);
+    if (rc) return rc;
+  }
+  if (comm->nranks > 1) {
+    const int rc = ccqp_comm_allgather_f64(comm, work, (int64_t)k * per, stream);
+    if (rc) return rc;
+  }
+  return ccqp_unpack_gathered_f64(ctx, work, k, per, cols, y, b, g, stream);
+}
+
+extern "C" int ccqp_shard_gemv2_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda,
+                                              const double* x1, const double* x2, const double* b, double* y1, double* g1,
+                                              double* y2, double* g2, int64_t rows_local, int64_t per, int64_t cols,
+                                              int variant, double* work, void* stream) {
+  const double* x[3] = {x1, x2, nullptr};
+  double* y[3] = {y1, y2, nullptr};
+  double* g[3] = {g1, g2, nullptr};
+  return ccqp_shard_gemvk_allgather_f64(ctx, comm, A_local, lda, 2, x, b, y, g, rows_local, per, cols, variant, work, stream);
 }

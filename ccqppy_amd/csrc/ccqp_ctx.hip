@@ -197,7 +197,7 @@ extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
   CCQP_REQUIRE(key >= 0 && key < CCQP_OPT_COUNT, "no such option");
   bool ok = value >= 0;
   switch (key) {
-    case CCQP_OPT_GEMV2_WPB: ok = value >= 0 && value <= 4; break;
+    case CCQP_OPT_GEMV2_WPB: ok = value >= 0 && value <= 8; break;
     case CCQP_OPT_GEMV2_SHAPE: ok = value == 0 || value == 44 || value == 43 || value == 82 || value == 83 || value == 84; break;
     case CCQP_OPT_GEMV2_GROUP: ok = value == 0 || (value >= 64 && value <= 512 && value % 16 == 0); break;
     case CCQP_OPT_BMV3_SHAPE: ok = value == 0 || value == 824 || value == 833 || value == 444 || value == 434; break;

@@ -420,37 +420,77 @@ extern "C" int ccqp_gemv_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const 
   return CCQP_OK;
 }
 
-// ---- two right-hand sides in one pass over A (gemv_lds2_body, ccqp_bodies.h): the LDS-staged form with both x pieces in
-// the ring's slot.  R = 4, S = 4; waves per workgroup, workgroups per CU, stagger and row stride as the single form's.
+// ---- two (three) right-hand sides in one pass over A (gemv_ldsk_body, ccqp_bodies.h): the LDS-staged form with all x
+// pieces in the ring's slot.  Waves per workgroup, workgroups per CU, stagger and row stride as the single form's.
+// (up to EIGHT waves per workgroup: launch bounds 512; the parked row sums take `rescap` doubles per wave)
 template <int R, int S, bool NT>
-__global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds2_kernel(const double* __restrict__ A, int64_t lda,
-                                                               const double* __restrict__ x1,
-                                                               const double* __restrict__ x2,
-                                                               const double* __restrict__ b, double* __restrict__ y1,
-                                                               double* __restrict__ g1, double* __restrict__ y2,
-                                                               double* __restrict__ g2, int64_t rows, int64_t cols,
-                                                               int64_t ntasks, int stagger, int64_t rs, int rescap) {
+__global__ __launch_bounds__(512) void gemv_lds2_kernel(const double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ x1, const double* __restrict__ x2,
+                                                        const double* __restrict__ b, double* __restrict__ y1,
+                                                        double* __restrict__ g1, double* __restrict__ y2,
+                                                        double* __restrict__ g2, int64_t rows, int64_t cols, int64_t ntasks,
+                                                        int stagger, int64_t rs, int rescap) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int RING = S * (R + 2) * 1024;
   const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * wpb + w;
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * rescap;
+  for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (staggered start)
+  gemv_ldsk_io<2> io;
+  io.x[0] = x1, io.x[1] = x2, io.y[0] = y1, io.y[1] = y2, io.g[0] = g1, io.g[1] = g2;
+  gemv_ldsk_body<R, S, 2, NT>(A, lda, io, b, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs, rescap);
+#endif
+}
+
+// three right-hand sides (a rank's row block under MPRGP's look-ahead, RowShardedOperator.matvec3)
+template <int R, int S, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds3_kernel(const double* __restrict__ A, int64_t lda,
+                                                               const gemv_ldsk_io<3> io, const double* __restrict__ b,
+                                                               int64_t rows, int64_t cols, int64_t ntasks, int stagger,
+                                                               int64_t rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int RING = S * (R + 3) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * wpb + w;
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   for (int i = (int)((wave * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (staggered start)
-  gemv_lds2_body<R, S, NT>(A, lda, x1, x2, b, y1, g1, y2, g2, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs,
-                           rescap);
+  gemv_ldsk_body<R, S, 3, NT>(A, lda, io, b, rows, cols, ntasks, wave, nwaves, ring + w * RING, res, rs, GEMV_LDS_RESCAP);
 #endif
+}
+
+template <int R, int S>
+static int launch_lds3(ccqp_ctx* ctx, int wpb, bool nt, int stagger, hipStream_t s, const double* A, int64_t lda,
+                       const gemv_ldsk_io<3>& io, const double* b, int64_t rows, int64_t cols) {
+  const size_t lds = (size_t)wpb * ((size_t)S * (R + 3) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), lda, rows, R);
+  const int64_t ntasks = gemv_lds_tasks(rows, R, rs);
+  int64_t blocks = (ntasks + wpb - 1) / wpb;
+  if (blocks > (int64_t)ctx->num_cu) blocks = ctx->num_cu;
+  if (blocks < 1) blocks = 1;
+  const int rc = ccqp_lds_raise(
+      ctx, reinterpret_cast<const void*>(nt ? gemv_lds3_kernel<R, S, true> : gemv_lds3_kernel<R, S, false>), lds);
+  if (rc) return rc;
+  if (nt)
+    hipLaunchKernelGGL((gemv_lds3_kernel<R, S, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, io, b, rows, cols,
+                       ntasks, stagger, rs);
+  else
+    hipLaunchKernelGGL((gemv_lds3_kernel<R, S, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, s, A, lda, io, b, rows, cols,
+                       ntasks, stagger, rs);
+  return CCQP_OK;
 }
 
 template <int R, int S>
 static int launch_lds2(ccqp_ctx* ctx, int wpb, int bpc, bool nt, int stagger, int rescap, hipStream_t s, const double* A,
                        int64_t lda, const double* x1, const double* x2, const double* b, double* y1, double* g1, double* y2,
                        double* g2, int64_t rows, int64_t cols) {
-  size_t lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+  size_t lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + (size_t)rescap * sizeof(double));
   while (wpb > 1 && lds > 160 * 1024) {           // (a ring that does not fit: fewer waves per workgroup)
     wpb -= 1;
-    lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + GEMV_LDS_RESCAP * sizeof(double));
+    lds = (size_t)wpb * ((size_t)S * (R + 2) * 1024 + (size_t)rescap * sizeof(double));
   }
   if (bpc < 1 || (size_t)bpc * lds > 160 * 1024) bpc = 1;
   const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), lda, rows, R);
@@ -553,6 +593,67 @@ extern "C" int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const
       LDS2_CASE(4, 4);
   }
 #undef LDS2_CASE
+  if (rc) return rc;
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// ---- k <= 3 products of a rows x cols block (ccqp_hip.h): one pass where the pair kernel would take one
+extern "C" int ccqp_gemvk_form(ccqp_ctx* ctx, int k, int64_t rows, int64_t cols, int variant, char* name, int buflen) {
+  CCQP_REQUIRE(ctx != nullptr && name != nullptr && buflen > 0, "NULL argument");
+  CCQP_REQUIRE(k >= 1 && k <= 3, "k outside [1, 3]");
+  if (k == 1) return ccqp_gemv_form(ctx, rows, cols, variant, name, buflen);
+  if (k == 2) return ccqp_gemv2_form(ctx, rows, cols, variant, name, buflen);
+  char two[64];
+  const int rc = ccqp_gemv2_form(ctx, rows, cols, variant, two, 64);
+  if (rc) return rc;
+  const char* kn = strcmp(two, "gemv_lds2_kernel") == 0 ? "gemv_lds3_kernel" : "three single matvecs";
+  strncpy(name, kn, (size_t)buflen - 1);
+  name[buflen - 1] = 0;
+  return CCQP_OK;
+}
+
+extern "C" int ccqp_gemvk_f64(ccqp_ctx* ctx, const double* A, int64_t lda, int k, const double* const* x, const double* b,
+                              double* const* y, double* const* g, int64_t rows, int64_t cols, int variant, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && x != nullptr && y != nullptr && g != nullptr, "NULL argument");
+  CCQP_REQUIRE(k >= 1 && k <= 3, "k outside [1, 3]");
+  if (k == 1) return ccqp_gemv_epilogue_f64(ctx, A, lda, x[0], b, y[0], g[0], rows, cols, variant, stream);
+  if (k == 2) return ccqp_gemv2_f64(ctx, A, lda, x[0], x[1], b, y[0], g[0], y[1], g[1], rows, cols, variant, stream);
+  bool fused = true;
+  for (int j = 0; j < 3; ++j) {
+    const int rc = gemv_check(ctx, A, lda, x[j], y[j], rows, cols);
+    if (rc) return rc;
+    CCQP_REQUIRE(g[j] == nullptr || b != nullptr, "g requested but b is NULL");
+    for (int i = 0; i < 3; ++i) {
+      CCQP_REQUIRE(y[j] != x[i] && (g[j] == nullptr || g[j] != x[i]), "outputs must not alias the inputs");
+      CCQP_REQUIRE(i == j || (y[j] != y[i] && (g[j] == nullptr || (g[j] != y[i] && g[j] != g[i]))),
+                   "outputs must not alias each other");
+    }
+    CCQP_REQUIRE(g[j] == nullptr || g[j] != y[j], "outputs must not alias each other");
+    fused = fused && (reinterpret_cast<uintptr_t>(x[j]) & 15) == 0;
+  }
+  if (rows == 0) return CCQP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  fused = fused && gemv2_fused(variant, A, lda, x[0], x[1], rows, cols);
+  if (!fused) {
+    for (int j = 0; j < 3; ++j) {
+      const int rc = ccqp_gemv_launch(ctx, A, lda, x[j], b, y[j], g[j], rows, cols, variant, s, nullptr);
+      if (rc) return rc;
+    }
+    CCQP_LAUNCH_CHECK();
+    return CCQP_OK;
+  }
+  const int v = gemv_lds_variant(variant == 0 ? GEMV_AUTO_LDS : gemv_resolve(variant, rows, cols, true));
+  int stagger = gemv_lds_decode(v).stagger;
+  if (stagger < 0) {
+    const double gib4 = 8.0 * (double)rows * (double)cols / 4294967296.0;
+    stagger = gib4 < 1.0 ? 1 : gib4 > 32.0 ? 32 : (int)(gib4 + 0.5);
+  }
+  const bool nt = !((v >> 8) & 1) && (double)rows * (double)cols * 8.0 > 192.0 * 1048576.0;
+  gemv_ldsk_io<3> io;
+  for (int j = 0; j < 3; ++j) io.x[j] = x[j], io.y[j] = y[j], io.g[j] = g[j];
+  // (the three-vector persistent launch's shape for few matrices: four rows per wave, four slots, four waves)
+  const int rc = launch_lds3<4, 4>(ctx, CCQP_BLOCK / 64, nt, stagger, s, A, lda, io, b, rows, cols);
   if (rc) return rc;
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;

@@ -589,7 +589,7 @@ def _bsegs_group(eng, items, n, max_mv, ahead, tune=0):
 
 _SPG_ROUNDS = 256         # rounds per call of the C driver (keeps the Python side interruptible)
 # A/B switch (tools, tests): True = the C driver advances the batch as ONE group instead of two alternating halves
-_SPG_ONE_GROUP = bool(int(__import__("os").environ.get("CCQP_SPG_ONE_GROUP", "0")))
+_SPG_ONE_GROUP = False    # (module attribute, set by the tool / test that wants it; the package reads no environment)
 _capsule_pointer = None
 
 

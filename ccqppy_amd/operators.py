@@ -120,6 +120,7 @@ class VectorExchange:
             raise ValueError("VectorExchange(mode='direct') needs the nccl (RCCL) backend, got %r" % backend)
         self.events = None
         self.calls = 0
+        self._many = {}                      # k -> (send, gathered) buffers of exchange_many
 
     def _run(self, fn, t):
         """Run collective `fn` on tensor t, staging through the host when the backend cannot
@@ -174,6 +175,92 @@ class VectorExchange:
         if ev is not None:
             ev[1].record(st)
             self.events.append(ev)
+
+    # ---- k products, ONE exchange (APGD's pair, MPRGP's look-ahead triple on a row-sharded matrix) -----------------
+    def slabs(self, k, like):
+        """k views of `rows` doubles each for this rank's slabs of k products: the local k-vector matvec writes them and
+        exchange_many ships them as they lie -- no staging copy.  Layout of the gathered buffer: rank r's slab of
+        product j at [(r k + j) per, + rows_r); all-gather: the views are a separate send buffer of k per doubles (send
+        and receive never alias); direct / all-reduce: they lie inside the gathered buffer at this rank's offset (RCCL's
+        in-place all-gather; the zero-padded sum)."""
+        key = (k, like.device)
+        bufs = self._many.get(key)
+        if bufs is None:
+            gathered = torch.zeros(self.world * k * self.per, dtype=torch.float64, device=like.device)
+            inplace = self.direct or self.mode == "allreduce"
+            lo = self.rank * k * self.per
+            send = gathered[lo:lo + k * self.per] if inplace else torch.zeros(k * self.per, dtype=torch.float64,
+                                                                               device=like.device)
+            bufs = self._many[key] = (send, gathered)
+        send = bufs[0]
+        return [send[j * self.per:j * self.per + self.rows] for j in range(k)]
+
+    def exchange_many(self, ys, b=None, gs=None, eng=None):
+        """After the local matvec has filled slabs(k, ...): ONE collective of k per doubles per rank, then ONE unpack
+        launch that scatters the slabs into the replicated vectors ys[j] and forms gs[j] = ys[j] + b where given (the same
+        single add as the fused epilogue: the same bits).  k = len(ys) <= 3."""
+        k = len(ys)
+        gs = [None] * k if gs is None else gs
+        send, gathered = self._many[(k, ys[0].device)]
+        dev = ys[0].is_cuda
+        ev = st = None
+        if dev:
+            st = eng.torch_stream if eng is not None else torch.cuda.current_stream(ys[0].device)
+        if self.events is not None and st is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(st)
+        if self.world > 1:
+            if st is not None and eng is not None and not self.direct:
+                with torch.cuda.stream(st):              # (one ordering domain with the matvec: see __call__)
+                    self._collective_many(k, send, gathered, eng)
+            else:
+                self._collective_many(k, send, gathered, eng)
+        elif send.data_ptr() != gathered.data_ptr():
+            gathered.copy_(send)
+        if dev and eng is not None:
+            eng.unpack_gathered(gathered, k, self.per, ys, b, gs)
+        else:                                            # CPU tensors (the gloo tests): the same index map, the same add
+            view = gathered.view(self.world, k, self.per)
+            for j in range(k):
+                ys[j].copy_(view[:, j, :].reshape(-1)[:self.n])
+                if gs[j] is not None:
+                    torch.add(ys[j], b, out=gs[j])
+        self.calls += 1
+        if ev is not None:
+            ev[1].record(st)
+            self.events.append(ev)
+
+    def _collective_many(self, k, send, gathered, eng):
+        dist, cnt = self.dist, k * self.per
+        if self.direct:
+            from . import _lib
+            _lib.check(eng.lib.ccqp_comm_allgather_f64(self._direct_comm(eng), gathered.data_ptr(), cnt, eng.stream))
+            return
+        if self.mode == "allreduce":
+            lo = self.rank * cnt
+            for a, z in ((0, lo), (lo + cnt, self.world * cnt)):
+                if z > a:
+                    if eng is not None and gathered.is_cuda:
+                        eng.fill(0.0, gathered[a:z])
+                    else:
+                        gathered[a:z].zero_()
+            self._run(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group), gathered)
+            return
+        if self.stage_cpu and gathered.is_cuda:          # gloo with device tensors (tests only): through the host
+            hs, hg = send.cpu(), torch.empty(gathered.numel(), dtype=gathered.dtype)
+            self._gather_flat(hg, hs)
+            gathered.copy_(hg)
+        else:
+            self._gather_flat(gathered, send)
+
+    def _gather_flat(self, full, src):
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(full, src, group=self.group)      # (an RCCL error is an error of the run)
+            return
+        try:
+            self.dist.all_gather_into_tensor(full, src, group=self.group)
+        except (RuntimeError, NotImplementedError):      # a CPU backend without the flat form (tests only)
+            self.dist.all_gather(list(full.chunk(self.world)), src, group=self.group)
 
     def open(self, eng):
         """Create the C-ABI RCCL communicator of mode="direct" now (collective: every rank of the group must call it;
@@ -516,24 +603,42 @@ class RowShardedOperator:
             eng.axpby(1.0, y, 1.0, b, g)   # same bits as the fused epilogue: one add
 
     def matvec2(self, x1, y1, g1, x2, y2, g2, b=None, engine=None):
-        """Two products in one pass over the local row block (Engine.gemv2), then the two exchanges."""
+        """Two products: ONE pass over the local row block (Engine.gemv2) straight into the exchange's send slabs, ONE
+        exchange, ONE unpack launch that also forms g_j = y_j + b -- per APGD iteration 1 matvec launch + 1 collective +
+        1 small launch (round 3: 1 + 2 copies + 2 collectives + 2 axpby)."""
+        self.matvec_many([x1, x2], [y1, y2], [g1, g2], b, engine)
+
+    def matvec3(self, xs, ys, gs, b=None, engine=None):
+        """ys[j] = A.xs[j] (gs[j] = ys[j] + b where given) for the j with ys[j] not None -- MPRGP's look-ahead on a
+        row-sharded matrix: one pass over the local block and one exchange for all of them."""
+        act = [j for j in range(len(xs)) if ys[j] is not None]
+        self.matvec_many([xs[j] for j in act], [ys[j] for j in act], [gs[j] for j in act], b, engine)
+
+    def matvec_many(self, xs, ys, gs, b=None, engine=None):
         eng = engine or self.engine
-        if self.sparse:
-            self.matvec(x1, y1, b, g1, eng)
-            self.matvec(x2, y2, b, g2, eng)
+        k = len(xs)
+        if k == 1 or self.sparse:
+            for x, y, g in zip(xs, ys, gs):
+                self.matvec(x, y, b, g, eng)
             return
-        sl = slice(self.row0, self.row0 + self.rows)
-        eng.gemv2(self.A, x1, x2, y1[sl], y2[sl])
-        self.exchange(y1, eng)
-        self.exchange(y2, eng)
-        if g1 is not None:
-            eng.axpby(1.0, y1, 1.0, b, g1)
-        if g2 is not None:
-            eng.axpby(1.0, y2, 1.0, b, g2)
+        slabs = self.exchange.slabs(k, ys[0])
+        if self.rows:
+            eng.gemvk(self.A, xs, slabs)
+        else:
+            eng.mv_executed += k                        # (a rank without rows still counts the products it takes part in)
+            eng.products_launched += k
+        self.exchange.exchange_many(ys, b, gs, eng)
+
+    def _block_aligned(self):
+        return (not self.sparse) and self.A.data_ptr() % 16 == 0 and self.A.stride(0) % 2 == 0
 
     def pair_in_one_pass(self, engine=None):
         eng = engine or self.engine
-        return (not self.sparse) and hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
+        return self._block_aligned() and hasattr(eng, "gemv2_form") and eng.gemv2_form(self.rows, self.n) == "gemv_lds2_kernel"
+
+    def triple_in_one_pass(self, engine=None):
+        eng = engine or self.engine
+        return self._block_aligned() and hasattr(eng, "gemvk_form") and eng.gemvk_form(3, self.rows, self.n) == "gemv_lds3_kernel"
 
 
 def as_operator(A, engine=None):

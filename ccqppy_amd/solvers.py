@@ -890,7 +890,8 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         look = self.look_ahead
         if look is None:
             look = hasattr(run.op, "triple_in_one_pass") and run.op.triple_in_one_pass(eng)
-        look = bool(look) and hasattr(run.op, "matvec3") and getattr(run.op, "rows", None) == run.n \
+        # (any operator with a matvec3: the whole dense matrix, or a rank's row block with ONE exchange for the products)
+        look = bool(look) and hasattr(run.op, "matvec3") and getattr(run.op, "n", None) == run.n \
             and not isinstance(eng, RecordingEngine)
         g_ahead = None                                  # A.x_k + b of the NEXT loop top, computed ahead (or in place)
         Ap_ahead = None                                 # A.p of the next :1100

@@ -59,7 +59,7 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  * always "the tuned default".  They are read by the launches made with THIS context only (nothing in the library reads
  * the environment); not thread-safe against launches in flight on the same context (one host thread per context).
  *   GEMV_ROW_STRIDE        k >= 1: a wave's R row streams lie k rows apart (LDS-staged matvecs; default: ~1 MiB apart)
- *   GEMV2_WPB              1..4 waves per workgroup of the two-vector launch ccqp_gemv2_f64 (default by shape)
+ *   GEMV2_WPB              1..8 waves per workgroup of the two-vector launch ccqp_gemv2_f64 (default 4)
  *   GEMV2_SHAPE            <R><S> of its ring as a two-digit number: 44, 43, 82, 83, 84 (rows per wave, ring slots)
  *   GEMV2_GROUP            row sums a wave parks before it stores them: 64 .. 512 (default 512)
  *   BMV3_SHAPE             <R><S><W> of the three-vector persistent launch: 824, 833, 444, 434
@@ -138,6 +138,14 @@ int ccqp_gemv2_form(ccqp_ctx* ctx, int64_t rows, int64_t cols, int variant, char
 int ccqp_gemv3_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const double* const* x, const double* b,
                    double* const* y, double* const* g, int64_t n, int variant, void* stream);
 int ccqp_gemv3_form(ccqp_ctx* ctx, int64_t n, int variant, char* name, int buflen);
+/* k = 1, 2 or 3 matvecs with one rows x cols BLOCK (any shape: a rank's row block) in one pass over it: y[j] = A x[j],
+ * g[j] = y[j] + b where g[j] != NULL, every j < k given.  k = 1 / 2: ccqp_gemv_epilogue_f64 / ccqp_gemv2_f64; k = 3:
+ * "gemv_lds3_kernel" wherever the pair kernel would take one pass, else three single matvecs (ccqp_gemvk_form).  Each
+ * product has the bits of its own ccqp_gemv_f64 call.  Replaces, on a row-sharded matrix, the A.dot(dx), A.dot(xk) and
+ * A.dot(p) across the end of an MPRGP iteration (solvers.py:1129 | :1163, :1086, :1100). */
+int ccqp_gemvk_f64(ccqp_ctx* ctx, const double* A, int64_t lda, int k, const double* const* x, const double* b,
+                   double* const* y, double* const* g, int64_t rows, int64_t cols, int variant, void* stream);
+int ccqp_gemvk_form(ccqp_ctx* ctx, int k, int64_t rows, int64_t cols, int variant, char* name, int buflen);
 /* Measurement hook (kernel-level roofline figures measured live, not only under a profiler): between
  * begin and end every BATCHED matvec launch of the lock-step drivers (ccqp_bpipe_*, ccqp_bapgd_*, ccqp_bmprgp_*,
  * ccqp_bsegs_*, ccqp_bspg_*) is bracketed by a pair of HIP events on its own stream, up to `max_pairs` of them (later
@@ -258,6 +266,24 @@ int ccqp_comm_allreduce_sum_f64(ccqp_comm* comm, double* buf, int64_t count, voi
 int ccqp_shard_gemv_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda, const double* x,
                                   double* y, int64_t rows_local, int64_t per, int64_t cols, int variant, int mode,
                                   void* stream);
+
+/* The k products of an APGD iteration (k = 2: solvers.py:290 and :275 of the next iteration, y_{k+1} is known as soon as
+ * x_{k+1} is) or across the end of an MPRGP iteration (k <= 3: :1129 | :1163, :1086, :1100) on a row-sharded matrix with
+ * ONE exchange: the local k-vector pass (ccqp_gemvk_f64) writes its slabs straight into this rank's part of `work`
+ * (k * per * nranks doubles of device memory owned by the caller; rank r's slab of product j at work[(r k + j) per ...)),
+ * one in-place all-gather of k * per doubles per rank, one unpack launch that scatters the slabs into the replicated
+ * vectors y[j] (cols entries each) and forms g[j] = y[j] + b where g[j] != NULL -- the same single add as the fused
+ * epilogue, so every product is bitwise its own single-GPU ccqp_gemv_epilogue_f64.  Per iteration: 1 matvec launch +
+ * 1 collective + 1 unpack launch.  ccqp_unpack_gathered_f64 is that last launch by itself (for callers that bring their
+ * own collective, e.g. torch.distributed). */
+int ccqp_shard_gemvk_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda, int k,
+                                   const double* const* x, const double* b, double* const* y, double* const* g,
+                                   int64_t rows_local, int64_t per, int64_t cols, int variant, double* work, void* stream);
+int ccqp_shard_gemv2_allgather_f64(ccqp_ctx* ctx, ccqp_comm* comm, const double* A_local, int64_t lda, const double* x1,
+                                   const double* x2, const double* b, double* y1, double* g1, double* y2, double* g2,
+                                   int64_t rows_local, int64_t per, int64_t cols, int variant, double* work, void* stream);
+int ccqp_unpack_gathered_f64(ccqp_ctx* ctx, const double* gathered, int k, int64_t per, int64_t n, double* const* y,
+                             const double* b, double* const* g, void* stream);
 
 /* ---- a5-a8 for ANY feasible set in <= 2 launches: the segmented engine (ccqp_segs.hip) -----------------------
  * Replaces the Python loop of DisjointProjOp.__call__ / normal_vector (solution_spaces.py:540-560, 512-525) and

@@ -24,6 +24,14 @@
     }                                                                          \
   } while (0)
 
+#define HIPCHECK(call)                                          \
+  do {                                                          \
+    if ((call) != hipSuccess) {                                 \
+      fprintf(stderr, "%s failed\n", #call);                    \
+      return 3;                                                 \
+    }                                                           \
+  } while (0)
+
 /* a caller-supplied source of uniform [0,1) doubles for the lock-step SPG driver (any generator with numpy's bitgen_t
  * layout will do; from Python it is a RandomState's own) */
 static double lcg_next_double(void* state) {
@@ -40,6 +48,27 @@ int main(void) {
   int dev = -1, ncu = 0;
   CHECK(ccqp_ctx_info(ctx, &dev, &ncu, arch, sizeof(arch)));
   printf("device %d: %s, %d CUs, ABI %d\n", dev, arch, ncu, ccqp_abi_version());
+  if (ccqp_abi_version() != CCQP_ABI_VERSION || CCQP_ABI_VERSION != 2) {
+    fprintf(stderr, "ABI version mismatch\n");
+    return 1;
+  }
+  {
+    /* tuning options live in the context (nothing in the library reads the environment): set, read back, range check */
+    int64_t v = -1;
+    int bad_opt = 0;
+    CHECK(ccqp_ctx_get_option(ctx, CCQP_OPT_GEMV_ROW_STRIDE, &v));
+    if (v != 0) bad_opt++;
+    CHECK(ccqp_ctx_set_option(ctx, CCQP_OPT_GEMV_ROW_STRIDE, 4));
+    CHECK(ccqp_ctx_get_option(ctx, CCQP_OPT_GEMV_ROW_STRIDE, &v));
+    if (v != 4) bad_opt++;
+    CHECK(ccqp_ctx_set_option(ctx, CCQP_OPT_GEMV_ROW_STRIDE, 0));
+    if (ccqp_ctx_set_option(ctx, CCQP_OPT_GEMV2_SHAPE, 45) != CCQP_ERR_INVALID) bad_opt++;
+    if (ccqp_ctx_set_option(ctx, CCQP_OPT_COUNT, 1) != CCQP_ERR_INVALID) bad_opt++;
+    if (bad_opt) {
+      fprintf(stderr, "context options misbehave\n");
+      return 1;
+    }
+  }
 
   double *A, *x, *b, *y, *g, *p;
   if (hipMalloc((void**)&A, n * n * sizeof(double)) || hipMalloc((void**)&x, n * sizeof(double)) ||
@@ -455,10 +484,44 @@ int main(void) {
     printf("matvec plan: %lld x %lld -> 1 launch; 131072 x 131072 -> 1 launch (LDS-staged), VALU form: %lld launches of "
            "%lld rows\n", (long long)n, (long long)n, (long long)launches, (long long)per);
     /* the batched matvec of the lock-step forms: one persistent LDS-DMA launch from n = 4096 and 1 GiB on */
-    CHECK(ccqp_bpipe_matvec_form(128, 8192, 1, form, 64));
+    CHECK(ccqp_bpipe_matvec_form(ctx, 128, 8192, 1, form, 64));
     if (strcmp(form, "bp_gemv_pers_kernel")) bad++;
-    CHECK(ccqp_bpipe_matvec_form(8, 512, 1, form, 64));
+    CHECK(ccqp_bpipe_matvec_form(ctx, 8, 512, 1, form, 64));
     if (strcmp(form, "batched VALU kernel")) bad++;
+    CHECK(ccqp_gemvk_form(ctx, 3, 8192, 16384, 0, form, 64));
+    if (strcmp(form, "gemv_lds3_kernel")) bad++;
+  }
+  {
+    /* three products of one block in one call (ccqp_gemvk_f64, the LDS-staged form forced onto this small matrix) and
+     * the unpack launch of the row-sharded path (one "rank"): every product bitwise its own ccqp_gemv_epilogue_f64 */
+    double *w3, *y3, *g3;
+    HIPCHECK(hipMalloc((void**)&w3, 3 * n * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&y3, 3 * n * sizeof(double)));
+    HIPCHECK(hipMalloc((void**)&g3, 3 * n * sizeof(double)));
+    const double* xs[3] = {x, b, p};
+    double* ws[3] = {w3, w3 + n, w3 + 2 * n};
+    double* none[3] = {NULL, NULL, NULL};
+    double* ys[3] = {y3, y3 + n, y3 + 2 * n};
+    double* gs[3] = {g3, NULL, g3 + 2 * n};
+    CHECK(ccqp_gemvk_f64(ctx, A, n, 3, xs, NULL, ws, none, n, n, 0x51001800, NULL));
+    CHECK(ccqp_unpack_gathered_f64(ctx, w3, 3, n, n, ys, b, gs, NULL));
+    double* hy = (double*)malloc(3 * n * sizeof(double));
+    double* hg = (double*)malloc(3 * n * sizeof(double));
+    double* hr = (double*)malloc(2 * n * sizeof(double));
+    HIPCHECK(hipMemcpy(hy, y3, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(hg, g3, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 3; ++j) {
+      CHECK(ccqp_gemv_epilogue_f64(ctx, A, n, xs[j], b, y, g, n, n, 0, NULL));
+      HIPCHECK(hipMemcpy(hr, y, n * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHECK(hipMemcpy(hr + n, g, n * sizeof(double), hipMemcpyDeviceToHost));
+      if (memcmp(hr, hy + j * n, n * sizeof(double))) bad++;
+      if (j != 1 && memcmp(hr + n, hg + j * n, n * sizeof(double))) bad++;
+    }
+    printf("three products in one call + unpack: mismatches so far %d\n", bad);
+    free(hy); free(hg); free(hr);
+    hipFree(w3); hipFree(y3); hipFree(g3);
+    /* leave y / g as the rest of the program expects them */
+    CHECK(ccqp_gemv_epilogue_f64(ctx, A, n, x, b, y, g, n, n, 0, NULL));
   }
   /* error path: message through ccqp_last_error */
   if (ccqp_gemv_f64(ctx, A, n - 1, x, y, n, n, 0, NULL) != CCQP_ERR_INVALID) bad++;

@@ -63,6 +63,11 @@ def test_two_rank_line_is_complete():
     for form in ("allgather", "allreduce"):
         assert ab[form]["calls"] == 50 and ab[form]["median_ms"] > 0
     assert ab["bitwise_equal_forms"] and ab["bitwise_equal_ranks"] and ab["no_nan_left"]
+    # the exchange of a pair of products: one collective + one unpack launch against two + two, same bits
+    pp = ab["pair_of_products"]["allgather"]
+    assert pp["bitwise_equal"] and pp["one_exchange_one_unpack"]["median_ms"] > 0 and pp["two_exchanges_two_axpby"]["calls"] == 50
+    # and the timed solve itself exchanged once per PAIR launch (exchange events = matvec launches)
+    assert d["roofline"]["exchange_ms_per_mv"] > 0 and d["roofline"]["exchanges_per_step"] == d["matvec_launches_per_step"]
 
 
 @pytest.mark.parametrize("fault", ["raise", "hang"])

@@ -87,6 +87,84 @@ def test_row_sharded_equals_single_gpu_bitwise(n, mode):
                 assert np.array_equal(x, x1), (name, rank)
 
 
+def _solve_sharing(op, b, n):
+    """The solvers whose products share passes -- and, on a row-sharded operator, ONE exchange per pass: APGD and its
+    anti-relaxation variant with paired matvecs, MPRGP with its look-ahead (forced on; single GPU: the plain loops)."""
+    from ccqppy_amd import solvers, solution_spaces as ss
+    sharded = hasattr(op, "exchange")
+    box = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
+    out = {}
+    for name, make in (("APGD", lambda: solvers.CCQPSolverAPGD(1e-8, 5000, pair_matvecs=sharded)),
+                       ("AR", lambda: solvers.CCQPSolverAPGDAntiRelaxation(1e-8, 5000, pair_matvecs=sharded)),
+                       ("APGD budget 9", lambda: solvers.CCQPSolverAPGD(1e-12, 9, pair_matvecs=sharded)),
+                       ("MPRGP", lambda: solvers.CCQPSolverMPRGP(1e-6, 300, look_ahead=sharded)),
+                       ("MPRGP budget 7", lambda: solvers.CCQPSolverMPRGP(1e-12, 7, look_ahead=sharded))):
+        eng = op.engine
+        calls0 = op.exchange.calls if sharded else 0
+        launched0 = eng.products_launched
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = make().solve(op, b, convex_proj_op=box)
+        out[name] = (r.solution.cpu().numpy().copy(), int(r.solution_num_matrix_vector_multiplications),
+                     int(r.executed_matrix_vector_multiplications), float(r.solution_residual),
+                     (op.exchange.calls - calls0) if sharded else None, eng.products_launched - launched0)
+    return out
+
+
+def _sharing_worker(rank, world, port, n, mode, variant, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from ccqppy_amd import problems
+        from ccqppy_amd._engine import get_engine
+        get_engine(0).gemv_variant = variant
+        op, b, _ = problems.random_problem(n, 1234, device=0, group=dist.group.WORLD, mode=mode)
+        forms = (op.pair_in_one_pass(), op.triple_in_one_pass())
+        q.put((rank, forms, _solve_sharing(op, b, n)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,mode,variant", [(1024, "allgather", 0x51001800), (1001, "allgather", 0x51001800),
+                                            (1024, "allreduce", 0x51001800), (1026, "allgather", 0)])
+def test_shared_passes_share_one_exchange_and_change_no_bit(n, mode, variant):
+    """Row-sharded APGD / anti-relaxation APGD with paired matvecs and MPRGP with its look-ahead, 2 ranks: per pass ONE
+    local multi-vector launch (variant 0x51001800 forces the LDS-staged forms gemv_lds2_kernel / gemv_lds3_kernel onto
+    these small blocks; n = 1001 and variant 0 fall back to single local launches) + ONE exchange + one unpack launch.
+    x, residual, reported and executed counts are bitwise those of the plain single-GPU solves; the number of exchanges
+    is the number of PASSES (fewer than the matvecs executed)."""
+    import torch.multiprocessing as mp
+    from ccqppy_amd import problems
+    op, b, _ = problems.random_problem(n, 1234, device=0)
+    single = _solve_sharing(op, b, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharing_worker, args=(r, 2, port, n, mode, variant, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, forms, res in results:
+        assert forms == ((True, True) if (variant and n % 2 == 0) else (False, False)), (rank, forms)
+        for name, (x, mv, execd, resid, exchanges, launched) in res.items():
+            x1, mv1, ex1, res1, _, _ = single[name]
+            assert (mv, execd) == (mv1, ex1), (name, rank)
+            if mode == "allgather":
+                assert np.array_equal(x.view(np.uint64), x1.view(np.uint64)), (name, rank)
+                assert resid == res1
+            else:
+                assert np.array_equal(x, x1), (name, rank)
+            # one exchange per pass: the products computed come in pairs / triples, each pass exchanged once
+            assert exchanges < launched and exchanges <= execd, (name, rank, exchanges, launched, execd)
+            if name == "APGD":
+                assert 2 * exchanges == launched, (name, rank, exchanges, launched)
+
+
 def _rccl_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -221,6 +299,37 @@ def _rccl_direct_worker(port, q):
                                                          y.data_ptr(), n, n, n, 0, mode, eng.stream))
             torch.cuda.synchronize()
             out["shard_mode%d" % mode] = bool(torch.equal(y.view(torch.int64), want.view(torch.int64)))
+        # k products, one exchange (ccqp_shard_gemv2_allgather_f64 / ccqp_shard_gemvk_allgather_f64): local pass into
+        # `work`, in-place all-gather, unpack with the + b epilogue -- each product bitwise its own matvec
+        xs = [x, problems.xstar(n, 6), problems.xstar(n, 7)]
+        bvec = problems.xstar(n, 8)
+        wants = []
+        for xj in xs:
+            yj, gj = eng.empty(n), eng.empty(n)
+            eng.gemv(A, xj, yj, bvec, gj)
+            wants.append((yj, gj))
+        for variant in (0, 0x51001800):
+            work = torch.full((3 * n,), float("nan"), dtype=torch.float64, device="cuda")
+            ys = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+            gs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+            _lib.check(lib.ccqp_shard_gemv2_allgather_f64(eng.ctx, comm, A.data_ptr(), A.stride(0), xs[0].data_ptr(),
+                                                          xs[1].data_ptr(), bvec.data_ptr(), ys[0].data_ptr(), gs[0].data_ptr(),
+                                                          ys[1].data_ptr(), None, n, n, n, variant, work.data_ptr(), eng.stream))
+            torch.cuda.synchronize()
+            ok = all(torch.equal(ys[j].view(torch.int64), wants[j][0].view(torch.int64)) for j in range(2))
+            ok = ok and torch.equal(gs[0].view(torch.int64), wants[0][1].view(torch.int64)) and bool(torch.isnan(gs[1]).all())
+            arr = ctypes.c_void_p * 3
+            for t in ys + gs:
+                t.fill_(float("nan"))
+            _lib.check(lib.ccqp_shard_gemvk_allgather_f64(eng.ctx, comm, A.data_ptr(), A.stride(0), 3,
+                                                          arr(*[t.data_ptr() for t in xs]), bvec.data_ptr(),
+                                                          arr(*[t.data_ptr() for t in ys]),
+                                                          arr(None, gs[1].data_ptr(), gs[2].data_ptr()), n, n, n, variant,
+                                                          work.data_ptr(), eng.stream))
+            torch.cuda.synchronize()
+            ok = ok and all(torch.equal(ys[j].view(torch.int64), wants[j][0].view(torch.int64)) for j in range(3))
+            ok = ok and all(torch.equal(gs[j].view(torch.int64), wants[j][1].view(torch.int64)) for j in (1, 2))
+            out["shard_many_%x" % variant] = bool(ok)
         # the collectives themselves, on our stream right behind one of our kernels (1 rank: identity / x1 sum)
         z = eng.empty(n)
         eng.scale(2.0, want, z)
@@ -250,4 +359,5 @@ def test_rccl_through_the_c_abi_single_rank():
     assert p.exitcode == 0
     assert out["version"] > 0 and out["info"] == (1, 0)
     assert out["shard_mode0"] and out["shard_mode1"] and out["collectives"] and out["bad_rank_rejected"]
+    assert out["shard_many_0"] and out["shard_many_51001800"]
     assert out["exchange_mode"] == (True, "allgather")

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 
 def main():
@@ -27,6 +28,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--scheduler", default="pipelined", choices=["fused", "lanes", "sequential", "pipelined"])
+    add_option_args(ap)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -35,6 +37,7 @@ def main():
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
+    options = apply_options(args, local)           # (per-context tuning options: the A/B switches, tools/README.md)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -83,6 +86,7 @@ def main():
         mv, conv = int(t[0].item()), int(t[1].item())
     if rank == 0:
         print(json.dumps({
+            "options": options,
             "config": "BASELINE config 5: %d x (n=%d MPRGP+Box, tol 1e-6), batch-sharded over %d GPU(s), scheduler=%s"
                       % (total, n, world, args.scheduler),
             "n_gpus": world, "problems": total, "wall_s": best, "problems_per_s": total / best,

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 
 def main():
@@ -22,7 +23,9 @@ def main():
     ap.add_argument("--solvers", default="BBPGD,APGD,MPRGP,SPG")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--set", default="box", help="box | union (a Sphere block and a Box block: the segmented lock-step forms)")
+    add_option_args(ap)
     args = ap.parse_args()
+    options = apply_options(args)                  # (per-context tuning options: the A/B switches, tools/README.md)
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     from ccqppy_amd._engine import get_engine
     lib = get_engine(0).lib
@@ -71,7 +74,7 @@ def main():
                               sum(r.executed_matrix_vector_multiplications for r in res), float(ms.sum()), int(len(ms)))
             same = bool(torch.equal(out["persistent_lds"][1].view(torch.int64), out["valu"][1].view(torch.int64)))
             mv = out["valu"][2]
-            print(json.dumps({"solver": kind, "set": args.set, "n": n, "problems": B, "executed_mv": int(mv),
+            print(json.dumps({"options": options, "solver": kind, "set": args.set, "n": n, "problems": B, "executed_mv": int(mv),
                               "problems_per_s_persistent_lds": B / out["persistent_lds"][0],
                               "problems_per_s_valu": B / out["valu"][0],
                               "gain": out["valu"][0] / out["persistent_lds"][0] - 1.0,

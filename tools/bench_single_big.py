@@ -15,13 +15,16 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="32768,65536")
     ap.add_argument("--reps", type=int, default=3)
+    add_option_args(ap)
     args = ap.parse_args()
+    options = apply_options(args)                  # (per-context tuning options: the A/B switches, tools/README.md)
     from ccqppy_amd import problems, solvers, solution_spaces as ss
     for n in (int(v) for v in args.sizes.split(",")):
         op, b, _ = problems.random_problem(n, 1234)
@@ -45,7 +48,7 @@ def main():
             same = bool(torch.equal(a.solution.view(torch.int64), c.solution.view(torch.int64))) and \
                 a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications and \
                 a.executed_matrix_vector_multiplications == c.executed_matrix_vector_multiplications
-            print(json.dumps({"n": n, "solver": name, "reported_mv": int(a.solution_num_matrix_vector_multiplications),
+            print(json.dumps({"n": n, "options": options, "solver": name, "reported_mv": int(a.solution_num_matrix_vector_multiplications),
                               "executed_mv": int(a.executed_matrix_vector_multiplications),
                               "wall_ms_one_pass_per_matvec": 1e3 * out[False][0], "wall_ms_multi_vector_passes": 1e3 * out[True][0],
                               "speedup": out[False][0] / out[True][0], "same_bits_and_counts": same,

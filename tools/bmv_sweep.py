@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 
 def main():
@@ -24,7 +25,9 @@ def main():
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--tunes", default="")
+    add_option_args(ap)
     args = ap.parse_args()
+    options = apply_options(args)                  # (per-context tuning options: the A/B switches, tools/README.md)
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     from ccqppy_amd._engine import get_engine
     from ccqppy_amd.operators import as_operator

@@ -33,6 +33,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 SOURCES = {
     "dense": ("ccqppy_amd/csrc/ccqp_gemv.hip", "ccqppy_amd/csrc/ccqp_bodies.h", "ccqppy_amd/csrc/ccqp_internal.h"),
@@ -330,7 +331,9 @@ def main():
     ap.add_argument("--problems", type=int, default=128)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--cpu", action="store_true")
+    add_option_args(ap)
     args = ap.parse_args()
+    options = apply_options(args)                  # (per-context tuning options: the A/B switches, tools/README.md)
     torch.cuda.set_device(0)
     line = config5(args) if args.which == "5" else dense_config(args.which, args)
     print(json.dumps(line), flush=True)

@@ -29,6 +29,12 @@ SHAPES = {
     "R8 S2 w2 x2/CU": (82, 2, 0, 2),
     "R4 S3 w3 x2/CU": (43, 3, 0, 2),
     "R4 S4 w2 x2/CU": (44, 2, 0, 2),
+    "R4 S4 w5": (44, 5, 0, 1),
+    "R4 S4 w6 g256": (44, 6, 256, 1),
+    "R4 S3 w5": (43, 5, 0, 1),
+    "R4 S3 w6": (43, 6, 0, 1),
+    "R4 S3 w7": (43, 7, 0, 1),
+    "R4 S3 w8 g128": (43, 8, 128, 1),
     "R4 S4 w4 g256": (44, 4, 256, 1),
     "R4 S4 w4 g128": (44, 4, 128, 1),
     "R8 S2 w4 g256": (82, 4, 256, 1),
@@ -100,7 +106,7 @@ def main():
             single = k.startswith("single")
             nbytes = 8.0 * (n * n + (2 if single else 4) * n)
             print(json.dumps({"n": n, "what": k, "ms": round(m, 5), "min_ms": round(min(t[k]), 5),
-                              "max_ms": round(max(t[k]), 5), "frac_of_8TBps": round(nbytes / m / 1e9 / 8000.0, 4),
+                              "max_ms": round(max(t[k]), 5), "frac_of_8TBps": round(nbytes / (m * 1e-3) / 1e9 / 8000.0, 4),
                               "same_bits_as_single_passes": same.get(k), "launches_per_sample": reps,
                               "rounds": args.rounds, "box": box.get("host"), "gpu_uuid": box.get("gpu_uuid")}), flush=True)
         for name in ("GEMV2_SHAPE", "GEMV2_WPB", "GEMV2_GROUP"):

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._opts import add_option_args, apply_options  # noqa: E402
 
 
 def main():
@@ -20,7 +21,9 @@ def main():
     ap.add_argument("--problems", type=int, default=128)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=3)
+    add_option_args(ap)
     args = ap.parse_args()
+    options = apply_options(args)                  # (per-context tuning options: the A/B switches, tools/README.md)
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     n, B = args.size, args.problems
     lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
@@ -54,7 +57,7 @@ def main():
         if ref is None:
             ref = x
         mv = sum(r.executed_matrix_vector_multiplications for r in res)
-        print(json.dumps({"variant": label, **kw, "n": n, "problems": B, "wall_s": best, "problems_per_s": B / best,
+        print(json.dumps({"options": options, "variant": label, **kw, "n": n, "problems": B, "wall_s": best, "problems_per_s": B / best,
                           "executed_mv": int(mv), "solve_level_hbm_frac": mv * 8.0 * (n * n + 2 * n) / best / 8e12,
                           "same_bits_as_first": bool(torch.equal(x.view(torch.int64), ref.view(torch.int64))),
                           "converged": int(sum(bool(r.solution_converged) for r in res))}), flush=True)
