@@ -17,7 +17,10 @@ import torch
 
 from . import _lib
 
+import weakref
+
 _engines = {}
+_live = weakref.WeakSet()  # every engine alive (lane engines are cached by their schedulers): set_default_option reaches them
 _default_options = {}      # device index -> {option name: value}: what every NEW engine (lane engines too) of the device starts with
 
 
@@ -59,7 +62,10 @@ def set_default_option(name, value, device=None):
     if name not in _lib.OPTIONS:
         raise KeyError("no such option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
     _default_options.setdefault(idx, {})[name] = int(value)
-    get_engine(idx).set_option(name, value)
+    get_engine(idx)
+    for eng in list(_live):
+        if eng.index == idx:
+            eng.set_option(name, value)
 
 
 def make_lanes(device, count):
@@ -92,6 +98,7 @@ class Engine:
         self.gemv_events = None   # list of (start, end) HIP events per matvec when profiling is on
         for name, value in _default_options.get(index, {}).items():
             self.set_option(name, value)
+        _live.add(self)
         self.own_stream = stream  # torch.cuda.Stream of a lane engine, None for the default engine
         self.torch_stream = stream
         self.stream = None        # raw hipStream_t (int) every launch goes to

@@ -194,6 +194,7 @@ SIGNATURES = {
     "ccqp_pipe_graph_destroy": [_P],
     "ccqp_bpipe_partials_doubles": [_I64],
     "ccqp_bpipe_matvec_form": [_P, _I, _I64, _I, _c.c_char_p, _I],
+    "ccqp_bmv3_shape": [_P, _I],
     "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],

@@ -350,6 +350,9 @@ extern "C" int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int f
   return CCQP_OK;
 }
 
+// ring shape of the three-vector persistent launch for `count` problems per launch: <rows per wave><slots><waves>
+extern "C" int ccqp_bmv3_shape(ccqp_ctx* ctx, int count) { return bp_gemv3_shape(ctx, count); }
+
 // doubles of partial-sum area one problem needs for vectors of length n
 extern "C" int64_t ccqp_bpipe_partials_doubles(int64_t n) {
   int64_t chunk;

@@ -850,6 +850,15 @@ class _MprgpRun:
             self.last = 0
         else:
             check(lib.ccqp_bmprgp_start_f64(ctx, dp, B, n, gd, flags, batch, st))
+            # what this run's batched matvec launches as (for tests / tools: config 5's share must be the >= 32-problem
+            # shape of the three-vector persistent launch)
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            check(lib.ccqp_bpipe_matvec_form(ctx, B, n, (flags & 0xFFFF) | (1 << 16) | (1 << 18), buf, 64))
+            stats["last_mprgp_run"] = {"problems": B, "n": n, "matvec": buf.value.decode(),
+                                       "triple_shape": int(lib.ccqp_bmv3_shape(ctx, B)),
+                                       "looks_ahead": buf.value.decode() == "bp_gemv_pers_kernel"
+                                       and not eng.get_option("MPRGP_LOOKAHEAD")}
         self.vec, self.slabs, self.keep = vec, slabs, (keep, words, dprobs)
 
     def finish(self):

@@ -431,6 +431,12 @@ class _APGDCore(CCQPSolverBase):
         return (xhat if AR else xkp1), res, mv_count
 
 
+    # largest n of a device-resident solve (pipeline=True).  Up to 2048 the whole solve is one launch or VALU rounds; from
+    # 4096 on the batch of one takes the persistent multi-vector matvec (one pass for A.x_{k+1} and A.y_{k+1}, the same
+    # kernel family as the host-driven loop's ccqp_gemv2_f64) and what is saved is the host's turn-around per iteration;
+    # beyond 16384 a pass over A (> 0.3 ms) hides the host completely.
+    _PIPELINE_MAX_N = 16384
+
     def _lockstep(self, run):
         """The whole solve as a lock-step batch of one (batch._bapgd_run); None if it does not apply or the matvec
         budget was reached first."""
@@ -439,7 +445,7 @@ class _APGDCore(CCQPSolverBase):
         from .operators import DenseOperator
         op, eng = run.op, run.eng
         elementwise = hasattr(run.P, "_dev_bb_tail")
-        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
                 and (elementwise or run.P._has_device_form())
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
@@ -841,7 +847,10 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     def name(self):
         return "MPRGP"
 
-    _PIPELINE_MAX_N = 1024     # beyond: the host-driven loop is as fast or faster (measured: x1.7 at 256, x1.3 at 1024, x0.9 at 2000)
+    # largest n of a device-resident solve (pipeline=True): round 3 measured the VALU rounds against the host-driven loop
+    # (x1.7 at 256, x1.3 at 1024, x0.9 at 2000); from 4096 on the batch of one looks ahead (three products per pass, the
+    # persistent launch) and saves the host's turn-around per stage
+    _PIPELINE_MAX_N = 16384
 
     def _lockstep(self, run):
         from ._record import RecordingEngine

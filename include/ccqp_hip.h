@@ -471,6 +471,11 @@ int64_t ccqp_bpipe_partials_doubles(int64_t n);
  * segmented forms -- already from n = 1024: set bit 16 of `flags` to ask for those) -- or "batched VALU kernel".  Same
  * bits either way. */
 int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int flags, char* name, int buflen);
+/* Ring shape of the three-vector persistent launch (bp_gemv3_pers_kernel<R, S>, the look-ahead of ccqp_bapgd_* /
+ * ccqp_bmprgp_*) for `count` problems per launch, as the number <R><S><waves per workgroup>: 824 from 32 problems on
+ * (config 5's share: 128), 444 below (and for the single-problem ccqp_gemv3_f64); the context's option BMV3_SHAPE
+ * overrides.  NOT an error code. */
+int ccqp_bmv3_shape(ccqp_ctx* ctx, int count);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
  * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_lockstep.h).  Bit 3 (8)

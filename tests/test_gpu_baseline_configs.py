@@ -220,6 +220,67 @@ def test_config5_n8192_mprgp_box_batch_through_sharded_entry():
     torch.cuda.empty_cache()
 
 
+def test_config5_its_own_launch_shape_32_problems_of_n8192():
+    """Config 5's share runs 128 problems per launch: from 32 problems per launch on the three-vector persistent launch
+    of lock-step MPRGP's look-ahead is bp_gemv3_pers_kernel<8, 2> x 4 waves (below: <4, 4>, what the 8-problem test
+    above reaches).  32 problems of n = 8192 (16 GiB of matrices) through `solve_batch_sharded`:
+      * the run reports the persistent form, the look-ahead and the shape 824; no problem falls back to the host;
+      * problems 0 and 1 are the REFERENCE's fixtures (tests/golden/big.npz: seeds 1234 / 1235, b from the fixture):
+        identical reported / executed counts, x within 1e-10 -- /root/reference/src/ccqppy/solvers.py:1026-1200;
+      * problems 7 and 19 against the oracle on the same matrices (counts, 1e-10);
+      * every problem bitwise equal to its own solve()."""
+    from ccqppy_amd import batch, lockstep, problems, solvers, solution_spaces as ss
+    n, count, tol, max_mv = 8192, 32, 1e-6, 300
+    torch.cuda.empty_cache()
+    lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
+    fixtures = {c["problem"]: c for c in BIG if c["id"].startswith("config5.")}
+    assert sorted(fixtures) == ["gen:8192:1234", "gen:8192:1235"]
+    built = {}
+
+    def make_problem(p):
+        op, b, _ = problems.random_problem(n, 1234 + p)
+        key = "gen:%d:%d" % (n, 1234 + p)
+        if key in fixtures:
+            b = op.engine.to_device(BIG_ARR[key + ".b"])         # the reference's own right-hand side
+        built[p] = (op, b, None, ss.BoxProjOp(n, lb, ub))
+        return built[p]
+
+    before = dict(lockstep.stats)
+    got = batch.solve_batch_sharded(lambda: solvers.CCQPSolverMPRGP(tol, max_mv), make_problem, count)
+    assert lockstep.stats["fallback_solves"] == before["fallback_solves"], "a lock-step solve fell back to the host"
+    assert lockstep.stats.get("auto_declined", 0) == before.get("auto_declined", 0)
+    assert lockstep.stats["halved_runs"] == before["halved_runs"]          # (32 problems: one run of 32 per launch)
+    run = lockstep.stats["last_mprgp_run"]
+    assert run == {"problems": 32, "n": 8192, "matvec": "bp_gemv_pers_kernel", "triple_shape": 824, "looks_ahead": True}, run
+    assert sorted(got) == list(range(count))
+    for p in range(count):
+        op, b, _, P = built[p]
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = solvers.CCQPSolverMPRGP(tol, max_mv).solve(op, b, convex_proj_op=P)
+        c = got[p]
+        assert c.solution_converged and one.solution_converged, p
+        assert c.solution_num_matrix_vector_multiplications == one.solution_num_matrix_vector_multiplications, p
+        assert c.executed_matrix_vector_multiplications == one.executed_matrix_vector_multiplications, p
+        assert float(c.solution_residual) == float(one.solution_residual), p
+        assert torch.equal(c.solution.view(torch.int64), one.solution.view(torch.int64)), p
+    for p, case in ((0, fixtures["gen:8192:1234"]), (1, fixtures["gen:8192:1235"])):
+        c = got[p]
+        assert c.solution_num_matrix_vector_multiplications == case["mv"]
+        assert c.executed_matrix_vector_multiplications == case["executed_mv"]
+        assert bool(c.solution_converged) == case["converged"]
+        want = BIG_ARR[case["id"] + ".x"]
+        assert np.linalg.norm(c.solution.cpu().numpy() - want) <= 1e-10 * np.linalg.norm(want)
+    for p in (7, 19):
+        op, b, _, _ = built[p]
+        o = cpu_ref.solve_mprgp(op.A.cpu().numpy(), b.cpu().numpy(), tol, max_mv, P=cpu_ref.Box(n, lb, ub))
+        assert got[p].solution_num_matrix_vector_multiplications == o.solution_num_matrix_vector_multiplications
+        assert got[p].executed_matrix_vector_multiplications == o.executed_mv
+        assert bool(o.solution_converged)
+        assert np.linalg.norm(got[p].solution.cpu().numpy() - o.solution) <= 1e-10 * np.linalg.norm(o.solution)
+    built.clear()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", BIG, ids=[c["id"] for c in BIG])
 def test_baseline_sizes_against_the_reference_itself(case):
     """BASELINE config 2 (n = 32768 APGD + Box), config 3's solver / set pair and an SPG + DisjointUnion(Box, Cone) solve
