@@ -17,8 +17,10 @@ MAX_DOTS = 8
 SMALL_SEG_MAX = 64
 MAX_STEPS = 16
 
+ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED = 1, 2, 3   # CCQP_ERR_*
 ABI_VERSION = 2          # CCQP_ABI_VERSION of include/ccqp_hip.h this binding was written against
 LOCKSTEP_LOOKAHEAD = 1 << 17   # CCQP_LOCKSTEP_LOOKAHEAD: flags bit of ccqp_bapgd_* (every problem carries ga / Aya)
+LOCKSTEP_FUSED_ROUNDS = 1 << 18  # CCQP_LOCKSTEP_FUSED_ROUNDS: one round per accepted APGD iteration (budget in slab slot 48)
 # per-context tuning options (ccqp_ctx_set_option): name -> key
 OPTIONS = {name: key for key, name in enumerate((
     "GEMV_ROW_STRIDE", "GEMV2_WPB", "GEMV2_SHAPE", "GEMV2_GROUP", "BMV3_SHAPE", "LOOKAHEAD_MIN_N", "MPRGP_LOOKAHEAD_MIN_N",
@@ -207,6 +209,9 @@ SIGNATURES = {
     "ccqp_bsolve_bbpgd_f64": [_P, _P, _I, _I64, _D, _D, _I64, _I, _P],
     "ccqp_bsolve_apgd_f64": [_P, _P, _I, _I64, _D, _D, _I, _P],
     "ccqp_bsolve_mprgp_f64": [_P, _P, _I, _I64, _D, _D, _D, _I, _P],
+    "ccqp_bapgd_stage_one_f64": [_P, _c.POINTER(PApgd), _P, _P, _I64, _D, _P, _P],
+    "ccqp_read_f64": [_P, _P, _I, _c.POINTER(_D), _P],
+    "ccqp_bsolve_apgd_grid_f64": [_P, _P, _I64, _D, _I, _I64, _P, _P],
     "ccqp_bapgd_start_f64": [_P, _P, _I, _I64, _I, _P, _P],
     "ccqp_bapgd_round_f64": [_P, _P, _I, _I64, _I64, _D, _I, _P, _P],
     "ccqp_bmprgp_partial_rows": [],

@@ -80,6 +80,30 @@ __device__ __forceinline__ void cg_direction_body(const double* psi, const doubl
   int64_t hi = lo + chunk;                   \
   if (hi > (n)) hi = (n);
 
+// A thread's walk over its elements of a chunk (i = lo + t, lo + t + 256, ...) with the LOADS of U consecutive
+// elements issued before the first of them is used: `body(i, v)` is called in increasing i with v[k] = p[k][i] (0.0 for
+// a NULL p[k]) -- the arithmetic order of the plain loop, hence the same bits, but U x NV loads in flight per thread
+// instead of one dependent group per iteration.  The stage-1 bodies of ONE problem are two to eight blocks whose threads
+// take eight elements each: written as a plain loop the compiler waits for every iteration's loads (vmcnt(0) per
+// element), ~2 us each -- the 15 us of a lock-step APGD decision at n = 4096 (profiles/r04_trace_rounds_n4096.json).
+template <int NV, int U, class F>
+__device__ __forceinline__ void ccqp_chunk_walk(const double* const (&p)[NV], int64_t lo, int64_t hi, F body) {
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)U * CCQP_BLOCK) {
+    double v[U][NV];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * CCQP_BLOCK;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[u][k] = (i < hi && p[k] != nullptr) ? p[k][i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * CCQP_BLOCK;
+      if (i < hi) body(i, v[u]);
+    }
+  }
+}
+
 __device__ __forceinline__ double dot_body(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
                                            int64_t chunk, int bx, double* lds4) {
   CHUNK_RANGE(n)

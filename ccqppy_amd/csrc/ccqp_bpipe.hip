@@ -415,8 +415,23 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_kernel(const ccqp_papgd
 }
 
 // L = |A d| / |d|, t = 1 / L (solvers.py:264-268) and the initial state
+// momentum weight beta of solvers.py:313 as a function of theta_k alone (the expressions of the accepting branch of
+// bapgd_decide_body, so the bits)
+__device__ __forceinline__ double bapgd_beta_of(double thk) {
+  const double tt = thk * thk;
+  const double root = sqrt(4.0 + tt);
+  const double m1 = (-thk) * thk;
+  const double m2 = thk * root;
+  const double thk1 = 0.5 * (m1 + m2);
+  const double num = thk * (1.0 - thk);
+  return num / (tt + thk1);
+}
+
+// `fuse` (elementwise look-ahead runs): the state after the first take-over -- the start's apply launch takes A.y_0 + b
+// over and forms the first trial point, so round 1 starts with the trial matvec (see bapgd_decide_body)
 __device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n, int64_t chunk, int nblk, int bx,
-                                                  double* lds4, int* is_last_p, double look = 0.0) {
+                                                  double* lds4, int* is_last_p, double look = 0.0, int fuse = 0) {
+  const ap_words z = ap_enter(q.slab);         // (the budget word AP_LIMIT, written by the caller before the start)
   double v[2];
   v[0] = dot_body(q.Ax1, q.Ax1, n, chunk, bx, lds4);
   v[1] = dot_body(q.X[1], q.X[1], n, chunk, bx, lds4);
@@ -444,14 +459,26 @@ __device__ __forceinline__ void bapgd_init_L_body(const ccqp_papgd& q, int64_t n
     s[AP_LOOK] = looks;
     s[AP_AHEAD] = looks;                       // (a look-ahead run's start multiplies y_0 beside x_0 - 1: bapgd_resolve3_start)
     s[AP_BETAS] = 0.0;
+    if (fuse) {
+      if (looks == 0.0 || (z.limit > 0.0 && z.limit < 3.0)) {
+        s[AP_DONE] = 2.0;                      // no buffers / no room for one trial: left to the host-driven loop
+      } else {
+        s[AP_PHASE] = 1.0;                     // as after the phase-0 decision of the unfused form (:275-278)
+        s[AP_ACT] = 4.0;
+        s[AP_FIRST] = 1.0;
+        s[AP_MV] = 2.0;
+        s[AP_BETAS] = bapgd_beta_of(1.0);
+        s[AP_AHEAD] = 0.0;
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
-                                                                  int64_t chunk, int nblk, double look = 0.0) {
+                                                                  int64_t chunk, int nblk, double look = 0.0, int fuse = 0) {
   __shared__ double lds4[4];
   __shared__ int is_last;
-  bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last, look);
+  bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last, look, fuse);
 }
 
 // LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call, converged counter); otherwise the problem
@@ -463,7 +490,15 @@ template <bool LOCKSTEP>
 __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_words& z, int bx, double gd,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
                                                   unsigned count, double seq, double* lds4, int* is_last_p, int ar,
-                                                  const ccqp_psegs* ps = nullptr, int64_t n_segs = 0) {
+                                                  const ccqp_psegs* ps = nullptr, int64_t n_segs = 0, int fuse = 0) {
+  // `fuse` (elementwise look-ahead runs, LOCKSTEP only): an ACCEPTING round also takes the decision of the phase-0 round
+  // that would follow -- the product A.y_{k+1} + b is already there (this round's launch computed it), so there is nothing
+  // to wait for: mv advances by two (the trial's matvec :290 and the product taken over where the reference computes it,
+  // :275-278), the state becomes "first trial of iteration k + 1" and the apply launch (ACT 4 / 5) takes the product
+  // over, forms the next trial point and its y.  One round per accepted iteration instead of two; a problem is never in
+  // phase 0 at a round's start.  The device enforces the budget itself (AP_LIMIT): a problem whose NEXT matvec would
+  // pass max_mv - 1 stops (AP_DONE = 2) and is left to the host-driven loop, exactly where the unfused run's round cap
+  // leaves it.
   double* s = q.slab;
   double v[8];
   if (z.phase == 0.0) {
@@ -478,14 +513,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
       if (z.look != 0.0) {
         // look-ahead: beta of :313 is a function of theta_k alone -- the apply launch forms y_{k+1} beside the trial
         // point, the next matvec launch multiplies both.  (The expressions of the accepting branch below, so the bits.)
-        const double thk = z.thk;
-        const double tt = thk * thk;
-        const double root = sqrt(4.0 + tt);
-        const double m1 = (-thk) * thk;
-        const double m2 = thk * root;
-        const double thk1 = 0.5 * (m1 + m2);
-        const double num = thk * (1.0 - thk);
-        s[AP_BETAS] = num / (tt + thk1);
+        s[AP_BETAS] = bapgd_beta_of(z.thk);
         s[AP_AHEAD] = 0.0;                                 // (A.y_k + b computed ahead has been taken: bapgd_take_ahead_kernel)
       }
       if (LOCKSTEP) bp_report(batch, host, count, seq);
@@ -509,32 +537,36 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
     const double c = q.c;
     CHUNK_RANGE(n)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += CCQP_BLOCK) {
-      const double xi = x1[i], yi = yk[i], bi = bv[i];
+    // (all loads of a thread's eight elements first -- ccqp_chunk_walk: the same arithmetic in the same order)
+    const bool elem = !ps;
+    const double* const vecs[10] = {x1, yk, bv, Ax1, gk, elem ? g1 : nullptr, ar ? xk : nullptr, first ? Ayk : nullptr,
+                                    elem ? sg.lb : nullptr, elem ? sg.ub : nullptr};
+    ccqp_chunk_walk<10, 8>(vecs, lo, hi, [&](int64_t, const double* e) {
+      const double xi = e[0], yi = e[1], bi = e[2];
       if (ar) {                                          // gk.(x_{k+1} - x_k), solvers.py:510
-        const double dk = xi - xk[i];
-        a6 = fma(gk[i], dk, a6);
+        const double dk = xi - e[6];
+        a6 = fma(e[4], dk, a6);
       }
       if (first) {
-        a0 = fma(yi, Ayk[i], a0);
+        a0 = fma(yi, e[7], a0);
         a1 = fma(yi, bi, a1);
       }
-      a2 = fma(xi, Ax1[i], a2);
+      a2 = fma(xi, e[3], a2);
       a3 = fma(xi, bi, a3);
       const double d = xi - yi;
-      a4 = fma(gk[i], d, a4);
+      a4 = fma(e[4], d, a4);
       a5 = fma(d, d, a5);
-      if (!ps) {
-        const double t = gd * g1[i];
+      if (elem) {
+        const double t = gd * e[5];
         const double u = xi - t;
-        const double lb = sg.lb ? sg.lb[i] : sg.lb_s;
-        const double ub = sg.ub ? sg.ub[i] : sg.ub_s;
+        const double lb = sg.lb ? e[8] : sg.lb_s;
+        const double ub = sg.ub ? e[9] : sg.ub_s;
         const double pr = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
         const double dd = xi - pr;
         const double w = c * dd;
         a7 = fma(w, w, a7);
       }
-    }
+    });
     v[0] = a0;
     v[1] = a1;
     v[2] = a2;
@@ -599,18 +631,36 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
         if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         const bool restart = ar && v[7] > 0.0;           // :510-512  y_{k+1} = copy(x_{k+1}), theta = 1
+        const double thnew = restart ? 1.0 : thk1;
         L = L * 0.9;
         s[AP_L] = L;
         s[AP_T] = 1.0 / L;
-        s[AP_THK] = restart ? 1.0 : thk1;
+        s[AP_THK] = thnew;
         s[AP_BETA] = beta;
         s[AP_IT] = (double)(it + 1);
-        s[AP_PHASE] = 0.0;
-        s[AP_ACT] = restart ? 3.0 : 2.0;
         s[AP_COPYHAT] = improved ? 1.0 : 0.0;
-        // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3); after an anti-relaxation restart y_{k+1} is
-        // x_{k+1} itself (:510-512) and its product the launch's FIRST one (2: taken from g1 / Ax1)
-        if (z.look != 0.0) s[AP_AHEAD] = restart ? 2.0 : 1.0;
+        if (fuse) {
+          // the take-over of the round that would follow, decided here: the product is counted (:275-278) and the next
+          // round's trial matvec must still fit the budget
+          const double mv2 = z.mv + 2.0;
+          if (z.limit > 0.0 && mv2 + 1.0 > z.limit) {
+            s[AP_DONE] = 2.0;
+            if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            s[AP_MV] = mv2;
+            s[AP_PHASE] = 1.0;
+            s[AP_ACT] = restart ? 5.0 : 4.0;
+            s[AP_FIRST] = 1.0;
+            s[AP_BETAS] = bapgd_beta_of(thnew);
+            s[AP_AHEAD] = 0.0;
+          }
+        } else {
+          s[AP_PHASE] = 0.0;
+          s[AP_ACT] = restart ? 3.0 : 2.0;
+          // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3); after an anti-relaxation restart y_{k+1} is
+          // x_{k+1} itself (:510-512) and its product the launch's FIRST one (2: taken from g1 / Ax1)
+          if (z.look != 0.0) s[AP_AHEAD] = restart ? 2.0 : 1.0;
+        }
       }
     } else {
       L = L * 2.0;
@@ -618,6 +668,10 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
       s[AP_T] = 1.0 / L;
       s[AP_ACT] = 1.0;
       s[AP_FIRST] = 0.0;
+      if (fuse && z.limit > 0.0 && (z.mv + 1.0) + 1.0 > z.limit) {   // (the retry's matvec would pass the budget)
+        s[AP_DONE] = 2.0;
+        if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (LOCKSTEP) bp_report(batch, host, count, seq);
   }
@@ -629,22 +683,24 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
                                                                   double* __restrict__ host, unsigned count,
                                                                   double seq, int ar,
                                                                   const ccqp_psegs* __restrict__ segs = nullptr,
-                                                                  int64_t n_segs = 0) {
+                                                                  int64_t n_segs = 0, int fuse = 0) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
   const ap_words z = ap_enter(q.slab);
-  if (z.done != 0.0) {                     // converged earlier: only the roll-call
+  if (z.done != 0.0) {                     // converged (or stopped) earlier: only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
   bapgd_decide_body<true>(q, z, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar,
-                          segs ? segs + blockIdx.y : nullptr, n_segs);
+                          segs ? segs + blockIdx.y : nullptr, n_segs, fuse);
 }
+
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0);
 
 // n_segs > 0: segmented form -- the trial step is taken by the segmented launches (ccqp_bsegs.hip), the vector length
 // comes from the caller
-__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0) {
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs) {
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0) return;
   const int it = (int)s[AP_IT];
@@ -658,6 +714,66 @@ __device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, in
       // dead): every thread reads back the elements it wrote itself (the same element partition in both bodies)
       const double beta = s[AP_BETAS];
       axpby_body(1.0 + beta, q.X[(it + 1) & 1], -beta, q.X[it & 1], q.Y[(it + 1) & 1], n, bx, nbx);
+    }
+  } else if (s[AP_ACT] >= 4.0) {
+    // fused rounds (bapgd_decide_body): iteration k + 1 accepted AND its first trial due.  `it` is the NEW count:
+    // X[it & 1] = x_{k+1}, Y[it & 1] = y_{k+1} as the trial's apply formed it (ACT 5, the anti-relaxation restart
+    // :510-512: y_{k+1} = copy(x_{k+1}), and the product to take over is the launch's FIRST one, A.x_{k+1}).
+    // Every body below walks the same element partition: a thread reads back only what it wrote itself.
+    // ONE pass per element, the loads of four elements in flight (the six separate bodies it replaces -- copy, copy,
+    // copy, copy, proj_elem_body, axpby_body -- each waited for its own loads: 5 us per launch at n = 4096): the same
+    // operations on the same values in the same order per element.
+    const bool restart = s[AP_ACT] == 5.0;
+    const bool copyhat = s[AP_COPYHAT] != 0.0;
+    const ccqp_segk sg = bp_segk_of(q);
+    const double mt = -s[AP_T];
+    const double beta = s[AP_BETAS];
+    const double pa = 1.0 + beta, pb = -beta;
+    const double* __restrict__ xk1 = q.X[it & 1];                  // x_{k+1}
+    double* __restrict__ yv = q.Y[it & 1];                         // y_{k+1} (restart: becomes a copy of x_{k+1})
+    const double* __restrict__ gsrc = restart ? q.g1 : q.ga;       // A.y_{k+1} + b, computed ahead: taken over
+    const double* __restrict__ ysrc = restart ? q.Ax1 : q.Aya;
+    double* __restrict__ gk = q.gk;
+    double* __restrict__ Ayk = q.Ayk;
+    double* __restrict__ x2 = q.X[(it + 1) & 1];                   // x_{k+2} trial (:283)
+    double* __restrict__ y2 = q.Y[(it + 1) & 1];                   // y_{k+2} (:316)
+    double* __restrict__ xhat = q.xhat;
+    constexpr int U = 4;
+    for (int64_t i0 = (int64_t)bx * CCQP_BLOCK + threadIdx.x; i0 < n; i0 += (int64_t)U * nbx * CCQP_BLOCK) {
+      double ex[U], ey[U], eg[U], ea[U], el[U], eu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * nbx * CCQP_BLOCK;
+        const bool ok = i < n;
+        ex[u] = ok ? xk1[i] : 0.0;
+        ey[u] = (ok && !restart) ? yv[i] : 0.0;
+        eg[u] = ok ? gsrc[i] : 0.0;
+        ea[u] = ok ? ysrc[i] : 0.0;
+        el[u] = (ok && sg.lb) ? sg.lb[i] : sg.lb_s;
+        eu[u] = (ok && sg.ub) ? sg.ub[i] : sg.ub_s;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * nbx * CCQP_BLOCK;
+        if (i >= n) continue;
+        const double xv = ex[u];
+        if (copyhat) xhat[i] = xv;                                 // xhat = copy(x_{k+1})
+        double y1 = ey[u];
+        if (restart) {                                             // y_{k+1} = copy(x_{k+1})
+          y1 = xv;
+          yv[i] = xv;
+        }
+        gk[i] = eg[u];
+        Ayk[i] = ea[u];
+        const double t1 = 1.0 * y1;                                // proj_elem_body(1.0, y_{k+1}, -t, g_{k+1})
+        const double t2 = mt * eg[u];
+        const double w = t1 + t2;
+        const double xn = ccqp_proj_elem(sg.kind, sg.flags, w, el[u], eu[u]);
+        x2[i] = xn;
+        const double s1 = pa * xn;                                 // axpby_body(1 + beta, x_{k+2}, -beta, x_{k+1})
+        const double s2 = pb * xv;
+        y2[i] = s1 + s2;
+      }
     }
   } else {
     if (s[AP_ACT] == 3.0) {                   // anti-relaxation restart: y_{k+1} = copy(x_{k+1})
@@ -824,7 +940,7 @@ int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, in
 extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
                                     uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
-  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0;
+  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0, fuse_asked = (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0;
   flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
@@ -833,6 +949,7 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
   const bool look = bapgd_looks_ahead(ctx, count, n, flags, asked);
+  const int fuse = look && fuse_asked;
   int rc;
   if (look) {
     // (a problem whose two buffers are NULL takes no part here and is multiplied by the single launch below; with every
@@ -847,7 +964,9 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   if (rc) return rc;
   // (the flag travels in the problems' slabs, set here: AP_LOOK)
   hipLaunchKernelGGL(bapgd_init_L_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, n, chunk, nblk,
-                     look ? 1.0 : 0.0);
+                     look ? 1.0 : 0.0, fuse);
+  // fused rounds: the first take-over and the first trial point belong to the start (ACT 4 of bapgd_apply_body)
+  if (fuse) hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }
@@ -858,15 +977,30 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   BP_CHECK_BATCH();
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
   const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0;
+  const int ar = (flags & BP_FLAG_CONST_STEP) != 0;
+  const bool fuse_asked = (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0;
   flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  const int rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 0, flags, asked, s);
+  const int fuse = fuse_asked && bapgd_looks_ahead(ctx, count, n, flags, asked);
+  int rc;
+  if (fuse) {
+    // every live problem is at a trial point: ONE launch multiplies x_{k+1} and y_{k+1} of each (nothing to take over
+    // here -- the apply launch of the accepting round did --, no single-product launch)
+    const bapgd_resolve3 rsv3 = {dev_probs};
+    rc = bp_launch_gemv3(ctx, rsv3, count, n, s);
+  } else {
+    rc = ccqp_bapgd_launch_gemv(ctx, dev_probs, count, n, 0, flags, asked, s);
+  }
   if (rc) return rc;
+  // (the decision and the update stay two launches: letting the deciding block walk the update alone -- one launch and
+  // one kernel boundary fewer -- was measured SLOWER, +4 us per round at n = 4096 and +11 us at n = 8192: one CU moves
+  // the ~100 bytes per element at 50-80 GB/s; profiles/r04_single_mid.jsonl)
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
-                     dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, (flags & BP_FLAG_CONST_STEP) != 0);
+                     dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, ar, (const ccqp_psegs*)nullptr,
+                     (int64_t)0, fuse);
   hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
@@ -1042,5 +1176,182 @@ extern "C" int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
     hipLaunchKernelGGL((bsolve_apgd_kernel<false>), dim3(count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, mv_limit, n,
                        (flags & BP_FLAG_CONST_STEP) != 0);
   CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// Staging of ONE lock-step APGD problem in ONE launch (the device-resident form of a single solve: the ~10 small host-paced
+// operations it replaces -- zero the slab and the counters, x0 or zeros into X[0], y_0 = x_0, xhat = ones, the descriptor's
+// upload -- cost 140 us of a 1.3 ms solve at n = 4096).  The descriptor travels BY VALUE as a kernel argument and is
+// written to `dev_desc`, where the round kernels read it.  words: [0] the problem's arrival counter, [1..2] the batch words.
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_stage_one_kernel(const ccqp_papgd desc, ccqp_papgd* __restrict__ dev_desc,
+                                                                     const double* __restrict__ x0, int64_t n, double limit,
+                                                                     uint32_t* __restrict__ words) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) *dev_desc = desc;
+    if (threadIdx.x < 64) desc.slab[threadIdx.x] = threadIdx.x == AP_LIMIT ? limit : 0.0;
+    if (threadIdx.x < 3) words[threadIdx.x] = 0u;
+  }
+  double* __restrict__ X0 = desc.X[0];
+  double* __restrict__ Y0 = desc.Y[0];
+  double* __restrict__ xhat = desc.xhat;
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    const double v = x0 ? x0[i] : 0.0;         // x0 = zeros if None (solvers.py:253-254)
+    X0[i] = v;
+    Y0[i] = v;                                 // yk = copy(x0) (:257-258)
+    if (xhat) xhat[i] = 1.0;                   // anti-relaxation: xhat = ones (:432)
+  }
+}
+
+extern "C" int ccqp_bapgd_stage_one_f64(ccqp_ctx* ctx, const ccqp_papgd* host_desc, ccqp_papgd* dev_desc, const double* x0,
+                                        int64_t n, double limit, uint32_t* words, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && host_desc != nullptr && dev_desc != nullptr && words != nullptr, "NULL argument");
+  CCQP_REQUIRE(n >= 1 && host_desc->X[0] != nullptr && host_desc->Y[0] != nullptr && host_desc->slab != nullptr,
+               "incomplete descriptor");
+  hipLaunchKernelGGL(bapgd_stage_one_kernel, dim3(bp_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, *host_desc,
+                     dev_desc, x0, n, limit, words);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
+// =====================================================================================================================
+// ONE problem, the WHOLE APGD solve in ONE launch on the whole chip (2048 < n <= 16384: where a pass over the matrix takes
+// 27 ... 340 us and the ~35 us of launch gaps and small kernels per lock-step round, or the host's turn-around per
+// iteration, are a third to a half of a solve).  One 4-wave workgroup per CU, launched COOPERATIVELY (the runtime
+// guarantees that all workgroups are resident together); a round is the fused lock-step round above -- the two-vector
+// matvec of the trial point and its momentum point through the per-wave LDS rings (gemv_lds3_multi_body with one matrix),
+// the decision in the first nblk workgroups (the same bodies, the same chunk geometry and meeting point, hence the bits
+// and counts of the lock-step rounds and of solve()), the elementwise update -- separated by GRID BARRIERS instead of
+// kernel boundaries.  Barrier: a monotone arrival counter (dev_batch[0]); one thread per workgroup drains its stores,
+// releases at agent scope, takes a ticket and polls with s_sleep; the poll is BOUNDED (~seconds): a workgroup that gives
+// up raises dev_batch[1], every other one sees it and leaves too, and the caller falls back to the lock-step rounds --
+// every wave reaches an exit whatever happens.
+#define APG_SPIN_LIMIT 4000000u
+__device__ __forceinline__ bool apg_grid_sync(unsigned* bar, unsigned nwg, unsigned& epoch) {
+  __shared__ int ok_s;
+  __syncthreads();
+  epoch += 1u;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = epoch * nwg;
+    bool ok = true;
+    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      __builtin_amdgcn_s_sleep(2);
+      if (spins > APG_SPIN_LIMIT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        ok = false;
+        break;
+      }
+    }
+    if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+
+template <int R, int S>
+__global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_grid_kernel(const ccqp_papgd* __restrict__ probs, int64_t n,
+                                                                      double gd, int ar, int64_t rs, int64_t chunk,
+                                                                      int nblk, int64_t max_rounds,
+                                                                      unsigned* __restrict__ bar) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  __shared__ double lds4[4];
+  __shared__ int is_last;
+  constexpr int RING = S * (R + 3) * 1024;
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
+  gemv_lds3_desc* D = reinterpret_cast<gemv_lds3_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
+  const ccqp_papgd& q = probs[0];
+  double* s = q.slab;
+  const unsigned nwg = gridDim.x;
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  const int64_t wave = (int64_t)bx * wpb + w, nwaves = (int64_t)nbx * wpb;
+  unsigned epoch = 0;
+  // ---- start-up (solvers.py:257-269): d = x0 - 1; A.d and A.y_0 + b in one pass; L, t; the first trial point
+  bapgd_init_d_body(q, n, bx, nbx);
+  if (!apg_grid_sync(bar, nwg, epoch)) return;
+  if (threadIdx.x == 0) {
+    const bapgd_resolve3_start r3 = {probs};
+    gemv_lds3_desc d;
+    (void)r3(0, &d);
+    D[0] = d;
+  }
+  __syncthreads();
+  gemv_lds3_multi_body<R, S, true>(D, 1, n, wave, nwaves, ring + w * RING, res, rs);
+  if (!apg_grid_sync(bar, nwg, epoch)) return;
+  if (bx < nblk) bapgd_init_L_body(q, n, chunk, nblk, bx, lds4, &is_last, 1.0, 1);
+  if (!apg_grid_sync(bar, nwg, epoch)) return;
+  bapgd_apply_body(q, bx, nbx);
+  if (!apg_grid_sync(bar, nwg, epoch)) return;
+  // ---- rounds: every workgroup reads the same slab between two barriers, so all of them take the same exit
+  for (int64_t round = 0; round < max_rounds; ++round) {
+    const ap_words z = ap_enter(s);
+    if (z.done != 0.0) break;
+    if (threadIdx.x == 0) {
+      const bapgd_resolve3 r3 = {probs};
+      gemv_lds3_desc d;
+      (void)r3(0, &d);
+      D[0] = d;
+    }
+    __syncthreads();
+    gemv_lds3_multi_body<R, S, true>(D, 1, n, wave, nwaves, ring + w * RING, res, rs);
+    if (!apg_grid_sync(bar, nwg, epoch)) return;
+    if (bx < nblk)
+      bapgd_decide_body<false>(q, z, bx, gd, chunk, nblk, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar, nullptr, 0, 1);
+    if (!apg_grid_sync(bar, nwg, epoch)) return;
+    bapgd_apply_body(q, bx, nbx);              // (nothing to do for a problem that has just converged or stopped)
+    if (!apg_grid_sync(bar, nwg, epoch)) return;
+  }
+#endif
+}
+
+// flags: bit 0 (aligned operands: required), bit 3 (the anti-relaxation variant).  The problem carries the two look-ahead
+// buffers; slab slot 48 = max_mv - 1 (0: none) as for the fused rounds; dev_batch: two zeroed words.  Results in the slab as
+// after ccqp_bapgd_round_f64 (slot 49: 1 converged, 2 stopped at the budget, 0 with dev_batch[1] != 0: the grid barrier
+// gave up -- the caller runs the problem some other way).  CCQP_ERR_UNSUPPORTED: no cooperative launch of this shape here.
+extern "C" int ccqp_bsolve_apgd_grid_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int64_t n, double gd, int flags,
+                                         int64_t max_rounds, uint32_t* dev_batch, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && dev_probs != nullptr && dev_batch != nullptr, "NULL argument");
+  CCQP_REQUIRE((flags & 1) && n >= 128 && n % 2 == 0, "needs aligned operands and an even n >= 128");
+  CCQP_REQUIRE(max_rounds >= 1, "max_rounds < 1");
+  hipStream_t s = (hipStream_t)stream;
+  int coop = 0;
+  CCQP_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device));
+  if (!coop) {
+    ccqp_set_error("%s: the device does not launch cooperatively", __func__);
+    return CCQP_ERR_UNSUPPORTED;
+  }
+  constexpr int R = 4, S = 4, WPB = 4;
+  const size_t lds = (size_t)WPB * ((size_t)S * (R + 3) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) + sizeof(gemv_lds3_desc);
+  const void* fn = reinterpret_cast<const void*>(bsolve_apgd_grid_kernel<R, S>);
+  int rc = ccqp_lds_raise(ctx, fn, lds);
+  if (rc) return rc;
+  int per_cu = 0;
+  CCQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds));
+  if (per_cu < 1) {
+    ccqp_set_error("%s: the workgroup does not fit a compute unit", __func__);
+    return CCQP_ERR_UNSUPPORTED;
+  }
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  CCQP_REQUIRE(nblk <= ctx->num_cu, "more reduction chunks than workgroups");
+  ccqp_lockstep_begin(ctx, dev_batch, s);       // (zeroes the two words: barrier counter, give-up flag)
+  int ar = (flags & BP_FLAG_CONST_STEP) != 0;
+  int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);
+  unsigned* bar = dev_batch;
+  void* args[] = {(void*)&dev_probs, (void*)&n, (void*)&gd, (void*)&ar, (void*)&rs, (void*)&chunk, (void*)&nblk,
+                  (void*)&max_rounds, (void*)&bar};
+  const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)ctx->num_cu), dim3(64 * WPB), args, (unsigned)lds, s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ccqp_set_error("%s: cooperative launch refused: %s", __func__, hipGetErrorString(e));
+    return CCQP_ERR_UNSUPPORTED;
+  }
   return CCQP_OK;
 }

@@ -34,7 +34,10 @@
 #define AP_LOOK 45
 #define AP_AHEAD 46
 #define AP_BETAS 47
-#define AP_DONE BP_DONE   // 49
+// fused rounds (elementwise look-ahead runs, flags bit 18): the matvec budget the DEVICE enforces, max_mv - 1 (0: none) --
+// a round that takes a product over counts two matvecs, so the host's round count no longer bounds the matvec count
+#define AP_LIMIT 48
+#define AP_DONE BP_DONE   // 49: 0 running | 1 converged | 2 stopped one short of the budget (left to the host-driven loop)
 #define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
 #define AP_RES2 BP_RES2   // 51
 #define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
@@ -73,7 +76,7 @@ __device__ __forceinline__ bp_words bp_enter(const double* __restrict__ slab) {
 }
 
 struct ap_words {                            // APGD / anti-relaxation APGD
-  double done, phase, mv, it, first, r1, r2, L, thk, resmin, look;
+  double done, phase, mv, it, first, r1, r2, L, thk, resmin, look, limit;
 };
 __device__ __forceinline__ ap_words ap_enter(const double* __restrict__ slab) {
   ap_words z;
@@ -88,6 +91,7 @@ __device__ __forceinline__ ap_words ap_enter(const double* __restrict__ slab) {
   z.thk = slab[AP_THK];
   z.resmin = slab[AP_RESMIN];
   z.look = slab[AP_LOOK];
+  z.limit = slab[AP_LIMIT];
   __syncthreads();
   return z;
 }

@@ -22,7 +22,7 @@ from ._engine import get_engine
 # Problems the device-resident runs handed back to the host-driven loop (matvec budget reached, device budget of a
 # single-launch kernel, MPRGP's unreachable branches).  The fall-back keeps every result right, so a device-side bug
 # can hide behind it: the tests assert that this counter does not move where no fall-back is expected.
-stats = {"fallback_solves": 0, "auto_declined": 0, "halved_runs": 0}
+stats = {"fallback_solves": 0, "auto_declined": 0, "halved_runs": 0, "grid_solves": 0, "grid_gave_up": 0}
 
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
 _BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
@@ -702,6 +702,25 @@ def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmen
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
+last_timing = {}            # host-side split of the last _bapgd_run: staging / queueing the rounds / waiting for the queue
+_APGD_FUSED_ROUNDS = True   # (module attribute for the A/B of tools / tests: False = two rounds per accepted iteration)
+# a batch of ONE problem of n >= 4096: the whole solve in one cooperative launch whose rounds are separated by grid barriers
+# (ccqp_bsolve_apgd_grid_f64).  OFF: measured on MI355X a grid barrier over 256 workgroups on 8 XCDs costs ~12 us (the
+# agent-scope release / acquire of every workgroup), a kernel boundary ~3.5 us -- the rounds are faster (n = 4096: 69
+# against 45 us per round, profiles/r04_single_mid.jsonl).  Kept selectable (same bits and counts, tested).
+_APGD_GRID_SOLVE = False
+
+
+def _sharing_form(eng, count, n, flags, mprgp=False):
+    """Does a run that shares passes (lock-step APGD / MPRGP with their look-ahead) take the persistent matvec?"""
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    q = (flags & 0xFFFF) | (1 << 16) | ((1 << 18) if mprgp else 0)
+    from . import _lib
+    _lib.check(eng.lib.ccqp_bpipe_matvec_form(eng.ctx, count, n, q, buf, 64))
+    return buf.value.decode() == "bp_gemv_pers_kernel"
+
+
 def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False, plans=None):
     """Lock-step APGD over `spec`; returns (converged mask, (B, n) device tensor of final iterates, residuals,
     matvec counts) -- rows of problems that did not converge inside the budget are meaningless.  `plans` (one segment
@@ -711,6 +730,7 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     from .solvers import _GD
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     B = len(spec)
+    t_enter = time.perf_counter()
     # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat ga Aya (the last two: products computed ahead, ccqp_bpipe.hip)
     vec, slabs, words, tab, planes, keep = _bpipe_table(eng, spec, n, _lib.PApgd, 11, 8)
     spec.stage_x0(vec[0])
@@ -722,6 +742,16 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     tab["ga"], tab["Aya"] = planes[9], planes[10]
     # bit 3: the anti-relaxation variant; bit 17: every problem carries the two look-ahead buffers (ga / Aya above)
     flags = _bpipe_flags(tab, n, tune) | (8 if ar else 0) | _lib.LOCKSTEP_LOOKAHEAD
+    # bit 18, elementwise sets: FUSED ROUNDS -- an accepting round also takes A.y_{k+1} + b over and forms the next trial
+    # point (one round per accepted iteration instead of two); the device then enforces the budget itself: max_mv - 1 in
+    # slab slot 48 (0 = none), a problem that reaches it stops with slot 49 = 2 and goes to the host-driven loop
+    if plans is None and _APGD_FUSED_ROUNDS:
+        flags |= _lib.LOCKSTEP_FUSED_ROUNDS
+        slabs[:, 48] = float(max_mv - 1) if np.isfinite(max_mv) else 0.0
+    # ONE problem whose matvec is the persistent multi-vector form (n >= 4096 by default): the whole solve in ONE cooperative
+    # launch on the whole chip, the fused rounds separated by grid barriers (ccqp_bsolve_apgd_grid_f64)
+    grid = B == 1 and plans is None and _APGD_FUSED_ROUNDS and _APGD_GRID_SOLVE and single_launch is not True \
+        and (flags & 1) and _sharing_form(eng, 1, n, flags) and (not np.isfinite(max_mv) or max_mv >= 4)
     dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
     dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
     check = _lib.check
@@ -742,15 +772,32 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
     if single_launch is None:
         single_launch = n <= _BSOLVE_MAX_N_APGD
     single_launch = bool(single_launch) and n <= 2048 and plans is None
-    if single_launch:
+    t_staged = time.perf_counter()
+    if grid and not single_launch:
+        rc = lib.ccqp_bsolve_apgd_grid_f64(ctx, dp, n, _GD, flags & 9, int(last) if np.isfinite(last) else 10 ** 7, batch, st)
+        if rc == _lib.ERR_UNSUPPORTED:
+            grid = False                                 # (no cooperative launch here: the rounds below)
+        else:
+            check(rc)
+            stats["grid_solves"] += 1
+    else:
+        grid = False
+    if grid:
+        pass                                             # (one launch; the blocking read below waits for it)
+    elif single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
         check(lib.ccqp_bsolve_apgd_f64(ctx, dp, B, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 9, st))
     else:
         check(lib.ccqp_bapgd_start_f64(ctx, dp, B, n, flags, batch, st))
         _bpipe_poll_loop(eng, B, launch, last, ahead)
+    t_queued = time.perf_counter()
     h = slabs[:, 32:52].cpu().numpy()                   # blocking: the queue has drained
-    done, its, mvs, res2 = h[:, 17] != 0.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
-    if not single_launch and not np.isfinite(max_mv) and not done.all():
+    last_timing.update(staging_s=t_staged - t_enter, rounds_s=t_queued - t_staged, drain_s=time.perf_counter() - t_queued)
+    # (slot 49: 1 = converged; 2 = a fused-rounds problem stopped one short of its budget -> not done here)
+    done, its, mvs, res2 = h[:, 17] == 1.0, h[:, 8].astype(np.int64), h[:, 18].astype(np.int64), h[:, 19]
+    if grid and not done.all() and int(words[B + 1].item()) != 0:
+        stats["grid_gave_up"] += 1                       # (the grid barrier gave up: the caller's host-driven loop takes over)
+    elif not single_launch and not np.isfinite(max_mv) and not done.all():
         raise RuntimeError("solve_batch_pipelined: mirror and slabs disagree")
     # the solution: x_{k+1} = X[(accepted iterations + 1) % 2]; anti-relaxation: xhat (plane 8) unless the converging
     # iterate was itself the best one so far (slot 43)
@@ -763,6 +810,88 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
         sols = vec[torch.from_numpy(pick).to(dev), torch.arange(B, device=dev)]
     del keep
     return done, sols, np.sqrt(res2), mvs
+
+
+class _OneWs:
+    """Workspace of the device-resident single APGD solve of one size on one engine, kept between solves: the eleven
+    vector planes, slab, partial sums, counters, the device copy of the descriptor and its host original."""
+    __slots__ = ("vec", "slab", "partials", "words", "ddesc", "desc", "host")
+
+
+def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
+    """ONE dense APGD / anti-relaxation APGD problem on an elementwise set, device-resident (the form of
+    CCQPSolverAPGD(pipeline=True) from n = 4096 on): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve
+    allocation, no host-paced torch operation, the descriptor by value), the fused lock-step rounds with the persistent
+    two-vector matvec queued `ahead` beyond the device's last report (or the one-launch cooperative form), the result words
+    through the pinned mirror.  Returns (done, x, residual, matvecs) or None where the form does not apply."""
+    import ctypes
+    from . import _lib
+    from .solvers import _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    A = op.A
+    aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
+    ar = bool(solver._anti_relaxation)
+    flags = 1 | (8 if ar else 0) | _lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS
+    max_mv = solver.max_matrix_vector_multiplications
+    if not (aligned and _APGD_FUSED_ROUNDS and _sharing_form(eng, 1, n, 1) and (not np.isfinite(max_mv) or max_mv >= 4)):
+        return None
+    cache = eng.__dict__.setdefault("_apgd_one_ws", {})
+    ws = cache.get(n)
+    if ws is None:
+        ws = cache[n] = _OneWs()
+        nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+        ws.vec = torch.empty((11, n), dtype=torch.float64, device=dev)
+        ws.slab = torch.zeros(64, dtype=torch.float64, device=dev)
+        ws.partials = torch.empty(8 * nblk, dtype=torch.float64, device=dev)
+        ws.words = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws.ddesc = torch.zeros(ctypes.sizeof(_lib.PApgd), dtype=torch.uint8, device=dev)
+        d = ws.desc = _lib.PApgd()
+        base = ws.vec.data_ptr()
+        plane = [base + 8 * n * j for j in range(11)]
+        # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat ga Aya
+        d.X[0], d.X[1], d.Y[0], d.Y[1] = plane[0], plane[1], plane[2], plane[3]
+        d.gk, d.g1, d.Ayk, d.Ax1, d.xhat, d.ga, d.Aya = plane[4:11]
+        d.slab, d.partials, d.counter = ws.slab.data_ptr(), ws.partials.data_ptr(), ws.words.data_ptr()
+        d.c = 1.0 / (3 * n * _GD)                        # solvers.py:138
+        ws.host = (ctypes.c_double * 20)()
+    d = ws.desc
+    d.A, d.lda, d.b = A.data_ptr(), A.stride(0), b.data_ptr()
+    d.seg = P._seg(eng, 0, n)
+    d.tol = float(solver.desired_residual_tol)
+    limit = float(max_mv - 1) if np.isfinite(max_mv) else 0.0
+    check = _lib.check
+    dp, batch = ws.ddesc.data_ptr(), ws.words.data_ptr() + 4
+    t0 = time.perf_counter()
+    check(lib.ccqp_bapgd_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n, limit,
+                                       ws.words.data_ptr(), st))
+    last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
+    grid = _APGD_GRID_SOLVE
+    if grid:
+        rc = lib.ccqp_bsolve_apgd_grid_f64(ctx, dp, n, _GD, flags & 9, int(last) if np.isfinite(last) else 10 ** 7, batch, st)
+        if rc == _lib.ERR_UNSUPPORTED:
+            grid = False
+        else:
+            check(rc)
+            stats["grid_solves"] += 1
+    t1 = time.perf_counter()
+    if not grid:
+        check(lib.ccqp_bapgd_start_f64(ctx, dp, 1, n, flags, batch, st))
+
+        def launch(r):
+            check(lib.ccqp_bapgd_round_f64(ctx, dp, 1, n, r, _GD, flags, batch, st))
+        _bpipe_poll_loop(eng, 1, launch, last, ahead)
+    t2 = time.perf_counter()
+    h = ws.host
+    check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 32, 20, h, st))      # blocking: the queue has drained
+    last_timing.update(staging_s=t1 - t0, rounds_s=t2 - t1, drain_s=time.perf_counter() - t2)
+    done = h[17] == 1.0
+    if not done:
+        if grid and int(ws.words[2].item()) != 0:
+            stats["grid_gave_up"] += 1
+        return False, None, None, None
+    pick = 8 if (ar and h[11] != 0.0) else (int(h[8]) + 1) % 2
+    # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
+    return True, ws.vec[pick], np.sqrt(np.float64(h[19])), int(h[18])
 
 
 def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):

@@ -52,6 +52,7 @@ class _Run:
         eng.bind()
         self.torch_out = isinstance(b, torch.Tensor)
         self.b = eng.to_device(b).reshape(-1)
+        self.x0_given = x0 is not None
         if x0 is None:
             self.x0 = torch.zeros(n, dtype=torch.float64, device=eng.device)             # :125-126
         else:
@@ -268,7 +269,7 @@ class _APGDCore(CCQPSolverBase):
     _anti_relaxation = False
 
     def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, reuse_matvec=False,
-                 pipeline=False, pair_matvecs=None):
+                 pipeline=None, pair_matvecs=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         # SAME results bit for bit, same MV counts: the two products of an iteration share ONE pass over A.
         # y_{k+1} = (1 + beta) x_{k+1} - beta x_k (solvers.py:313-316) depends on x_{k+1}, x_k and theta only -- not on
@@ -280,11 +281,16 @@ class _APGDCore(CCQPSolverBase):
         # anti-relaxation variant's restart (:510-512) makes y_{k+1} = x_{k+1}: then the product computed ahead is dropped
         # and A.x_{k+1}, which the same pass computed, is the next iteration's A.y_k.
         self.pair_matvecs = pair_matvecs
-        # Extension, OFF by default, SAME results bit for bit (plain APGD, dense operator with n <= 2048, elementwise
-        # set): line search, momentum and exit test run on the device and rounds are queued ahead (ccqp_bapgd_*, the
-        # lock-step batch scheduler with a batch of one): 1.2-1.9x lower latency.  Beyond n = 2048 the matvec hides the
-        # host's work and the host-driven loop below is as fast or faster (measured), so it is used there, as it is
-        # for a solve that would reach the matvec budget.
+        # SAME results bit for bit: the DEVICE-RESIDENT form of a solve (dense operator with n <= 16384, any set with a
+        # device form): line search, momentum and exit test run on the device and rounds are queued ahead (ccqp_bapgd_*, the
+        # lock-step batch scheduler with a batch of one: n <= 128 one launch for the whole solve; up to 2048 rounds of the
+        # VALU kernels; beyond, staging in one launch and FUSED rounds -- one per accepted iteration -- with the persistent
+        # two-vector matvec).  Against the host-driven loop below (one blocking scalar read + ~25 us of Python per
+        # iteration): 1.2-1.9x at n <= 2048, 1.2-1.4x at 4096, 1.05-1.15x at 8192 / 16384 (profiles/r04_single_mid.jsonl);
+        # beyond, a pass over A hides the host.  None (default): ON for elementwise sets when the matvec budget is at
+        # least 1000 (a solve that reaches its budget on the device is repeated by the host-driven loop -- the exit paths
+        # are the reference's -- so a solve MEANT to run into a small budget, the Cone configs, stays on the host loop);
+        # True / False force it.
         self.pipeline = pipeline
         # Extension, OFF by default: y_{k+1} = (1+beta) x_{k+1} - beta x_k is linear, so
         # A.y_{k+1} = (1+beta) A.x_{k+1} - beta A.x_k needs no matvec.  Saves one of the two matvecs per
@@ -296,7 +302,11 @@ class _APGDCore(CCQPSolverBase):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, b, AR = run.eng, run.b, self._anti_relaxation
         reuse = self.reuse_matvec
-        if self.pipeline and not reuse and self.trace is None:
+        pipeline = self.pipeline
+        if pipeline is None:
+            # (plain solve() on the default engine only: a lane of the host-driven batch schedulers keeps interleaving)
+            pipeline = hasattr(run.P, "_dev_bb_tail") and max_mv >= 1000 and eng.own_stream is None
+        if pipeline and not reuse and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
                 return out
@@ -449,6 +459,18 @@ class _APGDCore(CCQPSolverBase):
                 and (elementwise or run.P._has_device_form())
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
+        if elementwise and run.n > 2048:
+            # the rounds regime of ONE problem: staging in one launch, fused rounds with the persistent two-vector matvec
+            from .lockstep import _bapgd_one
+            out = _bapgd_one(eng, self, op, run.b, run.x0 if run.x0_given else None, run.P, run.n)
+            if out is not None:
+                done, x, res, mv = out
+                if not done:
+                    from . import lockstep
+                    lockstep.stats["fallback_solves"] += 1
+                    return None
+                eng.mv_executed += mv
+                return x, res, mv
         # (Sphere / Cone / DisjointUnion sets: the segmented rounds, ccqp_bsegs_apgd_round_f64)
         plans = None if elementwise else [run.P._segplan(eng, run.n)]
         done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
@@ -847,10 +869,11 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     def name(self):
         return "MPRGP"
 
-    # largest n of a device-resident solve (pipeline=True): round 3 measured the VALU rounds against the host-driven loop
-    # (x1.7 at 256, x1.3 at 1024, x0.9 at 2000); from 4096 on the batch of one looks ahead (three products per pass, the
-    # persistent launch) and saves the host's turn-around per stage
-    _PIPELINE_MAX_N = 16384
+    # largest n of a device-resident solve (pipeline=True): x1.7 at 256, x1.3 at 1024, x1.08-1.1 at 2048 against the
+    # host-driven loop; from 4096 on (the batch of one looks ahead: three products per pass, the persistent launch) its
+    # seven launches per round cost more than the host's turn-around: 0.91-0.98x at 4096 ... 16384
+    # (profiles/r04_single_mid.jsonl), so the host-driven loop with its own look-ahead stays the form there
+    _PIPELINE_MAX_N = 2048
 
     def _lockstep(self, run):
         from ._record import RecordingEngine

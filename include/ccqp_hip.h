@@ -94,6 +94,9 @@ int ccqp_scalars_read(ccqp_ctx* ctx, int slot0, int count, double* host_out, voi
  * has landed) and copies the values out of the pinned mirror.  One context per stream. */
 int ccqp_scalars_read_async(ccqp_ctx* ctx, int slot0, int count, void* stream);
 int ccqp_scalars_host(ccqp_ctx* ctx, int slot0, int count, double* host_out);
+/* Blocking read of count <= 64 doubles at ANY device address through the context's pinned mirror (publish + poll, as
+ * ccqp_scalars_read): e.g. the result words of a lock-step problem's own slab. */
+int ccqp_read_f64(ccqp_ctx* ctx, const double* dev, int count, double* host_out, void* stream);
 /* Device address of the slab (for kernels of the caller's own / for tests). */
 int ccqp_scalars_devptr(ccqp_ctx* ctx, double** out);
 
@@ -527,7 +530,8 @@ int ccqp_bsolve_bbpgd_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs, int count,
  * decide (all dot products + residual of :296-301,321-323 in one pass, sufficient-decrease test :302, momentum
  * :312-313, exit test, L update), apply (trial step x_{k+1} = P(y_k - t g_k)  or  y_{k+1} = (1+beta) x_{k+1} -
  * beta x_k).  Slab (>= 52 doubles, zeroed): 0..7 the host loop's eight scalars, 32..37 {L, t, theta_k, beta, r1,
- * r2}, 38..40 {phase, action, accepted iterations}, 49..51 {converged, matvecs so far, res2}.  A converged
+ * r2}, 38..40 {phase, action, accepted iterations}, 49..51 {converged (1; 2: stopped at the budget, fused rounds),
+ * matvecs so far, res2}.  A converged
  * problem's solution is X[(accepted iterations + 1) % 2].  ccqp_bpipe_poll reports {converged, round}.
  * `flags` bit 3 (8) selects the anti-relaxation variant (solvers.py:370-557; slots 41..43 {smallest residual,
  * copy pending, solution is xhat}): restart of the momentum where gk.(x_{k+1} - x_k) > 0, best iterate kept in xhat;
@@ -557,6 +561,13 @@ typedef struct ccqp_papgd {
  * caller has given every problem the two look-ahead buffers and asks the run to share passes where the persistent
  * batched matvec is its form.  The same value must be passed to every call of a run. */
 #define CCQP_LOCKSTEP_LOOKAHEAD (1 << 17)
+/* flags bit 18 of ccqp_bapgd_start_f64 / ccqp_bapgd_round_f64 (elementwise sets, with bit 17): FUSED ROUNDS -- a round
+ * that accepts iteration k also takes A.y_{k+1} + b over and forms the next trial point, so an accepted iteration is ONE
+ * round (3 launches) instead of two (10).  A round may then count two matvecs, so the device enforces the budget itself:
+ * the caller writes max_mv - 1 (0 = none) into slab slot 48 of every problem before the start; a problem whose next
+ * matvec would pass it stops with slot 49 = 2 (left to the host-driven loop, as the unfused run's round cap leaves it) and
+ * counts as finished in ccqp_bpipe_poll.  The same value for every call of a run.  Same bits, same counts. */
+#define CCQP_LOCKSTEP_FUSED_ROUNDS (1 << 18)
 int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int flags,
                          uint32_t* dev_batch, void* stream);
 int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round, double gd,
@@ -573,6 +584,24 @@ int ccqp_bsegs_apgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, const 
  * such a problem is left unconverged for the host-driven loop. */
 int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, double gd, double mv_limit,
                          int flags, void* stream);
+
+/* ONE problem of 128 <= n (even, aligned: flags bit 0), the whole APGD solve (flags bit 3: the anti-relaxation variant) in
+ * ONE cooperative launch on the whole chip: one 4-wave workgroup per CU, the rounds of the fused lock-step form (the
+ * two-vector persistent matvec of the trial point and its momentum point, the decision, the update) separated by grid
+ * barriers instead of kernel boundaries -- the device-resident form of a single solve of 2048 < n <= 16384, where launch
+ * gaps / host turn-around are a third to a half of a solve.  The problem carries ga / Aya; slab slot 48 = max_mv - 1
+ * (0: none); dev_batch: two words (barrier counter, give-up flag).  On return of the stream: slab as after
+ * ccqp_bapgd_round_f64 (slot 49: 1 converged | 2 stopped at the budget; 0 with dev_batch[1] != 0: the barrier gave up
+ * after seconds -- solve the problem another way).  CCQP_ERR_UNSUPPORTED: no cooperative launch of this shape on this
+ * device.  Replaces the loop solvers.py:271-334 (:446-523).  Per problem the bits and counts of its own solve(). */
+/* Staging of ONE lock-step APGD problem in one launch: *host_desc (a HOST copy of the descriptor, its pointers to device
+ * memory) is written to dev_desc; the problem's slab is zeroed with slot 48 = limit (max_mv - 1, 0: none); X[0] = Y[0] =
+ * x0 (NULL: zeros, solvers.py:253-258); xhat = ones where given (:432); words[0..2] (the problem's arrival counter, the
+ * two batch words) = 0.  Then ccqp_bapgd_start_f64 / ccqp_bapgd_round_f64 (or ccqp_bsolve_apgd_grid_f64) on dev_desc. */
+int ccqp_bapgd_stage_one_f64(ccqp_ctx* ctx, const ccqp_papgd* host_desc, ccqp_papgd* dev_desc, const double* x0, int64_t n,
+                             double limit, uint32_t* words, void* stream);
+int ccqp_bsolve_apgd_grid_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int64_t n, double gd, int flags,
+                              int64_t max_rounds, uint32_t* dev_batch, void* stream);
 
 /* And for MPRGP (solvers.py:1026-1200, README's "MPRGP-BB", BASELINE config 5), elementwise sets with array
  * bounds.  A ROUND = at most one matvec per live problem (A x_k + b | A p | A x_{k+1} + b | A dx, by the problem's

@@ -165,3 +165,49 @@ def test_look_ahead_with_problems_far_out_of_step(kind, segmented, n, count):
         with contextlib.redirect_stdout(io.StringIO()):
             s = make().solve(A, b, x0=x0, convex_proj_op=P)
         _same(s, look[p])
+
+
+@pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation"])
+def test_fused_rounds_enforce_the_budget_on_the_device(kind):
+    """Lock-step APGD with FUSED rounds (an accepting round also takes A.y_{k+1} + b over: a round may count two matvecs,
+    so the host's round count no longer bounds the matvec count and the device enforces max_mv itself, slab slot 48).
+    Problems of n = 256 through the persistent look-ahead rounds (context option PERS1_MIN_N = 128), budgets from 3 up
+    to past the matvec count of convergence, three tolerances: every result -- x bit for bit, reported and executed
+    counts, converged flag, residual -- equals the problem's own host-driven solve() (whose budget exits the reference
+    goldens pin), whether the device finished the problem or stopped it one short of the budget for the host loop;
+    with two matvecs of room past convergence the device finishes every problem itself."""
+    from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    cls = getattr(solvers, "CCQPSolver" + kind)
+    n = 256
+    eng = get_engine(0)
+    items = []
+    for p in range(4):
+        op, b, _ = problems.random_problem(n, 9100 + p)
+        items.append((op, b, None, ss.BoxProjOp(n, -0.3 * np.ones(n) - 0.02 * p, 0.4 * np.ones(n))))
+    eng.set_option("PERS1_MIN_N", 128)
+    try:
+        assert _form(len(items), n, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+        for tol in (1e-3, 1e-6, 1e-9):
+            conv = []
+            for it in items:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    conv.append(cls(tol, np.inf).solve(it[0], it[1], convex_proj_op=it[3]).solution_num_matrix_vector_multiplications)
+            budgets = sorted(set(list(range(3, 9)) + [m + d for m in conv for d in (-2, -1, 0, 1, 2, 3)]))
+            for max_mv in budgets:
+                before = lockstep.stats["fallback_solves"]
+                got = lockstep.solve_batch_pipelined(lambda: cls(tol, max_mv), items, device=0, single_launch=False)
+                fell = lockstep.stats["fallback_solves"] - before
+                for it, c, m in zip(items, got, conv):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        try:
+                            one = cls(tol, max_mv).solve(it[0], it[1], convex_proj_op=it[3])
+                        except UnboundLocalError:
+                            one = None
+                    if one is None:
+                        continue
+                    _same(one, c)
+                if max_mv >= max(conv) + 3:
+                    assert fell == 0, (tol, max_mv, conv, fell)
+    finally:
+        eng.set_option("PERS1_MIN_N", 0)

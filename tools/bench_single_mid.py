@@ -25,12 +25,14 @@ def main():
     ap.add_argument("--sizes", default="2048,4096,8192,16384")
     ap.add_argument("--solvers", default="APGD,APGDAntiRelaxation,MPRGP")
     ap.add_argument("--reps", type=int, default=9)
+    ap.add_argument("--grid", type=int, default=1, help="0: lock-step rounds instead of the one-launch cooperative solve")
     add_option_args(ap)
     args = ap.parse_args()
     options = apply_options(args)
     from bench import box_id
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     box = box_id(0)
+    lockstep._APGD_GRID_SOLVE = bool(args.grid)
     for n in (int(v) for v in args.sizes.split(",")):
         op, b, _ = problems.random_problem(n, 1234)
         P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
@@ -38,7 +40,7 @@ def main():
             cls = getattr(solvers, "CCQPSolver" + name)
             tolmv = (1e-6, 300) if name == "MPRGP" else (1e-8, 5000)
             out = {}
-            for label, kw in (("host_loop", {}), ("device_resident", {"pipeline": True})):
+            for label, kw in (("host_loop", {"pipeline": False}), ("device_resident", {"pipeline": True})):
                 ts, r = [], None
                 fb0 = lockstep.stats["fallback_solves"]
                 for rep in range(args.reps + 2):
@@ -64,6 +66,8 @@ def main():
                               "speedup": round(float(np.median(h)) / float(np.median(d)), 3),
                               "same_bits_and_counts": same, "device_resident_fell_back": out["device_resident"][2],
                               "converged": bool(a.solution_converged), "options": options,
+                              "device_resident_host_split_us": {k: round(1e6 * v, 1) for k, v in lockstep.last_timing.items()}
+                              if name.startswith("APGD") else None, "grid_solves": lockstep.stats.get("grid_solves"),
                               "box": box.get("host"), "gpu_uuid": box.get("gpu_uuid")}), flush=True)
         del op
         torch.cuda.empty_cache()
