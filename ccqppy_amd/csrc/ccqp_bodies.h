@@ -209,6 +209,21 @@ __device__ __forceinline__ double split_body(const ccqp_segk& sg, const double* 
     const double d = xi - p;
     acc = fma(d, d, acc);
   }
+  if (sg.dim <= CCQP_SMALL_SEG_MAX) {
+    // a tiny block (one chunk): |x - P(x)|^2 as the SEQUENTIAL chain of the thread-per-block kernel
+    // (small_segments_kernel, ccqp_proj.hip: what BoxProjOp.normal_vector of such a block -- and the host-driven MPRGP
+    // loop for n <= 64 -- computes; numpy's own order for short vectors), so that the one order-sensitive decision of an
+    // MPRGP iteration, sqrt(dist2) > 1e-8 (solution_spaces.py:310), has the same bits in every form of the solver
+    __syncthreads();
+    double sq = 0.0;
+    if (threadIdx.x == 0)
+      for (int64_t i = 0; i < sg.dim; ++i) {
+        const double d = x[i] - xp[i];
+        sq = fma(d, d, sq);
+      }
+    __syncthreads();
+    return sq;
+  }
   return ccqp_block_sum(acc, lds4);
 }
 

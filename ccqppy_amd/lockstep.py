@@ -126,11 +126,11 @@ def _why_not_one(kind, max_mv, s, A, b, P, device):
         if getattr(P, "_fixed_dim", False) and P.embedded_dimension != n:
             return ValueError("solve_batch_pipelined: the feasible set does not match b"), n, P
         return None, n, P
-    if kind.__name__ == "CCQPSolverMPRGP" and (P._scalar_bound_names() or n <= _lib.SMALL_SEG_MAX):
-        # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones; tiny blocks take the
-        # sequential-sum kernels of the literal path)
-        return TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds and n > %d"
-                         % _lib.SMALL_SEG_MAX), n, P
+    if kind.__name__ == "CCQPSolverMPRGP" and P._scalar_bound_names():
+        # (the reference's normal_vector indexes the bounds: a TypeError for scalar ones.  Tiny problems, n <= 64, are
+        # taken since round 4: the one order-sensitive decision of an iteration, |x - P(x)| > 1e-8, is summed there as the
+        # literal path's thread-per-block kernel sums it -- split_body, ccqp_bodies.h)
+        return TypeError("solve_batch_pipelined runs MPRGP on sets with array bounds"), n, P
     return None, n, P
 
 
@@ -1189,8 +1189,8 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
         plans = [feasible_set._segplan(eng, n)] * B      # (the tables are read-only: one plan for all problems)
     kind = {(False, False): _lib.OP_IDENTITY, (True, False): _lib.OP_LOWER, (False, True): _lib.OP_UPPER,
             (True, True): _lib.OP_BOX}[(lower is not None, upper is not None)]
-    if name == "MPRGP" and (is_scalar(lower) or is_scalar(upper) or n <= _lib.SMALL_SEG_MAX):
-        raise TypeError("solve_stacked runs MPRGP on sets with array bounds and n > %d" % _lib.SMALL_SEG_MAX)
+    if name == "MPRGP" and (is_scalar(lower) or is_scalar(upper)):
+        raise TypeError("solve_stacked runs MPRGP on sets with array bounds")
     seg = np.zeros(B, dtype=np.dtype(_lib.Seg))
     seg["kind"], seg["dim"] = kind, n
     keep = []

@@ -881,7 +881,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         from .operators import DenseOperator
         op, eng, P = run.op, run.eng, run.P
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
-                and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names() and run.n > ss._lib.SMALL_SEG_MAX
+                and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names()
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
         status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n),

@@ -331,15 +331,29 @@ def test_single_solve_pipeline_option():
             solvers.CCQPSolverMPRGP(1e-7, 500, pipeline=True).solve(op, b, convex_proj_op=ss.BoxProjOp(256, -0.5, 0.5))
 
 
-def test_rejects_scalar_bounds_and_tiny_problems():
-    from ccqppy_amd import batch, problems, solvers, solution_spaces as ss
+def test_rejects_scalar_bounds_and_takes_tiny_problems():
+    """Scalar bounds raise (the reference's normal_vector indexes them).  Tiny problems (n <= 64, where the host-driven
+    loop takes the literal kernels and BoxProjOp.normal_vector sums |x - P(x)|^2 sequentially) are taken since round 4:
+    lock-step rounds, the one-launch form and pipeline=True give the bits and counts of solve()."""
+    from ccqppy_amd import batch, lockstep, problems, solvers, solution_spaces as ss
     op, b, _ = problems.random_problem(128, 1)
     with pytest.raises(TypeError):
         batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8), [(op, b, None, ss.BoxProjOp(128, -0.5, 0.5))])
-    op, b, _ = problems.random_problem(48, 1)
-    with pytest.raises(TypeError):
-        batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-8),
-                                    [(op, b, None, ss.BoxProjOp(48, -0.5 * np.ones(48), 0.5 * np.ones(48)))])
+    for n in (48, 64, 17):
+        items = []
+        for p in range(5):
+            op, b, _ = problems.random_problem(n, 40 + p)
+            items.append((op, b, None, ss.BoxProjOp(n, -0.3 * np.ones(n) - 0.01 * p, 0.35 * np.ones(n))))
+        for single in (True, False):
+            before = lockstep.stats["fallback_solves"]
+            got = batch.solve_batch_pipelined(lambda: solvers.CCQPSolverMPRGP(1e-6, 3000), items, single_launch=single)
+            assert lockstep.stats["fallback_solves"] == before
+            for it, c in zip(items, got):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    one = solvers.CCQPSolverMPRGP(1e-6, 3000).solve(it[0], it[1], convex_proj_op=it[3])
+                    two = solvers.CCQPSolverMPRGP(1e-6, 3000, pipeline=True).solve(it[0], it[1], convex_proj_op=it[3])
+                _same(one, c)
+                _same(one, two)
 
 
 @pytest.mark.parametrize("n,count", [(4096, 9), (4098, 8), (6000, 4)])

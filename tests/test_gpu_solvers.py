@@ -173,7 +173,7 @@ def test_solver_golden_through_the_lockstep_scheduler(case):
     """The same reference-pinned fixtures, solved by the DEVICE-RESIDENT forms (batch.solve_batch_pipelined: lock-step
     rounds or the single-launch kernels; segmented forms for Sphere / Cone / DisjointUnion sets): a direct comparison
     with the reference's results, not only the transitive one through solve().  A batch of three copies of the
-    problem; cases the scheduler does not take (MPRGP on non-elementwise or scalar-bounded sets, n <= 64) are skipped
+    problem; cases the scheduler does not take (MPRGP on scalar-bounded sets or sets with a Cone block) are skipped
     by its own argument check.  SPG: every solver gets its own RandomState(rng_seed) -- the stream `np.random.seed(rng_seed)`
     gave the reference when the fixture was made (oracle/gen_golden.py)."""
     from ccqppy_amd import batch, lockstep

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--sizes", default="2048,4096,8192,16384")
     ap.add_argument("--solvers", default="APGD,APGDAntiRelaxation,MPRGP")
     ap.add_argument("--reps", type=int, default=9)
-    ap.add_argument("--grid", type=int, default=1, help="0: lock-step rounds instead of the one-launch cooperative solve")
+    ap.add_argument("--grid", type=int, default=0, help="0: lock-step rounds instead of the one-launch cooperative solve")
     add_option_args(ap)
     args = ap.parse_args()
     options = apply_options(args)
