@@ -997,7 +997,9 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   if (rc) return rc;
   // (the decision and the update stay two launches: letting the deciding block walk the update alone -- one launch and
   // one kernel boundary fewer -- was measured SLOWER, +4 us per round at n = 4096 and +11 us at n = 8192: one CU moves
-  // the ~100 bytes per element at 50-80 GB/s; profiles/r04_single_mid.jsonl)
+  // the ~100 bytes per element at 50-80 GB/s; and ONE block walking the 2 ... 4 chunks of the decision itself, without
+  // the inter-workgroup meeting: +5 us at 4096, +16 us at 8192 -- a chunk costs ~5 us wherever it runs;
+  // profiles/r04_single_mid.jsonl)
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, ar, (const ccqp_psegs*)nullptr,
                      (int64_t)0, fuse);

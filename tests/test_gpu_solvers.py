@@ -214,8 +214,12 @@ _SHARING_CASES = [c for c in _LOCKSTEP_CASES if c["solver"] in ("APGD", "APGDAnt
                   and int(c["problem"].split(":")[1]) >= 128 and int(c["problem"].split(":")[1]) % 2 == 0]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused_rounds", "two_rounds_per_iteration"])
-@pytest.mark.parametrize("case", _SHARING_CASES, ids=[c["id"] for c in _SHARING_CASES])
+# (APGD / anti-relaxation APGD: both round forms; MPRGP has one)
+_SHARING_RUNS = [(c, f) for c in _SHARING_CASES for f in ((True, False) if c["solver"] != "MPRGP" else (True,))]
+
+
+@pytest.mark.parametrize("case,fused", _SHARING_RUNS,
+                         ids=["%s-%s" % (c["id"], "fused_rounds" if f else "two_rounds_per_iteration") for c, f in _SHARING_RUNS])
 def test_sharing_goldens_through_the_persistent_lockstep_rounds(case, fused):
     """The reference-pinned APGD / anti-relaxation APGD / MPRGP fixtures (budget and exit-path cases included) through
     the lock-step ROUNDS with the persistent multi-vector matvec and the look-ahead -- the form a device-resident single
@@ -236,8 +240,6 @@ def test_sharing_goldens_through_the_persistent_lockstep_rounds(case, fused):
     if lockstep.why_not_pipelined([cls(case["tol"], max_mv, **case["kwargs"]) for _ in probs], probs,
                                   get_engine(0).device) is not None:
         pytest.skip("not a lock-step case")
-    if case["solver"] == "MPRGP" and not fused:
-        pytest.skip("MPRGP has one round form")
     eng = get_engine(0)
     old_fused = lockstep._APGD_FUSED_ROUNDS
     eng.set_option("PERS1_MIN_N", 128)
