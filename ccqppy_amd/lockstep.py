@@ -820,10 +820,11 @@ class _OneWs:
 
 def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     """ONE dense APGD / anti-relaxation APGD problem on an elementwise set, device-resident (the form of
-    CCQPSolverAPGD(pipeline=True) from n = 4096 on): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve
-    allocation, no host-paced torch operation, the descriptor by value), the fused lock-step rounds with the persistent
-    two-vector matvec queued `ahead` beyond the device's last report (or the one-launch cooperative form), the result words
-    through the pinned mirror.  Returns (done, x, residual, matvecs) or None where the form does not apply."""
+    CCQPSolverAPGD's default pipeline): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve allocation, no
+    host-paced torch operation, the descriptor by value); then n <= 128 the whole solve in one launch (one workgroup), up
+    to 2048 the lock-step rounds of the VALU kernels, beyond (where the batch of one takes the persistent two-vector
+    matvec) the FUSED rounds -- all queued `ahead` beyond the device's last report; the result words through the pinned
+    mirror.  Returns (done, x, residual, matvecs); done False: the budget was reached first (the host-driven loop's exits)."""
     import ctypes
     from . import _lib
     from .solvers import _GD
@@ -831,23 +832,25 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     A = op.A
     aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
     ar = bool(solver._anti_relaxation)
-    flags = 1 | (8 if ar else 0) | _lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS
     max_mv = solver.max_matrix_vector_multiplications
-    if not (aligned and _APGD_FUSED_ROUNDS and _sharing_form(eng, 1, n, 1) and (not np.isfinite(max_mv) or max_mv >= 4)):
-        return None
+    sharing = aligned and _APGD_FUSED_ROUNDS and _sharing_form(eng, 1, n, 1) and (not np.isfinite(max_mv) or max_mv >= 4)
+    flags = int(aligned) | (8 if ar else 0) | ((_lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS) if sharing else 0)
     cache = eng.__dict__.setdefault("_apgd_one_ws", {})
     ws = cache.get(n)
     if ws is None:
+        if len(cache) > 8:
+            cache.clear()
         ws = cache[n] = _OneWs()
         nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
-        ws.vec = torch.empty((11, n), dtype=torch.float64, device=dev)
+        stride = (n + 1) // 2 * 2                        # (planes 16 bytes apart for an odd n too)
+        ws.vec = torch.empty((11, stride), dtype=torch.float64, device=dev)
         ws.slab = torch.zeros(64, dtype=torch.float64, device=dev)
         ws.partials = torch.empty(8 * nblk, dtype=torch.float64, device=dev)
         ws.words = torch.zeros(4, dtype=torch.int32, device=dev)
         ws.ddesc = torch.zeros(ctypes.sizeof(_lib.PApgd), dtype=torch.uint8, device=dev)
         d = ws.desc = _lib.PApgd()
         base = ws.vec.data_ptr()
-        plane = [base + 8 * n * j for j in range(11)]
+        plane = [base + 8 * stride * j for j in range(11)]
         # planes: X0 X1 Y0 Y1 gk g1 Ayk Ax1 xhat ga Aya
         d.X[0], d.X[1], d.Y[0], d.Y[1] = plane[0], plane[1], plane[2], plane[3]
         d.gk, d.g1, d.Ayk, d.Ax1, d.xhat, d.ga, d.Aya = plane[4:11]
@@ -858,14 +861,17 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     d.A, d.lda, d.b = A.data_ptr(), A.stride(0), b.data_ptr()
     d.seg = P._seg(eng, 0, n)
     d.tol = float(solver.desired_residual_tol)
-    limit = float(max_mv - 1) if np.isfinite(max_mv) else 0.0
+    limit = float(max_mv - 1) if (sharing and np.isfinite(max_mv)) else 0.0
     check = _lib.check
     dp, batch = ws.ddesc.data_ptr(), ws.words.data_ptr() + 4
     t0 = time.perf_counter()
     check(lib.ccqp_bapgd_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n, limit,
                                        ws.words.data_ptr(), st))
     last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
-    grid = _APGD_GRID_SOLVE
+    grid = sharing and _APGD_GRID_SOLVE
+    # (ONE problem: the one-workgroup solve only for tiny matrices -- at n = 128 it takes 1.2 ms, the rounds 0.7;
+    # profiles/r04_single_mid.jsonl -- it is a form for MANY problems, one per compute unit)
+    single = n <= 64
     if grid:
         rc = lib.ccqp_bsolve_apgd_grid_f64(ctx, dp, n, _GD, flags & 9, int(last) if np.isfinite(last) else 10 ** 7, batch, st)
         if rc == _lib.ERR_UNSUPPORTED:
@@ -874,7 +880,11 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
             check(rc)
             stats["grid_solves"] += 1
     t1 = time.perf_counter()
-    if not grid:
+    if grid:
+        pass
+    elif single:
+        check(lib.ccqp_bsolve_apgd_f64(ctx, dp, 1, n, _GD, float(min(max_mv - 1, _device_budget(n))), flags & 9, st))
+    else:
         check(lib.ccqp_bapgd_start_f64(ctx, dp, 1, n, flags, batch, st))
 
         def launch(r):
@@ -891,7 +901,7 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
         return False, None, None, None
     pick = 8 if (ar and h[11] != 0.0) else (int(h[8]) + 1) % 2
     # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
-    return True, ws.vec[pick], np.sqrt(np.float64(h[19])), int(h[18])
+    return True, ws.vec[pick, :n], np.sqrt(np.float64(h[19])), int(h[18])
 
 
 def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):

@@ -459,18 +459,16 @@ class _APGDCore(CCQPSolverBase):
                 and (elementwise or run.P._has_device_form())
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        if elementwise and run.n > 2048:
-            # the rounds regime of ONE problem: staging in one launch, fused rounds with the persistent two-vector matvec
+        if elementwise:
+            # ONE problem on an elementwise set: staging in one launch, then the form its size asks for (lockstep._bapgd_one)
             from .lockstep import _bapgd_one
-            out = _bapgd_one(eng, self, op, run.b, run.x0 if run.x0_given else None, run.P, run.n)
-            if out is not None:
-                done, x, res, mv = out
-                if not done:
-                    from . import lockstep
-                    lockstep.stats["fallback_solves"] += 1
-                    return None
-                eng.mv_executed += mv
-                return x, res, mv
+            done, x, res, mv = _bapgd_one(eng, self, op, run.b, run.x0 if run.x0_given else None, run.P, run.n)
+            if not done:
+                from . import lockstep
+                lockstep.stats["fallback_solves"] += 1
+                return None
+            eng.mv_executed += mv
+            return x, res, mv
         # (Sphere / Cone / DisjointUnion sets: the segmented rounds, ccqp_bsegs_apgd_round_f64)
         plans = None if elementwise else [run.P._segplan(eng, run.n)]
         done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n), run.n,
