@@ -203,7 +203,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_gemv_lds_kernel(const ccqp_
   bmprgp_mv m;
   if (!bmprgp_mv_operands(q, init, &m)) return;
   constexpr int RING = S * (R + 1) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   gemv_lds_body<R, S, true>(q.A, q.lda, m.x, m.b, m.y, m.g, n, n, ntasks, (int64_t)blockIdx.x * wpb + w,
                             (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);

@@ -499,12 +499,16 @@ __device__ __forceinline__ void gemv_lds_body(const double* __restrict__ A, int6
         }
         const char* slot = mine + cslot * SLOT;
         if (s < nfull || mine_in_tail) {
+          // (all R + 1 pieces asked for back to back, then the fma chains: see gemv_ldsk_body)
           const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+          ccqp_d2 av[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) av[r] = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
-            acc[r] = fma(av.x, xv.x, acc[r]);
-            acc[r] = fma(av.y, xv.y, acc[r]);
+            acc[r] = fma(av[r].x, xv.x, acc[r]);
+            acc[r] = fma(av[r].y, xv.y, acc[r]);
           }
         }
         cslot = cslot + 1 == S ? 0 : cslot + 1;
@@ -604,16 +608,22 @@ __device__ __forceinline__ void gemv_ldsk_body(const double* __restrict__ A, int
         }
         const char* slot = mine + cslot * SLOT;
         if (s < nfull || mine_in_tail) {
-          ccqp_d2 xv[K];
+          // ALL R + K pieces of the slot are asked for back to back, then the fma chains run: left to itself the
+          // scheduler interleaves reads and fmas in three groups with a full LDS round trip (lgkmcnt(0)) between them,
+          // ~300 clocks per step on the wave's critical path -- and a wave that consumes slowly issues its next DMA
+          // late (why two waves per CU were 14 % short for the pair, profiles/r04_gemv2_shapes.jsonl)
+          ccqp_d2 xv[K], av[R];
 #pragma unroll
           for (int j = 0; j < K; ++j) xv[j] = *reinterpret_cast<const ccqp_d2*>(slot + (R + j) * PIECE + lane * 16);
 #pragma unroll
+          for (int r = 0; r < R; ++r) av[r] = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
           for (int r = 0; r < R; ++r) {
-            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-              acc[j][r] = fma(av.x, xv[j].x, acc[j][r]);
-              acc[j][r] = fma(av.y, xv[j].y, acc[j][r]);
+              acc[j][r] = fma(av[r].x, xv[j].x, acc[j][r]);
+              acc[j][r] = fma(av[r].y, xv[j].y, acc[j][r]);
             }
           }
         }
@@ -718,12 +728,16 @@ __device__ __forceinline__ void gemv_lds_multi_body(const gemv_lds_desc* D, int 
         }
         const char* slot = mine + cslot * SLOT;
         if (s < nfull || mine_in_tail) {
+          // (all R + 1 pieces asked for back to back, then the fma chains: see gemv_ldsk_body)
           const ccqp_d2 xv = *reinterpret_cast<const ccqp_d2*>(slot + R * PIECE + lane * 16);
+          ccqp_d2 av[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) av[r] = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
-            acc[r] = fma(av.x, xv.x, acc[r]);
-            acc[r] = fma(av.y, xv.y, acc[r]);
+            acc[r] = fma(av[r].x, xv.x, acc[r]);
+            acc[r] = fma(av[r].y, xv.y, acc[r]);
           }
         }
         cslot = cslot + 1 == S ? 0 : cslot + 1;
@@ -828,16 +842,18 @@ __device__ __forceinline__ void gemv_lds3_multi_body(const gemv_lds3_desc* D, in
         }
         const char* slot = mine + cslot * SLOT;
         if (s < nfull || mine_in_tail) {
-          ccqp_d2 xv[3];
+          ccqp_d2 xv[3], av[R];
 #pragma unroll
           for (int j = 0; j < 3; ++j) xv[j] = *reinterpret_cast<const ccqp_d2*>(slot + (R + j) * PIECE + lane * 16);
 #pragma unroll
+          for (int r = 0; r < R; ++r) av[r] = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
+          __builtin_amdgcn_sched_barrier(0);          // (reads back to back, then the fma chains: see gemv_ldsk_body)
+#pragma unroll
           for (int r = 0; r < R; ++r) {
-            const ccqp_d2 av = *reinterpret_cast<const ccqp_d2*>(slot + r * PIECE + lane * 16);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              acc[j][r] = fma(av.x, xv[j].x, acc[j][r]);
-              acc[j][r] = fma(av.y, xv[j].y, acc[j][r]);
+              acc[j][r] = fma(av[r].x, xv[j].x, acc[j][r]);
+              acc[j][r] = fma(av[r].y, xv[j].y, acc[j][r]);
             }
           }
         }

@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_grid_kernel(const ccqp
   __shared__ double lds4[4];
   __shared__ int is_last;
   constexpr int RING = S * (R + 3) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   gemv_lds3_desc* D = reinterpret_cast<gemv_lds3_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
   const ccqp_papgd& q = probs[0];

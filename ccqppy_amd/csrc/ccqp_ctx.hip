@@ -198,7 +198,9 @@ extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
   bool ok = value >= 0;
   switch (key) {
     case CCQP_OPT_GEMV2_WPB: ok = value >= 0 && value <= 8; break;
-    case CCQP_OPT_GEMV2_SHAPE: ok = value == 0 || value == 44 || value == 43 || value == 82 || value == 83 || value == 84; break;
+    case CCQP_OPT_GEMV2_SHAPE:
+      ok = value == 0 || value == 44 || value == 43 || value == 46 || value == 48 || value == 82 || value == 83 || value == 84;
+      break;
     case CCQP_OPT_GEMV2_GROUP: ok = value == 0 || (value >= 64 && value <= 512 && value % 16 == 0); break;
     case CCQP_OPT_BMV3_SHAPE: ok = value == 0 || value == 824 || value == 833 || value == 444 || value == 434; break;
     case CCQP_OPT_LOOKAHEAD_MIN_N:

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds_kernel(const double* __re
   // dynamic LDS: the four waves' rings, then their parked row sums
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int RING = S * (R + 1) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;      // (launched with 1, 2 or 4 waves per workgroup)
+  // (readfirstlane: the wave's task list, step counters and branches become scalar code -- see gemv_lds2_kernel)
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;   // (1, 2 or 4 waves per workgroup)
   const int64_t wave = (int64_t)blockIdx.x * wpb + w;
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
@@ -433,7 +434,10 @@ __global__ __launch_bounds__(512) void gemv_lds2_kernel(const double* __restrict
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int RING = S * (R + 2) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  // (the wave's index through readfirstlane: everything derived from it -- task list, step counters, ring slots, the
+  // loop's branches -- is then SCALAR code; as a function of threadIdx it would be vector arithmetic and exec-mask
+  // branches, ~2x the instructions of a step on the one wave a SIMD has here)
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * wpb + w;
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * rescap;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void gemv_lds3_kernel(const double* __r
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int RING = S * (R + 3) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * wpb + w;
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
@@ -586,6 +590,8 @@ extern "C" int ccqp_gemv2_f64(ccqp_ctx* ctx, const double* A, int64_t lda, const
     break
   switch (shape) {
     LDS2_CASE(4, 3);
+    LDS2_CASE(4, 6);
+    LDS2_CASE(4, 8);
     LDS2_CASE(8, 2);
     LDS2_CASE(8, 3);
     LDS2_CASE(8, 4);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
   extern __shared__ __attribute__((aligned(16))) char ring[];
   __shared__ int nlive_s;
   constexpr int RING = S * (R + 1) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   gemv_lds_desc* D = reinterpret_cast<gemv_lds_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
   // the live problems, in order, compacted by wave 0 (ballot + prefix over 64 problems at a time)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve
   extern __shared__ __attribute__((aligned(16))) char ring[];
   __shared__ int nlive_s;
   constexpr int RING = S * (R + 3) * 1024;
-  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
   double* res = reinterpret_cast<double*>(ring + wpb * RING) + w * GEMV_LDS_RESCAP;
   gemv_lds3_desc* D = reinterpret_cast<gemv_lds3_desc*>(ring + wpb * RING + wpb * GEMV_LDS_RESCAP * sizeof(double));
   if (w == 0) {

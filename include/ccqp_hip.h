@@ -60,7 +60,7 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  * the environment); not thread-safe against launches in flight on the same context (one host thread per context).
  *   GEMV_ROW_STRIDE        k >= 1: a wave's R row streams lie k rows apart (LDS-staged matvecs; default: ~1 MiB apart)
  *   GEMV2_WPB              1..8 waves per workgroup of the two-vector launch ccqp_gemv2_f64 (default 4)
- *   GEMV2_SHAPE            <R><S> of its ring as a two-digit number: 44, 43, 82, 83, 84 (rows per wave, ring slots)
+ *   GEMV2_SHAPE            <R><S> of its ring as a two-digit number: 44, 43, 46, 48, 82, 83, 84 (rows per wave, ring slots)
  *   GEMV2_GROUP            row sums a wave parks before it stores them: 64 .. 512 (default 512)
  *   BMV3_SHAPE             <R><S><W> of the three-vector persistent launch: 824, 833, 444, 434
  *   LOOKAHEAD_MIN_N        smallest n at which lock-step APGD looks ahead (>= 128; default 1024)

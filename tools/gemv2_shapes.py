@@ -29,6 +29,11 @@ SHAPES = {
     "R8 S2 w2 x2/CU": (82, 2, 0, 2),
     "R4 S3 w3 x2/CU": (43, 3, 0, 2),
     "R4 S4 w2 x2/CU": (44, 2, 0, 2),
+    "R4 S6 w2": (46, 2, 0, 1),
+    "R4 S8 w2": (48, 2, 0, 1),
+    "R4 S6 w3": (46, 3, 0, 1),
+    "R4 S8 w3 g256": (48, 3, 256, 1),
+    "R4 S6 w2 x2/CU": (46, 2, 256, 2),
     "R4 S4 w5": (44, 5, 0, 1),
     "R4 S4 w6 g256": (44, 6, 256, 1),
     "R4 S3 w5": (43, 5, 0, 1),
