@@ -8,7 +8,7 @@
 
 Workload (BASELINE.json `metric`): n = 131072 dense random-SPD fp64 box-constrained QP, APGD
 (tol 1e-8, max 5000 MVs), synthetic inputs generated on the GPU.  One STEP = one complete APGD solve
-from x0 = 0 (about 44 matvecs + all vector work + every host<->device scalar sync).
+from x0 = 0 (35 matvecs + all vector work + every host<->device scalar sync).
 `value` = matvecs executed per second over the whole job; `ms_per_step` = solve wall-clock.
 The solver is the package's default CCQPSolverAPGD: the two matvecs of an iteration (A.x_{k+1} and A.y_{k+1}; the second
 does not depend on the line search) are computed by ONE two-vector launch, ccqp_gemv2_f64 -- one pass over the matrix
