@@ -124,10 +124,20 @@ __device__ __forceinline__ bool bp_meet(double* partials, unsigned* counter, int
   }
   __syncthreads();
   if (!*is_last) return false;
-  for (int k = 0; k < nred; ++k) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) acc += partials[(int64_t)k * nblk + i];
-    v[k] = ccqp_block_sum(acc, lds4);
+  // eight sums at a time: per value the arithmetic of ccqp_block_sum (hence the bits), two workgroup barriers for the
+  // eight instead of sixteen -- the decision launch of a single problem spends ~2 us less here
+  for (int k0 = 0; k0 < nred; k0 += 8) {
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = 0.0;
+      if (k0 + j < nred)
+        for (int i = threadIdx.x; i < nblk; i += CCQP_BLOCK) a[j] += partials[(int64_t)(k0 + j) * nblk + i];
+    }
+    ccqp_block_sum_multi<8>(a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k0 + j < nred) v[k0 + j] = a[j];
   }
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
