@@ -196,6 +196,19 @@ class CCQPSolverBase(ABC):
     def _checkSolveInput(self, A, b, x0):
         pass
 
+    def _device_resident(self, run):
+        """The effective value of `pipeline` for this solve.  None (the default of APGD, anti-relaxation APGD, BBPGD,
+        BBPGDf and SPG) = ON for a plain solve() on the default engine with a dense operator, an elementwise feasible set
+        and a matvec budget of at least 1000: the device-resident forms give the same bits and counts 1.3-2.0x faster at
+        n <= 2048 and up to 1.4x at 4096 ... 16384 (profiles/r04_single_mid*.jsonl); a solve MEANT to run into a small
+        budget stays on the host-driven loop, whose exit paths are the reference's."""
+        pipeline = getattr(self, "pipeline", False)
+        if pipeline is None:
+            from .operators import DenseOperator
+            pipeline = isinstance(run.op, DenseOperator) and hasattr(run.P, "_dev_bb_tail") \
+                and self.max_matrix_vector_multiplications >= 1000 and run.eng.own_stream is None
+        return pipeline
+
     @property
     @abstractmethod
     def name(self):
@@ -302,10 +315,8 @@ class _APGDCore(CCQPSolverBase):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng, b, AR = run.eng, run.b, self._anti_relaxation
         reuse = self.reuse_matvec
-        pipeline = self.pipeline
-        if pipeline is None:
-            # (plain solve() on the default engine only: a lane of the host-driven batch schedulers keeps interleaving)
-            pipeline = hasattr(run.P, "_dev_bb_tail") and max_mv >= 1000 and eng.own_stream is None
+        # (None: plain solve() on the default engine only -- a lane of the host-driven batch schedulers keeps interleaving)
+        pipeline = self._device_resident(run)
         if pipeline and not reuse and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
@@ -504,9 +515,11 @@ class _BBPGDCore(CCQPSolverBase):
     _label = "BBPGDf"                                   # both print this, solvers.py:613,748
     _fallback = False
 
-    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=False):
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
-        # Extension, OFF by default, SAME results bit for bit: keep the per-iteration scalars (BB step length, exit
+        # SAME results bit for bit; None (default): ON where CCQPSolverBase._device_resident says so (dense operator,
+        # elementwise set, budget >= 1000: 1.4x at n <= 2048, 1.17x at 4096, 1.03-1.06x at 8192 / 16384), True / False /
+        # "graph" force it: keep the per-iteration scalars (BB step length, exit
         # test) on the device and queue iterations ahead instead of one host round trip per iteration
         # (ccqp_pipe_*; dense, sparse and sparse/diagonal composed operators, elementwise sets, plain solve()).  1.1-1.6x on 13-iteration solves with n <= 8k,
         # 1.7-1.9x on 125-iteration ones.  pipeline="graph" additionally replays three captured iterations as one
@@ -520,7 +533,7 @@ class _BBPGDCore(CCQPSolverBase):
         op = run.op
         ok_op = isinstance(op, (DenseOperator, SparseOperator)) or \
             (isinstance(op, ComposedOperator) and op.can_pipeline())
-        return (self.pipeline and self.trace is None and not self._fallback and ok_op
+        return (self._device_resident(run) and self.trace is None and not self._fallback and ok_op
                 and hasattr(run.P, "_dev_bb_tail") and not isinstance(run.eng, RecordingEngine)
                 and run.eng.gemv_events is None)
 
@@ -658,11 +671,11 @@ class _BBPGDCore(CCQPSolverBase):
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
-        if self.pipeline and self._fallback and self.trace is None:
+        if self._device_resident(run) and self._fallback and self.trace is None:
             out = self._lockstep_fallback_variant(run)
             if out is not None:
                 return out
-        if self.pipeline and not self._fallback and self.trace is None:
+        if self._device_resident(run) and not self._fallback and self.trace is None:
             out = self._lockstep_segments(run)
             if out is not None:
                 return out
@@ -747,7 +760,7 @@ class CCQPSolverSPG(CCQPSolverBase):
     _label = "SPG"
 
     def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf,
-                 m=5, tau=0.5, sigma1=0.01, sigma2=0.5, pipeline=False):
+                 m=5, tau=0.5, sigma1=0.01, sigma2=0.5, pipeline=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         # Extension, OFF by default, SAME results bit for bit and the same draws from the same generator (dense
         # operator, n <= 2048, any set built from the seven operators): the vector work of an iteration queued as four
@@ -798,7 +811,7 @@ class CCQPSolverSPG(CCQPSolverBase):
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
-        if self.pipeline and self.trace is None:
+        if self._device_resident(run) and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
                 return out

@@ -44,6 +44,7 @@ def main():
                 ts, r = [], None
                 fb0 = lockstep.stats["fallback_solves"]
                 for rep in range(args.reps + 2):
+                    np.random.seed(1234)                 # (SPG draws from numpy's global generator)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     with contextlib.redirect_stdout(io.StringIO()):
