@@ -24,7 +24,8 @@ LOCKSTEP_FUSED_ROUNDS = 1 << 18  # CCQP_LOCKSTEP_FUSED_ROUNDS: one round per acc
 # per-context tuning options (ccqp_ctx_set_option): name -> key
 OPTIONS = {name: key for key, name in enumerate((
     "GEMV_ROW_STRIDE", "GEMV2_WPB", "GEMV2_SHAPE", "GEMV2_GROUP", "BMV3_SHAPE", "LOOKAHEAD_MIN_N", "MPRGP_LOOKAHEAD_MIN_N",
-    "MPRGP_LOOKAHEAD", "APGD_LOOKAHEAD", "BMV_STAGGER", "MPRGP_FUSED_TAIL", "PERS1_MIN_N"))}
+    "MPRGP_LOOKAHEAD", "APGD_LOOKAHEAD", "BMV_STAGGER", "MPRGP_FUSED_TAIL", "PERS1_MIN_N", "BMV_LOADS",
+    "APGD_PAIR"))}
 
 OP_IDENTITY, OP_LOWER, OP_UPPER, OP_BOX, OP_SPHERE, OP_CONE = range(6)
 SEG_LB_INT, SEG_UB_INT, SEG_P0_INT = 1, 2, 4
@@ -197,6 +198,7 @@ SIGNATURES = {
     "ccqp_bpipe_partials_doubles": [_I64],
     "ccqp_bpipe_matvec_form": [_P, _I, _I64, _I, _c.c_char_p, _I],
     "ccqp_bmv3_shape": [_P, _I],
+    "ccqp_bapgd_fused_form": [_P, _I, _I64, _I],
     "ccqp_bpipe_start_f64": [_P, _P, _I, _I64, _D, _I, _P, _P],
     "ccqp_bpipe_iterate_f64": [_P, _P, _I, _I64, _I64, _D, _D, _I, _I, _P, _P],
     "ccqp_bpipe_poll": [_P, _c.POINTER(_D)],

@@ -322,11 +322,15 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
 // Non-blocking look at the host mirror: out = {problems converged, last sequence number all problems finished}.
 extern "C" int ccqp_bpipe_poll(ccqp_ctx* ctx, double* out) {
   CCQP_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
-  volatile double* m = ctx->host_slots + BP_MIRROR;
-  const double seq = m[1];
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  out[0] = m[0];
-  out[1] = seq;
+  const double v = *(volatile double*)(ctx->host_slots + BP_MIRROR + 1);      // (one word: bp_report)
+  if (v < 0.0) {
+    out[0] = 0.0;
+    out[1] = -1.0;
+  } else {
+    const double seq = floor(v / BP_MIRROR_SEQ_UNIT);
+    out[0] = v - seq * BP_MIRROR_SEQ_UNIT;
+    out[1] = seq;
+  }
   return CCQP_OK;
 }
 
@@ -481,24 +485,187 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_init_L_kernel(const ccqp_pap
   bapgd_init_L_body(probs[blockIdx.y], n, chunk, nblk, blockIdx.x, lds4, &is_last, look, fuse);
 }
 
+// A thread's share of the sums a trial round's decision needs, over chunk `bx` of the problem: one pass, the dot products
+// and the residual (residual_body's arithmetic, element for element).  v[0..7] are THREAD sums (the caller adds them over
+// the workgroup).  `tshift`: threadIdx.x - tshift is the thread's index within the 256 threads that walk the chunk (0 in
+// a 256-thread workgroup).  U: elements whose loads are in flight together.
+template <int U>
+__device__ __forceinline__ void bapgd_trial_sums(const ccqp_papgd& q, const ap_words& z, int bx, int64_t tshift, double gd,
+                                                 int64_t chunk, int ar, const ccqp_psegs* ps, int64_t n_segs, double* v) {
+  const ccqp_segk sg = bp_segk_of(q);
+  const int64_t n = ps ? n_segs : sg.dim;
+  const int it = (int)z.it;
+  const bool first = z.first != 0.0;
+  const double* __restrict__ x1 = q.X[(it + 1) & 1];
+  const double* __restrict__ yk = q.Y[it & 1];
+  const double* __restrict__ Ayk = q.Ayk;
+  const double* __restrict__ Ax1 = q.Ax1;
+  const double* __restrict__ gk = q.gk;
+  const double* __restrict__ bv = q.b;
+  const double* __restrict__ xk = q.X[it & 1];
+  const double* __restrict__ g1 = q.g1;
+  const double c = q.c;
+  CHUNK_RANGE(n)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+  // (all loads of a thread's U elements first -- ccqp_chunk_walk: the same arithmetic in the same order)
+  const bool elem = !ps;
+  const double* const vecs[10] = {x1, yk, bv, Ax1, gk, elem ? g1 : nullptr, ar ? xk : nullptr, first ? Ayk : nullptr,
+                                  elem ? sg.lb : nullptr, elem ? sg.ub : nullptr};
+  ccqp_chunk_walk<10, U>(vecs, lo - tshift, hi, [&](int64_t, const double* e) {
+    const double xi = e[0], yi = e[1], bi = e[2];
+    if (ar) {                                          // gk.(x_{k+1} - x_k), solvers.py:510
+      const double dk = xi - e[6];
+      a6 = fma(e[4], dk, a6);
+    }
+    if (first) {
+      a0 = fma(yi, e[7], a0);
+      a1 = fma(yi, bi, a1);
+    }
+    a2 = fma(xi, e[3], a2);
+    a3 = fma(xi, bi, a3);
+    const double d = xi - yi;
+    a4 = fma(e[4], d, a4);
+    a5 = fma(d, d, a5);
+    if (elem) {
+      const double t = gd * e[5];
+      const double u = xi - t;
+      const double lb = sg.lb ? e[8] : sg.lb_s;
+      const double ub = sg.ub ? e[9] : sg.ub_s;
+      const double pr = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
+      const double dd = xi - pr;
+      const double w = c * dd;
+      a7 = fma(w, w, a7);
+    }
+  });
+  v[0] = a0;
+  v[1] = a1;
+  v[2] = a2;
+  v[3] = a3;
+  v[4] = a4;
+  v[5] = a5;
+  v[6] = a7;
+  v[7] = a6;
+}
+
+// The decision of a trial round from the problem's sums v[0..7] (one thread): solvers.py:290-316 (+ :501-512).  Writes the
+// state words to `s` -- the problem's slab -- computing from the entry snapshot `z` alone.  `report`: also the batch's
+// roll-call (LOCKSTEP).
+// `fuse` (elementwise look-ahead runs, LOCKSTEP only): an ACCEPTING round also takes the decision of the phase-0 round
+// that would follow -- the product A.y_{k+1} + b is already there (this round's launch computed it), so there is nothing
+// to wait for: mv advances by two (the trial's matvec :290 and the product taken over where the reference computes it,
+// :275-278), the state becomes "first trial of iteration k + 1" and the apply launch (ACT 4 / 5) takes the product
+// over, forms the next trial point and its y.  One round per accepted iteration instead of two; a problem is never in
+// phase 0 at a round's start.  The device enforces the budget itself (AP_LIMIT): a problem whose NEXT matvec would
+// pass max_mv - 1 stops (AP_DONE = 2) and is left to the host-driven loop, exactly where the unfused run's round cap
+// leaves it.
+template <bool LOCKSTEP>
+__device__ __forceinline__ void bapgd_decide_scalars(const ccqp_papgd& q, double* s, const ap_words& z, const double* v,
+                                                     int ar, int fuse, bool report, unsigned* batch, double* host,
+                                                     unsigned count, double seq) {
+  const int it = (int)z.it;
+  const bool first = z.first != 0.0;
+  double r1, r2;
+  if (first) {
+    r1 = v[0] * 0.5;
+    r2 = v[1];
+    s[AP_R1] = r1;
+    s[AP_R2] = r2;
+    s[0] = v[0];
+    s[1] = v[1];
+  } else {
+    r1 = z.r1;
+    r2 = z.r2;
+  }
+  for (int k = 2; k < 6; ++k) s[k] = v[k];
+  s[6] = v[7];
+  s[7] = v[6];
+  double L = z.L;
+  const double l1 = v[2] * 0.5;
+  const double l2 = v[3];
+  const double r3 = v[4];
+  const double hL = 0.5 * L;
+  const double r4 = hL * v[5];
+  const double lhs = l1 + l2;
+  const double rhs = ((r1 + r2) + r3) + r4;
+  s[AP_MV] = z.mv + 1.0;
+  if (lhs <= rhs) {                                    // solvers.py:302
+    const double thk = z.thk;
+    const double tt = thk * thk;
+    const double root = sqrt(4.0 + tt);
+    const double m1 = (-thk) * thk;
+    const double m2 = thk * root;
+    const double thk1 = 0.5 * (m1 + m2);               // :312
+    const double num = thk * (1.0 - thk);
+    const double beta = num / (tt + thk1);             // :313
+    const double res = sqrt(v[6]);
+    s[AP_RES2] = v[6];
+    bool improved = false;
+    if (ar && res < z.resmin) {                        // :501-503  xhat = copy(x_{k+1})
+      s[AP_RESMIN] = res;
+      improved = true;
+    }
+    if (res < q.tol) {
+      s[AP_DONE] = 1.0;
+      if (improved) s[AP_SOLHAT] = 0.0;                // the solution is x_{k+1} itself; else the xhat kept so far
+      if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const bool restart = ar && v[7] > 0.0;           // :510-512  y_{k+1} = copy(x_{k+1}), theta = 1
+      const double thnew = restart ? 1.0 : thk1;
+      L = L * 0.9;
+      s[AP_L] = L;
+      s[AP_T] = 1.0 / L;
+      s[AP_THK] = thnew;
+      s[AP_BETA] = beta;
+      s[AP_IT] = (double)(it + 1);
+      s[AP_COPYHAT] = improved ? 1.0 : 0.0;
+      if (fuse) {
+        // the take-over of the round that would follow, decided here: the product is counted (:275-278) and the next
+        // round's trial matvec must still fit the budget
+        const double mv2 = z.mv + 2.0;
+        if (z.limit > 0.0 && mv2 + 1.0 > z.limit) {
+          s[AP_DONE] = 2.0;
+          if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          s[AP_MV] = mv2;
+          s[AP_PHASE] = 1.0;
+          s[AP_ACT] = restart ? 5.0 : 4.0;
+          s[AP_FIRST] = 1.0;
+          s[AP_BETAS] = bapgd_beta_of(thnew);
+          s[AP_AHEAD] = 0.0;
+        }
+      } else {
+        s[AP_PHASE] = 0.0;
+        s[AP_ACT] = restart ? 3.0 : 2.0;
+        // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3); after an anti-relaxation restart y_{k+1} is
+        // x_{k+1} itself (:510-512) and its product the launch's FIRST one (2: taken from g1 / Ax1)
+        if (z.look != 0.0) s[AP_AHEAD] = restart ? 2.0 : 1.0;
+      }
+    }
+  } else {
+    L = L * 2.0;
+    s[AP_L] = L;
+    s[AP_T] = 1.0 / L;
+    s[AP_ACT] = 1.0;
+    s[AP_FIRST] = 0.0;
+    if (fuse && z.limit > 0.0 && (z.mv + 1.0) + 1.0 > z.limit) {   // (the retry's matvec would pass the budget)
+      s[AP_DONE] = 2.0;
+      if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (LOCKSTEP && report) bp_report(batch, host, count, seq);
+}
+
 // LOCKSTEP: one of the batch's problems in a lock-step launch (roll-call, converged counter); otherwise the problem
 // of a single-launch solve (bx = 0, nblk = 1)
 // ps != NULL: the feasible set is not elementwise -- the problem's n comes from the caller, the residual from the
 // work-item sums the segmented residual launch (ccqp_bsegs.hip) has left in ps->workspace
 // `z`: the caller's entry snapshot of the slab (ap_enter) -- this function only WRITES the slab
+// `fuse`: see bapgd_decide_scalars
 template <bool LOCKSTEP>
 __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_words& z, int bx, double gd,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
                                                   unsigned count, double seq, double* lds4, int* is_last_p, int ar,
                                                   const ccqp_psegs* ps = nullptr, int64_t n_segs = 0, int fuse = 0) {
-  // `fuse` (elementwise look-ahead runs, LOCKSTEP only): an ACCEPTING round also takes the decision of the phase-0 round
-  // that would follow -- the product A.y_{k+1} + b is already there (this round's launch computed it), so there is nothing
-  // to wait for: mv advances by two (the trial's matvec :290 and the product taken over where the reference computes it,
-  // :275-278), the state becomes "first trial of iteration k + 1" and the apply launch (ACT 4 / 5) takes the product
-  // over, forms the next trial point and its y.  One round per accepted iteration instead of two; a problem is never in
-  // phase 0 at a round's start.  The device enforces the budget itself (AP_LIMIT): a problem whose NEXT matvec would
-  // pass max_mv - 1 stops (AP_DONE = 2) and is left to the host-driven loop, exactly where the unfused run's round cap
-  // leaves it.
   double* s = q.slab;
   double v[8];
   if (z.phase == 0.0) {
@@ -520,63 +687,8 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
     }
     return;
   }
-  const ccqp_segk sg = bp_segk_of(q);
-  const int64_t n = ps ? n_segs : sg.dim;
-  const int it = (int)z.it;
-  const bool first = z.first != 0.0;
-  const double* __restrict__ x1 = q.X[(it + 1) & 1];
-  const double* __restrict__ yk = q.Y[it & 1];
-  const double* __restrict__ Ayk = q.Ayk;
-  const double* __restrict__ Ax1 = q.Ax1;
-  const double* __restrict__ gk = q.gk;
-  const double* __restrict__ bv = q.b;
-  const double* __restrict__ xk = q.X[it & 1];
-  {
-    // one pass: the dot products and the residual (residual_body's arithmetic, element for element)
-    const double* __restrict__ g1 = q.g1;
-    const double c = q.c;
-    CHUNK_RANGE(n)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
-    // (all loads of a thread's eight elements first -- ccqp_chunk_walk: the same arithmetic in the same order)
-    const bool elem = !ps;
-    const double* const vecs[10] = {x1, yk, bv, Ax1, gk, elem ? g1 : nullptr, ar ? xk : nullptr, first ? Ayk : nullptr,
-                                    elem ? sg.lb : nullptr, elem ? sg.ub : nullptr};
-    ccqp_chunk_walk<10, 8>(vecs, lo, hi, [&](int64_t, const double* e) {
-      const double xi = e[0], yi = e[1], bi = e[2];
-      if (ar) {                                          // gk.(x_{k+1} - x_k), solvers.py:510
-        const double dk = xi - e[6];
-        a6 = fma(e[4], dk, a6);
-      }
-      if (first) {
-        a0 = fma(yi, e[7], a0);
-        a1 = fma(yi, bi, a1);
-      }
-      a2 = fma(xi, e[3], a2);
-      a3 = fma(xi, bi, a3);
-      const double d = xi - yi;
-      a4 = fma(e[4], d, a4);
-      a5 = fma(d, d, a5);
-      if (elem) {
-        const double t = gd * e[5];
-        const double u = xi - t;
-        const double lb = sg.lb ? e[8] : sg.lb_s;
-        const double ub = sg.ub ? e[9] : sg.ub_s;
-        const double pr = ccqp_proj_elem(sg.kind, sg.flags, u, lb, ub);
-        const double dd = xi - pr;
-        const double w = c * dd;
-        a7 = fma(w, w, a7);
-      }
-    });
-    v[0] = a0;
-    v[1] = a1;
-    v[2] = a2;
-    v[3] = a3;
-    v[4] = a4;
-    v[5] = a5;
-    v[6] = a7;
-    v[7] = a6;
-    ccqp_block_sum_multi<8>(v);
-  }
+  bapgd_trial_sums<8>(q, z, bx, 0, gd, chunk, ar, ps, n_segs, v);
+  ccqp_block_sum_multi<8>(v);
   if (!bp_meet(q.partials, q.counter, nblk, ar ? 8 : 7, v, lds4, is_last_p)) return;
   if (ps) {
     // the problem's last block: residual = the work items' sums in index order (ccqp_segs_residual_sq_f64)
@@ -584,97 +696,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
     const double r = ps->nwork == 1 ? respart[0] : partial_sum_body(respart, ps->nwork, lds4);
     if (threadIdx.x == 0) v[6] = r;
   }
-  if (threadIdx.x == 0) {
-    double r1, r2;
-    if (first) {
-      r1 = v[0] * 0.5;
-      r2 = v[1];
-      s[AP_R1] = r1;
-      s[AP_R2] = r2;
-      s[0] = v[0];
-      s[1] = v[1];
-    } else {
-      r1 = z.r1;
-      r2 = z.r2;
-    }
-    for (int k = 2; k < 6; ++k) s[k] = v[k];
-    s[6] = v[7];
-    s[7] = v[6];
-    double L = z.L;
-    const double l1 = v[2] * 0.5;
-    const double l2 = v[3];
-    const double r3 = v[4];
-    const double hL = 0.5 * L;
-    const double r4 = hL * v[5];
-    const double lhs = l1 + l2;
-    const double rhs = ((r1 + r2) + r3) + r4;
-    s[AP_MV] = z.mv + 1.0;
-    if (lhs <= rhs) {                                    // solvers.py:302
-      const double thk = z.thk;
-      const double tt = thk * thk;
-      const double root = sqrt(4.0 + tt);
-      const double m1 = (-thk) * thk;
-      const double m2 = thk * root;
-      const double thk1 = 0.5 * (m1 + m2);               // :312
-      const double num = thk * (1.0 - thk);
-      const double beta = num / (tt + thk1);             // :313
-      const double res = sqrt(v[6]);
-      s[AP_RES2] = v[6];
-      bool improved = false;
-      if (ar && res < z.resmin) {                        // :501-503  xhat = copy(x_{k+1})
-        s[AP_RESMIN] = res;
-        improved = true;
-      }
-      if (res < q.tol) {
-        s[AP_DONE] = 1.0;
-        if (improved) s[AP_SOLHAT] = 0.0;                // the solution is x_{k+1} itself; else the xhat kept so far
-        if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        const bool restart = ar && v[7] > 0.0;           // :510-512  y_{k+1} = copy(x_{k+1}), theta = 1
-        const double thnew = restart ? 1.0 : thk1;
-        L = L * 0.9;
-        s[AP_L] = L;
-        s[AP_T] = 1.0 / L;
-        s[AP_THK] = thnew;
-        s[AP_BETA] = beta;
-        s[AP_IT] = (double)(it + 1);
-        s[AP_COPYHAT] = improved ? 1.0 : 0.0;
-        if (fuse) {
-          // the take-over of the round that would follow, decided here: the product is counted (:275-278) and the next
-          // round's trial matvec must still fit the budget
-          const double mv2 = z.mv + 2.0;
-          if (z.limit > 0.0 && mv2 + 1.0 > z.limit) {
-            s[AP_DONE] = 2.0;
-            if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            s[AP_MV] = mv2;
-            s[AP_PHASE] = 1.0;
-            s[AP_ACT] = restart ? 5.0 : 4.0;
-            s[AP_FIRST] = 1.0;
-            s[AP_BETAS] = bapgd_beta_of(thnew);
-            s[AP_AHEAD] = 0.0;
-          }
-        } else {
-          s[AP_PHASE] = 0.0;
-          s[AP_ACT] = restart ? 3.0 : 2.0;
-          // this round's launch also computed A.y_{k+1} + b (bapgd_resolve3); after an anti-relaxation restart y_{k+1} is
-          // x_{k+1} itself (:510-512) and its product the launch's FIRST one (2: taken from g1 / Ax1)
-          if (z.look != 0.0) s[AP_AHEAD] = restart ? 2.0 : 1.0;
-        }
-      }
-    } else {
-      L = L * 2.0;
-      s[AP_L] = L;
-      s[AP_T] = 1.0 / L;
-      s[AP_ACT] = 1.0;
-      s[AP_FIRST] = 0.0;
-      if (fuse && z.limit > 0.0 && (z.mv + 1.0) + 1.0 > z.limit) {   // (the retry's matvec would pass the budget)
-        s[AP_DONE] = 2.0;
-        if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (LOCKSTEP) bp_report(batch, host, count, seq);
-  }
+  if (threadIdx.x == 0) bapgd_decide_scalars<LOCKSTEP>(q, s, z, v, ar, fuse, true, batch, host, count, seq);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_papgd* __restrict__ probs, double gd,
@@ -696,11 +718,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
                           segs ? segs + blockIdx.y : nullptr, n_segs, fuse);
 }
 
-__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0);
-
 // n_segs > 0: segmented form -- the trial step is taken by the segmented launches (ccqp_bsegs.hip), the vector length
-// comes from the caller
-__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs) {
+// comes from the caller.  U: elements of the fused update whose loads are in flight together.
+template <int U = 4>
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0) {
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0) return;
   const int it = (int)s[AP_IT];
@@ -738,7 +759,6 @@ __device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, in
     double* __restrict__ x2 = q.X[(it + 1) & 1];                   // x_{k+2} trial (:283)
     double* __restrict__ y2 = q.Y[(it + 1) & 1];                   // y_{k+2} (:316)
     double* __restrict__ xhat = q.xhat;
-    constexpr int U = 4;
     for (int64_t i0 = (int64_t)bx * CCQP_BLOCK + threadIdx.x; i0 < n; i0 += (int64_t)U * nbx * CCQP_BLOCK) {
       double ex[U], ey[U], eg[U], ea[U], el[U], eu[U];
 #pragma unroll
@@ -917,6 +937,58 @@ static bool bapgd_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int fla
          bp_pers_sharing(ctx, bp_mv_tune(count, n, flags), flags, count, n, false);
 }
 
+// ---- fused rounds of a HANDFUL of problems below the persistent form's sizes: both products from one VALU launch
+// A small batch of problems of n < 4096 is bound by the NUMBER of its launches (~5 us each), not by its matrices (they
+// sit in L2 / the MALL): the unfused rounds of an iteration are six launches -- matvec, decision, update,
+// twice.  The fused round needs the products of the trial point and of y_{k+1} (bapgd_resolve3); here blockIdx.z names
+// the product and each is multiplied by the batched VALU body of the unfused rounds (gemv_body: the bits are a function
+// of (row, n) only) -- ONE launch, then the decision and the update: three launches per accepted iteration.  `start`: the two
+// products of a look-ahead run's start (bapgd_resolve3_start).
+template <int U, bool ALIGNED, bool NT>
+__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_pair_kernel(const ccqp_papgd* __restrict__ probs, int start,
+                                                                     int64_t n) {
+  const ccqp_papgd& q = probs[blockIdx.y];
+  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
+  const bool second = blockIdx.z != 0;
+  if (start) {
+    if (!second)
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
+    else if (q.ga != nullptr && q.Aya != nullptr)
+      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.Y[0], q.b, q.Aya, q.ga, n, n, BP_TASKS(U, n), wave, nwaves);
+    return;
+  }
+  const double* s = q.slab;
+  if (s[AP_DONE] != 0.0 || s[AP_LOOK] == 0.0 || s[AP_PHASE] == 0.0) return;
+  const int it = (int)s[AP_IT];
+  if (!second)
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, BP_TASKS(U, n), wave, nwaves);
+  else
+    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.Y[(it + 1) & 1], q.b, q.Aya, q.ga, n, n, BP_TASKS(U, n), wave, nwaves);
+}
+
+static void bapgd_launch_gemv_pair(const ccqp_papgd* probs, int count, int64_t n, int start, int flags, hipStream_t s) {
+  bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  t.grid.z = 2;
+  BP_MV_LAUNCH(bapgd_gemv_pair_kernel, probs, start, n);
+}
+
+// The form of a run's FUSED rounds (flags bits 17 + 18 asked for them; every problem has its two buffers):
+// 1 = the persistent three-vector launch (bapgd_looks_ahead), 2 = the VALU pair launch above -- batches below the
+// persistent form's sizes whose matrices fit the MALL together (256 MiB: the second product of the launch re-reads them
+// from there), default tuning word (the context's option APGD_PAIR: 1 never, 2 whatever the batch) --, 0 = the rounds
+// are not fused.  Measured, whole solves, fused against unfused rounds (tools/bench_apgd_fused_small.py,
+// profiles/r04_apgd_fused_small.jsonl): n = 256: 4 problems +31 %, 32 +23 %, 128 (64 MiB) +16 %, 512 (256 MiB) +-0;
+// n = 1024: 4 +24 %, 16 (128 MiB) +7 %, 32 +-0, 100 -6 %; n = 2048: 4 (128 MiB) +10 %, 16 -1 %; n = 3072: 4 +2 %, 12 -4 %.
+#define AP_PAIR_MAX_BYTES 268435456.0
+static int bapgd_fused_form(const ccqp_ctx* ctx, int count, int64_t n, int flags, bool asked, bool fuse_asked) {
+  if (!asked || !fuse_asked || ccqp_opt(ctx, CCQP_OPT_APGD_LOOKAHEAD)) return 0;
+  if (bapgd_looks_ahead(ctx, count, n, flags, asked)) return 1;
+  const int64_t o = ccqp_opt(ctx, CCQP_OPT_APGD_PAIR);
+  if (o == 1 || (flags & ~(1 | 8 | 128)) != 0) return 0;
+  return (o == 2 || 8.0 * (double)n * (double)n * (double)count <= AP_PAIR_MAX_BYTES) ? 2 : 0;
+}
+
 int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, int64_t n, int init, int flags, bool look,
                            hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
@@ -948,10 +1020,14 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   ccqp_red_geometry(n, &chunk, &nblk);
   ccqp_lockstep_begin(ctx, dev_batch, s);
   hipLaunchKernelGGL(bapgd_init_d_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
-  const bool look = bapgd_looks_ahead(ctx, count, n, flags, asked);
-  const int fuse = look && fuse_asked;
+  const int form = bapgd_fused_form(ctx, count, n, flags, asked, fuse_asked);
+  const bool look = form == 2 || bapgd_looks_ahead(ctx, count, n, flags, asked);
+  const int fuse = form != 0;
   int rc;
-  if (look) {
+  if (form == 2) {
+    bapgd_launch_gemv_pair(dev_probs, count, n, 1, flags, s);
+    rc = CCQP_OK;
+  } else if (look) {
     // (a problem whose two buffers are NULL takes no part here and is multiplied by the single launch below; with every
     // problem looking ahead that launch finds nothing to do)
     const bapgd_resolve3_start rsv3 = {dev_probs};
@@ -971,6 +1047,13 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   return CCQP_OK;
 }
 
+// form of a run's fused rounds (see the header): 0 = not fused
+extern "C" int ccqp_bapgd_fused_form(ccqp_ctx* ctx, int count, int64_t n, int flags) {
+  if (count < 1 || n < 1) return 0;
+  const bool asked = (flags & CCQP_LOCKSTEP_LOOKAHEAD) != 0, fuse_asked = (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0;
+  return bapgd_fused_form(ctx, count, n, flags & 0xFFFF, asked, fuse_asked);
+}
+
 // Round `round` >= 1: one matvec for every live problem, the decision, the vector update it asks for.
 extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, int64_t n, int64_t round,
                                     double gd, int flags, uint32_t* dev_batch, void* stream) {
@@ -984,9 +1067,13 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
-  const int fuse = fuse_asked && bapgd_looks_ahead(ctx, count, n, flags, asked);
+  const int form = bapgd_fused_form(ctx, count, n, flags, asked, fuse_asked);
+  const int fuse = form != 0;
   int rc;
-  if (fuse) {
+  if (form == 2) {
+    bapgd_launch_gemv_pair(dev_probs, count, n, 0, flags, s);
+    rc = CCQP_OK;
+  } else if (fuse) {
     // every live problem is at a trial point: ONE launch multiplies x_{k+1} and y_{k+1} of each (nothing to take over
     // here -- the apply launch of the accepting round did --, no single-product launch)
     const bapgd_resolve3 rsv3 = {dev_probs};
@@ -1000,6 +1087,9 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   // the ~100 bytes per element at 50-80 GB/s; and ONE block walking the 2 ... 4 chunks of the decision itself, without
   // the inter-workgroup meeting: +5 us at 4096, +16 us at 8192 -- a chunk costs ~5 us wherever it runs;
   // profiles/r04_single_mid.jsonl)
+  // (and ONE workgroup per problem doing both, a group of 256 threads per chunk, the chunk sums met in LDS: level with the
+  // two launches up to n = 512, 5-7 % behind at 1024 ... 3072, +3 / +14 / +27 us per round at 4096 / 8192 / 16384 --
+  // one CU again; round 4, removed)
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, ar, (const ccqp_psegs*)nullptr,
                      (int64_t)0, fuse);

@@ -40,7 +40,7 @@
 #define AP_DONE BP_DONE   // 49: 0 running | 1 converged | 2 stopped one short of the budget (left to the host-driven loop)
 #define AP_MV BP_ITERS    // 50: matvecs so far (the reference's mv_count)
 #define AP_RES2 BP_RES2   // 51
-#define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[69..70] = {problems converged, sequence number}
+#define BP_MIRROR (CCQP_NUM_SLOTS + 5)     // host_slots[70] = sequence number * 65536 + problems converged (bp_report)
 
 // the descriptor records are built on the host with numpy dtypes derived from ctypes mirrors (ccqppy_amd/_lib.py,
 // tests/test_lockstep_host_cpu.py pins the same numbers)
@@ -193,22 +193,23 @@ __device__ __forceinline__ ccqp_segk bp_segk_of(const PROB& q) {
   return k;
 }
 
-// One thread per problem and launch calls this: the last of `count` publishes the progress of the whole batch.
+// One thread per problem and launch calls this: the last of `count` publishes the progress of the whole batch -- ONE
+// 8-byte word in the pinned host mirror, sequence number * 65536 + problems converged (count <= 65535), so the host can
+// never see one without the other and nothing has to be ordered around the store.  Only atomics travel between the
+// reporting threads (the arrival ticket `batch[0]`, the cumulative converged count `batch[1]`), so there is no data to
+// release or acquire; the one ordering that matters -- a thread's own increment of batch[1], issued before this call, is
+// performed before its ticket can be seen -- is the s_waitcnt (a write leaves vmcnt when L2 has it).  The host consumes
+// nothing else on the strength of this word: results are read behind the stream (ccqp_bpipe_poll's callers).  (Round 4:
+// the release / acquire fences, the second host store and its waits cost the deciding thread ~3 us per launch.)
+#define BP_MIRROR_SEQ_UNIT 65536.0
 __device__ __forceinline__ void bp_report(unsigned* batch, double* host, unsigned count, double seq) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned prev = __hip_atomic_fetch_add(batch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (prev + 1u == count) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(batch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned conv = __hip_atomic_load(batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    host[BP_MIRROR] = (double)conv;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(host + BP_MIRROR + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host + BP_MIRROR + 1, seq * BP_MIRROR_SEQ_UNIT + (double)conv, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -314,7 +315,7 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 // operands are resolved once per workgroup, into LDS, before the first DMA (an ordinary load beside the DMA stream
 // would make hipcc drain it).  Same bits as the VALU kernels (a function of (row, n) only).
 #define BMV_PERS_MAX 512                        // problems per launch (48 B of LDS each); larger batches: several launches
-template <int R, int S, class Resolve>
+template <int R, int S, class Resolve, bool NT = true>
 __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve rsv, int first, int count, int64_t n,
                                                                   int64_t rs, float stagger_per_problem) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
   float su = stagger_per_problem * (float)nlive;
   const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
   for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-  gemv_lds_multi_body<R, S, true>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
+  gemv_lds_multi_body<R, S, NT>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
 #endif
 }
 
@@ -385,21 +386,38 @@ static inline bool bp_pers_sharing(const ccqp_ctx* ctx, const bp_mv_tuning& t, i
   return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= m;
 }
 
+// Cache policy of the persistent launches' MATRIX loads: non-temporal (a stream that must not evict the vectors from L2)
+// unless the context's option BMV_LOADS says otherwise (1 non-temporal, 2 plain) ...
+static inline bool bp_pers_cacheable(const ccqp_ctx* ctx, int count, int64_t n) {
+  const int64_t o = ccqp_opt(ctx, CCQP_OPT_BMV_LOADS);
+  (void)count;
+  (void)n;
+  return o == 2;
+}
+
 template <int R, int S, class Resolve>
 static int bp_launch_gemv_pers(ccqp_ctx* ctx, const Resolve& rsv, int count, int64_t n, int wpb, int bpc, hipStream_t s) {
   const int chunk = count < BMV_PERS_MAX ? count : BMV_PERS_MAX;
   const size_t lds = (size_t)wpb * ((size_t)S * (R + 1) * 1024 + GEMV_LDS_RESCAP * sizeof(double)) +
                      (size_t)chunk * sizeof(gemv_lds_desc);
   // (the kernel also holds a few bytes of static LDS: ask for what is needed)
-  const int rcl = ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve>), lds);
+  const bool keep = bp_pers_cacheable(ctx, count, n);
+  const int rcl = keep ? ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve, false>), lds)
+                       : ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv_pers_kernel<R, S, Resolve, true>), lds);
   if (rcl) return rcl;
   // start delay unit of the waves per live problem: one unit per 4 GiB read, as the single matvec's (ccqp_gemv.hip)
   const float stagger = ccqp_opt(ctx, CCQP_OPT_BMV_STAGGER) ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
   const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
-  for (int first = 0; first < count; first += BMV_PERS_MAX)      // (more than BMV_PERS_MAX problems: one launch per group)
-    hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve>), dim3((unsigned)(ctx->num_cu * bpc)), dim3(64 * wpb), lds, s, rsv,
-                       first, count - first < BMV_PERS_MAX ? count - first : BMV_PERS_MAX, n, rs, stagger);
+  for (int first = 0; first < count; first += BMV_PERS_MAX) {    // (more than BMV_PERS_MAX problems: one launch per group)
+    const int m = count - first < BMV_PERS_MAX ? count - first : BMV_PERS_MAX;
+    if (keep)
+      hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve, false>), dim3((unsigned)(ctx->num_cu * bpc)), dim3(64 * wpb), lds,
+                         s, rsv, first, m, n, rs, stagger);
+    else
+      hipLaunchKernelGGL((bp_gemv_pers_kernel<R, S, Resolve, true>), dim3((unsigned)(ctx->num_cu * bpc)), dim3(64 * wpb), lds,
+                         s, rsv, first, m, n, rs, stagger);
+  }
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }
@@ -408,7 +426,7 @@ static int bp_launch_gemv_pers(ccqp_ctx* ctx, const Resolve& rsv, int count, int
 // `Resolve3` fills a gemv_lds3_desc, false = the problem takes no part.  At most BMV3_PERS_MAX problems per launch
 // (96 B of LDS each), more in several launches.
 #define BMV3_PERS_MAX 256
-template <int R, int S, class Resolve3>
+template <int R, int S, class Resolve3, bool NT = true>
 __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve3 rsv, int first, int count, int64_t n,
                                                                    int64_t rs, float stagger_per_problem) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -437,7 +455,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve
   float su = stagger_per_problem * (float)nlive;
   const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
   for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-  gemv_lds3_multi_body<R, S, true>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
+  gemv_lds3_multi_body<R, S, NT>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
 #endif
 }
 
@@ -450,14 +468,22 @@ static int bp_launch_gemv3_pers(ccqp_ctx* ctx, const Resolve3& rsv, int count, i
     ccqp_set_error("%s: ring does not fit", __func__);
     return CCQP_ERR_UNSUPPORTED;
   }
-  const int rcl = ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3>), lds);
+  const bool keep = bp_pers_cacheable(ctx, count, n);
+  const int rcl = keep ? ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3, false>), lds)
+                       : ccqp_lds_raise(ctx, reinterpret_cast<const void*>(bp_gemv3_pers_kernel<R, S, Resolve3, true>), lds);
   if (rcl) return rcl;
   const float stagger = ccqp_opt(ctx, CCQP_OPT_BMV_STAGGER) ? 0.f : (float)(8.0 * (double)n * (double)n / 4294967296.0);
   const int64_t rs = gemv_lds_row_stride(ccqp_opt(ctx, CCQP_OPT_GEMV_ROW_STRIDE), n, n, R);
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 0);
-  for (int first = 0; first < count; first += BMV3_PERS_MAX)
-    hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3>), dim3((unsigned)ctx->num_cu), dim3(64 * wpb), lds, s, rsv, first,
-                       count - first < BMV3_PERS_MAX ? count - first : BMV3_PERS_MAX, n, rs, stagger);
+  for (int first = 0; first < count; first += BMV3_PERS_MAX) {
+    const int m = count - first < BMV3_PERS_MAX ? count - first : BMV3_PERS_MAX;
+    if (keep)
+      hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3, false>), dim3((unsigned)ctx->num_cu), dim3(64 * wpb), lds, s, rsv,
+                         first, m, n, rs, stagger);
+    else
+      hipLaunchKernelGGL((bp_gemv3_pers_kernel<R, S, Resolve3, true>), dim3((unsigned)ctx->num_cu), dim3(64 * wpb), lds, s, rsv,
+                         first, m, n, rs, stagger);
+  }
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
 }

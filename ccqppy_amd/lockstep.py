@@ -823,10 +823,9 @@ class _OneWs:
 def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     """ONE dense APGD / anti-relaxation APGD problem on an elementwise set, device-resident (the form of
     CCQPSolverAPGD's default pipeline): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve allocation, no
-    host-paced torch operation, the descriptor by value); then n <= 128 the whole solve in one launch (one workgroup), up
-    to 2048 the lock-step rounds of the VALU kernels, beyond (where the batch of one takes the persistent two-vector
-    matvec) the FUSED rounds -- all queued `ahead` beyond the device's last report; the result words through the pinned
-    mirror.  Returns (done, x, residual, matvecs); done False: the budget was reached first (the host-driven loop's exits)."""
+    host-paced torch operation, the descriptor by value); then n <= 64 the whole solve in one launch (one workgroup),
+    beyond the FUSED lock-step rounds -- one round per accepted iteration: below n = 4096 both products from one launch of
+    the VALU kernel, from 4096 on the persistent three-vector matvec; then the decision, then the update -- all queued `ahead` beyond the device's last report; the result words through the pinned mirror.  Returns (done, x, residual, matvecs); done False: the budget was reached first (the host-driven loop's exits)."""
     import ctypes
     from . import _lib
     from .solvers import _GD
@@ -835,8 +834,14 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
     ar = bool(solver._anti_relaxation)
     max_mv = solver.max_matrix_vector_multiplications
-    sharing = aligned and _APGD_FUSED_ROUNDS and _sharing_form(eng, 1, n, 1) and (not np.isfinite(max_mv) or max_mv >= 4)
-    flags = int(aligned) | (8 if ar else 0) | ((_lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS) if sharing else 0)
+    # fused rounds (one round per accepted iteration, the budget enforced on the device): wherever the library has a form
+    # for them -- the persistent three-vector matvec from n = 4096 on, below it both products from one VALU launch
+    fused = _lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS
+    flags = int(aligned) | (8 if ar else 0)
+    sharing = _APGD_FUSED_ROUNDS and (not np.isfinite(max_mv) or max_mv >= 4) \
+        and lib.ccqp_bapgd_fused_form(ctx, 1, n, flags | fused) != 0
+    if sharing:
+        flags |= fused
     cache = eng.__dict__.setdefault("_apgd_one_ws", {})
     ws = cache.get(n)
     if ws is None:
@@ -870,7 +875,7 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     check(lib.ccqp_bapgd_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n, limit,
                                        ws.words.data_ptr(), st))
     last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
-    grid = sharing and _APGD_GRID_SOLVE
+    grid = sharing and _APGD_GRID_SOLVE and aligned and _sharing_form(eng, 1, n, 1)
     # (ONE problem: the one-workgroup solve only for tiny matrices -- at n = 128 it takes 1.2 ms, the rounds 0.7;
     # profiles/r04_single_mid.jsonl -- it is a form for MANY problems, one per compute unit)
     single = n <= 64

@@ -68,7 +68,10 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *   MPRGP_LOOKAHEAD, APGD_LOOKAHEAD   1 = the lock-step form does not look ahead (A/B of the shared passes)
  *   BMV_STAGGER            1 = no staggered start of the persistent batched matvec's waves
  *   MPRGP_FUSED_TAIL       1 = never the fused stage launch, 2 = wherever it can run (default: by shape)
- *   PERS1_MIN_N            smallest n at which a lock-step batch of ONE problem takes the persistent multi-vector matvec */
+ *   PERS1_MIN_N            smallest n at which a lock-step batch of ONE problem takes the persistent multi-vector matvec
+ *   BMV_LOADS              matrix loads of the persistent batched matvecs: 1 = non-temporal, 2 = plain (default: by size)
+ *   APGD_PAIR              fused lock-step APGD rounds BELOW the persistent matvec's sizes (both products of a round from one
+ *                          launch of the VALU kernel): 1 = never, 2 = whatever the batch (default: <= 256 MiB of matrices) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
   CCQP_OPT_GEMV2_WPB = 1,
@@ -82,7 +85,9 @@ enum {
   CCQP_OPT_BMV_STAGGER = 9,
   CCQP_OPT_MPRGP_FUSED_TAIL = 10,
   CCQP_OPT_PERS1_MIN_N = 11,
-  CCQP_OPT_COUNT = 12
+  CCQP_OPT_BMV_LOADS = 12,
+  CCQP_OPT_APGD_PAIR = 13,
+  CCQP_OPT_COUNT = 14
 };
 int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
 int ccqp_ctx_get_option(ccqp_ctx* ctx, int key, int64_t* value);
@@ -479,6 +484,13 @@ int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int flags, char*
  * (config 5's share: 128), 444 below (and for the single-problem ccqp_gemv3_f64); the context's option BMV3_SHAPE
  * overrides.  NOT an error code. */
 int ccqp_bmv3_shape(ccqp_ctx* ctx, int count);
+/* Form of the FUSED lock-step APGD rounds (ccqp_bapgd_round_f64 with CCQP_LOCKSTEP_LOOKAHEAD | _FUSED_ROUNDS in `flags`:
+ * one round -- the two products of an iteration from one launch, the decision, the update -- per accepted iteration) for
+ * `count` problems of size n: 1 = the persistent three-vector matvec (where ccqp_bpipe_matvec_form with bit 16 names it),
+ * 2 = both products from one launch of the batched VALU kernel (batches below those sizes whose matrices fit the MALL
+ * together, 256 MiB: bound by the number of their launches; the context's option APGD_PAIR overrides), 0 = this run's
+ * rounds are not fused.  NOT an error code. */
+int ccqp_bapgd_fused_form(ccqp_ctx* ctx, int count, int64_t n, int flags);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0
  * promises 16-byte aligned A rows and vectors (A, x, g pointers % 16 == 0 and lda even); the other bits are a
  * tuning word of the matvec that changes no result bit (0 = defaults; layout in csrc/ccqp_lockstep.h).  Bit 3 (8)

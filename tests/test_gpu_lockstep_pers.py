@@ -211,3 +211,76 @@ def test_fused_rounds_enforce_the_budget_on_the_device(kind):
                     assert fell == 0, (tol, max_mv, conv, fell)
     finally:
         eng.set_option("PERS1_MIN_N", 0)
+
+
+@pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation"])
+def test_fused_rounds_below_the_persistent_sizes_change_no_bit(kind):
+    """A handful of problems below the persistent matvec's sizes (n < 4096): fused rounds whose two products come from ONE
+    launch of the batched VALU kernel (bapgd_gemv_pair_kernel, blockIdx.z = the product) -- one round per accepted
+    iteration instead of two -- against the unfused rounds (context option APGD_PAIR = 1) and the host-driven solve(): x
+    bit for bit, counts, residual.  Sizes with one and two reduction chunks, rows 16-byte aligned and not (n = 777),
+    vector and scalar bounds, a budget that stops the device one short (AP_DONE = 2) and one that lets it finish; single
+    solves (pipeline=True) and a batch of five problems out of step with each other; and the same single solves at
+    n >= 4096, where the fused rounds are the persistent form's."""
+    from ccqppy_amd import _lib, lockstep, problems, solvers, solution_spaces as ss
+    from ccqppy_amd._engine import get_engine
+    cls = getattr(solvers, "CCQPSolver" + kind)
+    eng = get_engine(0)
+    fl = 1 | _lib.LOCKSTEP_LOOKAHEAD | _lib.LOCKSTEP_FUSED_ROUNDS
+    form = lambda count, n, f=fl: eng.lib.ccqp_bapgd_fused_form(eng.ctx, count, n, f)       # noqa: E731
+    try:
+        for n, scalar_bounds in ((130, False), (300, True), (777, False), (1500, False), (2500, True), (3072, False),
+                                 (5000, False), (8192, True)):
+            op, b, _ = problems.random_problem(n, 4400 + n)
+            P = ss.BoxProjOp(n, -0.35, 0.45) if scalar_bounds else \
+                ss.BoxProjOp(n, -0.3 * np.ones(n) - 1e-5 * np.arange(n), 0.4 * np.ones(n))
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = cls(1e-7, np.inf, pipeline=False)
+                ref.solve(op, b, convex_proj_op=P)
+            conv = ref.solution_num_matrix_vector_multiplications
+            assert conv > 8
+            for max_mv in (np.inf, conv + 3, conv - 3):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    host = cls(1e-7, max_mv, pipeline=False)
+                    host.solve(op, b, convex_proj_op=P)
+                for pair in (0, 1):
+                    eng.set_option("APGD_PAIR", pair)
+                    aligned = int(n % 2 == 0)
+                    want = 1 if (n >= 4096 and aligned) else (2 if pair == 0 else 0)
+                    assert form(1, n, (fl & ~1) | aligned) == want, (n, pair)
+                    before = dict(lockstep.stats)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        dev = cls(1e-7, max_mv, pipeline=True)
+                        dev.solve(op, b, convex_proj_op=P)
+                    _same(host, dev)
+                    if max_mv >= conv + 3:
+                        assert lockstep.stats["fallback_solves"] == before["fallback_solves"], (n, max_mv, pair)
+            del op
+        n = 512
+        items = []
+        for p in range(5):
+            op, b, _ = problems.random_problem(n, 4600 + p)
+            items.append((op, b, None, ss.BoxProjOp(n, (-0.3 - 0.1 * p) * np.ones(n), (0.4 - 0.05 * p) * np.ones(n))))
+        got = {}
+        for pair in (1, 0):
+            eng.set_option("APGD_PAIR", pair)
+            assert form(5, n) == (0 if pair == 1 else 2)
+            got[pair] = lockstep.solve_batch_pipelined(lambda: cls(1e-8, 500), items, device=0, single_launch=False)
+        for a, c in zip(got[1], got[0]):
+            _same(a, c)
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = cls(1e-8, 500, pipeline=False)
+            one.solve(items[2][0], items[2][1], convex_proj_op=items[2][3])
+        _same(one, got[0][2])
+    finally:
+        eng.set_option("APGD_PAIR", 0)
+    # the defaults
+    assert form(1, 4096) == 1 and form(128, 4096) == 1 and form(1, 2048) == 2 and form(32, 1024) == 2
+    assert form(33, 1024) == 0                       # more than 256 MiB of small matrices: unfused rounds
+    assert form(512, 2048) == 1                      # ... until the persistent form takes it
+    assert form(1, 4096, 1) == 0                     # fused rounds not asked for
+    eng.set_option("APGD_PAIR", 2)
+    try:
+        assert form(64, 1024) == 2
+    finally:
+        eng.set_option("APGD_PAIR", 0)

@@ -7,7 +7,8 @@ in a workgroup barrier) first and writes the slab only, computing from the snaps
 
   in every function whose body mentions `bp_meet(` or `*_enter(`, or whose signature takes a `_words&` snapshot, each textual use of
   the slab (`q.slab[...]`, `slab[...]`, `s[...]` where `s` aliases the slab) is the target of a plain assignment, and the
-  slab pointer is handed to nothing but an `_enter(` helper, `bbf_decide_a(` or `mp_tail<` (themselves checked).
+  slab pointer is handed to nothing but an `_enter(` helper, `bbf_decide_a(`, `bapgd_decide_scalars<` or `mp_tail<`
+  (themselves checked).
 
 A regression of round 1's race (a late wave reading the NEW state once per ~10^4 decisions) would need someone to add
 such a read; this test is what stops it."""
@@ -118,7 +119,7 @@ def test_no_slab_read_in_a_function_with_a_meeting_point(fname):
                 j -= 1
             callee = re.search(r"(\w+)\s*(?:<[^<>]*>)?\s*$", body[:j])
             callee = callee.group(1) if callee else "?"
-            assert callee.endswith("_enter") or callee in ("bbf_decide_a", "mp_tail"), \
+            assert callee.endswith("_enter") or callee in ("bbf_decide_a", "mp_tail", "bapgd_decide_scalars"), \
                 "%s:%s hands the slab to %s()" % (fname, name, callee)
     if fname in ("ccqp_bpipe.hip", "ccqp_bmprgp.hip", "ccqp_bsegs.hip"):
         assert checked >= 3, "the lint found no function with a meeting point in %s -- the parser is broken" % fname
