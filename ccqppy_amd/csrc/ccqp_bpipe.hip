@@ -937,56 +937,15 @@ static bool bapgd_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int fla
          bp_pers_sharing(ctx, bp_mv_tune(count, n, flags), flags, count, n, false);
 }
 
-// ---- fused rounds of a HANDFUL of problems below the persistent form's sizes: both products from one VALU launch
-// A small batch of problems of n < 4096 is bound by the NUMBER of its launches (~5 us each), not by its matrices (they
-// sit in L2 / the MALL): the unfused rounds of an iteration are six launches -- matvec, decision, update,
-// twice.  The fused round needs the products of the trial point and of y_{k+1} (bapgd_resolve3); here blockIdx.z names
-// the product and each is multiplied by the batched VALU body of the unfused rounds (gemv_body: the bits are a function
-// of (row, n) only) -- ONE launch, then the decision and the update: three launches per accepted iteration.  `start`: the two
-// products of a look-ahead run's start (bapgd_resolve3_start).
-template <int U, bool ALIGNED, bool NT>
-__global__ __launch_bounds__(CCQP_BLOCK) void bapgd_gemv_pair_kernel(const ccqp_papgd* __restrict__ probs, int start,
-                                                                     int64_t n) {
-  const ccqp_papgd& q = probs[blockIdx.y];
-  const int64_t wave = (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (CCQP_BLOCK / 64);
-  const bool second = blockIdx.z != 0;
-  if (start) {
-    if (!second)
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[1], nullptr, q.Ax1, nullptr, n, n, BP_TASKS(U, n), wave, nwaves);
-    else if (q.ga != nullptr && q.Aya != nullptr)
-      gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.Y[0], q.b, q.Aya, q.ga, n, n, BP_TASKS(U, n), wave, nwaves);
-    return;
-  }
-  const double* s = q.slab;
-  if (s[AP_DONE] != 0.0 || s[AP_LOOK] == 0.0 || s[AP_PHASE] == 0.0) return;
-  const int it = (int)s[AP_IT];
-  if (!second)
-    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.X[(it + 1) & 1], q.b, q.Ax1, q.g1, n, n, BP_TASKS(U, n), wave, nwaves);
-  else
-    gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(q.A, q.lda, q.Y[(it + 1) & 1], q.b, q.Aya, q.ga, n, n, BP_TASKS(U, n), wave, nwaves);
-}
-
-static void bapgd_launch_gemv_pair(const ccqp_papgd* probs, int count, int64_t n, int start, int flags, hipStream_t s) {
-  bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  t.grid.z = 2;
-  BP_MV_LAUNCH(bapgd_gemv_pair_kernel, probs, start, n);
-}
-
 // The form of a run's FUSED rounds (flags bits 17 + 18 asked for them; every problem has its two buffers):
-// 1 = the persistent three-vector launch (bapgd_looks_ahead), 2 = the VALU pair launch above -- batches below the
-// persistent form's sizes whose matrices fit the MALL together (256 MiB: the second product of the launch re-reads them
-// from there), default tuning word (the context's option APGD_PAIR: 1 never, 2 whatever the batch) --, 0 = the rounds
-// are not fused.  Measured, whole solves, fused against unfused rounds (tools/bench_apgd_fused_small.py,
-// profiles/r04_apgd_fused_small.jsonl): n = 256: 4 problems +31 %, 32 +23 %, 128 (64 MiB) +16 %, 512 (256 MiB) +-0;
-// n = 1024: 4 +24 %, 16 (128 MiB) +7 %, 32 +-0, 100 -6 %; n = 2048: 4 (128 MiB) +10 %, 16 -1 %; n = 3072: 4 +2 %, 12 -4 %.
-#define AP_PAIR_MAX_BYTES 268435456.0
+// 1 = the persistent three-vector launch (bapgd_looks_ahead), 2 = both products of a round from ONE launch of the batched
+// VALU body (bp_gemv3_valu_kernel with the descriptors of bapgd_resolve3: batches below the persistent form's sizes whose
+// matrices fit the MALL together, bp_valu_sharing) -- the unfused rounds of an iteration are six launches (matvec,
+// decision, update, twice), the fused round three --, 0 = the rounds are not fused.
 static int bapgd_fused_form(const ccqp_ctx* ctx, int count, int64_t n, int flags, bool asked, bool fuse_asked) {
   if (!asked || !fuse_asked || ccqp_opt(ctx, CCQP_OPT_APGD_LOOKAHEAD)) return 0;
   if (bapgd_looks_ahead(ctx, count, n, flags, asked)) return 1;
-  const int64_t o = ccqp_opt(ctx, CCQP_OPT_APGD_PAIR);
-  if (o == 1 || (flags & ~(1 | 8 | 128)) != 0) return 0;
-  return (o == 2 || 8.0 * (double)n * (double)n * (double)count <= AP_PAIR_MAX_BYTES) ? 2 : 0;
+  return bp_valu_sharing(ctx, flags, count, n) ? 2 : 0;
 }
 
 int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, int64_t n, int init, int flags, bool look,
@@ -1025,7 +984,8 @@ extern "C" int ccqp_bapgd_start_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   const int fuse = form != 0;
   int rc;
   if (form == 2) {
-    bapgd_launch_gemv_pair(dev_probs, count, n, 1, flags, s);
+    const bapgd_resolve3_start rsv3 = {dev_probs};
+    bp_launch_gemv3_valu(rsv3, count, n, flags, 2, s);
     rc = CCQP_OK;
   } else if (look) {
     // (a problem whose two buffers are NULL takes no part here and is multiplied by the single launch below; with every
@@ -1071,7 +1031,8 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   const int fuse = form != 0;
   int rc;
   if (form == 2) {
-    bapgd_launch_gemv_pair(dev_probs, count, n, 0, flags, s);
+    const bapgd_resolve3 rsv3 = {dev_probs};
+    bp_launch_gemv3_valu(rsv3, count, n, flags, 2, s);
     rc = CCQP_OK;
   } else if (fuse) {
     // every live problem is at a trial point: ONE launch multiplies x_{k+1} and y_{k+1} of each (nothing to take over

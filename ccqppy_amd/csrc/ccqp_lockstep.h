@@ -278,8 +278,10 @@ static bp_mv_tuning bp_mv_tune(int count, int64_t n, int flags) {
 #define BP_TASKS(C, n) (((n) + BP_R(C) - 1) / BP_R(C))
 
 // launches KERNEL<code, ALIGNED, NT>(args...) for the tuning `t`
+// (BP_EXTRA_TARGS: further template arguments of KERNEL, redefined around a BP_MV_LAUNCH by the launcher that needs them)
+#define BP_EXTRA_TARGS
 #define BP_MV_LAUNCH1(KERNEL, UU, AL, NTT, ...) \
-  hipLaunchKernelGGL((KERNEL<UU, AL, NTT>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
+  hipLaunchKernelGGL((KERNEL<UU, AL, NTT BP_EXTRA_TARGS>), t.grid, dim3(CCQP_BLOCK), 0, s, __VA_ARGS__)
 #define BP_MV_LAUNCH_U(KERNEL, AL, NTT, ...)                          \
   do {                                                                \
     if (t.U == 7) BP_MV_LAUNCH1(KERNEL, 8, AL, NTT, __VA_ARGS__);     \
@@ -486,6 +488,53 @@ static int bp_launch_gemv3_pers(ccqp_ctx* ctx, const Resolve3& rsv, int count, i
   }
   if (ccqp_mvt_on) ccqp_mvt_mark(s, 1);
   return CCQP_OK;
+}
+
+// ---- the products of a sharing launch from the batched VALU body, blockIdx.z = the product (round 4)
+// A batch whose matrices fit the MALL together (256 MiB: one problem of n < 4096, 32 of n = 1024, 512 of n = 256) is
+// bound by the NUMBER of its launches (~5 us each), not by its bytes: a second product re-reads the matrix from the
+// MALL / L2.  What the persistent three-vector launch shares for large matrices -- the pass -- is worth nothing here; what
+// lock-step APGD's fused rounds save is ROUNDS (one per accepted iteration instead of two).  So below the persistent
+// form's sizes the same `Resolve3` descriptors are multiplied by the VALU body of the single-product launches (gemv_body:
+// the bits are a function of (row, n) only), one grid slice per product.  `nz`: products a descriptor can name.
+// (MPRGP's look-ahead through this launch was measured too and is NOT taken: it saves passes, not rounds -- the M1 and
+// A.p rounds of a CG step remain, without a matvec -- and adds a launch per round: whole solves 0.81x at n = 256, 0.93-0.98x
+// at 1024, +-1 % at 2048 / 3072, one problem to 512; it would take fused MPRGP rounds)
+template <int U, bool ALIGNED, bool NT, class Resolve3>
+__global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_valu_kernel(const Resolve3 rsv, int64_t n) {
+  gemv_lds3_desc d;
+  if (!rsv((int)blockIdx.y, &d)) return;
+  const int z = blockIdx.z;
+  const double* x = z == 0 ? d.x[0] : z == 1 ? d.x[1] : d.x[2];
+  double* y = z == 0 ? d.y[0] : z == 1 ? d.y[1] : d.y[2];
+  double* g = z == 0 ? d.g[0] : z == 1 ? d.g[1] : d.g[2];
+  if (y == nullptr) return;
+  gemv_body<BP_R(U), BP_U(U), ALIGNED, NT>(d.A, d.lda, x, g ? d.b : nullptr, y, g, n, n, BP_TASKS(U, n),
+                                           (int64_t)blockIdx.x * (CCQP_BLOCK / 64) + (threadIdx.x >> 6),
+                                           (int64_t)gridDim.x * (CCQP_BLOCK / 64));
+}
+
+// whether a run that shares passes takes this form: default tuning word, the batch's matrices <= 256 MiB (the context's
+// option SMALL_SHARING: 1 never, 2 whatever the batch).  Measured on whole lock-step APGD solves, fused against unfused
+// rounds (tools/bench_small_sharing.py, profiles/r04_apgd_fused_small.jsonl): n = 256: 4 problems +31 %, 32 +23 %,
+// 128 (64 MiB) +16 %, 512 (256 MiB) +-0; n = 1024: 4 +24 %, 16 (128 MiB) +7 %, 32 +-0, 100 -6 %; n = 2048: 4 (128 MiB)
+// +10 %, 16 -1 %; n = 3072: 4 +2 %, 12 -4 %.
+#define BP_SMALL_SHARING_BYTES 268435456.0
+static inline bool bp_valu_sharing(const ccqp_ctx* ctx, int flags, int count, int64_t n) {
+  const int64_t o = ccqp_opt(ctx, CCQP_OPT_SMALL_SHARING);
+  if (o == 1 || (flags & ~(1 | 8 | 128)) != 0) return false;
+  return o == 2 || 8.0 * (double)n * (double)n * (double)count <= BP_SMALL_SHARING_BYTES;
+}
+
+template <class Resolve3>
+static void bp_launch_gemv3_valu(const Resolve3& rsv, int count, int64_t n, int flags, int nz, hipStream_t s) {
+  bp_mv_tuning t = bp_mv_tune(count, n, flags);
+  t.grid.z = (unsigned)nz;
+#undef BP_EXTRA_TARGS
+#define BP_EXTRA_TARGS , Resolve3
+  BP_MV_LAUNCH(bp_gemv3_valu_kernel, rsv, n);
+#undef BP_EXTRA_TARGS
+#define BP_EXTRA_TARGS
 }
 
 // ring shape of the three-vector launch: rows per wave, slots, waves per workgroup.  EIGHT rows per wave, two slots, four

@@ -70,8 +70,9 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *   MPRGP_FUSED_TAIL       1 = never the fused stage launch, 2 = wherever it can run (default: by shape)
  *   PERS1_MIN_N            smallest n at which a lock-step batch of ONE problem takes the persistent multi-vector matvec
  *   BMV_LOADS              matrix loads of the persistent batched matvecs: 1 = non-temporal, 2 = plain (default: by size)
- *   APGD_PAIR              fused lock-step APGD rounds BELOW the persistent matvec's sizes (both products of a round from one
- *                          launch of the VALU kernel): 1 = never, 2 = whatever the batch (default: <= 256 MiB of matrices) */
+ *   SMALL_SHARING          lock-step APGD BELOW the persistent matvec's sizes: fused rounds whose two products come from one
+ *                          launch of the VALU kernel: 1 = never, 2 = whatever the batch (default: batches with <= 256 MiB
+ *                          of matrices) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
   CCQP_OPT_GEMV2_WPB = 1,
@@ -86,7 +87,7 @@ enum {
   CCQP_OPT_MPRGP_FUSED_TAIL = 10,
   CCQP_OPT_PERS1_MIN_N = 11,
   CCQP_OPT_BMV_LOADS = 12,
-  CCQP_OPT_APGD_PAIR = 13,
+  CCQP_OPT_SMALL_SHARING = 13,
   CCQP_OPT_COUNT = 14
 };
 int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
@@ -488,7 +489,7 @@ int ccqp_bmv3_shape(ccqp_ctx* ctx, int count);
  * one round -- the two products of an iteration from one launch, the decision, the update -- per accepted iteration) for
  * `count` problems of size n: 1 = the persistent three-vector matvec (where ccqp_bpipe_matvec_form with bit 16 names it),
  * 2 = both products from one launch of the batched VALU kernel (batches below those sizes whose matrices fit the MALL
- * together, 256 MiB: bound by the number of their launches; the context's option APGD_PAIR overrides), 0 = this run's
+ * together, 256 MiB: bound by the number of their launches; the context's option SMALL_SHARING overrides), 0 = this run's
  * rounds are not fused.  NOT an error code. */
 int ccqp_bapgd_fused_form(ccqp_ctx* ctx, int count, int64_t n, int flags);
 /* g0 = A x0 + b, residual (exit test), A g0, alpha0 = g0.g0 / g0.A g0  (solvers.py:626-636).  `flags` bit 0

@@ -216,8 +216,8 @@ def test_fused_rounds_enforce_the_budget_on_the_device(kind):
 @pytest.mark.parametrize("kind", ["APGD", "APGDAntiRelaxation"])
 def test_fused_rounds_below_the_persistent_sizes_change_no_bit(kind):
     """A handful of problems below the persistent matvec's sizes (n < 4096): fused rounds whose two products come from ONE
-    launch of the batched VALU kernel (bapgd_gemv_pair_kernel, blockIdx.z = the product) -- one round per accepted
-    iteration instead of two -- against the unfused rounds (context option APGD_PAIR = 1) and the host-driven solve(): x
+    launch of the batched VALU kernel (bp_gemv3_valu_kernel, blockIdx.z = the product) -- one round per accepted
+    iteration instead of two -- against the unfused rounds (context option SMALL_SHARING = 1) and the host-driven solve(): x
     bit for bit, counts, residual.  Sizes with one and two reduction chunks, rows 16-byte aligned and not (n = 777),
     vector and scalar bounds, a budget that stops the device one short (AP_DONE = 2) and one that lets it finish; single
     solves (pipeline=True) and a batch of five problems out of step with each other; and the same single solves at
@@ -244,7 +244,7 @@ def test_fused_rounds_below_the_persistent_sizes_change_no_bit(kind):
                     host = cls(1e-7, max_mv, pipeline=False)
                     host.solve(op, b, convex_proj_op=P)
                 for pair in (0, 1):
-                    eng.set_option("APGD_PAIR", pair)
+                    eng.set_option("SMALL_SHARING", pair)
                     aligned = int(n % 2 == 0)
                     want = 1 if (n >= 4096 and aligned) else (2 if pair == 0 else 0)
                     assert form(1, n, (fl & ~1) | aligned) == want, (n, pair)
@@ -263,7 +263,7 @@ def test_fused_rounds_below_the_persistent_sizes_change_no_bit(kind):
             items.append((op, b, None, ss.BoxProjOp(n, (-0.3 - 0.1 * p) * np.ones(n), (0.4 - 0.05 * p) * np.ones(n))))
         got = {}
         for pair in (1, 0):
-            eng.set_option("APGD_PAIR", pair)
+            eng.set_option("SMALL_SHARING", pair)
             assert form(5, n) == (0 if pair == 1 else 2)
             got[pair] = lockstep.solve_batch_pipelined(lambda: cls(1e-8, 500), items, device=0, single_launch=False)
         for a, c in zip(got[1], got[0]):
@@ -273,14 +273,14 @@ def test_fused_rounds_below_the_persistent_sizes_change_no_bit(kind):
             one.solve(items[2][0], items[2][1], convex_proj_op=items[2][3])
         _same(one, got[0][2])
     finally:
-        eng.set_option("APGD_PAIR", 0)
+        eng.set_option("SMALL_SHARING", 0)
     # the defaults
     assert form(1, 4096) == 1 and form(128, 4096) == 1 and form(1, 2048) == 2 and form(32, 1024) == 2
     assert form(33, 1024) == 0                       # more than 256 MiB of small matrices: unfused rounds
     assert form(512, 2048) == 1                      # ... until the persistent form takes it
     assert form(1, 4096, 1) == 0                     # fused rounds not asked for
-    eng.set_option("APGD_PAIR", 2)
+    eng.set_option("SMALL_SHARING", 2)
     try:
         assert form(64, 1024) == 2
     finally:
-        eng.set_option("APGD_PAIR", 0)
+        eng.set_option("SMALL_SHARING", 0)
