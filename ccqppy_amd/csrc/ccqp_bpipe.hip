@@ -1266,6 +1266,38 @@ extern "C" int ccqp_bapgd_stage_one_f64(ccqp_ctx* ctx, const ccqp_papgd* host_de
   return CCQP_OK;
 }
 
+// The same for ONE problem of the BBPGD-type drivers (ccqp_bpipe_*: PGD / BBPGD / BBPGDf as a batch of one): the
+// descriptor by value, the slab zeroed (slot 48 = PGD's constant step), the three words, x0 or zeros into x[0] and -- BBPGDf,
+// solvers.py:762-763 -- copies of it into xmin and gmin.
+__global__ __launch_bounds__(CCQP_BLOCK) void bpipe_stage_one_kernel(const ccqp_pprob desc, ccqp_pprob* __restrict__ dev_desc,
+                                                                     const double* __restrict__ x0, int64_t n, double step,
+                                                                     uint32_t* __restrict__ words) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) *dev_desc = desc;
+    if (threadIdx.x < 64) desc.slab[threadIdx.x] = threadIdx.x == BP_ALPHA ? step : 0.0;
+    if (threadIdx.x < 3) words[threadIdx.x] = 0u;
+  }
+  double* __restrict__ X0 = desc.x[0];
+  double* __restrict__ xmin = desc.xmin;
+  double* __restrict__ gmin = desc.gmin;
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK) {
+    const double v = x0 ? x0[i] : 0.0;
+    X0[i] = v;
+    if (xmin) xmin[i] = v;
+    if (gmin) gmin[i] = v;
+  }
+}
+
+extern "C" int ccqp_bpipe_stage_one_f64(ccqp_ctx* ctx, const ccqp_pprob* host_desc, ccqp_pprob* dev_desc, const double* x0,
+                                        int64_t n, double step, uint32_t* words, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && host_desc != nullptr && dev_desc != nullptr && words != nullptr, "NULL argument");
+  CCQP_REQUIRE(n >= 1 && host_desc->x[0] != nullptr && host_desc->slab != nullptr, "incomplete descriptor");
+  hipLaunchKernelGGL(bpipe_stage_one_kernel, dim3(bp_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, *host_desc,
+                     dev_desc, x0, n, step, words);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 // =====================================================================================================================
 // ONE problem, the WHOLE APGD solve in ONE launch on the whole chip (2048 < n <= 16384: where a pass over the matrix takes
 // 27 ... 340 us and the ~35 us of launch gaps and small kernels per lock-step round, or the host's turn-around per

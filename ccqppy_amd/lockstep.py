@@ -817,7 +817,7 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
 class _OneWs:
     """Workspace of the device-resident single APGD solve of one size on one engine, kept between solves: the eleven
     vector planes, slab, partial sums, counters, the device copy of the descriptor and its host original."""
-    __slots__ = ("vec", "slab", "partials", "words", "ddesc", "desc", "host")
+    __slots__ = ("vec", "slab", "partials", "words", "ddesc", "desc", "host", "planes")
 
 
 def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
@@ -909,6 +909,76 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     pick = 8 if (ar and h[11] != 0.0) else (int(h[8]) + 1) % 2
     # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
     return True, ws.vec[pick, :n], np.sqrt(np.float64(h[19])), int(h[18])
+
+
+def _bpipe_one(eng, solver, op, b, x0, P, n, ahead=4):
+    """ONE dense PGD / BBPGDf (/ BBPGD) problem on an elementwise set, device-resident: _bpipe_run for a batch of one
+    without its per-batch host work -- a cached workspace per size, staging in ONE launch (ccqp_bpipe_stage_one_f64: the
+    descriptor by value, no host-paced torch operation), the result words through the pinned mirror.  n <= 64: the whole
+    solve in one launch (one workgroup), beyond the lock-step iterations queued `ahead` beyond the device's last report.
+    Returns (done, final iteration, x, residual, gave_up): gave_up = the DEVICE's own budget ended the run."""
+    import ctypes
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    A = op.A
+    aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
+    pgd, fallback = hasattr(solver, "step_size"), bool(getattr(solver, "_fallback", False))
+    flags = int(aligned) | (8 if pgd else 0) | (128 if fallback else 0)
+    max_mv = solver.max_matrix_vector_multiplications
+    cache = eng.__dict__.setdefault("_bpipe_one_ws", {})
+    ws = cache.get(n)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[n] = _OneWs()
+        nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+        stride = (n + 1) // 2 * 2                        # (planes 16 bytes apart for an odd n too)
+        ws.vec = torch.empty((9, stride), dtype=torch.float64, device=dev)
+        ws.slab = torch.zeros(64, dtype=torch.float64, device=dev)
+        ws.partials = torch.empty(3 * nblk, dtype=torch.float64, device=dev)
+        ws.words = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws.ddesc = torch.zeros(ctypes.sizeof(_lib.PProb), dtype=torch.uint8, device=dev)
+        d = ws.desc = _lib.PProb()
+        base = ws.vec.data_ptr()
+        plane = [base + 8 * stride * j for j in range(9)]
+        # planes: x ring, g ring, y, xmin, gmin
+        for j in range(3):
+            d.x[j], d.g[j] = plane[j], plane[3 + j]
+        d.y = plane[6]
+        d.slab, d.partials, d.counter = ws.slab.data_ptr(), ws.partials.data_ptr(), ws.words.data_ptr()
+        d.c = 1.0 / (3 * n * _GD)                        # solvers.py:138
+        ws.host = (ctypes.c_double * 4)()
+        ws.planes = plane
+    d = ws.desc
+    d.A, d.lda, d.b = A.data_ptr(), A.stride(0), b.data_ptr()
+    d.seg = P._seg(eng, 0, n)
+    d.tol = float(solver.desired_residual_tol)
+    d.xmin, d.gmin = (ws.planes[7], ws.planes[8]) if fallback else (None, None)
+    check = _lib.check
+    dp, batch = ws.ddesc.data_ptr(), ws.words.data_ptr() + 4
+    check(lib.ccqp_bpipe_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n,
+                                       float(solver.step_size) if pgd else 0.0, ws.words.data_ptr(), st))
+    # iteration k with 1 + k >= max_mv is the last one and has no tail: the reference breaks before the residual (:643-644)
+    last = max(1, max_mv - 1) if np.isfinite(max_mv) else np.inf
+    if n <= 64:
+        k = int(min(last, _device_budget(n)))
+        check(lib.ccqp_bsolve_bbpgd_f64(ctx, dp, 1, n, _GD, float(_EPS10), k, flags & 137, st))
+        capped = True
+    else:
+        def launch(k):
+            check(lib.ccqp_bpipe_iterate_f64(ctx, dp, 1, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
+        check(lib.ccqp_bpipe_start_f64(ctx, dp, 1, n, _GD, flags, batch, st))
+        k = _bpipe_poll_loop(eng, 1, launch, last, ahead)
+        capped = 1 + k >= max_mv
+    h = ws.host
+    check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 48, 4, h, st))       # blocking: the queue has drained
+    done, iters, res2 = h[1] != 0.0, int(h[2]), h[3]
+    if not capped and not done:
+        raise RuntimeError("device-resident solve: mirror and slab disagree")
+    final = iters if done else k
+    # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
+    return done, final, ws.vec[final % 3, :n], np.sqrt(np.float64(res2)), (not done) and k < last
 
 
 def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):

@@ -209,6 +209,30 @@ class CCQPSolverBase(ABC):
                 and self.max_matrix_vector_multiplications >= 1000 and run.eng.own_stream is None
         return pipeline
 
+    _LOCKSTEP_ONE_MAX_N = 2048
+
+    def _lockstep_one(self, run):
+        """PGD / BBPGDf with a device-resident solve (pipeline): the whole solve as a lock-step batch of ONE (ccqp_bpipe_*:
+        dense operator, n <= _LOCKSTEP_ONE_MAX_N, elementwise set) -- step, matvec and the fused tail queued ahead of the
+        device's reports, every scalar on the device; n <= 64: one launch (one workgroup: a form for MANY problems -- for
+        one it loses from n = 128 on, as APGD's).  Returns (x, residual, reported matvecs), or None where that does not
+        apply or the device's own budget was reached."""
+        from ._record import RecordingEngine
+        from .lockstep import _bpipe_one, stats
+        from .operators import DenseOperator
+        op, eng = run.op, run.eng
+        if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._LOCKSTEP_ONE_MAX_N
+                and hasattr(run.P, "_dev_bb_tail") and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
+            return None
+        done, k, x, res, gave_up = _bpipe_one(eng, self, op, run.b, run.x0 if run.x0_given else None, run.P, run.n)
+        if gave_up:
+            stats["fallback_solves"] += 1
+            return None
+        # (BBPGD-type: A.g0 of the start is executed, not counted -- unless x0 already meets the tolerance; PGD has none)
+        extra = 0 if hasattr(self, "step_size") else (0 if (done and k == 0) else 1)
+        eng.mv_executed += 1 + k + extra
+        return x, res, 1 + k
+
     @property
     @abstractmethod
     def name(self):
@@ -244,9 +268,14 @@ class CCQPSolverPGD(CCQPSolverBase):
     """Projected gradient descent with a constant step (solvers.py:71-194)."""
     _label = "PGD"
 
-    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, step_size=0.01):
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, step_size=0.01, pipeline=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         self.step_size = step_size
+        # SAME results bit for bit: None (default) = the device-resident form where _device_resident says so (a plain
+        # solve() with a dense operator of n <= 2048, an elementwise set, a budget of at least 1000): the lock-step batch
+        # scheduler with a batch of one -- step, matvec, residual and exit test on the device, iterations queued ahead.
+        # PGD takes thousands of iterations of ~25 us of host turn-around each; False = the host-driven loop below.
+        self.pipeline = pipeline
 
     @property
     def name(self):
@@ -254,6 +283,10 @@ class CCQPSolverPGD(CCQPSolverBase):
 
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
+        if self._device_resident(run) and self.trace is None:
+            out = self._lockstep_one(run)
+            if out is not None:
+                return out
         mv_count = 0
         xk = run.copy(run.x0)
         xkm1 = run.copy(run.x0)
@@ -631,26 +664,6 @@ class _BBPGDCore(CCQPSolverBase):
         eng.mv_executed += k
         return X[k % 3], (np.sqrt(res2) if kf >= 1 else res), 1 + k
 
-    def _lockstep_fallback_variant(self, run):
-        """BBPGDf with pipeline=True: the whole solve on the device as a lock-step batch of one (dense operator,
-        n <= 2048, elementwise set); None where that does not apply or the device budget was reached."""
-        from ._record import RecordingEngine
-        from .lockstep import _bpipe_run, _spec_from_items, stats
-        from .operators import DenseOperator
-        op, eng = run.op, run.eng
-        if not (isinstance(op, DenseOperator) and op.rows == op.n <= 2048 and hasattr(run.P, "_dev_bb_tail")
-                and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
-            return None
-        max_mv = self.max_matrix_vector_multiplications
-        done, final, sols, res, todo = _bpipe_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, run.P)], run.n),
-                                                  run.n, max_mv, 4)
-        if len(todo):
-            stats["fallback_solves"] += 1
-            return None
-        k = int(final[0])
-        eng.mv_executed += 1 if (done[0] and k == 0) else 2 + k
-        return sols[0], res[0], 1 + k
-
     def _lockstep_segments(self, run):
         """BBPGD with pipeline=True on a Sphere / Cone / DisjointUnion set: the whole solve on the device as a
         segmented lock-step batch of one (ccqp_bsegs_*; dense operator, n <= 2048); None where that does not apply."""
@@ -671,8 +684,10 @@ class _BBPGDCore(CCQPSolverBase):
     def _iterate(self, run):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
-        if self._device_resident(run) and self._fallback and self.trace is None:
-            out = self._lockstep_fallback_variant(run)
+        if self._device_resident(run) and self.trace is None and self.pipeline != "graph":
+            # (dense, n <= 2048, elementwise set: the lock-step batch of one -- BBPGD too: 0.22-0.30 ms per solve against
+            # 0.31-0.37 for the device-resident loop below, which stays for larger / sparse / matrix-free operators)
+            out = self._lockstep_one(run)
             if out is not None:
                 return out
         if self._device_resident(run) and not self._fallback and self.trace is None:

@@ -613,6 +613,11 @@ int ccqp_bsolve_apgd_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int count, 
  * two batch words) = 0.  Then ccqp_bapgd_start_f64 / ccqp_bapgd_round_f64 (or ccqp_bsolve_apgd_grid_f64) on dev_desc. */
 int ccqp_bapgd_stage_one_f64(ccqp_ctx* ctx, const ccqp_papgd* host_desc, ccqp_papgd* dev_desc, const double* x0, int64_t n,
                              double limit, uint32_t* words, void* stream);
+/* The same for ONE problem of the ccqp_bpipe_* drivers (PGD / BBPGD / BBPGDf as a batch of one): *host_desc to dev_desc,
+ * the slab zeroed with slot 48 = step (PGD's constant step, solvers.py:71-194; 0 otherwise), x[0] = x0 (NULL: zeros) and,
+ * where given, xmin = gmin = x0 (BBPGDf, :762-763), words[0..2] = 0.  Then ccqp_bpipe_start_f64 / ccqp_bpipe_iterate_f64. */
+int ccqp_bpipe_stage_one_f64(ccqp_ctx* ctx, const ccqp_pprob* host_desc, ccqp_pprob* dev_desc, const double* x0, int64_t n,
+                             double step, uint32_t* words, void* stream);
 int ccqp_bsolve_apgd_grid_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, int64_t n, double gd, int flags,
                               int64_t max_rounds, uint32_t* dev_batch, void* stream);
 

@@ -395,6 +395,26 @@ def test_single_solve_bbpgdf_pipeline_option():
                     assert lockstep.stats["fallback_solves"] == before       # (n = 3000: the host loop, by the gate)
 
 
+def test_single_solve_pgd_pipeline_option():
+    """CCQPSolverPGD(..., pipeline=True) -- and the default None for a budget of at least 1000 -- = the lock-step scheduler
+    with a batch of one (n <= 2048; n <= 64: one launch) against the host-driven loop pipeline=False: x bit for bit,
+    counts, residual, converged flag; budgets that end the solve early take the reference's exit paths."""
+    from ccqppy_amd import lockstep, solvers
+    for n in (50, 301, 1024, 2048, 3000):
+        for p, (op, b, x0, P) in enumerate(_problems(n, 3, 7300 + n)):
+            P2 = P if P is not None else _sets(n, 0)
+            for cap in (np.inf, 5000, 1, 2, 7, 60):
+                before = lockstep.stats["fallback_solves"]
+                with contextlib.redirect_stdout(io.StringIO()):
+                    a = solvers.CCQPSolverPGD(1e-6, cap, 0.3, pipeline=False).solve(op, b, x0=x0, convex_proj_op=P2)
+                    c = solvers.CCQPSolverPGD(1e-6, cap, 0.3, pipeline=True).solve(op, b, x0=x0, convex_proj_op=P2)
+                    d = solvers.CCQPSolverPGD(1e-6, cap, 0.3).solve(op, b, x0=x0, convex_proj_op=P2)
+                _same(a, c)
+                _same(a, d)
+                assert lockstep.stats["fallback_solves"] == before
+            assert a.solution_num_matrix_vector_multiplications > 7
+
+
 def test_mixed_sizes_are_grouped():
     probs = []
     for i, n in enumerate((96, 200, 96, 333, 200, 96)):

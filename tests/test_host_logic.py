@@ -22,8 +22,9 @@ def test_solver_surface_matches_reference():
             assert getattr(s, prop) is None
         sig = inspect.signature(cls.solve)
         assert list(sig.parameters) == ["self", "A", "b", "x0", "convex_proj_op"]
+    # (the reference's positional parameters first, in its order; then this engine's own keyword `pipeline`)
     assert list(inspect.signature(solvers.CCQPSolverPGD.__init__).parameters)[1:] == [
-        "desired_residual_tol", "max_matrix_vector_multiplications", "step_size"]
+        "desired_residual_tol", "max_matrix_vector_multiplications", "step_size", "pipeline"]
     assert solvers.CCQPSolverPGD(1e-3).step_size == 0.01
     spg = solvers.CCQPSolverSPG(1e-3, 10, 7, 0.25, 0.02, 0.4)
     assert (spg.m, spg.t, spg.sigma1, spg.sigma2) == (7, 0.25, 0.02, 0.4)

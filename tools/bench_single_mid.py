@@ -38,7 +38,7 @@ def main():
         P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
         for name in args.solvers.split(","):
             cls = getattr(solvers, "CCQPSolver" + name)
-            tolmv = (1e-6, 300) if name == "MPRGP" else (1e-8, 5000)
+            tolmv = (1e-6, 300) if name == "MPRGP" else (1e-8, 100000, 0.3) if name == "PGD" else (1e-8, 5000)
             out = {}
             for label, kw in (("host_loop", {"pipeline": False}), ("device_resident", {"pipeline": True})):
                 ts, r = [], None
