@@ -790,6 +790,32 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccq
 }
 
 // ---------------------------------------------------------------------------------------------------- entry points
+// Staging of ONE lock-step MPRGP problem in ONE launch (the device-resident form of a single solve, as
+// ccqp_bapgd_stage_one_f64): the descriptor by value to `dev_desc`, the slab zeroed, x0 (NULL: zeros) into X[1], the
+// problem's arrival counter and the two batch words zeroed.
+__global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_one_kernel(const ccqp_pmprgp desc, ccqp_pmprgp* __restrict__ dev_desc,
+                                                                      const double* __restrict__ x0, int64_t n,
+                                                                      uint32_t* __restrict__ words) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) *dev_desc = desc;
+    if (threadIdx.x < 64) desc.slab[threadIdx.x] = 0.0;
+    if (threadIdx.x < 3) words[threadIdx.x] = 0u;
+  }
+  double* __restrict__ X1 = desc.X[1];
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK)
+    X1[i] = x0 ? x0[i] : 0.0;
+}
+
+extern "C" int ccqp_bmprgp_stage_one_f64(ccqp_ctx* ctx, const ccqp_pmprgp* host_desc, ccqp_pmprgp* dev_desc, const double* x0,
+                                         int64_t n, uint32_t* words, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && host_desc != nullptr && dev_desc != nullptr && words != nullptr, "NULL argument");
+  CCQP_REQUIRE(n >= 1 && host_desc->X[1] != nullptr && host_desc->slab != nullptr, "incomplete descriptor");
+  hipLaunchKernelGGL(bmprgp_stage_one_kernel, dim3(bp_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, *host_desc,
+                     dev_desc, x0, n, words);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 // Start-up of all solves (solvers.py:1063-1081).  Expects x0 staged in X[1], slabs and counters zero.
 extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd,
                                      int flags, uint32_t* dev_batch, void* stream) {

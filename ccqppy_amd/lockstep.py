@@ -247,6 +247,21 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     return solvers
 
 
+def _host_solve(s, A, b, x0, P):
+    """The host-driven loop of solver `s` (whose exit paths are the reference's) for a problem the device-resident run
+    could not finish: `pipeline` off for the call -- the default None would send the solve through the device-resident
+    form of a batch of one first, to find out the same thing again."""
+    had = hasattr(s, "pipeline")
+    keep = getattr(s, "pipeline", None)
+    if had:
+        s.pipeline = False
+    try:
+        return s.solve(A, b, x0=x0, convex_proj_op=P)
+    finally:
+        if had:
+            s.pipeline = keep
+
+
 def _bpipe_poll_loop(eng, B, launch, last_round, ahead):
     """Queue rounds 1, 2, ... (`launch(k)`) at most `ahead` beyond the last one the device reported, until every
     problem has converged or `last_round` has been queued.  Returns the number of rounds queued."""
@@ -480,7 +495,7 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
                 stats["fallback_solves"] += 1
-                s.solve(A, b, x0=x0, convex_proj_op=P)
+                _host_solve(s, A, b, x0, P)
             continue
         mv = 1 + int(final[p])
         if it[5]:
@@ -687,7 +702,7 @@ def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmen
             # UnboundLocalError): the host-driven loop reproduces the reference's exception
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
-                s.solve(A, b, x0=x0, convex_proj_op=P)
+                _host_solve(s, A, b, x0, P)
             continue
         mv = int(host["mv"][p])
         if it[5]:
@@ -994,7 +1009,7 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segme
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
                 stats["fallback_solves"] += 1
-                s.solve(A, b, x0=x0, convex_proj_op=P)
+                _host_solve(s, A, b, x0, P)
             continue
         if it[5]:
             s._solution = sols[p]
@@ -1093,6 +1108,71 @@ class _MprgpRun:
         return status, sols, np.sqrt(res2), mvs, execd
 
 
+def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4):
+    """ONE dense MPRGP problem on an elementwise set with array bounds, device-resident: _bmprgp_run for a batch of one
+    without its per-batch host work (a cached workspace per size, staging in ONE launch -- ccqp_bmprgp_stage_one_f64 --,
+    the result words through the pinned mirror); n <= 64: one launch (one workgroup), beyond the lock-step rounds queued
+    `ahead` beyond the device's last report.  Returns (status, x, residual, reported matvecs, executed matvecs); status 1 =
+    converged, anything else = not finished here."""
+    import ctypes
+    from . import _lib
+    from .solvers import _EPS10, _GD
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    A = op.A
+    aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
+    flags = int(aligned)
+    max_mv = solver.max_matrix_vector_multiplications
+    cache = eng.__dict__.setdefault("_bmprgp_one_ws", {})
+    ws = cache.get(n)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[n] = _OneWs()
+        names = ("p", "Ap", "psi", "w", "nv", "txk", "dx", "Adx", "ytmp")
+        rows = int(lib.ccqp_bmprgp_partial_rows())
+        nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+        stride = (n + 1) // 2 * 2                        # (planes 16 bytes apart for an odd n too)
+        ws.vec = torch.empty((4 + len(names), stride), dtype=torch.float64, device=dev)
+        ws.slab = torch.zeros(64, dtype=torch.float64, device=dev)
+        ws.partials = torch.empty(rows * nblk, dtype=torch.float64, device=dev)
+        ws.words = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws.ddesc = torch.zeros(ctypes.sizeof(_lib.PMprgp), dtype=torch.uint8, device=dev)
+        d = ws.desc = _lib.PMprgp()
+        base = ws.vec.data_ptr()
+        plane = [base + 8 * stride * j for j in range(4 + len(names))]
+        d.X[0], d.X[1], d.G[0], d.G[1] = plane[0:4]
+        for j, name in enumerate(names):
+            setattr(d, name, plane[4 + j])
+        d.slab, d.partials, d.counter = ws.slab.data_ptr(), ws.partials.data_ptr(), ws.words.data_ptr()
+        d.c = 1.0 / (3 * n * _GD)                        # solvers.py:138
+        ws.host = (ctypes.c_double * 24)()
+    d = ws.desc
+    d.A, d.lda, d.b = A.data_ptr(), A.stride(0), b.data_ptr()
+    d.seg = P._seg(eng, 0, n)
+    d.tol = float(solver.desired_residual_tol)
+    check = _lib.check
+    dp, batch = ws.ddesc.data_ptr(), ws.words.data_ptr() + 4
+    check(lib.ccqp_bmprgp_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n,
+                                        ws.words.data_ptr(), st))
+    gd, eps10 = _GD, float(_EPS10)
+    if n <= 64:
+        check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, 1, n, gd, eps10, float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
+    else:
+        # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where the problem
+        # could reach the budget, whose exit paths (:1087, :1102, :1154, :1176) belong to the host-driven loop
+        last = max(0, max_mv - 3) if np.isfinite(max_mv) else np.inf
+        check(lib.ccqp_bmprgp_start_f64(ctx, dp, 1, n, gd, flags, batch, st))
+        if last >= 1:
+            def launch(r):
+                check(lib.ccqp_bmprgp_round_f64(ctx, dp, 1, n, r, gd, eps10, flags, batch, st))
+            _bpipe_poll_loop(eng, 1, launch, last, ahead)
+    h = ws.host
+    check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 32, 24, h, st))      # blocking: the queue has drained
+    status, its = h[17], int(h[8])
+    # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
+    return status, ws.vec[(its + 1) % 2, :n], np.sqrt(np.float64(h[19])), int(h[18]), int(h[20])
+
+
 _HALVES_DEFAULT = True           # lock-step MPRGP: large batches advance as two alternating halves (see _bmprgp_run)
 _HALF_MIN_PROBLEMS = 96          # ... from this many problems on ...
 _HALF_MIN_BYTES = 2.0 ** 35      # ... if one round of matvecs reads at least this much (32 GiB: 16 GiB per half) ...
@@ -1169,7 +1249,7 @@ def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segm
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
                 stats["fallback_solves"] += 1
-                s.solve(A, b, x0=x0, convex_proj_op=P)
+                _host_solve(s, A, b, x0, P)
             continue
         if it[5]:
             s._solution = sols[p]
@@ -1365,7 +1445,7 @@ def solve_stacked(solver, A, b, x0=None, lower=None, upper=None, tol=1e-8, max_m
                 s = cls(*args) if name != "SPG" else cls(*args, m=m, tau=tau, sigma1=sigma1, sigma2=sigma2)
                 if name == "SPG":                        # (nothing drawn yet: the host loop raises what the reference raises)
                     s.rng = rngs[p]
-                s = s.solve(A[p], b[p], x0=None if x0 is None else x0[p], convex_proj_op=P)
+                s = _host_solve(s, A[p], b[p], None if x0 is None else x0[p], P)
             sols[p].copy_(s.solution)
             res[p], mv[p] = s.solution_residual, s.solution_num_matrix_vector_multiplications
             execd[p] = s.executed_matrix_vector_multiplications

@@ -197,8 +197,7 @@ class CCQPSolverBase(ABC):
         pass
 
     def _device_resident(self, run):
-        """The effective value of `pipeline` for this solve.  None (the default of APGD, anti-relaxation APGD, BBPGD,
-        BBPGDf and SPG) = ON for a plain solve() on the default engine with a dense operator, an elementwise feasible set
+        """The effective value of `pipeline` for this solve.  None (the default of all seven solvers) = ON for a plain solve() on the default engine with a dense operator, an elementwise feasible set
         and a matvec budget of at least 1000: the device-resident forms give the same bits and counts 1.3-2.0x faster at
         n <= 2048 and up to 1.4x at 4096 ... 16384 (profiles/r04_single_mid*.jsonl); a solve MEANT to run into a small
         budget stays on the host-driven loop, whose exit paths are the reference's."""
@@ -876,7 +875,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     """MPRGP with BB proportioning/expansion steps (solvers.py:1002-1224); README's "MPRGP-BB"."""
     _label = "MPRGP"
 
-    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=False, look_ahead=None):
+    def __init__(self, desired_residual_tol, max_matrix_vector_multiplications=np.inf, pipeline=None, look_ahead=None):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         # SAME results bit for bit, same reported and executed MV counts: at the A.dx matvec of an iteration (:1129 after
         # a CG step, :1163 after an expansion step) x_{k+1} and p_{k+1} are known, so A.x_{k+1} + b (:1086 of the next
@@ -886,16 +885,18 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         # expansion step two instead of four.  None (default): wherever the operator reads its matrix once for the three
         # (square dense, aligned, an even n >= 4096); True / False force it.
         self.look_ahead = look_ahead
-        # Extension, OFF by default, SAME results bit for bit (dense operator, elementwise set with array bounds):
-        # every branch decision on the device, rounds queued ahead (ccqp_bmprgp_*, the lock-step batch scheduler with a
-        # batch of one); a solve that would reach the matvec budget falls back to the loop below
+        # SAME results bit for bit (dense operator of n <= 2048, elementwise set with array bounds): every branch decision on
+        # the device, rounds queued ahead (ccqp_bmprgp_*, the lock-step batch scheduler with a batch of one, staging in one
+        # launch); a solve that would reach the matvec budget falls back to the loop below.  None (default): ON where
+        # _device_resident says so (a plain solve(), budget >= 1000): 2.0-2.4x the host-driven loop at n <= 512, 1.6x at
+        # 1024, 1.24x at 2048 (profiles/r04_single_mprgp_small.jsonl); True / False force it.
         self.pipeline = pipeline
 
     @property
     def name(self):
         return "MPRGP"
 
-    # largest n of a device-resident solve (pipeline=True): x1.7 at 256, x1.3 at 1024, x1.08-1.1 at 2048 against the
+    # largest n of a device-resident solve: x2.2 at 256, x1.6 at 1024, x1.24 at 2048 against the
     # host-driven loop; from 4096 on (the batch of one looks ahead: three products per pass, the persistent launch) its
     # seven launches per round cost more than the host's turn-around: 0.91-0.98x at 4096 ... 16384
     # (profiles/r04_single_mid.jsonl), so the host-driven loop with its own look-ahead stays the form there
@@ -903,21 +904,20 @@ class CCQPSolverMPRGP(CCQPSolverBase):
 
     def _lockstep(self, run):
         from ._record import RecordingEngine
-        from .lockstep import _bmprgp_run, _spec_from_items
+        from .lockstep import _bmprgp_one
         from .operators import DenseOperator
         op, eng, P = run.op, run.eng, run.P
         if not (isinstance(op, DenseOperator) and op.rows == op.n <= self._PIPELINE_MAX_N
                 and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names()
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n),
-                                                    run.n, self.max_matrix_vector_multiplications, 4)
-        if status[0] != 1.0:
+        status, x, res, mv, execd = _bmprgp_one(eng, self, op, run.b, run.x0 if run.x0_given else None, P, run.n)
+        if status != 1.0:
             from . import lockstep
             lockstep.stats["fallback_solves"] += 1
             return None
-        eng.mv_executed += int(execd[0])
-        return sols[0], res[0], int(mvs[0])
+        eng.mv_executed += execd
+        return x, res, mv
 
     FUSED = True    # use the fused elementwise-set kernels (bitwise identical to the literal sequence)
 
@@ -935,7 +935,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         eng, P = run.eng, run.P
         # elementwise feasible set with array bounds: the proportioning test, the free gradient and
         # the CG direction run as fused kernels (ccqp_mprgp.hip); anything else takes the literal path
-        if self.pipeline and self.FUSED and self.trace is None:
+        if self._device_resident(run) and self.FUSED and self.trace is None:
             out = self._lockstep(run)
             if out is not None:
                 return out

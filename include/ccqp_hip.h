@@ -673,6 +673,11 @@ int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, cons
  * computed ahead.  Every product has the bits of its own pass and the two counters advance where the reference computes
  * the product, so results and counts are unchanged; ccqp_ctx_set_option(ctx, CCQP_OPT_MPRGP_LOOKAHEAD, 1) turns it off.  The
  * segmented form ccqp_bsegs_mprgp_* looks ahead in the same way.) */
+/* Staging of ONE lock-step MPRGP problem in one launch (as ccqp_bapgd_stage_one_f64): *host_desc to dev_desc, the slab
+ * zeroed, X[1] = x0 (NULL: zeros), words[0..2] (arrival counter, the two batch words) = 0.  Then ccqp_bmprgp_start_f64 /
+ * ccqp_bmprgp_round_f64 on dev_desc. */
+int ccqp_bmprgp_stage_one_f64(ccqp_ctx* ctx, const ccqp_pmprgp* host_desc, ccqp_pmprgp* dev_desc, const double* x0, int64_t n,
+                              uint32_t* words, void* stream);
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,
