@@ -1108,12 +1108,14 @@ class _MprgpRun:
         return status, sols, np.sqrt(res2), mvs, execd
 
 
-def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4):
+def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4, device_cap=None):
     """ONE dense MPRGP problem on an elementwise set with array bounds, device-resident: _bmprgp_run for a batch of one
     without its per-batch host work (a cached workspace per size, staging in ONE launch -- ccqp_bmprgp_stage_one_f64 --,
     the result words through the pinned mirror); n <= 64: one launch (one workgroup), beyond the lock-step rounds queued
     `ahead` beyond the device's last report.  Returns (status, x, residual, reported matvecs, executed matvecs); status 1 =
-    converged, anything else = not finished here."""
+    converged, anything else = not finished here.  `device_cap`: the device gives up after this many matvecs (the caller
+    then runs the host-driven loop: a solve that STALLS short of its tolerance -- MPRGP does at tol <= 1e-8 on well
+    conditioned boxes, SURVEY B.2 -- must not spend its whole budget here first)."""
     import ctypes
     from . import _lib
     from .solvers import _EPS10, _GD
@@ -1122,6 +1124,8 @@ def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4):
     aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
     flags = int(aligned)
     max_mv = solver.max_matrix_vector_multiplications
+    if device_cap is not None:
+        max_mv = min(max_mv, device_cap)
     cache = eng.__dict__.setdefault("_bmprgp_one_ws", {})
     ws = cache.get(n)
     if ws is None:

@@ -911,7 +911,10 @@ class CCQPSolverMPRGP(CCQPSolverBase):
                 and isinstance(P, ss._ElementwiseOp) and not P._scalar_bound_names()
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        status, x, res, mv, execd = _bmprgp_one(eng, self, op, run.b, run.x0 if run.x0_given else None, P, run.n)
+        # (the default form gives the device 1000 matvecs: converging solves take tens; one that stalls short of its
+        # tolerance -- SURVEY B.2: tol <= 1e-8 -- loses 1000 cheap rounds, not its whole budget, before the host loop)
+        status, x, res, mv, execd = _bmprgp_one(eng, self, op, run.b, run.x0 if run.x0_given else None, P, run.n,
+                                                device_cap=None if self.pipeline is True else 1000)
         if status != 1.0:
             from . import lockstep
             lockstep.stats["fallback_solves"] += 1

@@ -317,10 +317,22 @@ def test_single_solve_pipeline_option():
                 from ccqppy_amd import lockstep
                 before = lockstep.stats["fallback_solves"]
                 with contextlib.redirect_stdout(io.StringIO()):
-                    a = solvers.CCQPSolverMPRGP(1e-7, cap).solve(A, b, x0=x0, convex_proj_op=P)
+                    a = solvers.CCQPSolverMPRGP(1e-7, cap, pipeline=False).solve(A, b, x0=x0, convex_proj_op=P)
                     c = solvers.CCQPSolverMPRGP(1e-7, cap, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
+                    d = solvers.CCQPSolverMPRGP(1e-7, cap).solve(A, b, x0=x0, convex_proj_op=P)      # the default: None
                 _same(a, c)
+                _same(a, d)
                 assert cap < 2000 or lockstep.stats["fallback_solves"] == before   # really solved on the device
+    # the default form gives the device 1000 matvecs: a solve that stalls short of its tolerance goes to the
+    # host-driven loop after them, with the budget's own exit
+    from ccqppy_amd import lockstep
+    A, b, x0, P = _problems(256, 1, 77, 0.1)[0]
+    before = lockstep.stats["fallback_solves"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = solvers.CCQPSolverMPRGP(1e-13, 1300, pipeline=False).solve(A, b, convex_proj_op=P)
+        d = solvers.CCQPSolverMPRGP(1e-13, 1300).solve(A, b, convex_proj_op=P)
+    _same(a, d)
+    assert not a.solution_converged and lockstep.stats["fallback_solves"] == before + 1
     op, b, _ = problems.random_problem(256, 3)
     with contextlib.redirect_stdout(io.StringIO()):
         a = solvers.CCQPSolverMPRGP(1e-7, 500).solve(op, b, convex_proj_op=ss.SphereProjOp(256, 2.0))
