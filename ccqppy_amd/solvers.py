@@ -198,8 +198,8 @@ class CCQPSolverBase(ABC):
 
     def _device_resident(self, run):
         """The effective value of `pipeline` for this solve.  None (the default of all seven solvers) = ON for a plain solve() on the default engine with a dense operator, an elementwise feasible set
-        and a matvec budget of at least 1000: the device-resident forms give the same bits and counts 1.3-2.0x faster at
-        n <= 2048 and up to 1.4x at 4096 ... 16384 (profiles/r04_single_mid*.jsonl); a solve MEANT to run into a small
+        and a matvec budget of at least 1000: the device-resident forms give the same bits and counts 1.5-3.1x faster at
+        n <= 2048 and up to 1.4x at 4096 ... 16384 (profiles/r04_single_mid_all.jsonl); a solve MEANT to run into a small
         budget stays on the host-driven loop, whose exit paths are the reference's."""
         pipeline = getattr(self, "pipeline", False)
         if pipeline is None:
@@ -328,11 +328,11 @@ class _APGDCore(CCQPSolverBase):
         self.pair_matvecs = pair_matvecs
         # SAME results bit for bit: the DEVICE-RESIDENT form of a solve (dense operator with n <= 16384, any set with a
         # device form): line search, momentum and exit test run on the device and rounds are queued ahead (ccqp_bapgd_*, the
-        # lock-step batch scheduler with a batch of one: n <= 128 one launch for the whole solve; up to 2048 rounds of the
-        # VALU kernels; beyond, staging in one launch and FUSED rounds -- one per accepted iteration -- with the persistent
-        # two-vector matvec).  Against the host-driven loop below (one blocking scalar read + ~25 us of Python per
-        # iteration): 1.2-1.9x at n <= 2048, 1.2-1.4x at 4096, 1.05-1.15x at 8192 / 16384 (profiles/r04_single_mid.jsonl);
-        # beyond, a pass over A hides the host.  None (default): ON for elementwise sets when the matvec budget is at
+        # lock-step batch scheduler with a batch of one: n <= 64 one launch for the whole solve; beyond, staging in one
+        # launch and FUSED rounds -- one per accepted iteration: below n = 4096 its two products from one launch of the
+        # batched VALU kernel, from 4096 on the persistent two-vector matvec).  Against the host-driven loop below (one
+        # blocking scalar read + ~25 us of Python per iteration): 2.6-3.0x at n <= 1024, 2.0x at 2048, 1.3-1.5x at 4096,
+        # 1.05-1.15x at 8192 / 16384 (profiles/r04_single_mid_all.jsonl); beyond, a pass over A hides the host.  None (default): ON for elementwise sets when the matvec budget is at
         # least 1000 (a solve that reaches its budget on the device is repeated by the host-driven loop -- the exit paths
         # are the reference's -- so a solve MEANT to run into a small budget, the Cone configs, stays on the host loop);
         # True / False force it.
