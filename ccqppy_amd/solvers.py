@@ -208,7 +208,9 @@ class CCQPSolverBase(ABC):
                 and self.max_matrix_vector_multiplications >= 1000 and run.eng.own_stream is None
         return pipeline
 
-    _LOCKSTEP_ONE_MAX_N = 2048
+    # (with the one-launch staging the batch of one stays ahead of the host loop up to here: PGD 1.3x at 4096, 1.05x at
+    # 8192; BBPGD 1.33x / 1.06x; BBPGDf 1.8x / 1.3x, 1.1x at 16384 -- profiles/r04_single_cap_lifted.jsonl)
+    _LOCKSTEP_ONE_MAX_N = 16384
 
     def _lockstep_one(self, run):
         """PGD / BBPGDf with a device-resident solve (pipeline): the whole solve as a lock-step batch of ONE (ccqp_bpipe_*:
@@ -271,7 +273,7 @@ class CCQPSolverPGD(CCQPSolverBase):
         super().__init__(desired_residual_tol, max_matrix_vector_multiplications)
         self.step_size = step_size
         # SAME results bit for bit: None (default) = the device-resident form where _device_resident says so (a plain
-        # solve() with a dense operator of n <= 2048, an elementwise set, a budget of at least 1000): the lock-step batch
+        # solve() with a dense operator of n <= 16384, an elementwise set, a budget of at least 1000): the lock-step batch
         # scheduler with a batch of one -- step, matvec, residual and exit test on the device, iterations queued ahead.
         # PGD takes thousands of iterations of ~25 us of host turn-around each; False = the host-driven loop below.
         self.pipeline = pipeline
@@ -684,8 +686,9 @@ class _BBPGDCore(CCQPSolverBase):
         tol, max_mv = self.desired_residual_tol, self.max_matrix_vector_multiplications
         eng = run.eng
         if self._device_resident(run) and self.trace is None and self.pipeline != "graph":
-            # (dense, n <= 2048, elementwise set: the lock-step batch of one -- BBPGD too: 0.22-0.30 ms per solve against
-            # 0.31-0.37 for the device-resident loop below, which stays for larger / sparse / matrix-free operators)
+            # (dense, n <= 16384, elementwise set: the lock-step batch of one -- BBPGD too: 0.22-0.30 ms per solve at
+            # n <= 2048 against 0.31-0.37 for the device-resident loop below, 0.57 against 0.61 at 4096; that loop stays for
+            # larger, sparse and matrix-free operators)
             out = self._lockstep_one(run)
             if out is not None:
                 return out
@@ -885,7 +888,7 @@ class CCQPSolverMPRGP(CCQPSolverBase):
         # expansion step two instead of four.  None (default): wherever the operator reads its matrix once for the three
         # (square dense, aligned, an even n >= 4096); True / False force it.
         self.look_ahead = look_ahead
-        # SAME results bit for bit (dense operator of n <= 2048, elementwise set with array bounds): every branch decision on
+        # SAME results bit for bit (dense operator of n <= 16384, elementwise set with array bounds): every branch decision on
         # the device, rounds queued ahead (ccqp_bmprgp_*, the lock-step batch scheduler with a batch of one, staging in one
         # launch); a solve that would reach the matvec budget falls back to the loop below.  None (default): ON where
         # _device_resident says so (a plain solve(), budget >= 1000): 2.0-2.4x the host-driven loop at n <= 512, 1.6x at
@@ -896,11 +899,10 @@ class CCQPSolverMPRGP(CCQPSolverBase):
     def name(self):
         return "MPRGP"
 
-    # largest n of a device-resident solve: x2.2 at 256, x1.6 at 1024, x1.24 at 2048 against the
-    # host-driven loop; from 4096 on (the batch of one looks ahead: three products per pass, the persistent launch) its
-    # seven launches per round cost more than the host's turn-around: 0.91-0.98x at 4096 ... 16384
-    # (profiles/r04_single_mid.jsonl), so the host-driven loop with its own look-ahead stays the form there
-    _PIPELINE_MAX_N = 2048
+    # largest n of a device-resident solve: x2.2 at 256, x1.6 at 1024, x1.24 at 2048 against the host-driven loop; from
+    # 4096 on (the batch of one looks ahead: three products per pass, the persistent launch) x1.13 at 4096, x1.08 at 8192,
+    # x1.04 at 16384 with the one-launch staging (profiles/r04_single_cap_lifted.jsonl; before it 0.91-0.98x)
+    _PIPELINE_MAX_N = 16384
 
     def _lockstep(self, run):
         from ._record import RecordingEngine

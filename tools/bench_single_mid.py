@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--solvers", default="APGD,APGDAntiRelaxation,MPRGP")
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--grid", type=int, default=0, help="0: lock-step rounds instead of the one-launch cooperative solve")
+    ap.add_argument("--cap", type=int, default=0, help="A/B: largest n of the device-resident form of PGD / BBPGD(f) / MPRGP")
     add_option_args(ap)
     args = ap.parse_args()
     options = apply_options(args)
@@ -33,6 +34,9 @@ def main():
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     box = box_id(0)
     lockstep._APGD_GRID_SOLVE = bool(args.grid)
+    if args.cap:
+        solvers.CCQPSolverBase._LOCKSTEP_ONE_MAX_N = args.cap
+        solvers.CCQPSolverMPRGP._PIPELINE_MAX_N = args.cap
     for n in (int(v) for v in args.sizes.split(",")):
         op, b, _ = problems.random_problem(n, 1234)
         P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
