@@ -328,7 +328,7 @@ static int bmprgp_launch_gemv_on(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, in
                                  hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool ahead = elementwise && bmprgp_looks_ahead(ctx, count, n, flags);
-  if (ahead || bp_pers_default(t, flags, count, n)) {
+  if (ahead || bp_pers_default(ctx, t, flags, count, n)) {
     if (init == 0 && ahead) {
       hipLaunchKernelGGL(bmprgp_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, n);
       const bmprgp_resolve3 rsv3 = {dev_probs};

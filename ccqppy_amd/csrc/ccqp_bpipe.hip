@@ -247,7 +247,7 @@ struct bpipe_resolve {
 
 int ccqp_bp_gemv(ccqp_ctx* ctx, const ccqp_pprob* probs, int count, int64_t n, int i, int mode, int flags, hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n)) {
+  if (bp_pers_default(ctx, t, flags, count, n)) {
     const bpipe_resolve rsv = {probs, i, mode};
     return bp_launch_gemv_pers<4, 4>(ctx, rsv, count, n, 4, 1, s);
   }
@@ -346,7 +346,7 @@ extern "C" int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int f
   flags &= 0xFFFF;
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool lds_tuned = ((flags >> 1) & 3) == 3 && ((flags >> 4) & 7) >= 4;          // (MPRGP's explicit ring codes)
-  const char* k = (shares ? bp_pers_sharing(ctx, t, flags, count, n, mprgp) : bp_pers_default(t, flags, count, n)) ||
+  const char* k = (shares ? bp_pers_sharing(ctx, t, flags, count, n, mprgp) : bp_pers_default(ctx, t, flags, count, n)) ||
                           (lds_tuned && t.aligned && n % 2 == 0 && n >= 128)
                       ? "bp_gemv_pers_kernel" : "batched VALU kernel";
   strncpy(name, k, (size_t)buflen - 1);
@@ -952,7 +952,7 @@ int ccqp_bapgd_launch_gemv(ccqp_ctx* ctx, const ccqp_papgd* probs, int count, in
                            hipStream_t s, bool elementwise) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
   const bool ahead = elementwise && bapgd_looks_ahead(ctx, count, n, flags, look);
-  if (ahead || bp_pers_default(t, flags, count, n)) {
+  if (ahead || bp_pers_default(ctx, t, flags, count, n)) {
     if (init == 0 && ahead) {
       hipLaunchKernelGGL(bapgd_take_ahead_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, probs, n);
       const bapgd_resolve3 rsv3 = {probs};

@@ -316,7 +316,7 @@ struct bspg_resolve {
 static int bspg_gemv(ccqp_ctx* ctx, const ccqp_pspg* probs, const double* ctl, int count, int64_t n, int which, int flags,
                      hipStream_t s) {
   const bp_mv_tuning t = bp_mv_tune(count, n, flags);
-  if (bp_pers_default(t, flags, count, n)) {
+  if (bp_pers_default(ctx, t, flags, count, n)) {
     const bspg_resolve rsv = {probs, ctl, which};
     return bp_launch_gemv_pers<4, 4>(ctx, rsv, count, n, 4, 1, s);
   }

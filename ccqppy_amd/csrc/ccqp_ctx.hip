@@ -206,6 +206,7 @@ extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
     case CCQP_OPT_LOOKAHEAD_MIN_N:
     case CCQP_OPT_MPRGP_LOOKAHEAD_MIN_N:
     case CCQP_OPT_PERS1_MIN_N: ok = value == 0 || value >= 128; break;
+    case CCQP_OPT_PERS_MIN_MIB: ok = value >= 0 && value <= 1048576; break;
     case CCQP_OPT_MPRGP_LOOKAHEAD:
     case CCQP_OPT_APGD_LOOKAHEAD:
     case CCQP_OPT_BMV_STAGGER: ok = value == 0 || value == 1; break;

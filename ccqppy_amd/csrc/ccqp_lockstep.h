@@ -355,7 +355,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
 }
 
 // The tuned default of every lock-step solver (no loads / rows-x-steps / workgroups field in the tuning word; bits 3
-// and 7 are solver variants): from n = 4096 and 1 GiB of matrices on, the persistent form.  Measured against the VALU
+// and 7 are solver variants): from n = 4096 and 512 MiB of matrices on (1 GiB until round 4), the persistent form.  Measured against the VALU
 // kernels: the launch alone (tools/bmv_sweep.py, profiles/r03_bmv_sweep_stride.jsonl) 128 x 8192 +1.7 %, 512 x 4096
 // +3.4 %, 16 x 8192 +6.5 %, 4 x 8192 +12 %; whole solves (tools/bench_lockstep_matvec_forms.py,
 // profiles/r03_lockstep_matvec_forms.jsonl) n = 4096 / 8192: APGD, MPRGP, SPG, BBPGD +2 ... +6 %.  At n = 1024 / 2048 the
@@ -364,9 +364,17 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
 // `min_n`: solvers that LOOK AHEAD (APGD, MPRGP: two or three products per pass over a matrix) take the persistent form
 // from n = 1024 on -- there its single-product launch ties with the VALU kernels, and a shared pass replaces two or
 // three of them (profiles/r03_lockstep_matvec_forms_small.jsonl).
-static inline bool bp_pers_default(const bp_mv_tuning& t, int flags, int count, int64_t n, int64_t min_n = 4096) {
+// Round 4: the byte threshold is 512 MiB (was 1 GiB; the context's option PERS_MIN_MIB moves it -- the A/B switch of the
+// tools).  Whole solves between the two, persistent against VALU (profiles/r04_lockstep_forms_512mib.jsonl,
+// r04_single_pers_512mib.txt): 4 x 4096 (512 MiB) BBPGD +17 %, SPG +20 %; 6 x 4096 +11 / +15 %; 3 x 5120 +6 %; 1 x 8192
+// +4 ... +7 % (PGD / BBPGD / BBPGDf single solves 2.41 -> 2.25, 1.40 -> 1.32, 1.46 -> 1.38 ms); 2 x 6144 -9 % (and one
+// 6144 -8 %, one 4096 +-0: below the threshold).
+static inline bool bp_pers_default(const ccqp_ctx* ctx, const bp_mv_tuning& t, int flags, int count, int64_t n,
+                                   int64_t min_n = 4096) {
+  // (below n = 4096 -- the runs that share passes, `min_n` -- the threshold stays where it was measured: 1 GiB)
+  const int64_t mib = ccqp_opt(ctx, CCQP_OPT_PERS_MIN_MIB);
   return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= min_n &&
-         8.0 * (double)n * (double)n * (double)count >= 1073741824.0;
+         8.0 * (double)n * (double)n * (double)count >= 1048576.0 * (double)(mib ? mib : n >= 4096 ? 512 : 1024);
 }
 // smallest n at which a lock-step run that shares passes takes the persistent form (the context's options LOOKAHEAD_MIN_N
 // for APGD, MPRGP_LOOKAHEAD_MIN_N for MPRGP are the tools' A/B switches).  MPRGP shares up to three products per pass and
@@ -383,7 +391,7 @@ static inline int64_t bp_lookahead_min_n(const ccqp_ctx* ctx, bool mprgp = false
 // three single ones there (4096^2: 27 against 46 us for a pair, 31 against 71 us for a triple, profiles/r03_gemv2_small.jsonl),
 // which is what makes a device-resident single solve of 2048 < n <= 16384 faster than the host-driven loop.
 static inline bool bp_pers_sharing(const ccqp_ctx* ctx, const bp_mv_tuning& t, int flags, int count, int64_t n, bool mprgp) {
-  if (bp_pers_default(t, flags, count, n, bp_lookahead_min_n(ctx, mprgp))) return true;
+  if (bp_pers_default(ctx, t, flags, count, n, bp_lookahead_min_n(ctx, mprgp))) return true;
   const int64_t m = ccqp_opt(ctx, CCQP_OPT_PERS1_MIN_N) ? ccqp_opt(ctx, CCQP_OPT_PERS1_MIN_N) : 4096;
   return (flags & ~(1 | 8 | 128)) == 0 && t.aligned && n % 2 == 0 && n >= m;
 }

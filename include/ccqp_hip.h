@@ -72,7 +72,8 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *   BMV_LOADS              matrix loads of the persistent batched matvecs: 1 = non-temporal, 2 = plain (default: by size)
  *   SMALL_SHARING          lock-step APGD BELOW the persistent matvec's sizes: fused rounds whose two products come from one
  *                          launch of the VALU kernel: 1 = never, 2 = whatever the batch (default: batches with <= 256 MiB
- *                          of matrices) */
+ *                          of matrices)
+ *   PERS_MIN_MIB           MiB of matrices from which a lock-step batch of n >= 4096 takes the persistent matvec (512) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
   CCQP_OPT_GEMV2_WPB = 1,
@@ -88,7 +89,8 @@ enum {
   CCQP_OPT_PERS1_MIN_N = 11,
   CCQP_OPT_BMV_LOADS = 12,
   CCQP_OPT_SMALL_SHARING = 13,
-  CCQP_OPT_COUNT = 14
+  CCQP_OPT_PERS_MIN_MIB = 14,
+  CCQP_OPT_COUNT = 15
 };
 int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
 int ccqp_ctx_get_option(ccqp_ctx* ctx, int key, int64_t* value);
@@ -476,7 +478,7 @@ int64_t ccqp_bpipe_partials_doubles(int64_t n);
 /* Name of the kernel the batched matvec of ALL lock-step forms runs as for `count` problems of size n under `flags`
  * (bit 0 = aligned operands, the rest the tuning word): "bp_gemv_pers_kernel" -- ONE persistent LDS-DMA launch whose
  * waves walk the live problems' matrices (rows through per-wave LDS rings, a wave's 4 rows about 1 MiB apart); the
- * tuned default from n = 4096 and 1 GiB of matrices on (the runs that look ahead -- ccqp_bapgd_*, ccqp_bmprgp_* and their
+ * tuned default from n = 4096 and 512 MiB of matrices on (the runs that look ahead -- ccqp_bapgd_*, ccqp_bmprgp_* and their
  * segmented forms -- already from n = 1024: set bit 16 of `flags` to ask for those) -- or "batched VALU kernel".  Same
  * bits either way. */
 int ccqp_bpipe_matvec_form(ccqp_ctx* ctx, int count, int64_t n, int flags, char* name, int buflen);

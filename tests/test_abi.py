@@ -71,7 +71,7 @@ def test_product_fails_loudly_without_gpu():
 
 def test_which_form_the_batched_matvec_takes_is_host_arithmetic(built_lib):
     """ccqp_bpipe_matvec_form is a pure host query (no device call; a NULL context = no tuning options set): the persistent
-    LDS-DMA launch from n = 4096 and 1 GiB of matrices on; for the runs that share passes between products (bit 16) from
+    LDS-DMA launch from n = 4096 and 512 MiB of matrices on; for the runs that share passes between products (bit 16) from
     n = 1024 (APGD) / n = 512 (MPRGP, bit 18) on with 1 GiB of matrices, and from n = 4096 on whatever the bytes -- down to
     a batch of one problem."""
     from ccqppy_amd import _lib
@@ -93,4 +93,6 @@ def test_which_form_the_batched_matvec_takes_is_host_arithmetic(built_lib):
     assert form(4096, 512, 1 | (1 << 16) | (1 << 18)) == "bp_gemv_pers_kernel" and form(511, 512, 1 | (1 << 16) | (1 << 18)) == "batched VALU kernel"
     assert form(1, 4096, 1 | (1 << 16)) == "bp_gemv_pers_kernel" and form(1, 4096, 1) == "batched VALU kernel"
     assert form(1, 2048, 1 | (1 << 16)) == "batched VALU kernel" and form(3, 8192, 1 | (1 << 16)) == "bp_gemv_pers_kernel"
+    assert form(4, 4096, 1) == "bp_gemv_pers_kernel" and form(3, 4096, 1) == "batched VALU kernel"     # 512 MiB
+    assert form(1, 8192, 1) == "bp_gemv_pers_kernel" and form(1, 6144, 1) == "batched VALU kernel"
     assert lib.ccqp_bpipe_matvec_form(None, 0, 1024, 1, ctypes.create_string_buffer(8), 8) != 0

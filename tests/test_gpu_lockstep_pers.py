@@ -1,5 +1,5 @@
 """The batched matvec of every lock-step solver as ONE persistent LDS-DMA launch (bp_gemv_pers_kernel, the tuned default
-from n = 4096 and 1 GiB of matrices on) against the batched VALU kernels (an explicit rows-x-steps field in the tuning
+from n = 4096 and 512 MiB of matrices on) against the batched VALU kernels (an explicit rows-x-steps field in the tuning
 word keeps them): the same bits, MV counts and residuals per problem, and those of each problem's own solve()."""
 import contextlib
 import ctypes
@@ -35,7 +35,8 @@ def test_which_batches_take_the_persistent_form():
     assert _form(128, 8192, 1 | 8) == "bp_gemv_pers_kernel"          # (bits 3 / 7: solver variants, not tuning)
     assert _form(128, 8192, 1 | (3 << 4)) == "batched VALU kernel"    # an explicit rows-x-steps field
     assert _form(128, 8192, 0) == "batched VALU kernel"               # unaligned operands
-    assert _form(7, 4096, 1) == "batched VALU kernel"                 # below 1 GiB
+    assert _form(3, 4096, 1) == "batched VALU kernel"                 # below 512 MiB
+    assert _form(4, 4096, 1) == "bp_gemv_pers_kernel" and _form(1, 8192, 1) == "bp_gemv_pers_kernel"
     assert _form(512, 2048, 1) == "batched VALU kernel"               # n < 4096
     assert _form(8, 4097, 1) == "batched VALU kernel"                 # odd n
     assert _form(600, 4096, 1) == "bp_gemv_pers_kernel"               # (more than 512 problems: one launch per 512)
@@ -53,7 +54,7 @@ def test_which_batches_take_the_persistent_form():
                                             ("BBPGD", True), ("APGD", True), ("MPRGP", True), ("SPG", True)])
 def test_persistent_batched_matvec_changes_no_bit(kind, segmented):
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
-    n, count = 4096, 8                                    # 8 n^2 count = 1 GiB: the smallest batch that takes the form
+    n, count = 4096, 8                                    # 8 n^2 count = 1 GiB (the form is taken from 512 MiB on)
     assert _form(count, n, 1) == "bp_gemv_pers_kernel"
     probs = []
     for p in range(count):
