@@ -719,6 +719,10 @@ def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmen
         eng.mv_executed += s._executed_matrix_vector_mults
 
 
+# rounds a device-resident SINGLE solve is queued beyond the device's last report: the host needs ~8 us per round, the
+# device 15 ... 90, and every round queued past convergence is three to seven no-op launches -- 2 / 3 are 3-5 % ahead of
+# 6 / 8 on APGD, BBPGD and MPRGP solves of n = 256 ... 4096 (gpurun_out r04M, `tools/bench_single_mid.py --ahead`)
+_ONE_AHEAD = 3
 last_timing = {}            # host-side split of the last _bapgd_run: staging / queueing the rounds / waiting for the queue
 _APGD_FUSED_ROUNDS = True   # (module attribute for the A/B of tools / tests: False = two rounds per accepted iteration)
 # a batch of ONE problem of n >= 4096: the whole solve in one cooperative launch whose rounds are separated by grid barriers
@@ -835,7 +839,7 @@ class _OneWs:
     __slots__ = ("vec", "slab", "partials", "words", "ddesc", "desc", "host", "planes")
 
 
-def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
+def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=None):
     """ONE dense APGD / anti-relaxation APGD problem on an elementwise set, device-resident (the form of
     CCQPSolverAPGD's default pipeline): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve allocation, no
     host-paced torch operation, the descriptor by value); then n <= 64 the whole solve in one launch (one workgroup),
@@ -911,7 +915,7 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
 
         def launch(r):
             check(lib.ccqp_bapgd_round_f64(ctx, dp, 1, n, r, _GD, flags, batch, st))
-        _bpipe_poll_loop(eng, 1, launch, last, ahead)
+        _bpipe_poll_loop(eng, 1, launch, last, ahead or _ONE_AHEAD)
     t2 = time.perf_counter()
     h = ws.host
     check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 32, 20, h, st))      # blocking: the queue has drained
@@ -926,7 +930,7 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=4):
     return True, ws.vec[pick, :n], np.sqrt(np.float64(h[19])), int(h[18])
 
 
-def _bpipe_one(eng, solver, op, b, x0, P, n, ahead=4):
+def _bpipe_one(eng, solver, op, b, x0, P, n, ahead=None):
     """ONE dense PGD / BBPGDf (/ BBPGD) problem on an elementwise set, device-resident: _bpipe_run for a batch of one
     without its per-batch host work -- a cached workspace per size, staging in ONE launch (ccqp_bpipe_stage_one_f64: the
     descriptor by value, no host-paced torch operation), the result words through the pinned mirror.  n <= 64: the whole
@@ -984,7 +988,7 @@ def _bpipe_one(eng, solver, op, b, x0, P, n, ahead=4):
         def launch(k):
             check(lib.ccqp_bpipe_iterate_f64(ctx, dp, 1, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
         check(lib.ccqp_bpipe_start_f64(ctx, dp, 1, n, _GD, flags, batch, st))
-        k = _bpipe_poll_loop(eng, 1, launch, last, ahead)
+        k = _bpipe_poll_loop(eng, 1, launch, last, ahead or _ONE_AHEAD)
         capped = 1 + k >= max_mv
     h = ws.host
     check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 48, 4, h, st))       # blocking: the queue has drained
@@ -1108,7 +1112,7 @@ class _MprgpRun:
         return status, sols, np.sqrt(res2), mvs, execd
 
 
-def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4, device_cap=None):
+def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=None, device_cap=None):
     """ONE dense MPRGP problem on an elementwise set with array bounds, device-resident: _bmprgp_run for a batch of one
     without its per-batch host work (a cached workspace per size, staging in ONE launch -- ccqp_bmprgp_stage_one_f64 --,
     the result words through the pinned mirror); n <= 64: one launch (one workgroup), beyond the lock-step rounds queued
@@ -1169,7 +1173,7 @@ def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=4, device_cap=None):
         if last >= 1:
             def launch(r):
                 check(lib.ccqp_bmprgp_round_f64(ctx, dp, 1, n, r, gd, eps10, flags, batch, st))
-            _bpipe_poll_loop(eng, 1, launch, last, ahead)
+            _bpipe_poll_loop(eng, 1, launch, last, ahead or _ONE_AHEAD)
     h = ws.host
     check(lib.ccqp_read_f64(ctx, ws.slab.data_ptr() + 8 * 32, 24, h, st))      # blocking: the queue has drained
     status, its = h[17], int(h[8])

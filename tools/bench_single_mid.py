@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--solvers", default="APGD,APGDAntiRelaxation,MPRGP")
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--grid", type=int, default=0, help="0: lock-step rounds instead of the one-launch cooperative solve")
+    ap.add_argument("--ahead", type=int, default=0, help="A/B: rounds queued beyond the device's last report (4)")
     ap.add_argument("--cap", type=int, default=0, help="A/B: largest n of the device-resident form of PGD / BBPGD(f) / MPRGP")
     add_option_args(ap)
     args = ap.parse_args()
@@ -34,6 +35,8 @@ def main():
     from ccqppy_amd import lockstep, problems, solvers, solution_spaces as ss
     box = box_id(0)
     lockstep._APGD_GRID_SOLVE = bool(args.grid)
+    if args.ahead:
+        lockstep._ONE_AHEAD = args.ahead
     if args.cap:
         solvers.CCQPSolverBase._LOCKSTEP_ONE_MAX_N = args.cap
         solvers.CCQPSolverMPRGP._PIPELINE_MAX_N = args.cap
