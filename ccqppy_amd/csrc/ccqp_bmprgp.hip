@@ -766,8 +766,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_apply_kernel(const ccqp_pmp
 // The three stages and the update of a round in ONE launch, one workgroup per problem: the workgroup walks the problem's
 // chunks itself (bp_meet_seq), so the stages need no inter-workgroup meeting and follow each other behind workgroup
 // barriers: four launches, with their gaps, become one.  Same bodies, same partial sums in the same order: the bits of
-// the four launches.  Used where a round is bound by its launches -- problems of ONE chunk (n <= 2048), 64 or more of
-// them; at config 5's shape (4 chunks, 128 problems) one workgroup walking 12 chunk passes measured SLOWER than the four
+// the four launches.  Used where a round is bound by its launches -- problems of ONE chunk (n <= 2048), however many
+// (round 4: one problem to 48 problems, fused against four launches, whole solves: n = 128 / 256 +16 ... +22 %, 1024
+// +6 ... +11 %, 2048 +3 ... +4 %, profiles/r04_mprgp_fused_tail_small.jsonl; until then only from 64 problems on); at
+// config 5's shape (4 chunks, 128 problems) one workgroup walking 12 chunk passes measured SLOWER than the four
 // launches over 512 workgroups (not-matvec time of a solve 6.7 against 4.7 ms, profiles/r03_config5_fused_tail_ab.json),
 // so longer problems keep the four launches (MP_FUSED_MAX_BLK is the kernel's capacity, MP_FUSED_USE_BLK the rule).
 #define MP_FUSED_MAX_BLK 8
@@ -869,7 +871,7 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   // the A/B switches of the tools and of tests/test_gpu_bmprgp.py)
   const bool allow_fused = ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) != 1;
   const bool force_fused = ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) == 2;
-  const bool fuse = allow_fused && count >= 64 && nblk <= (force_fused ? MP_FUSED_MAX_BLK : MP_FUSED_USE_BLK);
+  const bool fuse = allow_fused && nblk <= (force_fused ? MP_FUSED_MAX_BLK : MP_FUSED_USE_BLK);
   if (fuse) {
     hipLaunchKernelGGL(bmprgp_tail_fused_kernel, dim3(count), blk, 0, s, dev_probs, gd, eps10, chunk, nblk, dev_batch,
                        ctx->host_slots_dev, (unsigned)count, (double)round);

@@ -103,23 +103,28 @@ def test_two_alternating_halves_change_no_bit(n, count, segmented, monkeypatch):
         _same(a, c)
 
 
-@pytest.mark.parametrize("n,count", [(300, 70), (2049, 64), (4500, 66)])
-def test_fused_stage_launch_of_wide_batches_changes_no_bit(n, count):
-    """From 64 problems of at most 8 reduction chunks on, the three decision stages and the update of a round are ONE
-    launch with one workgroup per problem walking the chunks itself (bmprgp_tail_fused_kernel, bp_meet_seq) instead of
-    four launches with inter-workgroup meeting points.  Same partial sums in the same order: the results of the same
-    problems solved in a narrower batch (the four-launch form) and of their own solve()."""
+@pytest.mark.parametrize("n,count", [(300, 70), (300, 3), (1024, 1), (2048, 5)])
+def test_fused_stage_launch_of_one_chunk_problems_changes_no_bit(n, count):
+    """Problems of ONE reduction chunk (n <= 2048), however many: the three decision stages and the update of a round are
+    ONE launch with one workgroup per problem (bmprgp_tail_fused_kernel, bp_meet_seq) instead of four launches.  Same
+    partial sums in the same order: the results of the four-launch form (context option MPRGP_FUSED_TAIL = 1) and of each
+    problem's own solve()."""
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
     probs = _problems(n, count, 5200 + n, width=0.25)
     tols = [1e-6] * count
-    wide = _batch(probs, tols, 3000, single_launch=False)
-    narrow = _batch(probs[:40], tols[:40], 3000, single_launch=False) + _batch(probs[40:], tols[40:], 3000, single_launch=False)
-    for a, c in zip(narrow, wide):
+    fused = _batch(probs, tols, 3000, single_launch=False)
+    eng.set_option("MPRGP_FUSED_TAIL", 1)
+    try:
+        plain = _batch(probs, tols, 3000, single_launch=False)
+    finally:
+        eng.set_option("MPRGP_FUSED_TAIL", 0)
+    for a, c in zip(plain, fused):
         assert c.solution_converged
         _same(a, c)
     ref = _reference(probs[::17], tols[::17], 3000)
-    for a, c in zip(ref, wide[::17]):
+    for a, c in zip(ref, fused[::17]):
         _same(a, c)
-    assert len({c.solution_num_matrix_vector_multiplications for c in wide}) >= 1
 
 
 def test_fused_stage_launch_forced_on_longer_problems_in_a_child_process():
