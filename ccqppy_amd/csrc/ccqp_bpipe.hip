@@ -661,7 +661,10 @@ __device__ __forceinline__ void bapgd_decide_scalars(const ccqp_papgd& q, double
 // work-item sums the segmented residual launch (ccqp_bsegs.hip) has left in ps->workspace
 // `z`: the caller's entry snapshot of the slab (ap_enter) -- this function only WRITES the slab
 // `fuse`: see bapgd_decide_scalars
-template <bool LOCKSTEP>
+// UW: elements of the chunk walk whose loads are in flight together (8 = the whole chunk of a thread: the latency-bound
+// lock-step launch of a FEW blocks; the single-launch solve -- thousands of workgroups, bound by how many of them a CU
+// holds -- takes 2: 237 -> fewer than 128 registers, four workgroups per CU instead of two)
+template <bool LOCKSTEP, int UW = 8>
 __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_words& z, int bx, double gd,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
                                                   unsigned count, double seq, double* lds4, int* is_last_p, int ar,
@@ -687,7 +690,7 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
     }
     return;
   }
-  bapgd_trial_sums<8>(q, z, bx, 0, gd, chunk, ar, ps, n_segs, v);
+  bapgd_trial_sums<UW>(q, z, bx, 0, gd, chunk, ar, ps, n_segs, v);
   ccqp_block_sum_multi<8>(v);
   if (!bp_meet(q.partials, q.counter, nblk, ar ? 8 : 7, v, lds4, is_last_p)) return;
   if (ps) {
@@ -1210,9 +1213,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bsolve_apgd_kernel(const ccqp_papg
     if (z.done != 0.0 || z.mv >= mv_limit) break;
     bapgd_gemv_body<4, ALIGNED, false>(q, 0, n, wave, nwaves);
     __syncthreads();
-    bapgd_decide_body<false>(q, z, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar);
+    bapgd_decide_body<false, 2>(q, z, 0, gd, chunk, 1, nullptr, nullptr, 0u, 0.0, lds4, &is_last, ar);
     __syncthreads();
-    bapgd_apply_body(q, 0, 1);                 // (nothing to do for a problem that has just converged)
+    bapgd_apply_body<1>(q, 0, 1);              // (nothing to do for a problem that has just converged)
     __syncthreads();
   }
 }

@@ -25,9 +25,29 @@ from ._engine import get_engine
 stats = {"fallback_solves": 0, "auto_declined": 0, "halved_runs": 0, "grid_solves": 0, "grid_gave_up": 0}
 
 _BPIPE_MAX = 16384        # problems per lock-step group (gridDim.y <= 65535; keeps the workspace bounded)
-_BSOLVE_MAX_N = 512       # BBPGD: up to this size one workgroup solves a whole problem in a single launch
-_BSOLVE_MAX_N_MPRGP = 128 # MPRGP: likewise
-_BSOLVE_MAX_N_APGD = 128  # APGD: likewise (measured: x3.5 at n = 32, x1.5 at 128, x0.9 at 256)
+# The single-launch form (one workgroup solves a whole problem: ccqp_bsolve_*) is a form for MANY SMALL problems: a
+# workgroup sits on one CU and walks its matrix alone, so it needs problems for every CU several times over -- and small
+# ones -- before it beats the lock-step rounds, which round 4 made cheaper (fused APGD rounds, the fused MPRGP stage
+# launch, the lean roll-call).  One workgroup per problem against the rounds (profiles/r04_single_launch_vs_rounds.jsonl:
+# whole batches through solve_batch_pipelined, host staging included; r04_stacked_single_launch_vs_rounds.jsonl: stacked
+# tensors, device-bound):
+#   BBPGD  n <= 128: x1.4-2.4 stacked, level to x1.3 through the list API at every count; 256: x1.03-1.12 from 256
+#          problems on, x0.70-0.80 below; 512: x0.87-0.94 stacked, x0.37-0.80 below 1024 problems
+#   APGD   (its single-launch kernel back under 128 registers -- the 80 loads in flight of the lock-step decision had cost
+#          it half its workgroups per CU) n = 32: x1.06 list, x1.7-1.9 stacked; 64: x0.72-0.79 up to 32 problems, level at
+#          256, x1.17-1.22 stacked; 128: x0.47-0.82 up to 256 problems, x1.06-1.26 from 1024 on; 256: x0.46-0.79
+#   MPRGP  n = 32: x1.2; 64: level below 256 problems, x1.08-1.21 above; 128: x0.69-0.94 up to 256, level beyond; 256 /
+#          512: x0.56-0.69
+# Default of `single_launch` (None), per solver: the size up to which it is taken whatever the count, then (size, smallest
+# count) steps.  (Until round 4: BBPGD n <= 512, APGD / MPRGP n <= 128, whatever the count.)
+_SINGLE_LAUNCH_RULE = {"bbpgd": (128, ((256, 256),)),
+                       "apgd": (32, ((64, 256), (128, 1024))),
+                       "mprgp": (32, ((64, 256), (128, 1024)))}
+
+
+def _single_launch_default(kind, n, count):
+    always, steps = _SINGLE_LAUNCH_RULE[kind]
+    return n <= always or any(n <= size and count >= least for size, least in steps)
 
 
 def _device_budget(n):
@@ -161,7 +181,8 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
     """Many dense problems (grouped by size n: one run per size), each solved by PGD, BBPGD, BBPGDf, APGD, anti-relaxation
     APGD or MPRGP with every scalar and branch decision on the device (ccqp_bpipe_* / ccqp_bapgd_* / ccqp_bmprgp_*):
     lock-step rounds of 3-5 launches per matvec for the whole batch while the host only polls a progress word, or --
-    small matrices (BBPGD-type n <= 512, APGD / MPRGP n <= 128 by default; `single_launch` forces it on, up to
+    small matrices, many of them (by default: BBPGD-type n <= 128, <= 256 from 256 problems on; APGD and MPRGP n <= 32,
+    <= 64 from 256 problems, <= 128 from 1024 -- _SINGLE_LAUNCH_RULE; `single_launch` forces it on, up to
     n = 2048, or off) -- ONE launch in which every problem is solved inside its own workgroup.  The host-driven
     schedulers of batch.py are bound by ~20 us of Python per problem and scalar read at n <= 4096; this one is not.
 
@@ -454,7 +475,7 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
         check(lib.ccqp_bpipe_iterate_f64(ctx, dp, B, n, k, _GD, float(_EPS10), flags, int(1 + k < max_mv), batch, st))
 
     if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N
+        single_launch = _single_launch_default("bbpgd", n, B)
     single_launch = bool(single_launch) and n <= 2048
     if single_launch:
         # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
@@ -791,7 +812,7 @@ def _bapgd_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, ar=False
             check(lib.ccqp_bapgd_round_f64(ctx, dp, B, n, r, _GD, flags, batch, st))
 
     if single_launch is None:
-        single_launch = n <= _BSOLVE_MAX_N_APGD
+        single_launch = _single_launch_default("apgd", n, B)
     single_launch = bool(single_launch) and n <= 2048 and plans is None
     t_staged = time.perf_counter()
     if grid and not single_launch:
@@ -842,7 +863,7 @@ class _OneWs:
 def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=None):
     """ONE dense APGD / anti-relaxation APGD problem on an elementwise set, device-resident (the form of
     CCQPSolverAPGD's default pipeline): staging in ONE launch (ccqp_bapgd_stage_one_f64: no per-solve allocation, no
-    host-paced torch operation, the descriptor by value); then n <= 64 the whole solve in one launch (one workgroup),
+    host-paced torch operation, the descriptor by value); then n <= 32 the whole solve in one launch (one workgroup),
     beyond the FUSED lock-step rounds -- one round per accepted iteration: below n = 4096 both products from one launch of
     the VALU kernel, from 4096 on the persistent three-vector matvec; then the decision, then the update -- all queued `ahead` beyond the device's last report; the result words through the pinned mirror.  Returns (done, x, residual, matvecs); done False: the budget was reached first (the host-driven loop's exits)."""
     import ctypes
@@ -895,9 +916,9 @@ def _bapgd_one(eng, solver, op, b, x0, P, n, ahead=None):
                                        ws.words.data_ptr(), st))
     last = max(0, max_mv - 2) if np.isfinite(max_mv) else np.inf
     grid = sharing and _APGD_GRID_SOLVE and aligned and _sharing_form(eng, 1, n, 1)
-    # (ONE problem: the one-workgroup solve only for tiny matrices -- at n = 128 it takes 1.2 ms, the rounds 0.7;
-    # profiles/r04_single_mid.jsonl -- it is a form for MANY problems, one per compute unit)
-    single = n <= 64
+    # (ONE problem: the one-workgroup solve only for tiny matrices -- at n = 128 it takes 1.2 ms, the rounds 0.5, at n = 64
+    # four problems 0.93 against 0.71 ms; profiles/r04_single_launch_vs_rounds.jsonl -- it is a form for MANY problems)
+    single = n <= 32
     if grid:
         rc = lib.ccqp_bsolve_apgd_grid_f64(ctx, dp, n, _GD, flags & 9, int(last) if np.isfinite(last) else 10 ** 7, batch, st)
         if rc == _lib.ERR_UNSUPPORTED:
@@ -1076,7 +1097,7 @@ class _MprgpRun:
             self.vec, self.slabs, self.keep = vec, slabs, (keep, words, dprobs, dsegs, seg_ws)
             return
         if single_launch is None:
-            single_launch = n <= _BSOLVE_MAX_N_MPRGP
+            single_launch = _single_launch_default("mprgp", n, B)
         self.single_launch = single_launch = bool(single_launch) and n <= 2048
         if single_launch:
             # small matrices: the whole solve of every problem in ONE launch, one workgroup per problem
@@ -1115,7 +1136,7 @@ class _MprgpRun:
 def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=None, device_cap=None):
     """ONE dense MPRGP problem on an elementwise set with array bounds, device-resident: _bmprgp_run for a batch of one
     without its per-batch host work (a cached workspace per size, staging in ONE launch -- ccqp_bmprgp_stage_one_f64 --,
-    the result words through the pinned mirror); n <= 64: one launch (one workgroup), beyond the lock-step rounds queued
+    the result words through the pinned mirror); n <= 32: one launch (one workgroup), beyond the lock-step rounds queued
     `ahead` beyond the device's last report.  Returns (status, x, residual, reported matvecs, executed matvecs); status 1 =
     converged, anything else = not finished here.  `device_cap`: the device gives up after this many matvecs (the caller
     then runs the host-driven loop: a solve that STALLS short of its tolerance -- MPRGP does at tol <= 1e-8 on well
@@ -1163,7 +1184,7 @@ def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=None, device_cap=None):
     check(lib.ccqp_bmprgp_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n,
                                         ws.words.data_ptr(), st))
     gd, eps10 = _GD, float(_EPS10)
-    if n <= 64:
+    if n <= 32:
         check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, 1, n, gd, eps10, float(min(max_mv - 1, _device_budget(n))), flags & 1, st))
     else:
         # the count stands at 2 after the start-up and grows by at most one per round; the rounds stop where the problem
@@ -1206,7 +1227,8 @@ def _bmprgp_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None, halves=
     -- 434-435 against 430-431 (+1.1 %; 256 x 4096: +0.5 %; 64 x 8192 and 256 x 2048: nothing or a loss, hence the
     thresholds)."""
     B = len(spec)
-    single = plans is None and (n <= _BSOLVE_MAX_N_MPRGP if single_launch is None else bool(single_launch)) and n <= 2048
+    single = plans is None and (_single_launch_default("mprgp", n, B) if single_launch is None else bool(single_launch)) \
+        and n <= 2048
     if halves is None:
         halves = _HALVES_DEFAULT and (not single) and tune == 0 and n >= _HALF_MIN_N and B >= _HALF_MIN_PROBLEMS \
             and 8.0 * n * n * B >= _HALF_MIN_BYTES

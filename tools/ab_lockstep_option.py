@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of ONE context option on whole lock-step solves: problems/s of `solve_batch_pipelined` for each shape n:B under
 every value given, best of a few repetitions, same bits and counts asserted across the values.
-    python tools/ab_lockstep_option.py --solver MPRGP --option MPRGP_FUSED_TAIL --values 0,2 --shapes 256:1,256:8,1024:4"""
+    python tools/ab_lockstep_option.py --solver MPRGP --option MPRGP_FUSED_TAIL --values 0,2 --shapes 256:1,256:8,1024:4
+    python tools/ab_lockstep_option.py --solver BBPGD --option SINGLE_LAUNCH --values 0,1 --shapes 128:4,256:16,512:64
+(SINGLE_LAUNCH is not a context option but the `single_launch` argument: rounds against one workgroup per problem)"""
 import argparse
 import json
 import os
@@ -40,17 +42,21 @@ def main():
         out, res = {}, {}
         try:
             for v in values:
-                eng.set_option(args.option, v)
+                # (the pseudo-option SINGLE_LAUNCH: 0 = lock-step rounds, 1 = one workgroup per problem, one launch)
+                single = bool(v) if args.option == "SINGLE_LAUNCH" else False
+                if args.option != "SINGLE_LAUNCH":
+                    eng.set_option(args.option, v)
                 best = np.inf
                 for _ in range(args.reps + 1):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    r = lockstep.solve_batch_pipelined(lambda: cls(*tolmv), probs, device=0, single_launch=False)
+                    r = lockstep.solve_batch_pipelined(lambda: cls(*tolmv), probs, device=0, single_launch=single)
                     torch.cuda.synchronize()
                     best = min(best, time.perf_counter() - t0)
                 out[v], res[v] = best, r
         finally:
-            eng.set_option(args.option, 0)
+            if args.option != "SINGLE_LAUNCH":
+                eng.set_option(args.option, 0)
         same = all(np.array_equal(host(a.solution).view(np.uint64), host(c.solution).view(np.uint64)) and
                    a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
                    for v in values[1:] for a, c in zip(res[values[0]], res[v]))
