@@ -43,8 +43,9 @@ def main():
         try:
             for v in values:
                 # (the pseudo-option SINGLE_LAUNCH: 0 = lock-step rounds, 1 = one workgroup per problem, one launch)
-                single = bool(v) if args.option == "SINGLE_LAUNCH" else False
-                if args.option != "SINGLE_LAUNCH":
+                # (DEFAULT: nothing set, `single_launch=None` -- the library's own choice of form)
+                single = bool(v) if args.option == "SINGLE_LAUNCH" else None if args.option == "DEFAULT" else False
+                if args.option not in ("SINGLE_LAUNCH", "DEFAULT"):
                     eng.set_option(args.option, v)
                 best = np.inf
                 for _ in range(args.reps + 1):
@@ -55,7 +56,7 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 out[v], res[v] = best, r
         finally:
-            if args.option != "SINGLE_LAUNCH":
+            if args.option not in ("SINGLE_LAUNCH", "DEFAULT"):
                 eng.set_option(args.option, 0)
         same = all(np.array_equal(host(a.solution).view(np.uint64), host(c.solution).view(np.uint64)) and
                    a.solution_num_matrix_vector_multiplications == c.solution_num_matrix_vector_multiplications
