@@ -502,6 +502,11 @@ def _bpipe_run(eng, spec, n, max_mv, ahead, tune=0, single_launch=None):
     return done, final, sols, np.sqrt(res2), todo
 
 
+def _rows(sols, count):
+    """The rows of a (B, n) result tensor as views, taken apart in one call (a batch of ONE hands over its (n,) row)."""
+    return sols.unbind(0) if sols.dim() == 2 else (sols,) * count
+
+
 def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     import contextlib
     import io
@@ -510,6 +515,9 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
     host = None
     todo = set(todo.tolist())
     pgd = hasattr(items[0][0], "step_size")
+    # (per problem only attribute stores: the rows, counts and residuals are taken apart once, not indexed 8192 times)
+    rows, finals, dones, ress = _rows(sols, len(items)), final.tolist(), done.tolist(), list(res)
+    executed = 0
     for p, it in enumerate(items):
         s = it[0]
         if p in todo:                                    # beyond the single-launch kernel's own budget
@@ -518,19 +526,21 @@ def _bpipe_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None):
                 stats["fallback_solves"] += 1
                 _host_solve(s, A, b, x0, P)
             continue
-        mv = 1 + int(final[p])
+        k = finals[p]
+        mv = 1 + k
         if it[5]:
-            s._solution = sols[p]
+            s._solution = rows[p]
         else:
             if host is None:
                 host = sols.cpu().numpy()
             s._solution = host[p]
         s._solution_converged = mv < max_mv
-        s._solution_residual = res[p]
+        s._solution_residual = ress[p]
         s._solution_num_matrix_vector_mults = mv
         # start-up: A x0 and -- BBPGD, unless the start already satisfies the tolerance -- A g0 (executed, not counted)
-        s._executed_matrix_vector_mults = mv if (pgd or (done[p] and final[p] == 0)) else 2 + int(final[p])
-        eng.mv_executed += s._executed_matrix_vector_mults
+        s._executed_matrix_vector_mults = ex = mv if (pgd or (dones[p] and k == 0)) else 2 + k
+        executed += ex
+    eng.mv_executed += executed
 
 
 def _psegs_table(plans, dev):
@@ -1028,25 +1038,29 @@ def _bapgd_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segme
     done, sols, res, mvs = _bapgd_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune, single_launch,
                                       ar=items[0][0]._anti_relaxation, plans=plans)
     host = None
+    rows, dones, mvl, ress = _rows(sols, len(items)), done.tolist(), mvs.tolist(), list(res)
+    executed = 0
     for p, it in enumerate(items):
         s = it[0]
-        if not done[p]:                                  # budget reached: the reference's own exit path
+        if not dones[p]:                                 # budget reached: the reference's own exit path
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
                 stats["fallback_solves"] += 1
                 _host_solve(s, A, b, x0, P)
             continue
         if it[5]:
-            s._solution = sols[p]
+            s._solution = rows[p]
         else:
             if host is None:
                 host = sols.cpu().numpy()
             s._solution = host[p]
-        s._solution_converged = int(mvs[p]) < max_mv
-        s._solution_residual = res[p]
-        s._solution_num_matrix_vector_mults = int(mvs[p])
-        s._executed_matrix_vector_mults = int(mvs[p])
-        eng.mv_executed += int(mvs[p])
+        mv = mvl[p]
+        s._solution_converged = mv < max_mv
+        s._solution_residual = ress[p]
+        s._solution_num_matrix_vector_mults = mv
+        s._executed_matrix_vector_mults = mv
+        executed += mv
+    eng.mv_executed += executed
 
 
 class _MprgpRun:
@@ -1273,25 +1287,28 @@ def _bmprgp_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segm
     status, sols, res, mvs, execd = _bmprgp_run(eng, _spec_from_items(eng, items, n), n, max_mv, ahead, tune,
                                                 single_launch, plans=plans)
     host = None
+    rows, stl, mvl, exl, ress = _rows(sols, len(items)), status.tolist(), mvs.tolist(), execd.tolist(), list(res)
+    executed = 0
     for p, it in enumerate(items):
         s = it[0]
-        if status[p] != 1.0:                             # budget reached (or the search that cannot terminate)
+        if stl[p] != 1.0:                                # budget reached (or the search that cannot terminate)
             A, b, x0, P = it[6]
             with contextlib.redirect_stdout(io.StringIO()):
                 stats["fallback_solves"] += 1
                 _host_solve(s, A, b, x0, P)
             continue
         if it[5]:
-            s._solution = sols[p]
+            s._solution = rows[p]
         else:
             if host is None:
                 host = sols.cpu().numpy()
             s._solution = host[p]
-        s._solution_converged = int(mvs[p]) < max_mv
-        s._solution_residual = res[p]
-        s._solution_num_matrix_vector_mults = int(mvs[p])
-        s._executed_matrix_vector_mults = int(execd[p])
-        eng.mv_executed += int(execd[p])
+        s._solution_converged = mvl[p] < max_mv
+        s._solution_residual = ress[p]
+        s._solution_num_matrix_vector_mults = mvl[p]
+        s._executed_matrix_vector_mults = exl[p]
+        executed += exl[p]
+    eng.mv_executed += executed
 
 
 # ---------------------------------------------------------------------------------------------
