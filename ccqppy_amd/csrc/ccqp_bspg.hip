@@ -335,6 +335,33 @@ struct bspg_group {
   bool inflight;          // a round with a dots launch is queued and not yet consumed
 };
 
+// Staging of ONE lock-step SPG problem in ONE launch (the device-resident form of a single solve, as
+// ccqp_bapgd_stage_one_f64): the descriptor by value to `dev_desc`, x0 (NULL: zeros) into x, the problem's arrival counter
+// and the two batch words, the eight exchange words (control | dot products) zeroed.
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_stage_one_kernel(const ccqp_pspg desc, ccqp_pspg* __restrict__ dev_desc,
+                                                                    const double* __restrict__ x0, int64_t n,
+                                                                    uint32_t* __restrict__ words, double* __restrict__ xchg) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) *dev_desc = desc;
+    if (threadIdx.x < 3) words[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) xchg[threadIdx.x] = 0.0;
+  }
+  double* __restrict__ x = desc.x;
+  for (int64_t i = (int64_t)blockIdx.x * CCQP_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CCQP_BLOCK)
+    x[i] = x0 ? x0[i] : 0.0;
+}
+
+extern "C" int ccqp_bspg_stage_one_f64(ccqp_ctx* ctx, const ccqp_pspg* host_desc, ccqp_pspg* dev_desc, const double* x0,
+                                       int64_t n, uint32_t* words, double* xchg, void* stream) {
+  CCQP_REQUIRE(ctx != nullptr && host_desc != nullptr && dev_desc != nullptr && words != nullptr && xchg != nullptr,
+               "NULL argument");
+  CCQP_REQUIRE(n >= 1 && host_desc->x != nullptr, "incomplete descriptor");
+  hipLaunchKernelGGL(bspg_stage_one_kernel, dim3(bp_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, *host_desc,
+                     dev_desc, x0, n, words, xchg);
+  CCQP_LAUNCH_CHECK();
+  return CCQP_OK;
+}
+
 extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, const ccqp_psegs* dev_segs,
                                  ccqp_spg_host* host, double* queue, int64_t qstride,
                                  const ccqp_draw_source* const* sources, int count, int64_t n, int64_t max_nwork,

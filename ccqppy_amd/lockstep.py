@@ -714,6 +714,62 @@ def _bspg_run(eng, spec, solvers, n, max_mv, tune=0, plans=None, rngs=None, para
     return host, vec[0]
 
 
+def _bspg_one(eng, solver, op, b, x0, P, n, rng):
+    """ONE dense SPG problem on an elementwise set, device-resident: _bspg_run for a batch of one without its per-batch
+    host work (a cached workspace per size, staging in ONE launch on the engine's stream -- ccqp_bspg_stage_one_f64 -- and
+    no stream synchronisation before the C driver, which runs on the same stream).  Returns (host record, x)."""
+    import contextlib
+    import ctypes
+    from . import _lib
+    lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
+    A = op.A
+    aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
+    flags = int(aligned) | (8 if _SPG_ONE_GROUP else 0)
+    cache = eng.__dict__.setdefault("_bspg_one_ws", {})
+    ws = cache.get(n)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[n] = _OneWs()
+        nblk = max(int(lib.ccqp_bpipe_partials_doubles(n)) // 3, 1)
+        stride = (n + 1) // 2 * 2
+        ws.vec = torch.empty((4, stride), dtype=torch.float64, device=dev)      # planes: x, g, d, Ad
+        ws.partials = torch.empty(3 * nblk, dtype=torch.float64, device=dev)
+        ws.words = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws.slab = torch.zeros(8, dtype=torch.float64, device=dev)               # (the exchange words: control | dots)
+        ws.ddesc = torch.zeros(ctypes.sizeof(_lib.PSpg), dtype=torch.uint8, device=dev)
+        d = ws.desc = _lib.PSpg()
+        base = ws.vec.data_ptr()
+        d.x, d.g, d.d, d.Ad = (base + 8 * stride * j for j in range(4))
+        d.partials, d.counter = ws.partials.data_ptr(), ws.words.data_ptr()
+    d = ws.desc
+    d.A, d.lda, d.b = A.data_ptr(), A.stride(0), b.data_ptr()
+    d.seg = P._seg(eng, 0, n)
+    _lib.check(lib.ccqp_bspg_stage_one_f64(ctx, ctypes.byref(d), ws.ddesc.data_ptr(),
+                                           None if x0 is None else x0.data_ptr(), n, ws.words.data_ptr(),
+                                           ws.slab.data_ptr(), st))
+    host = np.zeros(1, dtype=np.dtype(_lib.SpgHost))
+    host["tol"] = float(solver.desired_residual_tol)
+    host["max_mv"] = solver.max_matrix_vector_multiplications
+    host["m"], host["tau"], host["sigma1"], host["sigma2"] = solver.m, solver.t, solver.sigma1, solver.sigma2
+    qstride = int(solver.m)
+    queue = np.zeros((1, qstride))
+    sources = np.array([_draw_source(rng)], dtype=np.uint64)
+    more = ctypes.c_int(1)
+    start = 1
+    # (the C driver draws from the generator's bitgen_t record directly, outside the GIL: hold the generator's own lock)
+    with contextlib.ExitStack() as held:
+        held.enter_context(rng._bit_generator.lock)
+        while more.value:
+            _lib.check(lib.ccqp_bspg_run_f64(ctx, ws.ddesc.data_ptr(), None, host.ctypes.data, queue.ctypes.data, qstride,
+                                             sources.ctypes.data, 1, n, 0, 0, flags, start, _SPG_ROUNDS,
+                                             ws.slab.data_ptr(), ws.slab.data_ptr() + 32, ws.words.data_ptr() + 4,
+                                             ctypes.byref(more), st))
+            start = 0
+    # (a VIEW of the workspace: the caller's export copies it on this stream before the next solve can stage over it)
+    return host, ws.vec[0, :n]
+
+
 def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmented=False):
     import contextlib
     import io

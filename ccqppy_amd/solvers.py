@@ -797,13 +797,15 @@ class CCQPSolverSPG(CCQPSolverBase):
     def name(self):
         return "SPG-QP"
 
-    _PIPELINE_MAX_N = 2048
+    # (1.5-1.6x the host-driven loop at n <= 1024, 1.4x at 2048, 1.22x at 4096, 1.08x at 8192:
+    # profiles/r04_single_spg.jsonl)
+    _PIPELINE_MAX_N = 16384
 
     def _lockstep(self, run):
         """pipeline=True: the whole solve through the lock-step driver as a batch of one; None where that does not
         apply (the host-driven loop below then runs, and raises what the reference raises)."""
         from ._record import RecordingEngine
-        from .lockstep import _SPG_MAX_M, _bspg_run, _spec_from_items
+        from .lockstep import _SPG_MAX_M, _bspg_one, _bspg_run, _spec_from_items
         from .operators import DenseOperator
         op, eng, P = run.op, run.eng, run.P
         rng = self.rng if self.rng is not None else np.random.mtrand._rand      # numpy's global legacy generator
@@ -813,9 +815,12 @@ class CCQPSolverSPG(CCQPSolverBase):
                 and 1 <= self.m <= _SPG_MAX_M and (elementwise or P._has_device_form())
                 and not isinstance(eng, RecordingEngine) and eng.gemv_events is None):
             return None
-        plans = None if elementwise else [P._segplan(eng, run.n)]
-        host, sols = _bspg_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n), [self], run.n,
-                               self.max_matrix_vector_multiplications, plans=plans, rngs=[rng])
+        if elementwise:
+            host, x = _bspg_one(eng, self, op, run.b, run.x0 if run.x0_given else None, P, run.n, rng)
+            sols = [x]
+        else:
+            host, sols = _bspg_run(eng, _spec_from_items(eng, [(self, op, run.b, run.x0, P)], run.n), [self], run.n,
+                                   self.max_matrix_vector_multiplications, plans=[P._segplan(eng, run.n)], rngs=[rng])
         h = host[0]
         if h["status"] == 3:
             if h["used"]:                               # numpy's own OverflowError, after `used` successful draws (:959)

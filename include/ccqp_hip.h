@@ -740,6 +740,11 @@ typedef struct ccqp_draw_source {
 int ccqp_bspg_host_step(ccqp_spg_host* host, double* queue, int64_t qstride, const double* dots,
                         const ccqp_draw_source* const* sources, const double* u, const unsigned char* live,
                         int count);
+/* Staging of ONE lock-step SPG problem in one launch (as ccqp_bapgd_stage_one_f64): *host_desc to dev_desc, x = x0 (NULL:
+ * zeros), words[0..2] (arrival counter, the two batch words) = 0, xchg[0..7] (dev_ctl | dev_out of ccqp_bspg_run_f64 for
+ * one problem) = 0.  Then ccqp_bspg_run_f64 with count = 1 on the same stream. */
+int ccqp_bspg_stage_one_f64(ccqp_ctx* ctx, const ccqp_pspg* host_desc, ccqp_pspg* dev_desc, const double* x0, int64_t n,
+                            uint32_t* words, double* xchg, void* stream);
 /* Runs rounds until every problem has left status 0 (*more = 0) or `max_rounds` rounds have been run (*more = 1:
  * call again with start = 0; lets the caller stay interruptible).  start != 0 first does the start-up (:921-932: g0,
  * A g0, fk = g0.x0 (sic), alpha = g0.g0 / g0.A g0, mv = 2).

@@ -40,6 +40,7 @@ def main():
     if args.cap:
         solvers.CCQPSolverBase._LOCKSTEP_ONE_MAX_N = args.cap
         solvers.CCQPSolverMPRGP._PIPELINE_MAX_N = args.cap
+        solvers.CCQPSolverSPG._PIPELINE_MAX_N = args.cap
     for n in (int(v) for v in args.sizes.split(",")):
         op, b, _ = problems.random_problem(n, 1234)
         P = ss.BoxProjOp(n, -0.5 * np.ones(n), 0.5 * np.ones(n))
