@@ -355,9 +355,11 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv_pers_kernel(const Resolve 
   if (nlive == 0) return;
   // staggered start (gemv_lds_kernel, ccqp_gemv.hip): the waves walk the same column positions at the same pace; the
   // delay unit follows the bytes the LIVE problems make this launch read (a round in which one problem of 64 is left
-  // must not wait as the full batch would)
+  // must not wait as the full batch would); a launch that reads less than 1 GiB starts at once -- there the delay of
+  // up to 63 sleeps only lengthens the tail (single APGD solves, staggered -> not: n = 4096 1.053 -> 1.044 ms, 6144
+  // 1.830 -> 1.768, 8192 2.402 -> 2.384, but 16384 -- 2 GiB -- 6.37 -> 6.61: profiles/r04_single_stagger.txt)
   float su = stagger_per_problem * (float)nlive;
-  const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
+  const int stagger = (stagger_per_problem <= 0.f || su < 0.25f) ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
   for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
   gemv_lds_multi_body<R, S, NT>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
 #endif
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bp_gemv3_pers_kernel(const Resolve
   const int nlive = nlive_s;
   if (nlive == 0) return;
   float su = stagger_per_problem * (float)nlive;
-  const int stagger = stagger_per_problem <= 0.f ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
+  const int stagger = (stagger_per_problem <= 0.f || su < 0.25f) ? 0 : su < 1.f ? 1 : su > 32.f ? 32 : (int)(su + 0.5f);
   for (int i = (int)((((int64_t)blockIdx.x * wpb + w) * 37) & 63) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
   gemv_lds3_multi_body<R, S, NT>(D, nlive, n, (int64_t)blockIdx.x * wpb + w, (int64_t)gridDim.x * wpb, ring + w * RING, res, rs);
 #endif
