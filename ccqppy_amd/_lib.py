@@ -213,7 +213,8 @@ SIGNATURES = {
     "ccqp_bsolve_mprgp_f64": [_P, _P, _I, _I64, _D, _D, _D, _I, _P],
     "ccqp_bapgd_stage_one_f64": [_P, _c.POINTER(PApgd), _P, _P, _I64, _D, _P, _P],
     "ccqp_bpipe_stage_one_f64": [_P, _c.POINTER(PProb), _P, _P, _I64, _D, _P, _P],
-    "ccqp_bmprgp_stage_one_f64": [_P, _c.POINTER(PMprgp), _P, _P, _I64, _P, _P],
+    "ccqp_bmprgp_stage_one_f64": [_P, _c.POINTER(PMprgp), _P, _P, _I64, _D, _P, _P],
+    "ccqp_bmprgp_fused_form": [_P, _I, _I64, _I],
     "ccqp_bspg_stage_one_f64": [_P, _c.POINTER(PSpg), _P, _P, _I64, _P, _P, _P],
     "ccqp_read_f64": [_P, _P, _I, _c.POINTER(_D), _P],
     "ccqp_bsolve_apgd_grid_f64": [_P, _P, _I64, _D, _I, _I64, _P, _P],

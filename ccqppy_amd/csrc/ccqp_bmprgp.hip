@@ -50,6 +50,9 @@
 // computes the product (the stage of the M1 / AP round).
 #define MP_AHEAD 53
 #define MP_LOOK 54
+// fused rounds (round 4, flags bit 18: small batches of one-chunk problems): the matvec budget the DEVICE enforces,
+// max_mv - 1 (0: none) -- a launch may pass through several rounds, so the host's launch count no longer bounds the count
+#define MP_LIMIT 55
 #define MP_DONE BP_DONE  // 49: 1 converged, 2 the feasibility search cannot terminate (:1113-1118), 3 proportioning step
 #define MP_MV BP_ITERS   // 50: the reference's mv_count
 #define MP_RES2 BP_RES2  // 51
@@ -66,7 +69,7 @@ enum { ACT_NONE = 0, ACT_CGFULL, ACT_HALF, ACT_AFTER_G1 };
 
 // entry snapshot of a problem's steering words (ccqp_lockstep.h: the meeting-point invariant)
 struct mp_words {
-  double done, state, it, mv, exec, dist2, ng, af, tried, acg, s0, s1, ahead, look;
+  double done, state, it, mv, exec, dist2, ng, af, tried, acg, s0, s1, ahead, look, limit;
 };
 __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   mp_words z;
@@ -84,6 +87,7 @@ __device__ __forceinline__ mp_words mp_enter(const double* __restrict__ slab) {
   z.s1 = slab[MP_S1];
   z.ahead = slab[MP_AHEAD];
   z.look = slab[MP_LOOK];
+  z.limit = slab[MP_LIMIT];
   __syncthreads();
   return z;
 }
@@ -317,6 +321,46 @@ static bool bmprgp_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int fl
   return !ccqp_opt(ctx, CCQP_OPT_MPRGP_LOOKAHEAD) && bp_pers_sharing(ctx, bp_mv_tune(count, n, flags), flags, count, n, true);
 }
 
+// ---- fused rounds of small batches (round 4; flags bit 18 = CCQP_LOCKSTEP_FUSED_ROUNDS: slab slot 55 holds max_mv - 1)
+// A batch of one-chunk problems whose matrices fit the MALL together is bound by the NUMBER of its launches.  The
+// look-ahead alone does not help it (measured: it saves passes over the matrices, not rounds -- the M1 and A.p rounds of a
+// CG step remain, without a matvec); what helps is to pass THROUGH those rounds in the launch that already holds the
+// problem: the fused stage launch (one workgroup per problem, bmprgp_tail_fused_kernel) goes on to the next round as
+// long as that round's product is there -- A.x_k + b and A.p computed ahead by the A.dx launch, or a feasibility search
+// that repeats -- taking the product over itself (what bmprgp_take_ahead_kernel does between launches).  A CG step is
+// then TWO launches -- one batched VALU launch with the three products of the A.dx round as grid slices
+// (bp_gemv3_valu_kernel; a problem in any other state multiplies its one product in slice 0), one stage launch -- instead
+// of six (matvec + stages, three times).  The device enforces the budget (MP_LIMIT): a problem whose next round would
+// pass max_mv - 1 stops with MP_DONE = 4 and is left to the host-driven loop, where the unfused run's launch cap leaves
+// it.  Same bodies, same order per problem: the bits and counts of the unfused rounds.
+struct bmprgp_resolve3_any {
+  const ccqp_pmprgp* probs;
+  __device__ bool operator()(int p, gemv_lds3_desc* d) const {
+    const bmprgp_resolve3 r3 = {probs};
+    if (r3(p, d)) return true;
+    bmprgp_mv m;
+    if (!bmprgp_mv_operands(probs[p], 0, &m)) return false;
+    d->A = probs[p].A;
+    d->lda = probs[p].lda;
+    d->b = m.b;
+    d->x[0] = d->x[1] = d->x[2] = m.x;
+    d->y[0] = m.y;
+    d->g[0] = m.g;
+    d->y[1] = d->y[2] = nullptr;
+    d->g[1] = d->g[2] = nullptr;
+    return true;
+  }
+};
+
+#define MP_FUSED_PASSES 4                     // rounds one fused launch passes through at most
+static bool bmprgp_fused_rounds(const ccqp_ctx* ctx, int count, int64_t n, int flags, bool fuse_asked) {
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  return fuse_asked && !ccqp_opt(ctx, CCQP_OPT_MPRGP_LOOKAHEAD) && ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) != 1 &&
+         nblk <= 1 && !bmprgp_looks_ahead(ctx, count, n, flags) && bp_valu_sharing(ctx, flags, count, n);
+}
+
 template <int R, int S>
 static int bmprgp_launch_gemv_pers(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int init, int wpb,
                                    int bpc, hipStream_t s) {
@@ -482,7 +526,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
   double* s = q.slab;                         // written only (by the deciding thread); read through `z` alone
   const mp_words z = mp_enter(s);
   if (z.done != 0.0) {
-    if (LOCKSTEP && stage == 3 && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+    if (LOCKSTEP && host && stage == 3 && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
   const ccqp_segk sg = bp_segk_of(q);
@@ -664,7 +708,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
         s[MP_DONE] = 3.0;
         if (LOCKSTEP) __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (LOCKSTEP) bp_report(batch, host, count, seq);
+      if (LOCKSTEP && host) bp_report(batch, host, count, seq);
     }
     return;
   }
@@ -691,12 +735,13 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
       s[MP_AHALF] = v[0] / den;
       s[MP_ACT] = (double)ACT_HALF;
       s[MP_STATE] = (double)ST_G1;
-      if (LOCKSTEP) bp_report(batch, host, count, seq);
+      if (LOCKSTEP && host) bp_report(batch, host, count, seq);
     }
     return;
   }
   // nothing to reduce in this stage: the roll-call only.  (One designated thread: no state is written here.)
-  if (LOCKSTEP && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
+  // (host == NULL: the fused-rounds launch reports once, after its last pass)
+  if (LOCKSTEP && host && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
 }
 
 __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmprgp* __restrict__ probs, int stage,
@@ -778,29 +823,73 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccq
                                                                        double eps10, int64_t chunk, int nblk,
                                                                        unsigned* __restrict__ batch,
                                                                        double* __restrict__ host, unsigned count,
-                                                                       double seq) {
+                                                                       double seq, int passes) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   __shared__ double seqpart[MP_STEPS * MP_FUSED_MAX_BLK];
   const ccqp_pmprgp& q = probs[blockIdx.x];
-  for (int stage = 1; stage <= 3; ++stage) {
-    for (int bx = 0; bx < nblk; ++bx)
-      bmprgp_stage_body<true, true>(q, stage, bx, gd, eps10, chunk, nblk, batch, host, count, seq, lds4, &is_last, seqpart);
+  if (passes <= 0) {
+    // one round (the stage launch of the ordinary lock-step rounds)
+    for (int stage = 1; stage <= 3; ++stage) {
+      for (int bx = 0; bx < nblk; ++bx)
+        bmprgp_stage_body<true, true>(q, stage, bx, gd, eps10, chunk, nblk, batch, host, count, seq, lds4, &is_last, seqpart);
+      __syncthreads();
+    }
+    bmprgp_apply_body(q, 0, 1);
+    return;
+  }
+  // fused rounds (one chunk per problem): pass through the rounds whose product is already there
+  const int64_t n = q.seg.dim;
+  for (int pass = 0; pass < passes; ++pass) {
+    // (the slab words below were written by this workgroup's own thread 0 before the last barrier, or by earlier launches)
+    double* s = q.slab;
+    const double done = s[MP_DONE], mv = s[MP_MV], limit = s[MP_LIMIT];
+    const int st = (int)s[MP_STATE], ahead = (int)s[MP_AHEAD], it = (int)s[MP_IT];
+    int go = 1;
+    if (done != 0.0) {
+      go = 0;
+    } else if (pass > 0) {
+      // the round that would follow: only if it needs no matvec launch
+      go = (st == ST_M1 && (ahead & 5)) || (st == ST_AP && (ahead & 2)) || st == ST_FEAS_WAIT;
+    }
+    const bool counts = st == ST_M1 || st == ST_AP || st == ST_G1;        // (the rounds whose stage 1 counts a matvec)
+    if (go && counts && limit > 0.0 && mv + 1.0 > limit) {
+      // the budget: this problem is left to the host-driven loop (whose exits are the reference's)
+      __syncthreads();                          // (every thread has read the words above)
+      if (threadIdx.x == 0) {
+        s[MP_DONE] = 4.0;
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      go = 0;
+    }
+    if (!go) break;                             // (uniform: every thread read the same words)
+    if (st == ST_M1 && (ahead & 1)) {
+      // A.x_k + b was computed ahead into the OTHER gradient buffer: take it (bmprgp_take_ahead_kernel)
+      const double* __restrict__ from = q.G[(it + 1) & 1];
+      double* __restrict__ to = q.G[it & 1];
+      for (int64_t i = threadIdx.x; i < n; i += CCQP_BLOCK) to[i] = from[i];
+    }
+    __syncthreads();
+    for (int stage = 1; stage <= 3; ++stage) {
+      bmprgp_stage_body<true, true>(q, stage, 0, gd, eps10, chunk, 1, batch, nullptr, count, seq, lds4, &is_last, seqpart);
+      __syncthreads();
+    }
+    bmprgp_apply_body(q, 0, 1);
     __syncthreads();
   }
-  bmprgp_apply_body(q, 0, 1);
+  if (threadIdx.x == 0) bp_report(batch, host, count, seq);
 }
 
 // ---------------------------------------------------------------------------------------------------- entry points
 // Staging of ONE lock-step MPRGP problem in ONE launch (the device-resident form of a single solve, as
 // ccqp_bapgd_stage_one_f64): the descriptor by value to `dev_desc`, the slab zeroed, x0 (NULL: zeros) into X[1], the
-// problem's arrival counter and the two batch words zeroed.
+// problem's arrival counter and the two batch words zeroed; slab slot 55 = `limit` (fused rounds: max_mv - 1, 0: none).
 __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_one_kernel(const ccqp_pmprgp desc, ccqp_pmprgp* __restrict__ dev_desc,
-                                                                      const double* __restrict__ x0, int64_t n,
+                                                                      const double* __restrict__ x0, int64_t n, double limit,
                                                                       uint32_t* __restrict__ words) {
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) *dev_desc = desc;
-    if (threadIdx.x < 64) desc.slab[threadIdx.x] = 0.0;
+    if (threadIdx.x < 64) desc.slab[threadIdx.x] = threadIdx.x == MP_LIMIT ? limit : 0.0;
     if (threadIdx.x < 3) words[threadIdx.x] = 0u;
   }
   double* __restrict__ X1 = desc.X[1];
@@ -809,19 +898,27 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_one_kernel(const ccqp
 }
 
 extern "C" int ccqp_bmprgp_stage_one_f64(ccqp_ctx* ctx, const ccqp_pmprgp* host_desc, ccqp_pmprgp* dev_desc, const double* x0,
-                                         int64_t n, uint32_t* words, void* stream) {
+                                         int64_t n, double limit, uint32_t* words, void* stream) {
   CCQP_REQUIRE(ctx != nullptr && host_desc != nullptr && dev_desc != nullptr && words != nullptr, "NULL argument");
   CCQP_REQUIRE(n >= 1 && host_desc->X[1] != nullptr && host_desc->slab != nullptr, "incomplete descriptor");
   hipLaunchKernelGGL(bmprgp_stage_one_kernel, dim3(bp_vec_grid(n)), dim3(CCQP_BLOCK), 0, (hipStream_t)stream, *host_desc,
-                     dev_desc, x0, n, words);
+                     dev_desc, x0, n, limit, words);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
+}
+
+// whether a run's rounds are fused (see the header)
+extern "C" int ccqp_bmprgp_fused_form(ccqp_ctx* ctx, int count, int64_t n, int flags) {
+  if (count < 1 || n < 1) return 0;
+  return bmprgp_fused_rounds(ctx, count, n, flags & 0xFFFF, (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0) ? 2 : 0;
 }
 
 // Start-up of all solves (solvers.py:1063-1081).  Expects x0 staged in X[1], slabs and counters zero.
 extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd,
                                      int flags, uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
+  const bool fuse_asked = (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0;
+  flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
   int nblk;
@@ -831,7 +928,8 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   hipLaunchKernelGGL(bmprgp_init_x_kernel, vgrid, blk, 0, s, dev_probs);
   int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 1, flags, s);
   if (rc) return rc;
-  const bool look = bmprgp_looks_ahead(ctx, count, n, flags);
+  const bool fused = bmprgp_fused_rounds(ctx, count, n, flags, fuse_asked);
+  const bool look = fused || bmprgp_looks_ahead(ctx, count, n, flags);
   hipLaunchKernelGGL(bmprgp_init_res_kernel, rgrid, blk, 0, s, dev_probs, gd, chunk, nblk, dev_batch, look ? 1.0 : 0.0);
   if (look) {
     // p_0 first (it needs x_0 and g_0 only), then A.g_0 and A.p_0 in one pass over every matrix
@@ -840,7 +938,10 @@ extern "C" int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
     rc = ccqp_mv_stream_enter(ctx, s, &ms);
     if (rc) return rc;
     const bmprgp_resolve3_start rsv3 = {dev_probs};
-    rc = bp_launch_gemv3(ctx, rsv3, count, n, ms);
+    if (fused)
+      bp_launch_gemv3_valu(rsv3, count, n, flags, 2, ms);      // (fused rounds: the products as slices of a VALU launch)
+    else
+      rc = bp_launch_gemv3(ctx, rsv3, count, n, ms);
     if (rc) return rc;
     rc = ccqp_mv_stream_leave(ctx, s, ms);
     if (rc) return rc;
@@ -860,11 +961,28 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
                                      double gd, double eps10, int flags, uint32_t* dev_batch, void* stream) {
   BP_CHECK_BATCH();
   CCQP_REQUIRE(round >= 1, "rounds count from 1");
+  const bool fuse_asked = (flags & CCQP_LOCKSTEP_FUSED_ROUNDS) != 0;
+  flags &= 0xFFFF;
   hipStream_t s = (hipStream_t)stream;
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
   const dim3 rgrid(nblk, count), blk(CCQP_BLOCK);
+  if (bmprgp_fused_rounds(ctx, count, n, flags, fuse_asked)) {
+    // TWO launches: every live problem's product(s) -- the three of an A.dx round as grid slices --, then the stage
+    // launch that passes through the rounds whose products are there
+    hipStream_t ms = s;
+    int rcf = ccqp_mv_stream_enter(ctx, s, &ms);
+    if (rcf) return rcf;
+    const bmprgp_resolve3_any rsv = {dev_probs};
+    bp_launch_gemv3_valu(rsv, count, n, flags, 3, ms);
+    rcf = ccqp_mv_stream_leave(ctx, s, ms);
+    if (rcf) return rcf;
+    hipLaunchKernelGGL(bmprgp_tail_fused_kernel, dim3(count), blk, 0, s, dev_probs, gd, eps10, chunk, nblk, dev_batch,
+                       ctx->host_slots_dev, (unsigned)count, (double)round, (int)MP_FUSED_PASSES);
+    CCQP_LAUNCH_CHECK();
+    return CCQP_OK;
+  }
   const int rc = bmprgp_launch_gemv(ctx, dev_probs, count, n, 0, flags, s);
   if (rc) return rc;
   // (by shape; the context's option MPRGP_FUSED_TAIL: 1 keeps the four launches, 2 fuses wherever the kernel can run --
@@ -874,7 +992,7 @@ extern "C" int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs
   const bool fuse = allow_fused && nblk <= (force_fused ? MP_FUSED_MAX_BLK : MP_FUSED_USE_BLK);
   if (fuse) {
     hipLaunchKernelGGL(bmprgp_tail_fused_kernel, dim3(count), blk, 0, s, dev_probs, gd, eps10, chunk, nblk, dev_batch,
-                       ctx->host_slots_dev, (unsigned)count, (double)round);
+                       ctx->host_slots_dev, (unsigned)count, (double)round, 0);
   } else {
     for (int stage = 1; stage <= 3; ++stage)
       hipLaunchKernelGGL(bmprgp_stage_kernel, rgrid, blk, 0, s, dev_probs, stage, gd, eps10, chunk, nblk, dev_batch,

@@ -810,6 +810,7 @@ def _bspg_group(eng, items, n, max_mv, ahead, tune=0, single_launch=None, segmen
 # device 15 ... 90, and every round queued past convergence is three to seven no-op launches -- 2 / 3 are 3-5 % ahead of
 # 6 / 8 on APGD, BBPGD and MPRGP solves of n = 256 ... 4096 (gpurun_out r04M, `tools/bench_single_mid.py --ahead`)
 _ONE_AHEAD = 3
+_MPRGP_FUSED_ROUNDS = True  # (module attribute for the A/B of tools / tests: False = one round per launch everywhere)
 last_timing = {}            # host-side split of the last _bapgd_run: staging / queueing the rounds / waiting for the queue
 _APGD_FUSED_ROUNDS = True   # (module attribute for the A/B of tools / tests: False = two rounds per accepted iteration)
 # a batch of ONE problem of n >= 4096: the whole solve in one cooperative launch whose rounds are separated by grid barriers
@@ -1141,6 +1142,12 @@ class _MprgpRun:
         for j, name in enumerate(names[4:]):
             tab[name] = planes[4 + j]
         flags = _bpipe_flags(tab, n, tune)
+        if plans is None and _MPRGP_FUSED_ROUNDS:
+            # bit 18: FUSED ROUNDS where the library has a form for them (small batches of one-chunk problems: a launch
+            # passes through the rounds whose products are there); the device then enforces the budget itself: max_mv - 1 in
+            # slab slot 55 (0 = none), a problem that reaches it ends with slot 49 = 4 and goes to the host-driven loop
+            flags |= _lib.LOCKSTEP_FUSED_ROUNDS
+            slabs[:, 55] = float(max_mv - 1) if np.isfinite(max_mv) else 0.0
         dprobs = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
         dp, batch = dprobs.data_ptr(), words.data_ptr() + 4 * B
         check = _lib.check
@@ -1217,7 +1224,7 @@ def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=None, device_cap=None):
     lib, ctx, st, dev = eng.lib, eng.ctx, eng.stream, eng.device
     A = op.A
     aligned = n % 2 == 0 and A.data_ptr() % 16 == 0 and A.stride(0) % 2 == 0 and b.data_ptr() % 16 == 0
-    flags = int(aligned)
+    flags = int(aligned) | (_lib.LOCKSTEP_FUSED_ROUNDS if _MPRGP_FUSED_ROUNDS else 0)
     max_mv = solver.max_matrix_vector_multiplications
     if device_cap is not None:
         max_mv = min(max_mv, device_cap)
@@ -1252,7 +1259,7 @@ def _bmprgp_one(eng, solver, op, b, x0, P, n, ahead=None, device_cap=None):
     check = _lib.check
     dp, batch = ws.ddesc.data_ptr(), ws.words.data_ptr() + 4
     check(lib.ccqp_bmprgp_stage_one_f64(ctx, ctypes.byref(d), dp, None if x0 is None else x0.data_ptr(), n,
-                                        ws.words.data_ptr(), st))
+                                        float(max_mv - 1) if np.isfinite(max_mv) else 0.0, ws.words.data_ptr(), st))
     gd, eps10 = _GD, float(_EPS10)
     if n <= 32:
         check(lib.ccqp_bsolve_mprgp_f64(ctx, dp, 1, n, gd, eps10, float(min(max_mv - 1, _device_budget(n))), flags & 1, st))

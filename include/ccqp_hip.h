@@ -676,10 +676,21 @@ int ccqp_bsegs_mprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, cons
  * the product, so results and counts are unchanged; ccqp_ctx_set_option(ctx, CCQP_OPT_MPRGP_LOOKAHEAD, 1) turns it off.  The
  * segmented form ccqp_bsegs_mprgp_* looks ahead in the same way.) */
 /* Staging of ONE lock-step MPRGP problem in one launch (as ccqp_bapgd_stage_one_f64): *host_desc to dev_desc, the slab
- * zeroed, X[1] = x0 (NULL: zeros), words[0..2] (arrival counter, the two batch words) = 0.  Then ccqp_bmprgp_start_f64 /
+ * zeroed with slot 55 = limit (fused rounds: max_mv - 1, 0: none), X[1] = x0 (NULL: zeros), words[0..2] (arrival counter,
+ * the two batch words) = 0.  Then ccqp_bmprgp_start_f64 /
  * ccqp_bmprgp_round_f64 on dev_desc. */
 int ccqp_bmprgp_stage_one_f64(ccqp_ctx* ctx, const ccqp_pmprgp* host_desc, ccqp_pmprgp* dev_desc, const double* x0, int64_t n,
-                              uint32_t* words, void* stream);
+                              double limit, uint32_t* words, void* stream);
+/* FUSED ROUNDS of ccqp_bmprgp_start_f64 / ccqp_bmprgp_round_f64 (`flags` bit 18, CCQP_LOCKSTEP_FUSED_ROUNDS: the caller has
+ * put max_mv - 1 -- 0: no budget -- into slab slot 55 of every problem): for a batch of one-chunk problems (n <= 2048)
+ * whose matrices fit the MALL together (256 MiB; context option SMALL_SHARING) a round is TWO launches -- one batched VALU
+ * launch with the products of every live problem (the three of an A.dx round as grid slices: the run looks ahead), one
+ * stage launch that passes THROUGH the rounds whose product is already there (up to four) -- and a CG step one round
+ * instead of three.  The device enforces the budget: a problem whose next round would pass max_mv - 1 ends with slab
+ * slot 49 = 4 and counts as finished in ccqp_bpipe_poll (the caller runs it some other way).  Same bits, same counts.
+ * ccqp_bmprgp_fused_form: 2 if a run of `count` problems of size n under `flags` takes this form, else 0 (NOT an error
+ * code). */
+int ccqp_bmprgp_fused_form(ccqp_ctx* ctx, int count, int64_t n, int flags);
 int ccqp_bmprgp_start_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, double gd, int flags,
                           uint32_t* dev_batch, void* stream);
 int ccqp_bmprgp_round_f64(ccqp_ctx* ctx, const ccqp_pmprgp* dev_probs, int count, int64_t n, int64_t round, double gd,

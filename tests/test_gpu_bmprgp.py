@@ -199,7 +199,9 @@ def test_matvec_timing_hook_of_the_c_abi():
     _lib.check(lib.ccqp_mv_timing_end(buf, 64, ctypes.byref(cnt)))
     assert lib.ccqp_mv_timing_end(buf, 64, ctypes.byref(cnt)) != 0     # closed
     rounds = max(c.executed_matrix_vector_multiplications for c in timed)
-    assert 2 <= cnt.value <= 64 and cnt.value >= min(rounds, 64) - 1
+    # (one launch per executed matvec in the plain rounds; the fused rounds of this small batch multiply up to three
+    # products per launch)
+    assert 2 <= cnt.value <= 64 and cnt.value >= (min(rounds, 64) - 1) // 3
     ms = [buf[i] for i in range(cnt.value)]
     assert all(0.0 < t < 50.0 for t in ms)
     for a, c in zip(plain, timed):
@@ -404,3 +406,47 @@ def test_default_batched_matvec_is_the_persistent_lds_form_and_changes_no_bit(n,
     ref = _reference(probs[:2], tols[:2], 3000)
     for a, c in zip(ref, lds[:2]):
         _same(a, c)
+
+
+@pytest.mark.parametrize("n,count", [(100, 9), (256, 6), (777, 3), (1500, 4), (2048, 1)])
+def test_fused_rounds_of_small_batches_change_no_bit(n, count):
+    """A small batch of one-chunk problems (<= 256 MiB of matrices): a launch of the stage kernel passes THROUGH the rounds
+    whose product is already there (A.x_k + b and A.p computed ahead by the A.dx launch as grid slices of one VALU launch; a
+    feasibility search that repeats) -- two launches per CG step instead of six; the device enforces the budget (slab slot
+    55).  Against the unfused rounds (context option SMALL_SHARING = 1) and each problem's own host-driven solve: x bit
+    for bit, reported and executed counts, residual, converged flag -- wide and tight boxes (expansion steps, repeated
+    feasibility searches), rows 16-byte aligned and not (n = 777), budgets from a handful of matvecs to past convergence."""
+    from ccqppy_amd import _lib, lockstep, solvers
+    from ccqppy_amd._engine import get_engine
+    eng = get_engine(0)
+    fl = int(n % 2 == 0) | _lib.LOCKSTEP_FUSED_ROUNDS
+    for width in (0.3, 0.04):
+        probs = _problems(n, count, 6100 + n, width)
+        tols = [1e-7] * count
+        with contextlib.redirect_stdout(io.StringIO()):
+            full = [solvers.CCQPSolverMPRGP(1e-7, 3000, pipeline=False).solve(A, b, x0=x0, convex_proj_op=P)
+                    for A, b, x0, P in probs]
+        longest = max(r.solution_num_matrix_vector_multiplications for r in full)
+        for cap in (3000, 4, 7, 12, longest - 1, longest, longest + 2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = [solvers.CCQPSolverMPRGP(1e-7, cap, pipeline=False).solve(A, b, x0=x0, convex_proj_op=P)
+                       for A, b, x0, P in probs]
+            got = {}
+            try:
+                for off in (1, 0):
+                    eng.set_option("SMALL_SHARING", off)
+                    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, count, n, fl) == (0 if off else 2)
+                    got[off] = _batch(probs, tols, cap, single_launch=False)
+            finally:
+                eng.set_option("SMALL_SHARING", 0)
+            for a, c, d in zip(ref, got[0], got[1]):
+                _same(a, c)
+                _same(a, d)
+        A, b, x0, P = probs[0]
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = solvers.CCQPSolverMPRGP(1e-7, 3000, pipeline=True).solve(A, b, x0=x0, convex_proj_op=P)
+        _same(full[0], one)
+    assert max(r.executed_matrix_vector_multiplications - r.solution_num_matrix_vector_multiplications for r in full) > 0
+    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 4, 4096, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 0      # two chunks
+    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 33, 1024, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 0     # > 256 MiB
+    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 4, 1024, 1) == 0                                   # not asked for
