@@ -870,7 +870,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccq
       for (int64_t i = threadIdx.x; i < n; i += CCQP_BLOCK) to[i] = from[i];
     }
     __syncthreads();
-    for (int stage = 1; stage <= 3; ++stage) {
+    // (an A.dx or half-step round is over after its first stage: the other two would only read the state again)
+    const int stages = (st == ST_ADXC || st == ST_ADXH || st == ST_G1) ? 1 : 3;
+    for (int stage = 1; stage <= stages; ++stage) {
       bmprgp_stage_body<true, true>(q, stage, 0, gd, eps10, chunk, 1, batch, nullptr, count, seq, lds4, &is_last, seqpart);
       __syncthreads();
     }

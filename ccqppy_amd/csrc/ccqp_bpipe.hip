@@ -168,9 +168,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pp
                                                                    int icur, double gd, double eps10, int64_t chunk,
                                                                    int nblk, unsigned* __restrict__ batch,
                                                                    double* __restrict__ host, unsigned count,
-                                                                   double seq) {
+                                                                   double seq, int step_next) {
   __shared__ double lds4[4];
   __shared__ int is_last;
+  __shared__ double alpha_s;
   const ccqp_pprob& q = probs[blockIdx.y];
   const bp_words z = bp_enter(q.slab);
   if (z.done != 0.0) {                      // converged (now or earlier): only the roll-call
@@ -183,11 +184,20 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pp
   if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
     const double den = v[1] + eps10;
+    const double alpha = v[0] / den;
     q.slab[1] = v[0];
     q.slab[2] = v[1];
-    q.slab[BP_ALPHA] = v[0] / den;
+    q.slab[BP_ALPHA] = alpha;
     q.slab[BP_ITERS] = z.iters + 1.0;
-    bp_report(batch, host, count, seq);
+    alpha_s = alpha;
+    if (!step_next) bp_report(batch, host, count, seq);
+  }
+  if (step_next) {
+    // one-chunk problems (this block is the problem's only one): the step of the NEXT iteration, x = P(x_new - alpha g_new)
+    // (bpipe_step_kernel), taken here -- an iteration is then matvec + tail, not step + matvec + tail
+    __syncthreads();
+    proj_elem_body(bp_segk_of(q), 1.0, q.x[inew], -alpha_s, q.g[inew], q.x[(inew + 1) % 3], 0, 1);
+    if (threadIdx.x == 0) bp_report(batch, host, count, seq);
   }
 }
 
@@ -196,9 +206,10 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
                                                                 int icur, double gd, double eps10, int64_t chunk,
                                                                 int nblk, unsigned* __restrict__ batch,
                                                                 double* __restrict__ host, unsigned count,
-                                                                double seq, int const_step) {
+                                                                double seq, int const_step, int step_next) {
   __shared__ double lds4[4];
   __shared__ int is_last;
+  __shared__ double alpha_s;                // (step_next: the step length of the next iteration; NaN = converged, no step)
   const ccqp_pprob& q = probs[blockIdx.y];
   const bp_words z = bp_enter(q.slab);
   if (z.done != 0.0) {                      // converged earlier: only the roll-call
@@ -213,17 +224,29 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tail_kernel(const ccqp_pprob
     // the host loop's scalar step (solvers.py:647-656): res = sqrt(res2); alpha = dx.dx / (dx.dg + 10 eps)
     const double res = sqrt(v[0]);
     const double den = v[2] + eps10;
+    const double alpha = const_step ? z.alpha : v[1] / den;
     q.slab[0] = v[0];
     q.slab[1] = v[1];
     q.slab[2] = v[2];
     q.slab[BP_RES2] = v[0];
-    if (!const_step) q.slab[BP_ALPHA] = v[1] / den;
+    if (!const_step) q.slab[BP_ALPHA] = alpha;
     q.slab[BP_ITERS] = z.iters + 1.0;
-    if (res < q.tol) {
+    const bool conv = res < q.tol;
+    if (conv) {
       q.slab[BP_DONE] = 1.0;
       __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bp_report(batch, host, count, seq);
+    alpha_s = alpha;
+    is_last = conv ? 2 : 1;                 // (2: converged -- no step)
+    if (!step_next) bp_report(batch, host, count, seq);
+  }
+  if (step_next) {
+    // one-chunk problems (this block is the problem's only one): the step of the NEXT iteration, x = P(x_new - alpha g_new)
+    // (bpipe_step_kernel), taken here -- an iteration is then matvec + tail, not step + matvec + tail
+    __syncthreads();
+    if (is_last != 2)
+      proj_elem_body(bp_segk_of(q), 1.0, q.x[inew], -alpha_s, q.g[inew], q.x[(inew + 1) % 3], 0, 1);
+    if (threadIdx.x == 0) bp_report(batch, host, count, seq);
   }
 }
 
@@ -297,22 +320,28 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   CCQP_REQUIRE(iteration >= 1, "iterations count from 1");
   hipStream_t s = (hipStream_t)stream;
   const int inew = (int)(iteration % 3), icur = (int)((iteration - 1) % 3);
-  hipLaunchKernelGGL(bpipe_step_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur);
+  int64_t chunk;
+  int nblk;
+  ccqp_red_geometry(n, &chunk, &nblk);
+  // one-chunk problems (n <= 2048): the tail of an iteration takes the NEXT iteration's step with it (its only block has
+  // the new step length at hand) -- from the second iteration on a round is two launches, matvec + tail, instead of three
+  // (context option BPIPE_STEP_IN_TAIL = 1: off, the A/B switch of the tools)
+  const int step_in_tail = nblk == 1 && !ccqp_opt(ctx, CCQP_OPT_BPIPE_STEP_IN_TAIL);
+  if (!(step_in_tail && iteration >= 2))
+    hipLaunchKernelGGL(bpipe_step_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur);
   const int rc = bp_gemv(ctx, dev_probs, count, n, inew, 0, flags, s);
   if (rc) return rc;
   if (with_tail) {
-    int64_t chunk;
-    int nblk;
-    ccqp_red_geometry(n, &chunk, &nblk);
     if (flags & BP_FLAG_FALLBACK) {
       hipLaunchKernelGGL(bpipe_tailf_a_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, gd, eps10,
                          chunk, nblk, dev_batch);
       hipLaunchKernelGGL(bpipe_tailf_b_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd,
-                         eps10, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration);
+                         eps10, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
+                         step_in_tail);
     } else {
       hipLaunchKernelGGL(bpipe_tail_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd, eps10,
                          chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
-                         (flags & BP_FLAG_CONST_STEP) != 0);
+                         (flags & BP_FLAG_CONST_STEP) != 0, step_in_tail);
     }
   }
   CCQP_LAUNCH_CHECK();

@@ -209,6 +209,7 @@ extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
     case CCQP_OPT_PERS_MIN_MIB: ok = value >= 0 && value <= 1048576; break;
     case CCQP_OPT_MPRGP_LOOKAHEAD:
     case CCQP_OPT_APGD_LOOKAHEAD:
+    case CCQP_OPT_BPIPE_STEP_IN_TAIL:
     case CCQP_OPT_BMV_STAGGER: ok = value == 0 || value == 1; break;
     case CCQP_OPT_MPRGP_FUSED_TAIL:
     case CCQP_OPT_BMV_LOADS:

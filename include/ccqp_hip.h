@@ -73,7 +73,9 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *   SMALL_SHARING          lock-step APGD BELOW the persistent matvec's sizes: fused rounds whose two products come from one
  *                          launch of the VALU kernel: 1 = never, 2 = whatever the batch (default: batches with <= 256 MiB
  *                          of matrices)
- *   PERS_MIN_MIB           MiB of matrices from which a lock-step batch of n >= 4096 takes the persistent matvec (512) */
+ *   PERS_MIN_MIB           MiB of matrices from which a lock-step batch of n >= 4096 takes the persistent matvec (512)
+ *   BPIPE_STEP_IN_TAIL     1 = lock-step PGD / BBPGD / BBPGDf always launch their step (default: problems of one reduction
+ *                          chunk, n <= 2048, take the next iteration's step in the tail launch) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
   CCQP_OPT_GEMV2_WPB = 1,
@@ -90,7 +92,8 @@ enum {
   CCQP_OPT_BMV_LOADS = 12,
   CCQP_OPT_SMALL_SHARING = 13,
   CCQP_OPT_PERS_MIN_MIB = 14,
-  CCQP_OPT_COUNT = 15
+  CCQP_OPT_BPIPE_STEP_IN_TAIL = 15,
+  CCQP_OPT_COUNT = 16
 };
 int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
 int ccqp_ctx_get_option(ccqp_ctx* ctx, int key, int64_t* value);
