@@ -172,14 +172,38 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bpipe_tailf_b_kernel(const ccqp_pp
   __shared__ double lds4[4];
   __shared__ int is_last;
   __shared__ double alpha_s;
+  __shared__ int part_a[3];                 // (step_next: part A's decision -- improved, fall back, converged)
   const ccqp_pprob& q = probs[blockIdx.y];
   const bp_words z = bp_enter(q.slab);
   if (z.done != 0.0) {                      // converged (now or earlier): only the roll-call
     if (blockIdx.x == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
     return;
   }
+  bool improved = z.improved != 0.0, fallback = z.fallback != 0.0;
+  if (step_next) {
+    // one-chunk problems: part A (bpipe_tailf_a_kernel: the residual, the exit test, "best so far", "fall back") runs HERE,
+    // in the problem's only block, instead of in a launch of its own -- the same body and decision, the flags handed on
+    // through LDS instead of the slab
+    const double r = residual_body(bp_segk_of(q), q.x[inew], q.g[inew], q.c, gd, chunk, 0, lds4);
+    if (threadIdx.x == 0) {
+      const bool conv = bbf_decide_a(q.slab, z, r, q.tol, eps10);
+      if (conv) {
+        q.slab[BP_ITERS] = z.iters + 1.0;
+        q.slab[BP_DONE] = 1.0;
+        __hip_atomic_fetch_add(batch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bp_report(batch, host, count, seq);
+      }
+      part_a[0] = sqrt(r) < z.resmin;       // (bbf_decide_a: :793-796)
+      part_a[1] = z.alpha < eps10;          // (:799)
+      part_a[2] = conv;
+    }
+    __syncthreads();
+    if (part_a[2]) return;
+    improved = part_a[0] != 0;
+    fallback = part_a[1] != 0;
+  }
   double v[2];
-  bbf_tail_b_body(q, bp_segk_of(q), inew, icur, z.improved != 0.0, z.fallback != 0.0, gd, chunk,
+  bbf_tail_b_body(q, bp_segk_of(q), inew, icur, improved, fallback, gd, chunk,
                   blockIdx.x, lds4, &v[0], &v[1]);
   if (!bp_meet(q.partials, q.counter, nblk, 2, v, lds4, &is_last)) return;
   if (threadIdx.x == 0) {
@@ -333,8 +357,9 @@ extern "C" int ccqp_bpipe_iterate_f64(ccqp_ctx* ctx, const ccqp_pprob* dev_probs
   if (rc) return rc;
   if (with_tail) {
     if (flags & BP_FLAG_FALLBACK) {
-      hipLaunchKernelGGL(bpipe_tailf_a_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, gd, eps10,
-                         chunk, nblk, dev_batch);
+      if (!step_in_tail)                    // (one-chunk problems: part A runs inside the launch below)
+        hipLaunchKernelGGL(bpipe_tailf_a_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, gd, eps10,
+                           chunk, nblk, dev_batch);
       hipLaunchKernelGGL(bpipe_tailf_b_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, inew, icur, gd,
                          eps10, chunk, nblk, dev_batch, ctx->host_slots_dev, (unsigned)count, (double)iteration,
                          step_in_tail);
