@@ -322,7 +322,7 @@ static bool bmprgp_looks_ahead(const ccqp_ctx* ctx, int count, int64_t n, int fl
 }
 
 // ---- fused rounds of small batches (round 4; flags bit 18 = CCQP_LOCKSTEP_FUSED_ROUNDS: slab slot 55 holds max_mv - 1)
-// A batch of one-chunk problems whose matrices fit the MALL together is bound by the NUMBER of its launches.  The
+// A batch of one-chunk problems below the persistent matvec's sizes is bound by the NUMBER of its launches.  The
 // look-ahead alone does not help it (measured: it saves passes over the matrices, not rounds -- the M1 and A.p rounds of a
 // CG step remain, without a matvec); what helps is to pass THROUGH those rounds in the launch that already holds the
 // problem: the fused stage launch (one workgroup per problem, bmprgp_tail_fused_kernel) goes on to the next round as
@@ -357,8 +357,12 @@ static bool bmprgp_fused_rounds(const ccqp_ctx* ctx, int count, int64_t n, int f
   int64_t chunk;
   int nblk;
   ccqp_red_geometry(n, &chunk, &nblk);
+  // (no byte limit, unlike APGD's fused rounds: nothing is read twice here that the unfused rounds read once -- the three
+  // products of an A.dx round are three passes either way; forced beyond 256 MiB: 1024 / 4096 x 256 +6 / +11 %, 100 x 1024
+  // +6 %, 16 / 24 x 2048 +10 %, 60 x 2048 +-0 -- up to where the persistent look-ahead takes the run, 1 GiB from n = 512)
   return fuse_asked && !ccqp_opt(ctx, CCQP_OPT_MPRGP_LOOKAHEAD) && ccqp_opt(ctx, CCQP_OPT_MPRGP_FUSED_TAIL) != 1 &&
-         nblk <= 1 && !bmprgp_looks_ahead(ctx, count, n, flags) && bp_valu_sharing(ctx, flags, count, n);
+         ccqp_opt(ctx, CCQP_OPT_SMALL_SHARING) != 1 && (flags & ~(1 | 8 | 128)) == 0 && nblk <= 1 &&
+         !bmprgp_looks_ahead(ctx, count, n, flags);
 }
 
 template <int R, int S>

@@ -686,7 +686,7 @@ int ccqp_bmprgp_stage_one_f64(ccqp_ctx* ctx, const ccqp_pmprgp* host_desc, ccqp_
                               double limit, uint32_t* words, void* stream);
 /* FUSED ROUNDS of ccqp_bmprgp_start_f64 / ccqp_bmprgp_round_f64 (`flags` bit 18, CCQP_LOCKSTEP_FUSED_ROUNDS: the caller has
  * put max_mv - 1 -- 0: no budget -- into slab slot 55 of every problem): for a batch of one-chunk problems (n <= 2048)
- * whose matrices fit the MALL together (256 MiB; context option SMALL_SHARING) a round is TWO launches -- one batched VALU
+ * below the persistent matvec's sizes (context option SMALL_SHARING = 1: off) a round is TWO launches -- one batched VALU
  * launch with the products of every live problem (the three of an A.dx round as grid slices: the run looks ahead), one
  * stage launch that passes THROUGH the rounds whose product is already there (up to four) -- and a CG step one round
  * instead of three.  The device enforces the budget: a problem whose next round would pass max_mv - 1 ends with slab

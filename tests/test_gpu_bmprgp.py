@@ -448,5 +448,6 @@ def test_fused_rounds_of_small_batches_change_no_bit(n, count):
         _same(full[0], one)
     assert max(r.executed_matrix_vector_multiplications - r.solution_num_matrix_vector_multiplications for r in full) > 0
     assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 4, 4096, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 0      # two chunks
-    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 33, 1024, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 0     # > 256 MiB
+    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 100, 1024, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 2    # (no byte limit ...)
+    assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 128, 1024, 1 | _lib.LOCKSTEP_FUSED_ROUNDS) == 0    # ... up to the persistent form
     assert eng.lib.ccqp_bmprgp_fused_form(eng.ctx, 4, 1024, 1) == 0                                   # not asked for
