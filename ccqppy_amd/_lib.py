@@ -25,7 +25,8 @@ LOCKSTEP_FUSED_ROUNDS = 1 << 18  # CCQP_LOCKSTEP_FUSED_ROUNDS: one round per acc
 OPTIONS = {name: key for key, name in enumerate((
     "GEMV_ROW_STRIDE", "GEMV2_WPB", "GEMV2_SHAPE", "GEMV2_GROUP", "BMV3_SHAPE", "LOOKAHEAD_MIN_N", "MPRGP_LOOKAHEAD_MIN_N",
     "MPRGP_LOOKAHEAD", "APGD_LOOKAHEAD", "BMV_STAGGER", "MPRGP_FUSED_TAIL", "PERS1_MIN_N", "BMV_LOADS",
-    "SMALL_SHARING", "PERS_MIN_MIB", "BPIPE_STEP_IN_TAIL"))}
+    "SMALL_SHARING", "PERS_MIN_MIB", "BPIPE_STEP_IN_TAIL",
+    "APGD_UPDATE_IN_DECISION"))}
 
 OP_IDENTITY, OP_LOWER, OP_UPPER, OP_BOX, OP_SPHERE, OP_CONE = range(6)
 SEG_LB_INT, SEG_UB_INT, SEG_P0_INT = 1, 2, 4

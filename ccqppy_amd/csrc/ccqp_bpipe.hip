@@ -756,13 +756,17 @@ __device__ __forceinline__ void bapgd_decide_body(const ccqp_papgd& q, const ap_
   if (threadIdx.x == 0) bapgd_decide_scalars<LOCKSTEP>(q, s, z, v, ar, fuse, true, batch, host, count, seq);
 }
 
+// (defined below; U: elements of the fused update whose loads are in flight together)
+template <int U = 4>
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0);
+
 __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_papgd* __restrict__ probs, double gd,
                                                                   int64_t chunk, int nblk,
                                                                   unsigned* __restrict__ batch,
                                                                   double* __restrict__ host, unsigned count,
                                                                   double seq, int ar,
                                                                   const ccqp_psegs* __restrict__ segs = nullptr,
-                                                                  int64_t n_segs = 0, int fuse = 0) {
+                                                                  int64_t n_segs = 0, int fuse = 0, int update = 0) {
   __shared__ double lds4[4];
   __shared__ int is_last;
   const ccqp_papgd& q = probs[blockIdx.y];
@@ -773,12 +777,18 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bapgd_decide_kernel(const ccqp_pap
   }
   bapgd_decide_body<true>(q, z, blockIdx.x, gd, chunk, nblk, batch, host, count, seq, lds4, &is_last, ar,
                           segs ? segs + blockIdx.y : nullptr, n_segs, fuse);
+  if (update) {
+    // one-chunk problems (this block is the problem's only one): the update the decision asks for, taken here
+    // (bapgd_apply_kernel) -- a fused round is then two launches
+    __syncthreads();
+    bapgd_apply_body(q, 0, 1);
+  }
 }
 
 // n_segs > 0: segmented form -- the trial step is taken by the segmented launches (ccqp_bsegs.hip), the vector length
 // comes from the caller.  U: elements of the fused update whose loads are in flight together.
-template <int U = 4>
-__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs = 0) {
+template <int U>
+__device__ __forceinline__ void bapgd_apply_body(const ccqp_papgd& q, int bx, int nbx, int64_t n_segs) {
   const double* s = q.slab;
   if (s[AP_DONE] != 0.0) return;
   const int it = (int)s[AP_IT];
@@ -1108,10 +1118,17 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   // (and ONE workgroup per problem doing both, a group of 256 threads per chunk, the chunk sums met in LDS: level with the
   // two launches up to n = 512, 5-7 % behind at 1024 ... 3072, +3 / +14 / +27 us per round at 4096 / 8192 / 16384 --
   // one CU again; round 4, removed)
+  // Small one-chunk problems: the update inside the decision launch, whose only block has the new state at hand -- a fused
+  // round is then TWO launches.  Whole solves, one problem to 64 (profiles/r04_apgd_update_in_decision.jsonl): +6 ... +12 %
+  // at n <= 512, +2 ... +5 % at 1024, -1 ... -5 % at 2048 (one CU moves the update's ~100 bytes per element): taken up to
+  // n = 1024 (the context's option APGD_UPDATE_IN_DECISION: 1 never, 2 for every one-chunk problem).  (The first attempt at
+  // this -- a kernel of its own with an LDS copy of the slab, before the roll-call was made cheap -- had come out level.)
+  const int64_t uopt = ccqp_opt(ctx, CCQP_OPT_APGD_UPDATE_IN_DECISION);
+  const int update = fuse && nblk == 1 && uopt != 1 && (uopt == 2 || n <= 1024);
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, ar, (const ccqp_psegs*)nullptr,
-                     (int64_t)0, fuse);
-  hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
+                     (int64_t)0, fuse, update);
+  if (!update) hipLaunchKernelGGL(bapgd_apply_kernel, dim3(bp_vec_grid(n), count), dim3(CCQP_BLOCK), 0, s, dev_probs);
   CCQP_LAUNCH_CHECK();
   return CCQP_OK;
 }

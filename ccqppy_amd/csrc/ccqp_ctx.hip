@@ -213,6 +213,7 @@ extern "C" int ccqp_ctx_set_option(ccqp_ctx* c, int key, int64_t value) {
     case CCQP_OPT_BMV_STAGGER: ok = value == 0 || value == 1; break;
     case CCQP_OPT_MPRGP_FUSED_TAIL:
     case CCQP_OPT_BMV_LOADS:
+    case CCQP_OPT_APGD_UPDATE_IN_DECISION:
     case CCQP_OPT_SMALL_SHARING: ok = value >= 0 && value <= 2; break;
     default: break;
   }

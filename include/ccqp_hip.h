@@ -75,7 +75,9 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *                          of matrices)
  *   PERS_MIN_MIB           MiB of matrices from which a lock-step batch of n >= 4096 takes the persistent matvec (512)
  *   BPIPE_STEP_IN_TAIL     1 = lock-step PGD / BBPGD / BBPGDf always launch their step (default: problems of one reduction
- *                          chunk, n <= 2048, take the next iteration's step in the tail launch) */
+ *                          chunk, n <= 2048, take the next iteration's step in the tail launch)
+ *   APGD_UPDATE_IN_DECISION fused lock-step APGD rounds update inside the decision launch: 1 = never, 2 = every one-chunk
+ *                          problem (default: n <= 1024) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
   CCQP_OPT_GEMV2_WPB = 1,
@@ -93,7 +95,8 @@ enum {
   CCQP_OPT_SMALL_SHARING = 13,
   CCQP_OPT_PERS_MIN_MIB = 14,
   CCQP_OPT_BPIPE_STEP_IN_TAIL = 15,
-  CCQP_OPT_COUNT = 16
+  CCQP_OPT_APGD_UPDATE_IN_DECISION = 16,
+  CCQP_OPT_COUNT = 17
 };
 int ccqp_ctx_set_option(ccqp_ctx* ctx, int key, int64_t value);
 int ccqp_ctx_get_option(ccqp_ctx* ctx, int key, int64_t* value);
