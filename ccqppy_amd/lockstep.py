@@ -6,7 +6,7 @@ scalar part of each iteration done in C on the host for the whole batch at once 
   solve_batch_pipelined   a list of (A, b, x0, set) problems -> solver objects (grouped by size)
   solve_stacked           stacked tensors A (B, n, n), b (B, n) -> stacked results, no per-problem host work
 
-Two execution forms, chosen by size: lock-step ROUNDS (3-5 launches per matvec for the whole batch, the host polls a
+Two execution forms, chosen by size: lock-step ROUNDS (2-5 launches per matvec for the whole batch, the host polls a
 progress word in pinned memory) and, for small matrices, ONE launch in which each problem is solved inside its own
 workgroup.  Either way problem p gets bit for bit the result of its own `solve()`: the kernels run the bodies of the
 single-problem kernels with the same reduction geometry and the same matvec lane map, and the scalar arithmetic of
@@ -180,7 +180,7 @@ def solve_batch_pipelined(make_solver, problems, device=None, quiet=True, ahead=
                           timing=None):
     """Many dense problems (grouped by size n: one run per size), each solved by PGD, BBPGD, BBPGDf, APGD, anti-relaxation
     APGD or MPRGP with every scalar and branch decision on the device (ccqp_bpipe_* / ccqp_bapgd_* / ccqp_bmprgp_*):
-    lock-step rounds of 3-5 launches per matvec for the whole batch while the host only polls a progress word, or --
+    lock-step rounds of 2-5 launches per matvec for the whole batch while the host only polls a progress word, or --
     small matrices, many of them (by default: BBPGD-type n <= 128, <= 256 from 256 problems on; APGD and MPRGP n <= 32,
     <= 64 from 256 problems, <= 128 from 1024 -- _SINGLE_LAUNCH_RULE; `single_launch` forces it on, up to
     n = 2048, or off) -- ONE launch in which every problem is solved inside its own workgroup.  The host-driven
