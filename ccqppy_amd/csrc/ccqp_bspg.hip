@@ -119,10 +119,23 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bspg_ctl_kernel(const double* __re
 }
 
 // grid (blocks, problems).  DIRECTION: also d = P(x - alpha g) - x for an elementwise set
+// host_ctl != NULL: the round's control words are still in the pinned host buffer -- every block reads its problem's four
+// from there and the problem's first block leaves them in `ctl` for the launches that follow (instead of a copy launch
+// of its own in front: four launches per round become three)
 template <bool DIRECTION>
-__global__ __launch_bounds__(CCQP_BLOCK) void bspg_step_kernel(const ccqp_pspg* __restrict__ probs,
-                                                               const double* __restrict__ ctl, int64_t n) {
-  const double* c = ctl + 4 * blockIdx.y;
+__global__ __launch_bounds__(CCQP_BLOCK) void bspg_step_kernel(const ccqp_pspg* __restrict__ probs, double* __restrict__ ctl,
+                                                               int64_t n, const double* __restrict__ host_ctl = nullptr) {
+  double cw[4];
+  {
+    const double* src = (host_ctl ? host_ctl : ctl) + 4 * blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cw[k] = src[k];
+    if (host_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ctl[4 * blockIdx.y + k] = cw[k];
+    }
+  }
+  const double* c = cw;
   const int mode = (int)c[SPG_MODE];
   if (mode == 0) return;
   const bool upd = c[SPG_UPDATE] != 0.0;
@@ -476,17 +489,18 @@ extern "C" int ccqp_bspg_run_f64(ccqp_ctx* ctx, const ccqp_pspg* dev_probs, cons
     double* ctl = dev_ctl + 4 * p0;
     const dim3 vgrid(bp_vec_grid(n), cnt);
     __atomic_thread_fence(__ATOMIC_RELEASE);
-    hipLaunchKernelGGL(bspg_ctl_kernel, dim3((4 * cnt + CCQP_BLOCK - 1) / CCQP_BLOCK), blk, 0, s, hctl_dev + 4 * p0, ctl,
-                       4 * cnt);
     if (segs) {
-      hipLaunchKernelGGL(bspg_step_kernel<false>, vgrid, blk, 0, s, probs, ctl, n);
+      hipLaunchKernelGGL(bspg_ctl_kernel, dim3((4 * cnt + CCQP_BLOCK - 1) / CCQP_BLOCK), blk, 0, s, hctl_dev + 4 * p0, ctl,
+                         4 * cnt);
+      hipLaunchKernelGGL(bspg_step_kernel<false>, vgrid, blk, 0, s, probs, ctl, n, (const double*)nullptr);
       if (nlive) {
         if (max_nnorm > 0)
           hipLaunchKernelGGL(bspg_norm_kernel, dim3((unsigned)max_nnorm, cnt), blk, 0, s, probs, segs, ctl);
         hipLaunchKernelGGL(bspg_apply_kernel, dim3((unsigned)max_nwork, cnt), blk, 0, s, probs, segs, ctl);
       }
     } else {
-      hipLaunchKernelGGL(bspg_step_kernel<true>, vgrid, blk, 0, s, probs, ctl, n);
+      // (elementwise sets: the step launch fetches the control words itself)
+      hipLaunchKernelGGL(bspg_step_kernel<true>, vgrid, blk, 0, s, probs, ctl, n, (const double*)(hctl_dev + 4 * p0));
     }
     if (!nlive) return 2;                                // only final updates: nothing will be reported
     G.seq += 1.0;
