@@ -32,7 +32,11 @@ extern "C" {
 
 /* 2: struct ccqp_papgd grew `ga` / `Aya` and the look-ahead of the lock-step forms became an explicit request (flags
  *    bit 17, CCQP_LOCKSTEP_LOOKAHEAD) instead of "ga != NULL"; ccqp_bpipe_matvec_form takes the context; tuning / A-B
- *    switches are per-context options (ccqp_ctx_set_option) instead of environment variables. */
+ *    switches are per-context options (ccqp_ctx_set_option) instead of environment variables.
+ *    Additive since (same version): ccqp_b{apgd,pipe,mprgp,spg}_stage_one_f64, ccqp_bapgd_fused_form,
+ *    ccqp_bmprgp_fused_form, ccqp_read_f64, ccqp_gemvk_f64 / ccqp_shard_gemvk_allgather_f64 / ccqp_unpack_gathered_f64,
+ *    the options of CCQP_OPT_*; `flags` bit 18 (CCQP_LOCKSTEP_FUSED_ROUNDS) is a request of ccqp_bmprgp_start_f64 /
+ *    _round_f64 too (their tuning word ends at bit 15, as that of ccqp_bapgd_*). */
 #define CCQP_ABI_VERSION 2
 
 enum {
