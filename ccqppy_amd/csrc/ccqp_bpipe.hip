@@ -1124,7 +1124,7 @@ extern "C" int ccqp_bapgd_round_f64(ccqp_ctx* ctx, const ccqp_papgd* dev_probs, 
   // n = 1024 (the context's option APGD_UPDATE_IN_DECISION: 1 never, 2 for every one-chunk problem).  (The first attempt at
   // this -- a kernel of its own with an LDS copy of the slab, before the roll-call was made cheap -- had come out level.)
   const int64_t uopt = ccqp_opt(ctx, CCQP_OPT_APGD_UPDATE_IN_DECISION);
-  const int update = fuse && nblk == 1 && uopt != 1 && (uopt == 2 || n <= 1024);
+  const int update = nblk == 1 && uopt != 1 && (uopt == 2 || n <= 1024);      // (fused or not)
   hipLaunchKernelGGL(bapgd_decide_kernel, dim3(nblk, count), dim3(CCQP_BLOCK), 0, s, dev_probs, gd, chunk, nblk,
                      dev_batch, ctx->host_slots_dev, (unsigned)count, (double)round, ar, (const ccqp_psegs*)nullptr,
                      (int64_t)0, fuse, update);

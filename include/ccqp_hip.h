@@ -80,7 +80,7 @@ int ccqp_ctx_info(ccqp_ctx* ctx, int* device, int* num_cu, char* arch_buf, int b
  *   PERS_MIN_MIB           MiB of matrices from which a lock-step batch of n >= 4096 takes the persistent matvec (512)
  *   BPIPE_STEP_IN_TAIL     1 = lock-step PGD / BBPGD / BBPGDf always launch their step (default: problems of one reduction
  *                          chunk, n <= 2048, take the next iteration's step in the tail launch)
- *   APGD_UPDATE_IN_DECISION fused lock-step APGD rounds update inside the decision launch: 1 = never, 2 = every one-chunk
+ *   APGD_UPDATE_IN_DECISION lock-step APGD rounds update inside the decision launch: 1 = never, 2 = every one-chunk
  *                          problem (default: n <= 1024) */
 enum {
   CCQP_OPT_GEMV_ROW_STRIDE = 0,
