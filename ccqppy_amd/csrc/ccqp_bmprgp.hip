@@ -496,9 +496,11 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_init_p_kernel(const ccqp_pm
 // ---------------------------------------------------------------------------------------------------- the stages
 // tail of an outer iteration (solvers.py:1184-1192): BB step length, exit test, swap of the iterates
 template <bool LOCKSTEP>
+// (`slab_copy`: the fused-rounds launch keeps the problem's slab in LDS -- see bmprgp_tail_fused_kernel)
 __device__ __forceinline__ void mp_tail(const ccqp_pmprgp& q, const mp_words& z, double s0, double s1, double r2,
-                                        double eps10, unsigned* batch) {
+                                        double eps10, unsigned* batch, double* slab_copy = nullptr) {
   double* s = q.slab;
+  if (slab_copy) s = slab_copy;
   const double den = s1 + eps10;
   s[MP_ABB] = s0 / den;
   s[MP_S2] = r2;
@@ -526,8 +528,9 @@ template <bool LOCKSTEP, bool SEQ = false>
 __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stage, int bx, double gd, double eps10,
                                                   int64_t chunk, int nblk, unsigned* batch, double* host,
                                                   unsigned count, double seq, double* lds4, int* is_last_p,
-                                                  double* seqpart = nullptr) {
+                                                  double* seqpart = nullptr, double* slab_copy = nullptr) {
   double* s = q.slab;                         // written only (by the deciding thread); read through `z` alone
+  if (slab_copy) s = slab_copy;               // (the fused-rounds launch: the workgroup's LDS copy of the slab)
   const mp_words z = mp_enter(s);
   if (z.done != 0.0) {
     if (LOCKSTEP && host && stage == 3 && bx == 0 && threadIdx.x == 0) bp_report(batch, host, count, seq);
@@ -627,7 +630,7 @@ __device__ __forceinline__ void bmprgp_stage_body(const ccqp_pmprgp& q, int stag
           s[MP_S1] = v[1];
           s[MP_ACT] = (double)ACT_NONE;
           s[MP_EXEC] = z.exec + 1.0;
-          mp_tail<LOCKSTEP>(q, z, v[0], v[1], v[2], eps10, batch);
+          mp_tail<LOCKSTEP>(q, z, v[0], v[1], v[2], eps10, batch, slab_copy);
         }
         return;
       }
@@ -761,8 +764,9 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_stage_kernel(const ccqp_pmp
 
 #undef MP_MEET
 
-__device__ __forceinline__ void bmprgp_apply_body(const ccqp_pmprgp& q, int bx, int nbx) {
+__device__ __forceinline__ void bmprgp_apply_body(const ccqp_pmprgp& q, int bx, int nbx, const double* slab_copy = nullptr) {
   const double* s = q.slab;
+  if (slab_copy) s = slab_copy;
   if (s[MP_DONE] != 0.0) return;
   const int act = (int)s[MP_ACT];
   if (act == ACT_NONE) return;
@@ -842,11 +846,16 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccq
     bmprgp_apply_body(q, 0, 1);
     return;
   }
-  // fused rounds (one chunk per problem): pass through the rounds whose product is already there
+  // fused rounds (one chunk per problem): pass through the rounds whose product is already there.  The problem's slab is
+  // this workgroup's alone for the launch: it works on a copy in LDS (every stage reads fifteen steering words, and a
+  // launch runs up to twelve stages -- from global memory that was a round trip each time) and writes it back at the end.
+  __shared__ double slab_s[CCQP_NUM_SLOTS];
+  if (threadIdx.x < CCQP_NUM_SLOTS) slab_s[threadIdx.x] = q.slab[threadIdx.x];
+  __syncthreads();
   const int64_t n = q.seg.dim;
   for (int pass = 0; pass < passes; ++pass) {
-    // (the slab words below were written by this workgroup's own thread 0 before the last barrier, or by earlier launches)
-    double* s = q.slab;
+    // (the words below were written by this workgroup's own thread 0 before the last barrier, or by earlier launches)
+    double* s = slab_s;
     const double done = s[MP_DONE], mv = s[MP_MV], limit = s[MP_LIMIT];
     const int st = (int)s[MP_STATE], ahead = (int)s[MP_AHEAD], it = (int)s[MP_IT];
     int go = 1;
@@ -877,12 +886,15 @@ __global__ __launch_bounds__(CCQP_BLOCK) void bmprgp_tail_fused_kernel(const ccq
     // (an A.dx or half-step round is over after its first stage: the other two would only read the state again)
     const int stages = (st == ST_ADXC || st == ST_ADXH || st == ST_G1) ? 1 : 3;
     for (int stage = 1; stage <= stages; ++stage) {
-      bmprgp_stage_body<true, true>(q, stage, 0, gd, eps10, chunk, 1, batch, nullptr, count, seq, lds4, &is_last, seqpart);
+      bmprgp_stage_body<true, true>(q, stage, 0, gd, eps10, chunk, 1, batch, nullptr, count, seq, lds4, &is_last, seqpart,
+                                    slab_s);
       __syncthreads();
     }
-    bmprgp_apply_body(q, 0, 1);
+    bmprgp_apply_body(q, 0, 1, slab_s);
     __syncthreads();
   }
+  __syncthreads();
+  if (threadIdx.x < CCQP_NUM_SLOTS) q.slab[threadIdx.x] = slab_s[threadIdx.x];
   if (threadIdx.x == 0) bp_report(batch, host, count, seq);
 }
 
